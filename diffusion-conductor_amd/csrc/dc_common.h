@@ -1,0 +1,83 @@
+// dc_common.h - shared host/device definitions for libdc_ddim.so (gfx950 only).
+//
+// Vocabulary
+//   token      one motion frame of one clip; tokens are numbered flat, tok = b*T + n
+//   group      32 consecutive tokens = the work of one wavefront (MFMA 32x32 tile width)
+//   FT tile    a 32-feature x 32-token fp32 tile in the v_mfma_f32_32x32x16 C/D register
+//              layout: lane l, reg r  <->  feature (r&3)+8*(r>>2)+4*(l>>5), token l&31
+//   TF tile    the same layout with tokens on rows and features on columns
+//   frag       one MFMA A/B operand: 64 lanes x 8 bf16 (1 KiB), stored lane-major so a
+//              wave reads it with one coalesced 16-B-per-lane load
+#pragma once
+#include <stdint.h>
+
+#define DC_D 128        // latent_dim
+#define DC_H 8          // heads
+#define DC_HD 16        // head dim
+#define DC_F 64         // ffn dim
+#define DC_E 512        // time_embed_dim == music_latent_dim
+#define DC_C 64         // music feature channels
+#define DC_PMAX 32      // input_feats padded to one MFMA tile
+#define DC_MAX_LAYERS 16
+#define DC_FILM_TILES_PER_BLOCK 8   // 256 FiLM outputs = 4 scale tiles + 4 shift tiles
+#define DC_KS_E (DC_E / 16)         // 32 k-steps of 16 over the 512-wide embedding
+
+// one partial record of the linear-attention K-softmax / K^T V reduction
+// (per group, per clip slot): column max, column sum of exp, and the 4 diagonal
+// 32x32 blocks of exp(K-m)^T V in accumulator layout.
+#define DC_REC_FLOATS (128 + 128 + 4 * 64 * 16)
+
+#ifdef __HIPCC__
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) _Float16 f16x16;
+#else
+struct bf16x8 { uint16_t v[8]; };
+#endif
+
+// Device pointers to the packed weight image of one StylizationBlock
+struct DcStyl {
+    const float* ln_g;   // ftvec [4][2][16]
+    const float* ln_b;
+    const bf16x8* wo;    // chained pack, OT=4 KT=4 (hi frags then lo frags)
+    const float* bo;     // ftvec
+};
+
+struct DcLayer {
+    const float *sa_ln_g, *sa_ln_b;            // ftvec
+    const bf16x8 *sa_wq, *sa_wk, *sa_wv;       // chained pack 4x4
+    const float *sa_bq;                        // ftvec
+    const float *sa_bk, *sa_bv;                // plain [128]
+    DcStyl sa_styl;
+    const float *ca_ln_g, *ca_ln_b;            // ftvec
+    const bf16x8* ca_wq;
+    const float* ca_bq;                        // ftvec
+    const bf16x8 *ca_wk, *ca_wv;               // natural-k pack, OT=4, KS=32 (text_norm folded in)
+    const float *ca_bk, *ca_bv;                // plain [128] (text_norm bias folded in)
+    DcStyl ca_styl;
+    const bf16x8 *ffn_w1;                      // chained pack OT=2 KT=4
+    const bf16x8 *ffn_w2;                      // chained pack OT=4 KT=2
+    const float *ffn_b1, *ffn_b2;              // ftvec (2 tiles / 4 tiles)
+    DcStyl ffn_styl;
+};
+
+struct DcModel {
+    DcLayer layer[DC_MAX_LAYERS];
+    const bf16x8* je_w;      // joint_embed, chained pack OT=4 KT=1
+    const float* je_b;       // ftvec
+    const float* seq_emb;    // row-major [num_frames][128]
+    const bf16x8* out_w;     // chained pack OT=1 KT=4
+    const float* out_b;      // ftvec (1 tile)
+    const bf16x8* film_w;    // natural-k pack [24*L/8... = 3*L*8 tiles][32 ks]; hi then lo
+    const float* film_b;     // ftvec [3*L*8 tiles]
+    const float* lin_wt;     // `linear` weight transposed [64][512]
+    const float* lin_b;      // [512]
+    const float* temb;       // [max_timesteps][512]
+    int num_layers;
+    int input_feats;
+    int num_frames;
+    int max_timesteps;
+};

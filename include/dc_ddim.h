@@ -1,0 +1,157 @@
+/*
+ * dc_ddim.h - C ABI of libdc_ddim.so: the MI355X (gfx950) DDIM sampler of
+ * Diffusion-Conductor's Diffusion_Stage.
+ *
+ * The reference has no FFI layer: its boundary is three Python call surfaces
+ * (SURVEY.md section 8b).  These entry points are what a binding for that path binds
+ * *below* those surfaces; each one names the reference code it replaces (paths
+ * relative to Diffusion_Stage/).  Plain pointers and sizes only, no torch types.
+ *
+ * Conventions
+ *   - every function returns DC_OK (0) or a negative dc_status; dc_last_error() gives
+ *     the message of the last failure on the calling thread;
+ *   - `d_` arguments are DEVICE pointers (caller-owned, e.g. tensor.data_ptr());
+ *     `h_` arguments are HOST pointers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Work is
+ *     ordered after everything already enqueued on `stream` and later work on `stream`
+ *     is ordered after it; calls are asynchronous unless stated otherwise;
+ *   - a dc_sampler is not thread-safe; use one per host thread / per GPU;
+ *   - there is NO CPU fallback anywhere in this library.
+ */
+#ifndef DC_DDIM_H
+#define DC_DDIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dc_sampler dc_sampler;
+
+typedef enum dc_status {
+    DC_OK = 0,
+    DC_ERR_INVALID = -1,      /* bad argument / wrong call order          */
+    DC_ERR_NO_DEVICE = -2,    /* no HIP device visible                    */
+    DC_ERR_HIP = -3,          /* a HIP runtime call failed                */
+    DC_ERR_PARAM = -4,        /* unknown / missing / mis-sized parameter  */
+    DC_ERR_UNSUPPORTED = -5   /* configuration outside the built path     */
+} dc_status;
+
+/* GEMM operand precision of the denoiser (accumulation is always fp32). */
+typedef enum dc_precision {
+    DC_PREC_BF16 = 0,   /* every MFMA operand plain bf16                                      */
+    DC_PREC_MIXED = 1,  /* K=512 FiLM GEMM plain bf16; all 128-wide GEMMs split-bf16 (3 MFMA) */
+    DC_PREC_BF16X3 = 2  /* split-bf16 everywhere (validation mode, ~fp32 accuracy)            */
+} dc_precision;
+
+/* Mirrors the constructor arguments the sampler path consumes:
+ * MotionTransformer.__init__ (models/transformer.py:360-374) and
+ * tools/visualization.py:169-178 (build_models). */
+typedef struct dc_config {
+    int32_t input_feats;   /* 26  (dim_pose, 13 joints x 2)            */
+    int32_t num_frames;    /* 1800 rows of sequence_embedding          */
+    int32_t latent_dim;    /* 128 (only value the reference supports)  */
+    int32_t ff_size;       /* 64                                       */
+    int32_t num_layers;    /* 8                                        */
+    int32_t num_heads;     /* 8                                        */
+    int32_t no_eff;        /* 0 = linear attention (default), 1 = full T x T attention */
+    int32_t precision;     /* dc_precision                             */
+    int32_t max_timesteps; /* size of the timestep-embedding table (>= diffusion_steps), e.g. 1000 */
+    int32_t device;        /* HIP device ordinal                       */
+} dc_config;
+
+const char* dc_last_error(void);
+const char* dc_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Host-only helpers (no GPU needed; usable and tested on a CPU-only box).
+ * ---------------------------------------------------------------------------------- */
+
+/* get_named_beta_schedule('linear', n) (models/gaussian_diffusion.py:228-245) and the
+ * tables GaussianDiffusion.__init__ derives from it (:342-361), all fp64, each [n]. */
+int dc_linear_beta_schedule(int32_t num_steps, double* h_betas, double* h_alphas_cumprod,
+                            double* h_alphas_cumprod_prev, double* h_sqrt_recip_alphas_cumprod,
+                            double* h_sqrt_recipm1_alphas_cumprod);
+
+/* The four fp32 scalars ddim_sample (models/gaussian_diffusion.py:812-830) uses at
+ * timestep t with eta = 0, from fp64 alphas_cumprod[n]:
+ *   h_coef[t*4 + 0] = (float)sqrt(1/abar_t)            (sqrt_recip_alphas_cumprod)
+ *   h_coef[t*4 + 1] = (float)sqrt(1/abar_t - 1)        (sqrt_recipm1_alphas_cumprod)
+ *   h_coef[t*4 + 2] = sqrtf((float)abar_{t-1})         (coefficient of pred_xstart)
+ *   h_coef[t*4 + 3] = sqrtf(1 - (float)abar_{t-1})     (coefficient of eps)          */
+int dc_ddim_coefficients(int32_t num_steps, const double* h_alphas_cumprod, float* h_coef);
+
+/* Test hook: pack a row-major Linear weight W[n_out][k_in] (torch layout) into the
+ * MFMA fragment-major bf16 image the kernels read (see DESIGN.md "weight image").
+ * `chained` != 0 uses the accumulator-as-operand k order, 0 the natural k order.
+ * h_hi / h_lo receive ceil(n_out/32)*ceil(k_in/32)*2*64*8 uint16 (bf16 bits) each. */
+int dc_pack_weight(const float* h_w, int32_t n_out, int32_t k_in, int32_t chained,
+                   uint16_t* h_hi, uint16_t* h_lo);
+
+/* ------------------------------------------------------------------------------------
+ * Sampler object
+ * ---------------------------------------------------------------------------------- */
+
+/* Replaces constructing MotionTransformer (models/transformer.py:360-445) +
+ * GaussianDiffusion (models/gaussian_diffusion.py:328-379) for sampling. */
+int dc_sampler_create(const dc_config* cfg, dc_sampler** out);
+void dc_sampler_destroy(dc_sampler* s);
+
+/* Replaces nn.Module.load_state_dict for the entries of state['encoder']
+ * (trainers/ddpm_trainer.py:303-319): call once per float tensor with the reference's
+ * own key (e.g. "temporal_decoder_blocks.3.sa_block.query.weight") and its contiguous
+ * fp32 data, then dc_sampler_finalize_params.  Unknown keys -> DC_ERR_PARAM. */
+int dc_sampler_set_param(dc_sampler* s, const char* name, const float* h_data, int64_t numel);
+
+/* Packs all parameters into the device weight image and builds the
+ * timestep_embedding + time_embed table (models/transformer.py:8-25, 410-414, 482).
+ * Missing entries -> DC_ERR_PARAM.  Synchronous. */
+int dc_sampler_finalize_params(dc_sampler* s);
+
+/* Step-invariant part of MotionTransformer.forward (models/transformer.py:479-482 and
+ * the K/V/attention half of LinearTemporalCrossAttention.forward :149-155): applies
+ * `linear` to xf_proj / xf_out, and builds the per-clip cross-attention matrices for
+ * all layers.  d_xf_proj, d_xf_out: fp32 [B, T, 64] (the pair encode_music returns);
+ * h_length: int32 [B] (model_kwargs['length']), NULL = all T.
+ * Must be called before dc_sampler_denoise / dc_sampler_ddim_loop; (re)allocates the
+ * workspace for (B, T). */
+int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const float* d_xf_out,
+                                const int32_t* h_length, int32_t B, int32_t T, void* stream);
+
+/* One MotionTransformer.forward (models/transformer.py:469-497) on the conditioning set
+ * above: d_x fp32 [B, T, input_feats], h_timesteps int32 [B] -> d_out fp32 [B, T, input_feats]. */
+int dc_sampler_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timesteps,
+                       float* d_out, void* stream);
+
+/* GaussianDiffusion.ddim_sample_loop (models/gaussian_diffusion.py:871-965) with
+ * model_mean_type=START_X, clip_denoised=False, eta=0, cond_fn=denoised_fn=None, as
+ * DDPMTrainer.generate_music_motion calls it (trainers/ddpm_trainer.py:190-200).
+ *   d_noise  fp32 [B,T,P]  x_T (the `noise=` argument; the caller draws it)
+ *   d_out    fp32 [B,T,P]  final sample (== pred_xstart of the last step)
+ *   num_steps              diffusion_steps S; timesteps run S-1 .. 0
+ *   h_coef   fp32 [S,4]    per-timestep scalars, see dc_ddim_coefficients
+ *   h_snap_iters int32[n_snap], d_snaps fp32 [n_snap,B,T,P]: `idxs` - the sample after
+ *                          iteration i (0 = after the first step) is also stored; may be NULL/0.
+ * The step sequence is captured once into a hipGraph per (B,T,S) and replayed. */
+int dc_sampler_ddim_loop(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps,
+                         const float* h_coef, const int32_t* h_snap_iters, int32_t n_snap,
+                         float* d_snaps, void* stream);
+
+/* Timing hook for bench.py: device time (ms, HIP events on the library's own stream)
+ * of the last dc_sampler_ddim_loop and the summed duration + launch count of its
+ * dominant kernel are not observable from outside a graph, so the library can run the
+ * same loop eagerly with per-kernel events.  Fills h_ms[kernel_id] with the total ms
+ * and h_count[kernel_id] with launches for each kernel id < n (see dc_kernel_name). */
+int dc_sampler_profile_loop(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps,
+                            const float* h_coef, float* h_ms, int32_t* h_count, int32_t n, void* stream);
+const char* dc_kernel_name(int32_t kernel_id);
+int32_t dc_kernel_count(void);
+
+/* Introspection used by tests: bytes of device workspace currently held. */
+int64_t dc_sampler_workspace_bytes(const dc_sampler* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DC_DDIM_H */

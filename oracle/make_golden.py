@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by IMPORTING THE REFERENCE (build container only).
+
+Run:  python oracle/make_golden.py            (needs /root/reference; ~5 min on 8 cores)
+
+What it does
+  1. stubs the imports the reference needs but this image lacks (`cv2`, `mmcv`), adds
+     /root/reference/Diffusion_Stage to sys.path and imports the reference's
+     MotionTransformer / GaussianDiffusion / DDPMTrainer;
+  2. loads the seeded synthetic checkpoint (diffusion-conductor_amd/synthetic.py) with
+     load_state_dict(strict=True) and switches to eval();
+  3. runs the reference on seeded inputs and stores inputs (when not regenerable from a
+     seed) and outputs as small fixtures;
+  4. runs oracle/ddim_oracle.py on the same inputs and asserts agreement - this is what
+     pins the oracle ("pinned against the reference run here").
+
+Only data (inputs / expected outputs) is written; no reference source text is copied.
+The GPU box never runs this file (it has no /root/reference).
+"""
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/Diffusion_Stage"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _stub_modules():
+    cv2 = types.ModuleType("cv2")
+    cv2.norm = lambda *a, **k: None
+    sys.modules["cv2"] = cv2
+    mmcv = types.ModuleType("mmcv")
+    runner = types.ModuleType("mmcv.runner")
+    runner.get_dist_info = lambda: (0, 1)
+    runner.init_dist = lambda *a, **k: None
+    utils = types.ModuleType("mmcv.utils")
+
+    class Registry:
+        def __init__(self, *a, **k):
+            pass
+
+        def register_module(self, *a, **k):
+            return lambda c: c
+
+    utils.Registry = Registry
+    utils.build_from_cfg = lambda *a, **k: None
+    parallel = types.ModuleType("mmcv.parallel")
+    parallel.MMDataParallel = object
+    parallel.MMDistributedDataParallel = object
+    parallel.collate = lambda *a, **k: None
+    mmcv.runner, mmcv.utils, mmcv.parallel = runner, utils, parallel
+    for n, m in (("mmcv", mmcv), ("mmcv.runner", runner), ("mmcv.utils", utils), ("mmcv.parallel", parallel)):
+        sys.modules[n] = m
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def main():
+    assert os.path.isdir(REF), "the reference is only present in the build container"
+    _stub_modules()
+    sys.path.insert(0, REF)
+    from models.transformer import MotionTransformer  # noqa: E402  (the reference)
+    from models import gaussian_diffusion as rgd       # noqa: E402
+    from diffusion_conductor_amd.synthetic import (synthetic_state_dict, batch_mel, batch_noise,
+                                                   batch_music_features)
+    from diffusion_conductor_amd.param_spec import DenoiserConfig
+    from oracle import ddim_oracle as O
+
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    sd_np = synthetic_state_dict(DenoiserConfig(), seed=0)
+    sd_t = {k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}
+    p = O.to_torch_params(sd_np)
+
+    def ref_model(no_eff=False):
+        m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128,
+                              device="cpu", music_model_path=None, no_clip=True, no_eff=no_eff)
+        m.load_state_dict(sd_t, strict=True)
+        return m.eval()
+
+    model = ref_model()
+    log = {}
+
+    # ---- G1: schedule tables straight from the reference's GaussianDiffusion ----------
+    g1 = {}
+    for S in (50, 1000):
+        betas = rgd.get_named_beta_schedule("linear", S)
+        gd = rgd.GaussianDiffusion(betas=betas, model_mean_type=rgd.ModelMeanType.START_X,
+                                   model_var_type=rgd.ModelVarType.FIXED_SMALL, loss_type=rgd.LossType.MSE)
+        tab = O.ddim_tables(O.linear_beta_schedule(S))
+        for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+                  "sqrt_recipm1_alphas_cumprod"):
+            ref = getattr(gd, k)
+            assert np.array_equal(ref, tab[k]), (S, k)
+            g1[f"S{S}_{k}"] = ref
+        # the fp32 per-step scalars as ddim_sample forms them (gaussian_diffusion.py:812-830)
+        t = torch.arange(S)
+        shp = (S, 1)
+        ex = rgd._extract_into_tensor
+        ab, abp = ex(gd.alphas_cumprod, t, shp), ex(gd.alphas_cumprod_prev, t, shp)
+        sigma = 0.0 * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+        co = torch.cat([ex(gd.sqrt_recip_alphas_cumprod, t, shp), ex(gd.sqrt_recipm1_alphas_cumprod, t, shp),
+                        torch.sqrt(abp), torch.sqrt(1 - abp - sigma ** 2), sigma], dim=1).numpy()
+        mine = O.ddim_step_coefficients(tab)
+        assert np.allclose(co, mine, rtol=2e-7, atol=0), S   # torch sqrt: stride-0 vs contiguous paths differ by <=1 ulp
+        g1[f"S{S}_step_coeff"] = co
+    np.savez_compressed(os.path.join(OUT, "g1_schedule.npz"), **g1)
+
+    # ---- G2: timestep embedding + time_embed MLP table ---------------------------------
+    with torch.no_grad():
+        t = torch.arange(1000)
+        from models.transformer import timestep_embedding as ref_te
+        te = ref_te(t, 128)
+        assert torch.equal(te, O.timestep_embedding(t, 128))
+        table = model.time_embed(te).numpy()
+    mine = torch.nn.functional.linear(torch.nn.functional.silu(torch.nn.functional.linear(
+        te, p["time_embed.0.weight"], p["time_embed.0.bias"])), p["time_embed.2.weight"], p["time_embed.2.bias"]).numpy()
+    assert np.array_equal(table, mine)
+    rows = np.array([0, 1, 7, 24, 49, 500, 998, 999])
+    np.savez_compressed(os.path.join(OUT, "g2_time_embed.npz"), rows=rows, table_rows=table[rows],
+                        table_sum=np.float64(table.astype(np.float64).sum()),
+                        table_abs_sum=np.float64(np.abs(table.astype(np.float64)).sum()))
+
+    # ---- G3: block-level known answers at B=2, T=64, ragged length ---------------------
+    B, T = 2, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, T, 26, generator=g)
+    h = torch.randn(B, T, 128, generator=g)
+    xf_proj = torch.randn(B, T, 64, generator=g)
+    xf_out = torch.randn(B, T, 64, generator=g)
+    tt = torch.tensor([37, 5])
+    length = torch.tensor([64, 40])
+    g3 = dict(x=x.numpy(), h=h.numpy(), xf_proj=xf_proj.numpy(), xf_out=xf_out.numpy(), t=tt.numpy(),
+              length=length.numpy())
+    with torch.no_grad():
+        emb = model.time_embed(ref_te(tt, 128)).unsqueeze(1) + model.linear(xf_proj)
+        xo = model.linear(xf_out)
+        mask = model.generate_src_mask(T, length).unsqueeze(-1)
+        blk = model.temporal_decoder_blocks[2]
+        g3["emb"] = emb.numpy()
+        g3["styl"] = blk.sa_block.proj_out(h, emb).numpy()
+        g3["sa"] = blk.sa_block(h, emb, mask).numpy()
+        g3["ca"] = blk.ca_block(h, xo, emb).numpy()
+        g3["ffn"] = blk.ffn(h, emb).numpy()
+        g3["layer"] = blk(h, xo, emb, mask).numpy()
+        g3["forward"] = model(x, tt, length=length, xf_proj=xf_proj, xf_out=xf_out).numpy()
+        m_ne = ref_model(no_eff=True)
+        blk_ne = m_ne.temporal_decoder_blocks[2]
+        g3["full_sa"] = blk_ne.sa_block(h, emb, mask).numpy()
+        g3["full_ca"] = blk_ne.ca_block(h, xo, emb).numpy()
+        g3["forward_no_eff"] = m_ne(x, tt, length=length, xf_proj=xf_proj, xf_out=xf_out).numpy()
+    pre = "temporal_decoder_blocks.2"
+    with torch.no_grad():
+        chk = {
+            "styl": O.stylization(p, pre + ".sa_block.proj_out", h, emb),
+            "sa": O.linear_self_attention(p, pre + ".sa_block", h, emb, mask, 8),
+            "ca": O.linear_cross_attention(p, pre + ".ca_block", h, xo, emb, 8),
+            "ffn": O.ffn(p, pre + ".ffn", h, emb),
+            "full_sa": O.full_self_attention(p, pre + ".sa_block", h, emb, mask, 8),
+            "full_ca": O.full_cross_attention(p, pre + ".ca_block", h, xo, emb, 8),
+            "forward": O.denoiser_forward(p, x, tt, length, xf_proj, xf_out),
+            "forward_no_eff": O.denoiser_forward(p, x, tt, length, xf_proj, xf_out, no_eff=True),
+        }
+    for k, v in chk.items():
+        log[f"g3_{k}"] = rel_l2(v.numpy(), g3[k])
+        assert log[f"g3_{k}"] < 5e-6, (k, log[f"g3_{k}"])  # fp32 summation-order noise only
+    np.savez_compressed(os.path.join(OUT, "g3_blocks.npz"), **g3)
+
+    # ---- G4: encode_music -----------------------------------------------------------------
+    mel_small = torch.from_numpy(batch_mel(1, 270)[..., :])
+    with torch.no_grad():
+        rp, rx = model.encode_music(mel_small, "cpu")
+        op_, ox = O.encode_music(p, mel_small)
+    assert torch.equal(rp, op_) and torch.equal(rx, ox)
+    mel_full = torch.from_numpy(batch_mel(1, 5400))
+    with torch.no_grad():
+        rpf, rxf = model.encode_music(mel_full, "cpu")
+        opf, oxf = O.encode_music(p, mel_full)
+    log["g4_full_xproj"] = rel_l2(opf.numpy(), rpf.numpy())
+    assert log["g4_full_xproj"] < 1e-6
+    np.savez_compressed(os.path.join(OUT, "g4_encode_music.npz"), small_x_proj=rp.numpy(), small_x=rx.numpy(),
+                        full_x_proj_sub=rpf.numpy()[:, ::25], full_x_sub=rxf.numpy()[:, ::25])
+
+    # ---- G5: end-to-end DDIM-50, config 1 (B=1, T=1800) -------------------------------
+    def ref_ddim(m, S, noise, xfp, xfo, length, idxs=()):
+        gd = rgd.GaussianDiffusion(betas=rgd.get_named_beta_schedule("linear", S),
+                                   model_mean_type=rgd.ModelMeanType.START_X,
+                                   model_var_type=rgd.ModelVarType.FIXED_SMALL, loss_type=rgd.LossType.MSE)
+        return gd.ddim_sample_loop(m, tuple(noise.shape), noise=noise, clip_denoised=False, progress=False,
+                                   model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.as_tensor(length)},
+                                   idxs=list(idxs))
+
+    xf = torch.from_numpy(batch_music_features(1, 1800))
+    with torch.no_grad():
+        xfp = torch.nn.functional.linear(xf, p["proj.weight"], p["proj.bias"])
+    noise = torch.from_numpy(batch_noise(1, 1800))
+    t0 = time.time()
+    ref = ref_ddim(model, 50, noise, xfp, xf, [1800], idxs=(0, 24))
+    log["g5_ref_seconds"] = time.time() - t0
+    t0 = time.time()
+    with torch.no_grad():
+        mine = O.ddim_sample_loop(p, noise, xfp, xf, [1800], 50, idxs=(0, 24))
+    log["g5_oracle_seconds"] = time.time() - t0
+    for k in ref:
+        log[f"g5_idx{k}"] = rel_l2(mine[k].numpy(), ref[k].numpy())
+        assert log[f"g5_idx{k}"] < 1e-6, (k, log[f"g5_idx{k}"])
+    np.savez_compressed(os.path.join(OUT, "g5_ddim50_b1.npz"), x0=ref[50].numpy(),
+                        idx0_sub=ref[0].numpy()[:, ::20], idx24_sub=ref[24].numpy()[:, ::20])
+
+    # ---- G6: 30 s clips (T=900) B=2 ragged, DDIM-50; DDIM-1000 B=1 --------------------
+    xf2 = torch.from_numpy(batch_music_features(2, 900, first=10))
+    with torch.no_grad():
+        xfp2 = torch.nn.functional.linear(xf2, p["proj.weight"], p["proj.bias"])
+    noise2 = torch.from_numpy(batch_noise(2, 900, first=10))
+    ref2 = ref_ddim(model, 50, noise2, xfp2, xf2, [900, 700])
+    with torch.no_grad():
+        mine2 = O.ddim_sample_loop(p, noise2, xfp2, xf2, [900, 700], 50)
+    log["g6_t900"] = rel_l2(mine2.numpy(), ref2.numpy())
+    assert log["g6_t900"] < 1e-6
+    t0 = time.time()
+    ref1000 = ref_ddim(model, 1000, noise, xfp, xf, [1800])
+    log["g6_ref1000_seconds"] = time.time() - t0
+    np.savez_compressed(os.path.join(OUT, "g6_variants.npz"), t900_x0=ref2.numpy(), ddim1000_x0=ref1000.numpy())
+
+    # ---- G6b: no_eff DDIM at small T (full T x T attention) ---------------------------
+    xf3 = torch.from_numpy(batch_music_features(2, 96, first=20))
+    with torch.no_grad():
+        xfp3 = torch.nn.functional.linear(xf3, p["proj.weight"], p["proj.bias"])
+    noise3 = torch.from_numpy(batch_noise(2, 96, first=20))
+    ref3 = ref_ddim(m_ne, 50, noise3, xfp3, xf3, [96, 70])
+    with torch.no_grad():
+        mine3 = O.ddim_sample_loop(p, noise3, xfp3, xf3, [96, 70], 50, no_eff=True)
+    log["g6_no_eff"] = rel_l2(mine3.numpy(), ref3.numpy())
+    assert log["g6_no_eff"] < 1e-5, log["g6_no_eff"]
+    np.savez_compressed(os.path.join(OUT, "g6b_no_eff.npz"), x0=ref3.numpy())
+
+    # ---- G7: the harness, DDPMTrainer.generate_music_motion ---------------------------
+    import trainers.ddpm_trainer as rt  # noqa: E402
+
+    class _NoPretrain:
+        def __init__(self):
+            self.motion_encoder = torch.nn.Identity()
+
+    rt.MotionPretrain = _NoPretrain           # hard-coded /home/... checkpoint path
+    opt = types.SimpleNamespace(device=torch.device("cpu"), diffusion_steps=50, is_train=False)
+    rt.DDPMTrainer.to = lambda self, device: None
+    trainer = rt.DDPMTrainer(opt, model)
+    mel = batch_mel(1, 5400)[0]
+    torch.manual_seed(1234)
+    out = trainer.generate_music_motion(mel, 26)
+    torch.manual_seed(1234)
+    nz = torch.randn(1, 1800, 26)
+    with torch.no_grad():
+        mine = O.generate_music_motion(p, mel, 26, 50, nz)
+    log["g7_harness"] = rel_l2(mine.numpy(), out.numpy())
+    assert log["g7_harness"] < 1e-6
+    np.savez_compressed(os.path.join(OUT, "g7_harness.npz"), x0=out.numpy(), torch_seed=np.int64(1234))
+
+    with open(os.path.join(OUT, "PINNING.txt"), "w") as f:
+        f.write("oracle/ddim_oracle.py vs the imported reference (rel-L2; 0.0 = bit-identical)\n")
+        f.write(f"torch {torch.__version__}, numpy {np.__version__}, threads {torch.get_num_threads()}\n")
+        for k, v in log.items():
+            f.write(f"{k}: {v:.3e}\n")
+    for k, v in log.items():
+        print(f"{k}: {v:.3e}")
+
+
+if __name__ == "__main__":
+    main()
