@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py - DDIM sampling throughput of the MI355X-native sampler (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path over one batch: a full DDIM-50 sampling loop (x_T -> x_0) for
+bs=32 clips of 60 s (T=1800 frames) per GPU - BASELINE.json configs[1].  Conditioning (xf_proj',
+cross-attention matrices) and x_T are resident in HBM when the timed region starts (the loop-only
+number SURVEY.md section 8d defines as the roofline number).  value = frames completed by all ranks
+per second = n_gpus * 32 * 1800 * K / max-over-ranks(time).
+
+Multi-GPU: one process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE); clips are
+sharded (weak scaling: 32 per GPU); the only collective is one RCCL all-gather of the final poses
+per step, inside the timed region.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (k_film_gemm) algorithmic FLOPs per launch / its mean duration,
+                measured with HIP events on the library's own stream in a separate eager pass;
+                peak = 2.5 PFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
+  cpu_baseline  the oracle (a port of the reference's eager path, PyTorch CPU ops) timed on this
+                box's host cores on a bounded sample of config 1 (bs=1, T=1800, a few DDIM steps)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_FLOPS = 2.5e15            # dense bf16 MFMA, MI355X
+FLOP_PER_TOKEN_STEP = 2 * 4250112   # algorithmic, hoisted (SURVEY.md section 8d / BASELINE.md section 4)
+FILM_FLOP_PER_TOKEN = 2 * 512 * 6144
+
+
+def cpu_baseline(steps_sample=6):
+    """Oracle on the host cores: bs=1, T=1800, `steps_sample` DDIM steps of the 50-step schedule
+    (every step costs the same), extrapolated to frames/s of a full DDIM-50 run."""
+    import torch
+    from diffusion_conductor_amd.synthetic import batch_music_features, batch_noise, synthetic_state_dict
+    from oracle import ddim_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = O.to_torch_params(synthetic_state_dict())
+    xf = torch.from_numpy(batch_music_features(1, 1800))
+    xfp = torch.nn.functional.linear(xf, p["proj.weight"], p["proj.bias"])
+    x = torch.from_numpy(batch_noise(1, 1800))
+    t = torch.tensor([49])
+    with torch.no_grad():
+        O.denoiser_forward(p, x, t, [1800], xfp, xf)      # warm-up
+        t0 = time.perf_counter()
+        for i in range(steps_sample):
+            O.denoiser_forward(p, x, torch.tensor([49 - i]), [1800], xfp, xf)
+        dt = (time.perf_counter() - t0) / steps_sample
+    return {"value": round(1800 / (50 * dt), 1), "unit": "frames/s", "cores": int(torch.get_num_threads()),
+            "kind": "port", "sample": f"bs=1 T=1800: {steps_sample} denoiser steps timed ({dt*1e3:.0f} ms/step), x50 for DDIM-50"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bs", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=1800)
+    ap.add_argument("--ddim", type=int, default=50)
+    ap.add_argument("--precision", default="mixed", choices=["mixed", "bf16", "bf16x3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from diffusion_conductor_amd import MotionTransformer
+    from diffusion_conductor_amd.sampler import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,
+                                                 get_named_beta_schedule)
+    from diffusion_conductor_amd.sharding import gather_poses
+    from diffusion_conductor_amd.synthetic import batch_music_features, batch_noise, synthetic_state_dict
+
+    B, T, S = args.bs, args.frames, args.ddim
+    sd = synthetic_state_dict()
+    model = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device=dev,
+                              no_clip=True, precision=args.precision)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(dev).eval()
+    gd = GaussianDiffusion(betas=get_named_beta_schedule("linear", S), model_mean_type=ModelMeanType.START_X,
+                           model_var_type=ModelVarType.FIXED_SMALL, loss_type=LossType.MSE)
+    # this rank's shard of the global batch (clip ids rank*B .. rank*B+B-1), synthetic, resident in HBM
+    xf = torch.from_numpy(batch_music_features(B, T, first=rank * B)).to(dev)
+    xfp = torch.nn.functional.linear(xf, model.proj.weight, model.proj.bias).contiguous()
+    noise = torch.from_numpy(batch_noise(B, T, first=rank * B)).to(dev)
+    nat = model.set_conditioning(xfp, xf, [T] * B)
+    coef = gd.native_coefficients()
+
+    def step():
+        out, _ = nat.ddim_loop(noise, coef)
+        return gather_poses(out, world * B) if world > 1 else out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(out).all()
+
+    frames = world * B * T * args.steps
+    value = frames / dt
+    line = {
+        "metric": "motion frames/sec (DDIM-50, 60s clip, bs=32 per GPU)", "value": round(value, 1), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if args.precision != "bf16x3" else "bf16x3", "data": "synthetic",
+        "config": {"workload": f"configs[1]: DDIM-{S} sampling loop, bs={B} clips/GPU x {T} frames (60 s), linear attention, "
+                               f"precision={args.precision}, conditioning + x_T resident in HBM (loop-only)",
+                   "clips_per_gpu": B, "frames_per_clip": T, "ddim_steps": S, "parallelism": f"clip-dp{world}"},
+        "mfma_roofline_frac_whole_loop": round(value / world * S * FLOP_PER_TOKEN_STEP / PEAK_BF16_FLOPS, 4),
+    }
+    if rank == 0:
+        # roofline of the dominant kernel: separate eager pass with per-launch HIP events
+        prof, _ = nat.profile_loop(noise, coef)
+        tot = sum(ms for ms, _ in prof.values())
+        ms, cnt = prof["k_film_gemm"]
+        per_launch = ms / cnt * 1e-3
+        achieved = FILM_FLOP_PER_TOKEN * B * T / per_launch / 1e12
+        line["roofline"] = {"bound": "mfma", "kernel": "k_film_gemm", "achieved": round(achieved, 1), "peak": PEAK_BF16_FLOPS / 1e12,
+                            "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_FLOPS, 4), "traffic": None,
+                            "avg_launch_us": round(per_launch * 1e6, 1), "launches": cnt,
+                            "time_share_by_kernel": {k: round(v[0] / tot, 3) for k, v in prof.items()}}
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+            line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,821 @@
+// dc_api.hip - host side of libdc_ddim.so: parameter packing, workspace, step enqueue,
+// hipGraph capture/replay and the C ABI declared in include/dc_ddim.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dc_ddim.h"
+#include "dc_common.h"
+#include "dc_launch.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(DC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- bf16 helpers (round to nearest even; inputs are finite weights) -------------------
+inline uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf2f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+inline int tile_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Weight image, "chained" k order: frag (ot, kt, s), lane (i = l&31, hh = l>>5), element j
+//   = W[32ot + i][32kt + 16s + 8(j>>2) + 4hh + (j&3)]
+// i.e. the k order in which an accumulator tile, converted in registers, presents its rows.
+// "natural" k order: frag (ot, ks): element j = W[32ot + i][16ks + 8hh + j].
+void pack_weight(const float* w, int n_out, int k_in, bool chained, uint16_t* hi, uint16_t* lo) {
+    const int OT = cdiv(n_out, 32), KT = cdiv(k_in, 32);
+    for (int ot = 0; ot < OT; ++ot)
+        for (int kt = 0; kt < KT; ++kt)
+            for (int s = 0; s < 2; ++s)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = l & 31, hh = l >> 5;
+                        const int row = 32 * ot + i;
+                        const int col = chained ? 32 * kt + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)
+                                                : 32 * kt + 16 * s + 8 * hh + j;
+                        const float v = (row < n_out && col < k_in) ? w[(size_t)row * k_in + col] : 0.f;
+                        const size_t o = ((((size_t)ot * KT + kt) * 2 + s) * 64 + l) * 8 + j;
+                        const uint16_t h = f2bf(v);
+                        hi[o] = h;
+                        lo[o] = f2bf(v - bf2f(h));
+                    }
+}
+size_t packed_elems(int n_out, int k_in) { return (size_t)cdiv(n_out, 32) * cdiv(k_in, 32) * 2 * 64 * 8; }
+
+// per-feature vector in FT register order: out[(t*2+hh)*16 + r] = v[32t + tile_row(r,hh)]
+void pack_ftvec(const float* v, int n, int NT, float* out) {
+    for (int t = 0; t < NT; ++t)
+        for (int hh = 0; hh < 2; ++hh)
+            for (int r = 0; r < 16; ++r) {
+                const int f = 32 * t + tile_row(r, hh);
+                out[(t * 2 + hh) * 16 + r] = f < n ? v[f] : 0.f;
+            }
+}
+
+// ---- device arena builder --------------------------------------------------------------
+struct Arena {
+    std::vector<uint8_t> host;
+    size_t add(const void* p, size_t bytes) {
+        size_t off = (host.size() + 255) & ~(size_t)255;
+        host.resize(off + bytes);
+        memcpy(host.data() + off, p, bytes);
+        return off;
+    }
+};
+
+enum KernelId { K_BEGIN = 0, K_SILU, K_FILM, K_EMBED, K_COMBINE, K_LAYER, K_COUNT };
+const char* kKernelNames[K_COUNT] = {"k_begin_step", "k_silu_emb", "k_film_gemm", "k_embed_front", "k_attn_combine", "k_layer"};
+
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> ev;     // pairs
+    std::vector<int> ids;
+};
+
+}  // namespace
+
+struct dc_sampler {
+    dc_config cfg{};
+    bool split_small = false, split_film = false;
+    std::map<std::string, std::vector<float>> params;
+    bool finalized = false;
+
+    uint8_t* d_arena = nullptr;
+    size_t arena_bytes = 0;
+    DcModel* d_model = nullptr;
+    DcModel h_model{};
+    int NT = 0;   // FiLM feature tiles = 3 * L * 8
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+
+    // workspace (capacity-tracked)
+    int B = 0, T = 0, M = 0, G = 0;
+    size_t cap_G = 0, cap_B = 0, cap_MP = 0, cap_steps = 0, cap_snap = 0;
+    int* d_length = nullptr;
+    float* d_pp = nullptr;
+    void *d_s_hi = nullptr, *d_s_lo = nullptr;
+    void* d_E = nullptr;
+    float* d_h = nullptr;
+    float* d_recs = nullptr;
+    void *d_a_sa = nullptr, *d_a_ca = nullptr;
+    float* d_x = nullptr;
+    float* d_snaps = nullptr;
+    // conditioning temporaries
+    float *d_y = nullptr, *d_mean = nullptr, *d_rstd = nullptr, *d_recs_ca = nullptr;
+    void *d_nh_hi = nullptr, *d_nh_lo = nullptr;
+    // step state
+    int *d_iter = nullptr, *d_t_clip = nullptr, *d_snap_cur = nullptr, *d_t_of_iter = nullptr, *d_snap_of_iter = nullptr;
+    float *d_coef_cur = nullptr, *d_coef_of_t = nullptr;
+    bool cond_set = false;
+    int64_t ws_bytes = 0;
+
+    // graph cache: one per (B,T,steps_per_graph)
+    hipGraphExec_t graph = nullptr;
+    int graph_B = 0, graph_T = 0, graph_K = 0;
+
+    Prof prof;
+    int dbg_layers = -1, dbg_stage = 0;   // test hooks (dc_sampler_debug_denoise)
+};
+
+namespace {
+
+template <class P>
+int dev_alloc(dc_sampler* s, P*& p, size_t bytes) {
+    if (p) {
+        HIP_TRY(hipFree(p));
+        p = nullptr;
+    }
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, bytes));
+    p = (P*)q;
+    s->ws_bytes += (int64_t)bytes;
+    return DC_OK;
+}
+
+void drop_graph(dc_sampler* s) {
+    if (s->graph) {
+        hipGraphExecDestroy(s->graph);
+        s->graph = nullptr;
+    }
+}
+
+const std::vector<float>* find(dc_sampler* s, const std::string& n) {
+    auto it = s->params.find(n);
+    return it == s->params.end() ? nullptr : &it->second;
+}
+
+struct ParamReq {
+    std::string name;
+    size_t numel;
+};
+
+std::vector<ParamReq> required_params(const dc_config& c) {
+    std::vector<ParamReq> r;
+    const size_t D = c.latent_dim, E = 4 * D, L = 512, F = c.ff_size, P = c.input_feats;
+    r.push_back({"sequence_embedding", (size_t)c.num_frames * D});
+    r.push_back({"linear.weight", L * 64});
+    r.push_back({"linear.bias", L});
+    r.push_back({"joint_embed.weight", D * P});
+    r.push_back({"joint_embed.bias", D});
+    r.push_back({"time_embed.0.weight", E * D});
+    r.push_back({"time_embed.0.bias", E});
+    r.push_back({"time_embed.2.weight", E * E});
+    r.push_back({"time_embed.2.bias", E});
+    auto styl = [&](const std::string& p) {
+        r.push_back({p + ".emb_layers.1.weight", 2 * D * E});
+        r.push_back({p + ".emb_layers.1.bias", 2 * D});
+        r.push_back({p + ".norm.weight", D});
+        r.push_back({p + ".norm.bias", D});
+        r.push_back({p + ".out_layers.2.weight", D * D});
+        r.push_back({p + ".out_layers.2.bias", D});
+    };
+    for (int i = 0; i < c.num_layers; ++i) {
+        const std::string p = "temporal_decoder_blocks." + std::to_string(i);
+        r.push_back({p + ".sa_block.norm.weight", D});
+        r.push_back({p + ".sa_block.norm.bias", D});
+        for (const char* n : {"query", "key", "value"}) {
+            r.push_back({p + ".sa_block." + n + ".weight", D * D});
+            r.push_back({p + ".sa_block." + n + ".bias", D});
+        }
+        styl(p + ".sa_block.proj_out");
+        r.push_back({p + ".ca_block.norm.weight", D});
+        r.push_back({p + ".ca_block.norm.bias", D});
+        r.push_back({p + ".ca_block.text_norm.weight", L});
+        r.push_back({p + ".ca_block.text_norm.bias", L});
+        r.push_back({p + ".ca_block.query.weight", D * D});
+        r.push_back({p + ".ca_block.query.bias", D});
+        for (const char* n : {"key", "value"}) {
+            r.push_back({p + ".ca_block." + n + ".weight", D * L});
+            r.push_back({p + ".ca_block." + n + ".bias", D});
+        }
+        styl(p + ".ca_block.proj_out");
+        r.push_back({p + ".ffn.linear1.weight", F * D});
+        r.push_back({p + ".ffn.linear1.bias", F});
+        r.push_back({p + ".ffn.linear2.weight", D * F});
+        r.push_back({p + ".ffn.linear2.bias", D});
+        styl(p + ".ffn.proj_out");
+    }
+    r.push_back({"out.weight", P * D});
+    r.push_back({"out.bias", P});
+    return r;
+}
+
+// true for reference keys the sampler path does not consume here (music encoder, proj):
+// accepted and ignored so a whole state_dict can be streamed in.
+bool ignorable_param(const std::string& n) {
+    return n.rfind("music_encoder.", 0) == 0 || n == "proj.weight" || n == "proj.bias";
+}
+
+struct Offsets {   // arena offsets mirrored into DcModel after upload
+    std::vector<std::pair<const void**, size_t>> fix;
+};
+
+int build_model(dc_sampler* s) {
+    const dc_config& c = s->cfg;
+    const int D = DC_D, L = c.num_layers, P = c.input_feats;
+    Arena A;
+    Offsets O;
+    DcModel& m = s->h_model;
+    memset(&m, 0, sizeof m);
+    auto P_ = [&](const std::string& n) -> const float* { return find(s, n)->data(); };
+
+    auto add_packed = [&](const bf16x8** dst, const float* w, int n_out, int k_in, bool chained) {
+        const size_t ne = packed_elems(n_out, k_in);
+        std::vector<uint16_t> buf(2 * ne);
+        pack_weight(w, n_out, k_in, chained, buf.data(), buf.data() + ne);
+        O.fix.push_back({(const void**)dst, A.add(buf.data(), buf.size() * 2)});
+    };
+    auto add_ft = [&](const float** dst, const float* v, int n, int NT) {
+        std::vector<float> buf((size_t)NT * 32);
+        pack_ftvec(v, n, NT, buf.data());
+        O.fix.push_back({(const void**)dst, A.add(buf.data(), buf.size() * 4)});
+    };
+    auto add_raw = [&](const float** dst, const float* v, size_t n) {
+        O.fix.push_back({(const void**)dst, A.add(v, n * 4)});
+    };
+    auto add_styl = [&](DcStyl& st, const std::string& p) {
+        add_ft(&st.ln_g, P_(p + ".norm.weight"), D, 4);
+        add_ft(&st.ln_b, P_(p + ".norm.bias"), D, 4);
+        add_packed(&st.wo, P_(p + ".out_layers.2.weight"), D, D, true);
+        add_ft(&st.bo, P_(p + ".out_layers.2.bias"), D, 4);
+    };
+
+    // FiLM: all 3L blocks stacked along the output axis -> one [3L*256][512] GEMM operand
+    const int NT = 3 * L * DC_FILM_TILES_PER_BLOCK;
+    s->NT = NT;
+    std::vector<float> film_w((size_t)NT * 32 * DC_E), film_b((size_t)NT * 32);
+    for (int i = 0; i < L; ++i) {
+        const std::string p = "temporal_decoder_blocks." + std::to_string(i);
+        DcLayer& y = m.layer[i];
+        add_ft(&y.sa_ln_g, P_(p + ".sa_block.norm.weight"), D, 4);
+        add_ft(&y.sa_ln_b, P_(p + ".sa_block.norm.bias"), D, 4);
+        add_packed(&y.sa_wq, P_(p + ".sa_block.query.weight"), D, D, true);
+        add_packed(&y.sa_wk, P_(p + ".sa_block.key.weight"), D, D, true);
+        add_packed(&y.sa_wv, P_(p + ".sa_block.value.weight"), D, D, true);
+        add_ft(&y.sa_bq, P_(p + ".sa_block.query.bias"), D, 4);
+        add_raw(&y.sa_bk, P_(p + ".sa_block.key.bias"), D);
+        add_raw(&y.sa_bv, P_(p + ".sa_block.value.bias"), D);
+        add_styl(y.sa_styl, p + ".sa_block.proj_out");
+        add_ft(&y.ca_ln_g, P_(p + ".ca_block.norm.weight"), D, 4);
+        add_ft(&y.ca_ln_b, P_(p + ".ca_block.norm.bias"), D, 4);
+        add_packed(&y.ca_wq, P_(p + ".ca_block.query.weight"), D, D, true);
+        add_ft(&y.ca_bq, P_(p + ".ca_block.query.bias"), D, 4);
+        // fold text_norm's affine (transformer.py:149,153) into the K/V projections:
+        //   W (g*n + b) + c = (W*g) n + (W b + c)
+        {
+            const float* g = P_(p + ".ca_block.text_norm.weight");
+            const float* bt = P_(p + ".ca_block.text_norm.bias");
+            for (int kv = 0; kv < 2; ++kv) {
+                const std::string nm = p + ".ca_block." + (kv ? "value" : "key");
+                const float* w = P_(nm + ".weight");
+                const float* bb = P_(nm + ".bias");
+                std::vector<float> wf((size_t)D * DC_E), bf(D);
+                for (int o = 0; o < D; ++o) {
+                    double acc = bb[o];
+                    for (int k = 0; k < DC_E; ++k) {
+                        wf[(size_t)o * DC_E + k] = w[(size_t)o * DC_E + k] * g[k];
+                        acc += (double)w[(size_t)o * DC_E + k] * bt[k];
+                    }
+                    bf[o] = (float)acc;
+                }
+                add_packed(kv ? &y.ca_wv : &y.ca_wk, wf.data(), D, DC_E, false);
+                add_raw(kv ? &y.ca_bv : &y.ca_bk, bf.data(), D);
+            }
+        }
+        add_styl(y.ca_styl, p + ".ca_block.proj_out");
+        add_packed(&y.ffn_w1, P_(p + ".ffn.linear1.weight"), DC_F, D, true);
+        add_packed(&y.ffn_w2, P_(p + ".ffn.linear2.weight"), D, DC_F, true);
+        add_ft(&y.ffn_b1, P_(p + ".ffn.linear1.bias"), DC_F, 2);
+        add_ft(&y.ffn_b2, P_(p + ".ffn.linear2.bias"), D, 4);
+        add_styl(y.ffn_styl, p + ".ffn.proj_out");
+        const char* blk[3] = {".sa_block.proj_out", ".ca_block.proj_out", ".ffn.proj_out"};
+        for (int j = 0; j < 3; ++j) {
+            const size_t row0 = (size_t)(3 * i + j) * 256;
+            memcpy(&film_w[row0 * DC_E], P_(p + blk[j] + ".emb_layers.1.weight"), (size_t)256 * DC_E * 4);
+            memcpy(&film_b[row0], P_(p + blk[j] + ".emb_layers.1.bias"), 256 * 4);
+        }
+    }
+    add_packed(&m.film_w, film_w.data(), NT * 32, DC_E, false);
+    add_ft(&m.film_b, film_b.data(), NT * 32, NT);
+    add_packed(&m.je_w, P_("joint_embed.weight"), D, P, true);
+    add_ft(&m.je_b, P_("joint_embed.bias"), D, 4);
+    add_raw(&m.seq_emb, P_("sequence_embedding"), (size_t)c.num_frames * D);
+    add_packed(&m.out_w, P_("out.weight"), P, D, true);
+    add_ft(&m.out_b, P_("out.bias"), P, 1);
+    {
+        const float* w = P_("linear.weight");   // [512][64] -> transposed [64][512]
+        std::vector<float> wt((size_t)64 * 512);
+        for (int k = 0; k < 512; ++k)
+            for (int i = 0; i < 64; ++i) wt[(size_t)i * 512 + k] = w[(size_t)k * 64 + i];
+        add_raw(&m.lin_wt, wt.data(), wt.size());
+        add_raw(&m.lin_b, P_("linear.bias"), 512);
+    }
+    // timestep table storage + MLP operands (transposed for coalesced reads)
+    const int nt = c.max_timesteps;
+    std::vector<float> zeros((size_t)nt * 512, 0.f);
+    add_raw(&m.temb, zeros.data(), zeros.size());
+    const float *d_freqs = nullptr, *d_w0t = nullptr, *d_b0 = nullptr, *d_w2t = nullptr, *d_b2 = nullptr;
+    {
+        std::vector<float> fr(64);
+        for (int k = 0; k < 64; ++k) fr[k] = expf((float)(-std::log(10000.0)) * (float)k / 64.f);   // transformer.py:18-20 in fp32
+        std::vector<float> w0t((size_t)128 * 512), w2t((size_t)512 * 512);
+        const float* w0 = P_("time_embed.0.weight");
+        const float* w2 = P_("time_embed.2.weight");
+        for (int o = 0; o < 512; ++o) {
+            for (int i = 0; i < 128; ++i) w0t[(size_t)i * 512 + o] = w0[(size_t)o * 128 + i];
+            for (int i = 0; i < 512; ++i) w2t[(size_t)i * 512 + o] = w2[(size_t)o * 512 + i];
+        }
+        add_raw(&d_freqs, fr.data(), 64);
+        add_raw(&d_w0t, w0t.data(), w0t.size());
+        add_raw(&d_b0, P_("time_embed.0.bias"), 512);
+        add_raw(&d_w2t, w2t.data(), w2t.size());
+        add_raw(&d_b2, P_("time_embed.2.bias"), 512);
+    }
+    m.num_layers = L;
+    m.input_feats = P;
+    m.num_frames = c.num_frames;
+    m.max_timesteps = nt;
+
+    if (s->d_arena) hipFree(s->d_arena);
+    s->arena_bytes = A.host.size();
+    HIP_TRY(hipMalloc((void**)&s->d_arena, s->arena_bytes));
+    HIP_TRY(hipMemcpy(s->d_arena, A.host.data(), s->arena_bytes, hipMemcpyHostToDevice));
+    for (auto& f : O.fix) *f.first = s->d_arena + f.second;
+    if (!s->d_model) HIP_TRY(hipMalloc((void**)&s->d_model, sizeof(DcModel)));
+    HIP_TRY(hipMemcpy(s->d_model, &m, sizeof(DcModel), hipMemcpyHostToDevice));
+    HIP_TRY(dc_launch_temb_table(s->stream, d_freqs, d_w0t, d_b0, d_w2t, d_b2, (float*)m.temb, nt));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return DC_OK;
+}
+
+int ensure_workspace(dc_sampler* s, int B, int T) {
+    const int M = B * T, G = cdiv(M, 32), L = s->cfg.num_layers, P = s->cfg.input_feats;
+    if ((size_t)G > s->cap_G) {
+        drop_graph(s);
+        const size_t g = (size_t)G;
+        int rc;
+        if ((rc = dev_alloc(s, s->d_pp, g * 32 * 64 * 8 * 4))) return rc;
+        if ((rc = dev_alloc(s, s->d_s_hi, g * 32 * 64 * 16))) return rc;
+        if ((rc = dev_alloc(s, s->d_s_lo, g * 32 * 64 * 16))) return rc;
+        if ((rc = dev_alloc(s, s->d_E, g * s->NT * 64 * 32))) return rc;
+        if ((rc = dev_alloc(s, s->d_h, g * 4 * 64 * 64))) return rc;
+        if ((rc = dev_alloc(s, s->d_recs, g * 2 * DC_REC_FLOATS * 4))) return rc;
+        if ((rc = dev_alloc(s, s->d_y, g * 32 * 512 * 4))) return rc;
+        if ((rc = dev_alloc(s, s->d_mean, g * 32 * 4))) return rc;
+        if ((rc = dev_alloc(s, s->d_rstd, g * 32 * 4))) return rc;
+        if ((rc = dev_alloc(s, s->d_nh_hi, g * 32 * 64 * 16))) return rc;
+        if ((rc = dev_alloc(s, s->d_nh_lo, g * 32 * 64 * 16))) return rc;
+        if ((rc = dev_alloc(s, s->d_recs_ca, (size_t)L * g * 2 * DC_REC_FLOATS * 4))) return rc;
+        s->cap_G = g;
+    }
+    if ((size_t)B > s->cap_B) {
+        drop_graph(s);
+        int rc;
+        if ((rc = dev_alloc(s, s->d_length, (size_t)B * 4))) return rc;
+        if ((rc = dev_alloc(s, s->d_t_clip, (size_t)B * 4))) return rc;
+        if ((rc = dev_alloc(s, s->d_a_sa, (size_t)B * 16 * 1024))) return rc;
+        if ((rc = dev_alloc(s, s->d_a_ca, (size_t)L * B * 16 * 1024))) return rc;
+        s->cap_B = (size_t)B;
+    }
+    if ((size_t)M * P > s->cap_MP) {
+        drop_graph(s);
+        int rc;
+        if ((rc = dev_alloc(s, s->d_x, (size_t)M * P * 4))) return rc;
+        s->cap_MP = (size_t)M * P;
+    }
+    if (!s->d_iter) {
+        int rc;
+        if ((rc = dev_alloc(s, s->d_iter, 16))) return rc;
+        if ((rc = dev_alloc(s, s->d_snap_cur, 16))) return rc;
+        if ((rc = dev_alloc(s, s->d_coef_cur, 16))) return rc;
+    }
+    if (s->B != B || s->T != T) drop_graph(s);
+    s->B = B;
+    s->T = T;
+    s->M = M;
+    s->G = G;
+    return DC_OK;
+}
+
+int ensure_steps(dc_sampler* s, int S) {
+    if ((size_t)S > s->cap_steps) {
+        drop_graph(s);
+        int rc;
+        if ((rc = dev_alloc(s, s->d_t_of_iter, (size_t)S * 4))) return rc;
+        if ((rc = dev_alloc(s, s->d_snap_of_iter, (size_t)S * 4))) return rc;
+        if ((rc = dev_alloc(s, s->d_coef_of_t, (size_t)S * 16))) return rc;
+        s->cap_steps = (size_t)S;
+    }
+    return DC_OK;
+}
+
+struct Timed {   // RAII-less helper: wraps a launch with events when profiling
+    dc_sampler* s;
+    int id;
+};
+
+#define LAUNCH(id, expr)                                              \
+    do {                                                              \
+        if (s->prof.on) {                                             \
+            hipEvent_t a_, b_;                                        \
+            HIP_TRY(hipEventCreate(&a_));                             \
+            HIP_TRY(hipEventCreate(&b_));                             \
+            HIP_TRY(hipEventRecord(a_, st));                          \
+            HIP_TRY(expr);                                            \
+            HIP_TRY(hipEventRecord(b_, st));                          \
+            s->prof.ev.push_back(a_);                                 \
+            s->prof.ev.push_back(b_);                                 \
+            s->prof.ids.push_back(id);                                \
+        } else {                                                      \
+            HIP_TRY(expr);                                            \
+        }                                                             \
+    } while (0)
+
+// One denoiser evaluation (+ DDIM update when loop_mode) enqueued on st.
+int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_src, float* x_dst) {
+    const int B = s->B, T = s->T, M = s->M, G = s->G, L = s->cfg.num_layers;
+    const bool ss = s->split_small, sf = s->split_film;
+    if (loop_mode)
+        LAUNCH(K_BEGIN, dc_launch_begin_step(st, s->d_iter, s->d_t_of_iter, s->d_coef_of_t, s->d_snap_of_iter,
+                                             s->d_t_clip, s->d_coef_cur, s->d_snap_cur, B));
+    LAUNCH(K_SILU, dc_launch_silu_emb(st, sf, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, G, T, B));
+    LAUNCH(K_FILM, dc_launch_film_gemm(st, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT));
+    LAUNCH(K_EMBED, dc_launch_embed_front(st, ss, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G));
+    const int nl_run = (s->dbg_layers >= 0 && s->dbg_layers < L) ? s->dbg_layers : L;
+    for (int l = 0; l < nl_run; ++l) {
+        const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
+        LAUNCH(K_COMBINE, dc_launch_attn_combine(st, s->d_recs, s->d_a_sa, T, G, B, 1));
+        LAUNCH(K_LAYER, dc_launch_layer(st, ss, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
+                                        s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur,
+                                        s->d_snaps, M, T, G, B, dbg));
+    }
+    return DC_OK;
+}
+
+int sync_in(dc_sampler* s, hipStream_t user) {
+    HIP_TRY(hipEventRecord(s->ev_in, user));
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_in, 0));
+    return DC_OK;
+}
+int sync_out(dc_sampler* s, hipStream_t user) {
+    HIP_TRY(hipEventRecord(s->ev_out, s->stream));
+    HIP_TRY(hipStreamWaitEvent(user, s->ev_out, 0));
+    return DC_OK;
+}
+
+int steps_per_graph(int S) {
+    if (S <= 64) return S;
+    for (int k = 64; k >= 1; --k)
+        if (S % k == 0) return k;
+    return 1;
+}
+
+int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const float* h_coef,
+                const int32_t* h_snap_iters, int n_snap, float* d_snaps_user, hipStream_t user, bool profile) {
+    if (!s || !s->finalized) return fail(DC_ERR_INVALID, "sampler not finalized");
+    if (!s->cond_set) return fail(DC_ERR_INVALID, "dc_sampler_set_conditioning must be called first");
+    if (S < 1 || S > s->cfg.max_timesteps) return fail(DC_ERR_INVALID, "num_steps %d outside [1, max_timesteps=%d]", S, s->cfg.max_timesteps);
+    if (!d_noise || !d_out || !h_coef) return fail(DC_ERR_INVALID, "null pointer argument");
+    int rc;
+    if ((rc = ensure_steps(s, S))) return rc;
+    const size_t MP = (size_t)s->M * s->cfg.input_feats;
+    if ((size_t)n_snap > s->cap_snap) {
+        drop_graph(s);
+        if ((rc = dev_alloc(s, s->d_snaps, (size_t)n_snap * MP * 4))) return rc;
+        s->cap_snap = (size_t)n_snap;
+    }
+    std::vector<int> t_of_iter(S), snap_of_iter(S, -1);
+    for (int i = 0; i < S; ++i) t_of_iter[i] = S - 1 - i;            // indices = range(num_timesteps)[::-1] (gaussian_diffusion.py:943)
+    for (int k = 0; k < n_snap; ++k) {
+        if (h_snap_iters[k] < 0 || h_snap_iters[k] >= S) return fail(DC_ERR_INVALID, "snapshot iteration %d outside [0,%d)", h_snap_iters[k], S);
+        snap_of_iter[h_snap_iters[k]] = k;
+    }
+    if ((rc = sync_in(s, user))) return rc;
+    hipStream_t st = s->stream;
+    HIP_TRY(hipMemcpyAsync(s->d_t_of_iter, t_of_iter.data(), S * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_snap_of_iter, snap_of_iter.data(), S * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_coef_of_t, h_coef, (size_t)S * 16, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(s->d_iter, 0, 16, st));
+    HIP_TRY(hipMemcpyAsync(s->d_x, d_noise, MP * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // the host vectors above go out of scope
+
+    const bool no_graph = getenv("DC_DISABLE_GRAPH") != nullptr;
+    if (profile || no_graph) {
+        s->prof.on = profile;
+        for (int i = 0; i < S; ++i)
+            if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x))) {
+                s->prof.on = false;
+                return rc;
+            }
+        s->prof.on = false;
+    } else {
+        const int K = steps_per_graph(S);
+        if (!s->graph || s->graph_B != s->B || s->graph_T != s->T || s->graph_K != K) {
+            drop_graph(s);
+            hipGraph_t g = nullptr;
+            HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            for (int i = 0; i < K; ++i)
+                if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x))) {
+                    hipStreamEndCapture(st, &g);
+                    if (g) hipGraphDestroy(g);
+                    return rc;
+                }
+            HIP_TRY(hipStreamEndCapture(st, &g));
+            hipError_t e = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0);
+            hipGraphDestroy(g);
+            if (e != hipSuccess) return fail(DC_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+            s->graph_B = s->B;
+            s->graph_T = s->T;
+            s->graph_K = K;
+        }
+        for (int i = 0; i < S / K; ++i) HIP_TRY(hipGraphLaunch(s->graph, st));
+    }
+    HIP_TRY(hipMemcpyAsync(d_out, s->d_x, MP * 4, hipMemcpyDeviceToDevice, st));
+    if (n_snap > 0 && d_snaps_user)
+        HIP_TRY(hipMemcpyAsync(d_snaps_user, s->d_snaps, (size_t)n_snap * MP * 4, hipMemcpyDeviceToDevice, st));
+    return sync_out(s, user);
+}
+
+}  // namespace
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+extern "C" {
+
+const char* dc_last_error(void) { return g_err.c_str(); }
+const char* dc_version(void) { return "dc_ddim 0.1 (gfx950)"; }
+
+int dc_linear_beta_schedule(int32_t n, double* betas, double* ac, double* ac_prev, double* sr, double* srm1) {
+    if (n < 1 || !betas) return fail(DC_ERR_INVALID, "bad schedule arguments");
+    const double scale = 1000.0 / n, b0 = scale * 0.0001, b1 = scale * 0.02;
+    double cp = 1.0;
+    for (int i = 0; i < n; ++i) {
+        // np.linspace(start, stop, n): start + i*step with step=(stop-start)/(n-1); last point is `stop` exactly
+        const double step = n > 1 ? (b1 - b0) / (n - 1) : 0.0;
+        betas[i] = (i == n - 1 && n > 1) ? b1 : b0 + i * step;
+        const double prev = cp;
+        cp *= (1.0 - betas[i]);
+        if (ac) ac[i] = cp;
+        if (ac_prev) ac_prev[i] = prev;
+        if (sr) sr[i] = std::sqrt(1.0 / cp);
+        if (srm1) srm1[i] = std::sqrt(1.0 / cp - 1.0);
+    }
+    return DC_OK;
+}
+
+int dc_ddim_coefficients(int32_t n, const double* ac, float* coef) {
+    if (n < 1 || !ac || !coef) return fail(DC_ERR_INVALID, "bad coefficient arguments");
+    for (int t = 0; t < n; ++t) {
+        const float a_prev = t == 0 ? 1.0f : (float)ac[t - 1];
+        coef[4 * t + 0] = (float)std::sqrt(1.0 / ac[t]);
+        coef[4 * t + 1] = (float)std::sqrt(1.0 / ac[t] - 1.0);
+        coef[4 * t + 2] = sqrtf(a_prev);
+        coef[4 * t + 3] = sqrtf(1.0f - a_prev);
+    }
+    return DC_OK;
+}
+
+int dc_pack_weight(const float* w, int32_t n_out, int32_t k_in, int32_t chained, uint16_t* hi, uint16_t* lo) {
+    if (!w || !hi || !lo || n_out < 1 || k_in < 1) return fail(DC_ERR_INVALID, "bad pack arguments");
+    pack_weight(w, n_out, k_in, chained != 0, hi, lo);
+    return DC_OK;
+}
+
+int dc_sampler_create(const dc_config* cfg, dc_sampler** out) {
+    if (!cfg || !out) return fail(DC_ERR_INVALID, "null argument");
+    if (cfg->latent_dim != DC_D || cfg->num_heads != DC_H || cfg->ff_size != DC_F)
+        return fail(DC_ERR_UNSUPPORTED, "built for latent_dim=128, num_heads=8, ff_size=64 (got %d, %d, %d); latent_dim*4 must equal 512 "
+                    "(transformer.py:385,404,482)", cfg->latent_dim, cfg->num_heads, cfg->ff_size);
+    if (cfg->input_feats < 1 || cfg->input_feats > DC_PMAX) return fail(DC_ERR_UNSUPPORTED, "input_feats must be in [1,32]");
+    if (cfg->num_layers < 1 || cfg->num_layers > DC_MAX_LAYERS) return fail(DC_ERR_UNSUPPORTED, "num_layers must be in [1,%d]", DC_MAX_LAYERS);
+    if (cfg->no_eff) return fail(DC_ERR_UNSUPPORTED, "no_eff (full T x T attention) is not built yet");
+    if (cfg->precision < DC_PREC_BF16 || cfg->precision > DC_PREC_BF16X3) return fail(DC_ERR_INVALID, "unknown precision %d", cfg->precision);
+    if (cfg->max_timesteps < 1) return fail(DC_ERR_INVALID, "max_timesteps must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(DC_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(DC_ERR_INVALID, "device %d out of range (0..%d)", cfg->device, ndev - 1);
+    HIP_TRY(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(DC_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", cfg->device, prop.gcnArchName);
+    dc_sampler* s = new dc_sampler();
+    s->cfg = *cfg;
+    s->split_small = cfg->precision != DC_PREC_BF16;
+    s->split_film = cfg->precision == DC_PREC_BF16X3;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming) != hipSuccess) {
+        delete s;
+        return fail(DC_ERR_HIP, "stream/event creation failed");
+    }
+    *out = s;
+    return DC_OK;
+}
+
+void dc_sampler_destroy(dc_sampler* s) {
+    if (!s) return;
+    hipSetDevice(s->cfg.device);
+    hipDeviceSynchronize();
+    drop_graph(s);
+    void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
+                    s->d_a_ca, s->d_x, s->d_snaps, s->d_y, s->d_mean, s->d_rstd, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
+                    s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (s->ev_in) hipEventDestroy(s->ev_in);
+    if (s->ev_out) hipEventDestroy(s->ev_out);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int dc_sampler_set_param(dc_sampler* s, const char* name, const float* data, int64_t numel) {
+    if (!s || !name || !data || numel < 0) return fail(DC_ERR_INVALID, "null argument");
+    const std::string n(name);
+    if (ignorable_param(n)) return DC_OK;
+    for (const auto& r : required_params(s->cfg))
+        if (r.name == n) {
+            if ((size_t)numel != r.numel) return fail(DC_ERR_PARAM, "parameter %s has %lld elements, expected %zu", name, (long long)numel, r.numel);
+            s->params[n].assign(data, data + numel);
+            s->finalized = false;
+            return DC_OK;
+        }
+    return fail(DC_ERR_PARAM, "unknown parameter key '%s'", name);
+}
+
+int dc_sampler_finalize_params(dc_sampler* s) {
+    if (!s) return fail(DC_ERR_INVALID, "null sampler");
+    for (const auto& r : required_params(s->cfg))
+        if (!find(s, r.name)) return fail(DC_ERR_PARAM, "missing parameter '%s'", r.name.c_str());
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    drop_graph(s);
+    s->cap_G = 0;   // NT may have changed: force workspace rebuild
+    int rc = build_model(s);
+    if (rc) return rc;
+    s->finalized = true;
+    s->cond_set = false;
+    return DC_OK;
+}
+
+int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const float* d_xf_out, const int32_t* h_length,
+                                int32_t B, int32_t T, void* stream) {
+    if (!s || !s->finalized) return fail(DC_ERR_INVALID, "sampler not finalized");
+    if (!d_xf_proj || !d_xf_out || B < 1 || T < 32) return fail(DC_ERR_INVALID, "bad conditioning arguments (need B >= 1, T >= 32)");
+    if (T > s->cfg.num_frames) return fail(DC_ERR_INVALID, "T=%d exceeds num_frames=%d rows of sequence_embedding", T, s->cfg.num_frames);
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    int rc;
+    if ((rc = ensure_workspace(s, B, T))) return rc;
+    std::vector<int> len(B, T);
+    if (h_length)
+        for (int b = 0; b < B; ++b) {
+            if (h_length[b] < 1 || h_length[b] > T) return fail(DC_ERR_INVALID, "length[%d]=%d outside [1,%d]", b, h_length[b], T);
+            len[b] = h_length[b];
+        }
+    hipStream_t user = (hipStream_t)stream, st = s->stream;
+    if ((rc = sync_in(s, user))) return rc;
+    const int M = s->M, G = s->G, Mpad = 32 * G, L = s->cfg.num_layers;
+    HIP_TRY(hipMemcpyAsync(s->d_length, len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    // emb's step-invariant term: linear(xf_proj) as fp32 operand image
+    HIP_TRY(dc_launch_cond_linear(st, d_xf_proj, s->h_model.lin_wt, s->h_model.lin_b, s->d_y, M, Mpad));
+    HIP_TRY(dc_launch_cond_pack(st, 0, s->d_y, nullptr, nullptr, s->d_pp, nullptr, nullptr, G));
+    // cross-attention: linear(xf_out) -> text_norm (affine folded into K/V) -> per-layer K,V -> A_ca
+    HIP_TRY(dc_launch_cond_linear(st, d_xf_out, s->h_model.lin_wt, s->h_model.lin_b, s->d_y, M, Mpad));
+    HIP_TRY(dc_launch_row_stats(st, s->d_y, s->d_mean, s->d_rstd, Mpad));
+    HIP_TRY(dc_launch_cond_pack(st, 1, s->d_y, s->d_mean, s->d_rstd, nullptr, s->d_nh_hi, s->d_nh_lo, G));
+    // one-time cost: always split precision (plain bf16 here alone costs ~2e-3 on A_cross)
+    HIP_TRY(dc_launch_ca_partials(st, true, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_recs_ca, M, T, G, L));
+    HIP_TRY(dc_launch_attn_combine(st, s->d_recs_ca, s->d_a_ca, T, G, B, L));
+    HIP_TRY(hipStreamSynchronize(st));   // `len` is host memory
+    s->cond_set = true;
+    return sync_out(s, user);
+}
+
+int dc_sampler_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timesteps, float* d_out, void* stream) {
+    if (!s || !s->finalized) return fail(DC_ERR_INVALID, "sampler not finalized");
+    if (!s->cond_set) return fail(DC_ERR_INVALID, "dc_sampler_set_conditioning must be called first");
+    if (!d_x || !h_timesteps || !d_out) return fail(DC_ERR_INVALID, "null pointer argument");
+    for (int b = 0; b < s->B; ++b)
+        if (h_timesteps[b] < 0 || h_timesteps[b] >= s->cfg.max_timesteps)
+            return fail(DC_ERR_INVALID, "timestep %d outside [0,%d)", h_timesteps[b], s->cfg.max_timesteps);
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    hipStream_t user = (hipStream_t)stream, st = s->stream;
+    int rc;
+    if ((rc = sync_in(s, user))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_t_clip, h_timesteps, (size_t)s->B * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = enqueue_step(s, st, false, d_x, d_out))) return rc;
+    return sync_out(s, user);
+}
+
+int dc_sampler_ddim_loop(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps, const float* h_coef,
+                         const int32_t* h_snap_iters, int32_t n_snap, float* d_snaps, void* stream) {
+    if (s) HIP_TRY(hipSetDevice(s->cfg.device));
+    if (n_snap < 0 || (n_snap > 0 && (!h_snap_iters || !d_snaps))) return fail(DC_ERR_INVALID, "bad snapshot arguments");
+    return loop_common(s, d_noise, d_out, num_steps, h_coef, h_snap_iters, n_snap, d_snaps, (hipStream_t)stream, false);
+}
+
+int dc_sampler_profile_loop(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps, const float* h_coef,
+                            float* h_ms, int32_t* h_count, int32_t n, void* stream) {
+    if (!s || !h_ms || !h_count) return fail(DC_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    s->prof.ev.clear();
+    s->prof.ids.clear();
+    int rc = loop_common(s, d_noise, d_out, num_steps, h_coef, nullptr, 0, nullptr, (hipStream_t)stream, true);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < n; ++i) {
+        h_ms[i] = 0.f;
+        h_count[i] = 0;
+    }
+    for (size_t i = 0; i < s->prof.ids.size(); ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->prof.ev[2 * i], s->prof.ev[2 * i + 1]));
+        const int id = s->prof.ids[i];
+        if (id < n) {
+            h_ms[id] += ms;
+            h_count[id] += 1;
+        }
+    }
+    for (hipEvent_t e : s->prof.ev) hipEventDestroy(e);
+    s->prof.ev.clear();
+    s->prof.ids.clear();
+    return DC_OK;
+}
+
+int dc_sampler_debug_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timesteps, float* d_out,
+                             int32_t n_layers, int32_t stage, void* stream) {
+    if (!s) return fail(DC_ERR_INVALID, "null sampler");
+    s->dbg_layers = n_layers;
+    s->dbg_stage = stage;
+    const int rc = dc_sampler_denoise(s, d_x, h_timesteps, d_out, stream);
+    s->dbg_layers = -1;
+    s->dbg_stage = 0;
+    return rc;
+}
+
+int dc_sampler_debug_read(dc_sampler* s, const char* what, void* h_out, int64_t nbytes) {
+    if (!s || !what || !h_out) return fail(DC_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const std::string w(what);
+    const size_t g = (size_t)s->G;
+    const void* src = nullptr;
+    size_t have = 0;
+    if (w == "h") { src = s->d_h; have = g * 4 * 64 * 64; }
+    else if (w == "pp") { src = s->d_pp; have = g * 32 * 64 * 32; }
+    else if (w == "s_hi") { src = s->d_s_hi; have = g * 32 * 64 * 16; }
+    else if (w == "s_lo") { src = s->d_s_lo; have = g * 32 * 64 * 16; }
+    else if (w == "E") { src = s->d_E; have = g * s->NT * 64 * 32; }
+    else if (w == "recs") { src = s->d_recs; have = g * 2 * DC_REC_FLOATS * 4; }
+    else if (w == "a_sa") { src = s->d_a_sa; have = (size_t)s->B * 16 * 1024; }
+    else if (w == "a_ca") { src = s->d_a_ca; have = (size_t)s->cfg.num_layers * s->B * 16 * 1024; }
+    else if (w == "temb") { src = s->h_model.temb; have = (size_t)s->cfg.max_timesteps * 512 * 4; }
+    else return fail(DC_ERR_INVALID, "unknown debug buffer '%s'", what);
+    if (!src) return fail(DC_ERR_INVALID, "buffer '%s' not allocated yet", what);
+    if ((size_t)nbytes > have) return fail(DC_ERR_INVALID, "buffer '%s' holds %zu bytes, asked for %lld", what, have, (long long)nbytes);
+    HIP_TRY(hipMemcpy(h_out, src, (size_t)nbytes, hipMemcpyDeviceToHost));
+    return DC_OK;
+}
+
+const char* dc_kernel_name(int32_t id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
+int32_t dc_kernel_count(void) { return K_COUNT; }
+int64_t dc_sampler_workspace_bytes(const dc_sampler* s) { return s ? s->ws_bytes + (int64_t)s->arena_bytes : 0; }
+
+}  // extern "C"

@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void k_layer(const DcModel* __restrict__ dm, i
                                                float* __restrict__ recs, const int* __restrict__ length,
                                                const float* __restrict__ xin, float* __restrict__ xout, int out_mode,
                                                const float* __restrict__ coef_cur, const int* __restrict__ snap_cur,
-                                               float* __restrict__ snaps, int M, int T, int G, int B) {
+                                               float* __restrict__ snaps, int M, int T, int G, int B, int dbg) {
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= G) return;
     const int lane = threadIdx.x & 63;
@@ -791,6 +791,7 @@ __global__ __launch_bounds__(256) void k_layer(const DcModel* __restrict__ dm, i
 #pragma unroll
         for (int t = 0; t < 4; ++t) h[t] += o[t];
     }
+    if (dbg == 1) { store_h(h, hbuf, g, lane); return; }   // test hook: stop after self-attention
     // ---------------- cross-attention ----------------
     {
         f32x16 q[4];
@@ -828,6 +829,7 @@ __global__ __launch_bounds__(256) void k_layer(const DcModel* __restrict__ dm, i
 #pragma unroll
         for (int t = 0; t < 4; ++t) h[t] += o[t];
     }
+    if (dbg == 2) { store_h(h, hbuf, g, lane); return; }   // test hook: stop after cross-attention
     // ---------------- FFN ----------------
     {
         XFrag<SPLIT> hf[4];
@@ -854,6 +856,7 @@ __global__ __launch_bounds__(256) void k_layer(const DcModel* __restrict__ dm, i
         for (int t = 0; t < 4; ++t) h[t] += o[t];
     }
 
+    if (dbg == 3) { store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
     if (l + 1 < nl) {
         store_h(h, hbuf, g, lane);
         sa_front<SPLIT>(h, dm->layer[l + 1], cx, M, T, length, recs + (size_t)g * 2 * DC_REC_FLOATS);
@@ -987,13 +990,13 @@ hipError_t dc_launch_embed_front(hipStream_t st, bool split, const DcModel* dm, 
 hipError_t dc_launch_layer(hipStream_t st, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                           int M, int T, int G, int B) {
+                           int M, int T, int G, int B, int dbg) {
     const dim3 grid((G + 3) / 4);
     if (split)
         hipLaunchKernelGGL(k_layer<true>, grid, dim3(256), 0, st, dm, l, hbuf, (const f16x16*)E, NT, (const bf16x8*)a_sa,
-                           (const bf16x8*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B);
+                           (const bf16x8*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg);
     else
         hipLaunchKernelGGL(k_layer<false>, grid, dim3(256), 0, st, dm, l, hbuf, (const f16x16*)E, NT, (const bf16x8*)a_sa,
-                           (const bf16x8*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B);
+                           (const bf16x8*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg);
     return LAUNCH_CHECK();
 }

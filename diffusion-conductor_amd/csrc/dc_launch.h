@@ -23,4 +23,4 @@ hipError_t dc_launch_embed_front(hipStream_t st, bool split, const DcModel* dm, 
 hipError_t dc_launch_layer(hipStream_t st, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                           int M, int T, int G, int B);
+                           int M, int T, int G, int B, int dbg);

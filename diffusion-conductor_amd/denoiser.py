@@ -1,0 +1,133 @@
+"""Drop-in for the reference's ``MotionTransformer`` on the sampling path.
+
+Mirrors Diffusion_Stage/models/transformer.py:360-497: same constructor keywords, the same
+``state_dict`` keys (so ``load_state_dict`` takes the reference's ``state['encoder']``), and
+``forward`` / ``encode_music`` / ``generate_src_mask`` with the reference's argument meaning.
+``forward`` runs entirely in libdc_ddim.so (hand-written gfx950 kernels); there is no
+PyTorch-op or CPU fallback for it.
+
+``encode_music`` (the one-time MusicEncoder conv stack, transformer.py:289-340,447-459) still
+runs on PyTorch-ROCm ops in this round (next to move to HIP).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .native import NativeSampler
+from .param_spec import DenoiserConfig, param_shapes
+
+
+class _Node(nn.Module):
+    """Anonymous container so that parameter paths equal the reference's state_dict keys."""
+
+
+def _build_tree(root: nn.Module, shapes):
+    for name, shape in shapes.items():
+        parts = name.split(".")
+        node = root
+        for p in parts[:-1]:
+            if p not in node._modules:
+                node.add_module(p, _Node())
+            node = node._modules[p]
+        leaf = parts[-1]
+        if leaf in ("running_mean", "running_var"):
+            node.register_buffer(leaf, torch.ones(shape) if leaf == "running_var" else torch.zeros(shape))
+        elif leaf == "num_batches_tracked":
+            node.register_buffer(leaf, torch.tensor(0, dtype=torch.long))
+        else:
+            node.register_parameter(leaf, nn.Parameter(torch.zeros(shape), requires_grad=False))
+
+
+class MotionTransformer(nn.Module):
+    def __init__(self, input_feats, num_frames=240, latent_dim=16, ff_size=64, num_layers=8, num_heads=8,
+                 dropout=0, activation="gelu", device="cuda", text_num_heads=4, music_model_path=None,
+                 no_eff=False, precision="mixed", max_timesteps=1000, **kargs):
+        # `no_clip=` and other reference-only keywords are swallowed by **kargs, as in the reference.
+        super().__init__()
+        if dropout != 0:
+            raise NotImplementedError("sampling path only: dropout must be 0 (reference default)")
+        self.cfg = DenoiserConfig(input_feats=input_feats, num_frames=num_frames, latent_dim=latent_dim,
+                                  ff_size=ff_size, num_layers=num_layers, num_heads=num_heads, no_eff=bool(no_eff))
+        self.num_frames, self.latent_dim, self.ff_size = num_frames, latent_dim, ff_size
+        self.num_layers, self.num_heads, self.input_feats = num_layers, num_heads, input_feats
+        self.time_embed_dim = latent_dim * 4
+        self.device = device
+        self.precision = precision
+        self.max_timesteps = max_timesteps
+        _build_tree(self, param_shapes(self.cfg))
+        if music_model_path is not None:
+            # transformer.py:394-401: seed the MusicEncoder from the stage-1 checkpoint
+            base = torch.load(music_model_path, map_location="cpu")
+            sub = {k.replace("module.music_encoder.", "music_encoder."): v for k, v in base.items()
+                   if k.startswith("module.music_encoder")}
+            self.load_state_dict(sub, strict=False)
+        self._native = None
+        self._native_dirty = True
+        self._cond_key = None
+        self.eval()
+
+    # ---- weights ------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._native_dirty = True
+        return out
+
+    def _ensure_native(self, device):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("MotionTransformer.forward runs only on an MI355X (gfx950) device; "
+                               "there is no CPU path (use oracle/ for CPU reference results)")
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if self._native is None or self._native.device != idx:
+            if self._native is not None:
+                self._native.close()
+            self._native = NativeSampler(self.cfg, self.precision, self.max_timesteps, idx)
+            self._native_dirty = True
+        if self._native_dirty:
+            self._native.load_state_dict(self.state_dict())
+            self._native_dirty = False
+            self._cond_key = None
+        return self._native
+
+    # ---- reference surface ----------------------------------------------------------------
+    def generate_src_mask(self, T, length):
+        """transformer.py:461-467 (vectorised)."""
+        length = torch.as_tensor(length)
+        return (torch.arange(T)[None, :] < length.cpu()[:, None]).float()
+
+    def encode_music(self, text, device):
+        """transformer.py:447-459 in eval mode: mel [B,Tm,128] -> (x_proj, x), each [B,Tm/3,64]."""
+        if self.training:
+            raise NotImplementedError("sampling path only: call .eval() (training-time token dropout not built)")
+        from .music_encoder import music_encoder_forward
+        with torch.no_grad():
+            mel = text.to(device=device, dtype=torch.float32)
+            x = music_encoder_forward(self, mel)
+            x_proj = F.linear(x, self.proj.weight, self.proj.bias)
+        return x_proj, x
+
+    def set_conditioning(self, xf_proj, xf_out, length=None):
+        nat = self._ensure_native(xf_proj.device)
+        T = xf_proj.shape[1]
+        if length is None:
+            length = [T] * xf_proj.shape[0]
+        ln = tuple(int(v) for v in (length.tolist() if hasattr(length, "tolist") else length))
+        key = (xf_proj.data_ptr(), xf_out.data_ptr(), xf_proj._version, xf_out._version, tuple(xf_proj.shape), ln)
+        if key != self._cond_key:
+            nat.set_conditioning(xf_proj.contiguous().float(), xf_out.contiguous().float(), list(ln))
+            self._cond_key = key
+        return nat
+
+    def forward(self, x, timesteps, length=None, text=None, xf_proj=None, xf_out=None):
+        """transformer.py:469-497.  x [B,T,P] (or [B,T,J,2]); timesteps [B]; returns [B,T,P]."""
+        B, T = x.shape[0], x.shape[1]
+        if xf_proj is None or xf_out is None:
+            if text is None:
+                raise ValueError("need xf_proj/xf_out or text (mel)")
+            xf_proj, xf_out = self.encode_music(text, x.device)
+        if x.dim() == 4:
+            x = torch.flatten(x, start_dim=2, end_dim=3)
+        nat = self.set_conditioning(xf_proj, xf_out, length)
+        return nat.denoise(x.contiguous().float(), timesteps).view(B, T, -1).contiguous()

@@ -1,0 +1,68 @@
+"""Drop-in for the sampling half of the reference's ``DDPMTrainer``.
+
+Mirrors Diffusion_Stage/trainers/ddpm_trainer.py: constructor (:82-108, minus the training-only
+MotionPretrain/ST-GCN and mmcv imports), ``load`` (:303-319), ``eval_mode``, ``to`` and
+``generate_music_motion`` (:183-201).  Extensions over the reference: ``music_mel`` may be a
+batch ``[B,5400,128]``; ``noise=`` / ``seed=`` make sampling reproducible; under an initialised
+``torch.distributed`` group the clips are sharded over ranks (sharding.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .sampler import GaussianDiffusion, LossType, ModelMeanType, ModelVarType, get_named_beta_schedule
+from .sharding import dist_info, sharded_sample
+
+
+class DDPMTrainer(object):
+    def __init__(self, args, encoder):
+        self.opt = args
+        self.device = args.device
+        self.encoder = encoder
+        self.diffusion_steps = args.diffusion_steps
+        betas = get_named_beta_schedule("linear", self.diffusion_steps)
+        self.diffusion = GaussianDiffusion(betas=betas, model_mean_type=ModelMeanType.START_X,
+                                           model_var_type=ModelVarType.FIXED_SMALL, loss_type=LossType.MSE)
+        if getattr(args, "is_train", False):
+            raise NotImplementedError("this package covers the sampling path only")
+        self.to(self.device)
+
+    def to(self, device):
+        self.encoder.to(device)
+
+    def eval_mode(self):
+        self.encoder.eval()
+
+    def load(self, model_dir):
+        """ddpm_trainer.py:303-319 (inference branch): checkpoint['encoder'] with strict=False."""
+        checkpoint = torch.load(model_dir, map_location="cpu")
+        self.encoder.load_state_dict(checkpoint["encoder"], strict=False)
+        return checkpoint.get("ep", 0), checkpoint.get("total_it", 0)
+
+    def _sample_local(self, mel, noise, dim_pose, idxs):
+        xf_proj, xf_out = self.encoder.encode_music(mel, self.device)
+        B, T = mel.shape[0], xf_proj.shape[1]
+        return self.diffusion.ddim_sample_loop(
+            self.encoder, (B, T, dim_pose), noise=noise, clip_denoised=False, progress=False,
+            model_kwargs={"xf_proj": xf_proj, "xf_out": xf_out,
+                          "length": torch.LongTensor([T] * B)},
+            idxs=idxs)
+
+    def generate_music_motion(self, music_mel, dim_pose, batch_size=1024, idxs=[], noise=None, seed=None):
+        """music_mel: np.ndarray/tensor [5400,128] (reference) or [B,5400,128] -> tensor [B,1800,dim_pose]."""
+        mel = torch.as_tensor(np.asarray(music_mel) if not torch.is_tensor(music_mel) else music_mel)
+        if mel.dim() == 2:
+            mel = mel.unsqueeze(0)
+        mel = mel.to(self.device, dtype=torch.float32)
+        B, T = mel.shape[0], mel.shape[1] // 3
+        if noise is None and seed is not None:
+            g = torch.Generator().manual_seed(int(seed))
+            noise = torch.randn(B, T, dim_pose, generator=g)
+        if noise is not None:
+            noise = torch.as_tensor(noise).to(self.device, dtype=torch.float32)
+        _, world = dist_info()
+        with torch.no_grad():
+            if world == 1 or len(idxs):
+                return self._sample_local(mel, noise, dim_pose, idxs)
+            return sharded_sample(lambda m, n: self._sample_local(m, n, dim_pose, []), mel, noise)

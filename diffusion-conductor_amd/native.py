@@ -1,0 +1,261 @@
+"""ctypes binding of libdc_ddim.so (include/dc_ddim.h).
+
+There is deliberately no fallback: if the shared library is missing or no gfx950 device
+is visible, construction raises.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdc_ddim.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+DC_PREC = {"bf16": 0, "mixed": 1, "bf16x3": 2}
+
+EXPORTS = [
+    "dc_last_error", "dc_version", "dc_linear_beta_schedule", "dc_ddim_coefficients", "dc_pack_weight",
+    "dc_sampler_create", "dc_sampler_destroy", "dc_sampler_set_param", "dc_sampler_finalize_params",
+    "dc_sampler_set_conditioning", "dc_sampler_denoise", "dc_sampler_ddim_loop", "dc_sampler_profile_loop",
+    "dc_kernel_name", "dc_kernel_count", "dc_sampler_workspace_bytes", "dc_sampler_debug_denoise",
+    "dc_sampler_debug_read",
+]
+
+
+class DcConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("input_feats", "num_frames", "latent_dim", "ff_size", "num_layers",
+                                         "num_heads", "no_eff", "precision", "max_timesteps", "device")]
+
+
+class DcError(RuntimeError):
+    pass
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libdc_ddim.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("dc_kernels.hip", "dc_api.hip")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("dc_common.h", "dc_launch.h")] + \
+        [os.path.join(os.path.dirname(_HERE), "include", "dc_ddim.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           *srcs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (never builds implicitly on a GPU box: the prebuilt .so travels)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DcError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(there is no CPU fallback for the sampler)")
+    L = C.CDLL(LIB_PATH)
+    L.dc_last_error.restype = C.c_char_p
+    L.dc_version.restype = C.c_char_p
+    L.dc_kernel_name.restype = C.c_char_p
+    L.dc_kernel_name.argtypes = [C.c_int32]
+    L.dc_kernel_count.restype = C.c_int32
+    L.dc_sampler_workspace_bytes.restype = C.c_int64
+    L.dc_sampler_workspace_bytes.argtypes = [C.c_void_p]
+    dp, fp, ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    L.dc_linear_beta_schedule.argtypes = [C.c_int32, dp, dp, dp, dp, dp]
+    L.dc_ddim_coefficients.argtypes = [C.c_int32, dp, fp]
+    L.dc_pack_weight.argtypes = [fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]
+    L.dc_sampler_create.argtypes = [C.POINTER(DcConfig), C.POINTER(C.c_void_p)]
+    L.dc_sampler_destroy.argtypes = [C.c_void_p]
+    L.dc_sampler_destroy.restype = None
+    L.dc_sampler_set_param.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_int64]
+    L.dc_sampler_finalize_params.argtypes = [C.c_void_p]
+    L.dc_sampler_set_conditioning.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, ip, C.c_int32, C.c_int32, C.c_void_p]
+    L.dc_sampler_denoise.argtypes = [C.c_void_p, C.c_void_p, ip, C.c_void_p, C.c_void_p]
+    L.dc_sampler_ddim_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, fp, ip, C.c_int32, C.c_void_p, C.c_void_p]
+    L.dc_sampler_debug_denoise.argtypes = [C.c_void_p, C.c_void_p, ip, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    L.dc_sampler_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+    L.dc_sampler_profile_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, fp, fp, ip, C.c_int32, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise DcError(f"libdc_ddim error {rc}: {lib().dc_last_error().decode()}")
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+# ---------------------------------------------------------------------------------------
+# host-only helpers (work without a GPU)
+# ---------------------------------------------------------------------------------------
+def linear_beta_schedule(num_steps: int) -> dict:
+    """dc_linear_beta_schedule: the fp64 tables of GaussianDiffusion.__init__."""
+    n = int(num_steps)
+    arrs = [np.empty(n, np.float64) for _ in range(5)]
+    dp = C.POINTER(C.c_double)
+    _check(lib().dc_linear_beta_schedule(n, *[a.ctypes.data_as(dp) for a in arrs]))
+    keys = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod")
+    return dict(zip(keys, arrs))
+
+
+def ddim_coefficients(alphas_cumprod: np.ndarray) -> np.ndarray:
+    ac = np.ascontiguousarray(alphas_cumprod, np.float64)
+    out = np.empty((ac.shape[0], 4), np.float32)
+    _check(lib().dc_ddim_coefficients(ac.shape[0], ac.ctypes.data_as(C.POINTER(C.c_double)), _fptr(out)))
+    return out
+
+
+def pack_weight(w: np.ndarray, chained: bool):
+    w = np.ascontiguousarray(w, np.float32)
+    n_out, k_in = w.shape
+    ne = ((n_out + 31) // 32) * ((k_in + 31) // 32) * 2 * 64 * 8
+    hi, lo = np.empty(ne, np.uint16), np.empty(ne, np.uint16)
+    u16 = C.POINTER(C.c_uint16)
+    _check(lib().dc_pack_weight(_fptr(w), n_out, k_in, int(chained), hi.ctypes.data_as(u16), lo.ctypes.data_as(u16)))
+    return hi, lo
+
+
+def tile_row(r, hh):
+    return (r & 3) + 8 * (r >> 2) + 4 * hh
+
+
+def unpack_ft(raw):
+    """[G][NT][64 lanes][16 regs] FT tiles -> row-major [32*G tokens][32*NT features]."""
+    G, NT = raw.shape[0], raw.shape[1]
+    out = np.empty((G, 32, NT, 32), raw.dtype)
+    lane = np.arange(64)
+    for r in range(16):
+        feat = tile_row(r, lane >> 5)
+        out[:, lane & 31, :, feat] = raw[:, :, lane, r].transpose(2, 0, 1)
+    return out.reshape(G * 32, NT * 32)
+
+
+# ---------------------------------------------------------------------------------------
+# the sampler object
+# ---------------------------------------------------------------------------------------
+class NativeSampler:
+    """Owns one dc_sampler.  Tensors are torch CUDA(ROCm) tensors; only their data_ptr()
+    crosses the ABI."""
+
+    def __init__(self, cfg, precision="mixed", max_timesteps=1000, device=0):
+        self._h = C.c_void_p()
+        c = DcConfig(cfg.input_feats, cfg.num_frames, cfg.latent_dim, cfg.ff_size, cfg.num_layers, cfg.num_heads,
+                     int(bool(cfg.no_eff)), DC_PREC[precision], int(max_timesteps), int(device))
+        _check(lib().dc_sampler_create(C.byref(c), C.byref(self._h)))
+        self.cfg, self.precision, self.device, self.max_timesteps = cfg, precision, int(device), int(max_timesteps)
+        self.B = self.T = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().dc_sampler_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, state_dict):
+        """state_dict: name -> torch tensor / ndarray, with the reference's keys."""
+        for k, v in state_dict.items():
+            a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            if a.dtype.kind != "f":
+                continue   # BatchNorm.num_batches_tracked
+            a = np.ascontiguousarray(a, np.float32)
+            _check(lib().dc_sampler_set_param(self._h, k.encode(), _fptr(a), a.size))
+        _check(lib().dc_sampler_finalize_params(self._h))
+
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def set_conditioning(self, xf_proj, xf_out, length=None):
+        import torch
+        assert xf_proj.is_cuda and xf_proj.dtype == torch.float32 and xf_proj.is_contiguous()
+        assert xf_out.is_cuda and xf_out.dtype == torch.float32 and xf_out.is_contiguous()
+        B, T, Cc = xf_proj.shape
+        assert Cc == 64 and tuple(xf_out.shape) == (B, T, 64)
+        lp = None
+        if length is not None:
+            la = np.ascontiguousarray(np.asarray(length.cpu() if hasattr(length, "cpu") else length), np.int32)
+            assert la.shape == (B,)
+            lp = _iptr(la)
+        _check(lib().dc_sampler_set_conditioning(self._h, xf_proj.data_ptr(), xf_out.data_ptr(), lp, B, T, self._stream()))
+        self.B, self.T = B, T
+
+    def denoise(self, x, timesteps):
+        import torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        assert tuple(x.shape) == (self.B, self.T, self.cfg.input_feats)
+        ta = np.ascontiguousarray(np.asarray(timesteps.cpu() if hasattr(timesteps, "cpu") else timesteps), np.int32)
+        assert ta.shape == (self.B,)
+        out = torch.empty_like(x)
+        _check(lib().dc_sampler_denoise(self._h, x.data_ptr(), _iptr(ta), out.data_ptr(), self._stream()))
+        return out
+
+    def ddim_loop(self, noise, coef, snap_iters=()):
+        import torch
+        assert noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous()
+        assert tuple(noise.shape) == (self.B, self.T, self.cfg.input_feats)
+        coef = np.ascontiguousarray(coef, np.float32)
+        S = coef.shape[0]
+        out = torch.empty_like(noise)
+        si = np.ascontiguousarray(np.asarray(list(snap_iters), np.int32))
+        snaps = torch.empty((len(si),) + tuple(noise.shape), dtype=torch.float32, device=noise.device) if len(si) else None
+        _check(lib().dc_sampler_ddim_loop(self._h, noise.data_ptr(), out.data_ptr(), S, _fptr(coef),
+                                          _iptr(si) if len(si) else None, len(si),
+                                          snaps.data_ptr() if snaps is not None else None, self._stream()))
+        return out, snaps
+
+    def profile_loop(self, noise, coef):
+        import torch
+        coef = np.ascontiguousarray(coef, np.float32)
+        n = lib().dc_kernel_count()
+        ms, cnt = np.zeros(n, np.float32), np.zeros(n, np.int32)
+        out = torch.empty_like(noise)
+        _check(lib().dc_sampler_profile_loop(self._h, noise.data_ptr(), out.data_ptr(), coef.shape[0], _fptr(coef),
+                                             _fptr(ms), _iptr(cnt), n, self._stream()))
+        names = [lib().dc_kernel_name(i).decode() for i in range(n)]
+        return {names[i]: (float(ms[i]), int(cnt[i])) for i in range(n)}, out
+
+    # ---- test hooks ---------------------------------------------------------------------
+    def debug_denoise(self, x, timesteps, n_layers, stage):
+        import torch
+        ta = np.ascontiguousarray(np.asarray(timesteps), np.int32)
+        out = torch.zeros_like(x)
+        _check(lib().dc_sampler_debug_denoise(self._h, x.data_ptr(), _iptr(ta), out.data_ptr(), n_layers, stage,
+                                              self._stream()))
+        return out
+
+    def debug_read(self, what, dtype, count):
+        a = np.empty(count, dtype)
+        _check(lib().dc_sampler_debug_read(self._h, what.encode(), a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return a
+
+    def read_h(self):
+        """Residual stream [M_pad, 128] unpacked from the FT-tile image [G][4][64][16]."""
+        G = (self.B * self.T + 31) // 32
+        raw = self.debug_read("h", np.float32, G * 4 * 64 * 16).reshape(G, 4, 64, 16)
+        return unpack_ft(raw)
+
+    def workspace_bytes(self):
+        return int(lib().dc_sampler_workspace_bytes(self._h))

@@ -1,0 +1,225 @@
+"""Drop-in for the sampling half of the reference's ``GaussianDiffusion``.
+
+Mirrors Diffusion_Stage/models/gaussian_diffusion.py: ``get_named_beta_schedule`` (:228-245),
+the enums (:275-308), the constructor tables (:328-379) and the DDIM entry points
+``ddim_sample`` (:783-831), ``ddim_sample_loop`` (:871-915) and
+``ddim_sample_loop_progressive`` (:917-965), with the reference's argument names.
+
+Fast path: when ``model`` is this package's MotionTransformer, ``model_mean_type`` is START_X,
+``eta == 0`` and no clipping / denoised_fn / cond_fn is requested - exactly how
+DDPMTrainer.generate_music_motion calls it - the whole loop runs inside libdc_ddim.so as a
+replayed hipGraph.  Any other combination runs the same update rule step by step with the
+model call still going through the native denoiser.
+
+Training-time members (losses, VLB terms, ancestral p_sample, schedule samplers) are out of
+scope for this path and are not provided.
+"""
+from __future__ import annotations
+
+import enum
+import math
+
+import numpy as np
+import torch as th
+
+from . import native
+from .denoiser import MotionTransformer
+
+
+def get_named_beta_schedule(schedule_name, num_diffusion_timesteps):
+    """gaussian_diffusion.py:228-245."""
+    if schedule_name == "linear":
+        scale = 1000 / num_diffusion_timesteps
+        return np.linspace(scale * 0.0001, scale * 0.02, num_diffusion_timesteps, dtype=np.float64)
+    if schedule_name == "cosine":
+        return betas_for_alpha_bar(num_diffusion_timesteps,
+                                   lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2)
+    raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
+
+
+def betas_for_alpha_bar(num_diffusion_timesteps, alpha_bar, max_beta=0.999):
+    """gaussian_diffusion.py:248-266."""
+    betas = []
+    for i in range(num_diffusion_timesteps):
+        t1 = i / num_diffusion_timesteps
+        t2 = (i + 1) / num_diffusion_timesteps
+        betas.append(min(1 - alpha_bar(t2) / alpha_bar(t1), max_beta))
+    return np.array(betas)
+
+
+class ModelMeanType(enum.Enum):
+    PREVIOUS_X = enum.auto()
+    START_X = enum.auto()
+    EPSILON = enum.auto()
+
+
+class ModelVarType(enum.Enum):
+    LEARNED = enum.auto()
+    FIXED_SMALL = enum.auto()
+    FIXED_LARGE = enum.auto()
+    LEARNED_RANGE = enum.auto()
+
+
+class LossType(enum.Enum):
+    MSE = enum.auto()
+    RESCALED_MSE = enum.auto()
+    KL = enum.auto()
+    RESCALED_KL = enum.auto()
+
+    def is_vb(self):
+        return self == LossType.KL or self == LossType.RESCALED_KL
+
+
+def _extract(arr, timesteps, broadcast_shape):
+    """_extract_into_tensor (gaussian_diffusion.py:1168-1181) without the per-call H2D copy of the
+    whole table: the needed scalars are gathered on the host."""
+    t = timesteps.detach().cpu().numpy()
+    res = th.from_numpy(np.asarray(arr)[t]).float().to(timesteps.device)
+    while len(res.shape) < len(broadcast_shape):
+        res = res[..., None]
+    return res.expand(broadcast_shape)
+
+
+class GaussianDiffusion:
+    def __init__(self, *, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False):
+        self.model_mean_type = model_mean_type
+        self.model_var_type = model_var_type
+        self.loss_type = loss_type
+        self.rescale_timesteps = rescale_timesteps
+        betas = np.array(betas, dtype=np.float64)
+        self.betas = betas
+        assert len(betas.shape) == 1, "betas must be 1-D"
+        assert (betas > 0).all() and (betas <= 1).all()
+        self.num_timesteps = int(betas.shape[0])
+        alphas = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.alphas_cumprod_next = np.append(self.alphas_cumprod[1:], 0.0)
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self._native_coef = None
+
+    # ---- helpers ------------------------------------------------------------------------
+    def _scale_timesteps(self, t):
+        if self.rescale_timesteps:
+            return t.float() * (1000.0 / self.num_timesteps)
+        return t
+
+    def _predict_eps_from_xstart(self, x_t, t, pred_xstart):
+        return (_extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - pred_xstart) / \
+            _extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape)
+
+    def _predict_xstart_from_eps(self, x_t, t, eps):
+        return _extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - \
+            _extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * eps
+
+    def _pred_xstart(self, model, x, t, clip_denoised, denoised_fn, model_kwargs):
+        """The part of p_mean_variance (gaussian_diffusion.py:442-536) DDIM reads: pred_xstart."""
+        if model_kwargs is None:
+            model_kwargs = {}
+        assert t.shape == (x.shape[0],)
+        model_output = model(x, self._scale_timesteps(t), **model_kwargs)
+        if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
+            raise NotImplementedError("learned variance is not used by Diffusion-Conductor (ddpm_trainer.py:93)")
+        if self.model_mean_type == ModelMeanType.START_X:
+            pred = model_output
+        elif self.model_mean_type == ModelMeanType.EPSILON:
+            pred = self._predict_xstart_from_eps(x_t=x, t=t, eps=model_output)
+        else:
+            raise NotImplementedError(self.model_mean_type)
+        if denoised_fn is not None:
+            pred = denoised_fn(pred)
+        if clip_denoised:
+            pred = pred.clamp(-1, 1)
+        assert pred.shape == x.shape
+        return pred
+
+    # ---- DDIM ---------------------------------------------------------------------------
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                    eta=0.0):
+        """gaussian_diffusion.py:783-831."""
+        if cond_fn is not None:
+            raise NotImplementedError("cond_fn (classifier guidance) is not on the Diffusion-Conductor path")
+        pred_xstart = self._pred_xstart(model, x, t, clip_denoised, denoised_fn, model_kwargs)
+        eps = self._predict_eps_from_xstart(x, t, pred_xstart)
+        alpha_bar = _extract(self.alphas_cumprod, t, x.shape)
+        alpha_bar_prev = _extract(self.alphas_cumprod_prev, t, x.shape)
+        sigma = eta * th.sqrt((1 - alpha_bar_prev) / (1 - alpha_bar)) * th.sqrt(1 - alpha_bar / alpha_bar_prev)
+        mean_pred = pred_xstart * th.sqrt(alpha_bar_prev) + th.sqrt(1 - alpha_bar_prev - sigma ** 2) * eps
+        sample = mean_pred
+        if eta != 0.0:
+            noise = th.randn_like(x)
+            nonzero_mask = (t != 0).float().view(-1, *([1] * (len(x.shape) - 1)))
+            sample = mean_pred + nonzero_mask * sigma * noise
+        return {"sample": sample, "pred_xstart": pred_xstart}
+
+    def _fast_path_ok(self, model, clip_denoised, denoised_fn, cond_fn, eta):
+        return (isinstance(model, MotionTransformer) and self.model_mean_type == ModelMeanType.START_X
+                and self.model_var_type in (ModelVarType.FIXED_SMALL, ModelVarType.FIXED_LARGE)
+                and not clip_denoised and denoised_fn is None and cond_fn is None and eta == 0.0
+                and not self.rescale_timesteps)
+
+    def native_coefficients(self):
+        if self._native_coef is None:
+            self._native_coef = native.ddim_coefficients(self.alphas_cumprod)
+        return self._native_coef
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                         model_kwargs=None, device=None, progress=False, eta=0.0, idxs=[]):
+        """gaussian_diffusion.py:871-915.  Returns the final sample, or when `idxs` is non-empty a
+        dict {iteration: sample} for the listed iterations plus {num_timesteps: final}."""
+        if self._fast_path_ok(model, clip_denoised, denoised_fn, cond_fn, eta):
+            if device is None:
+                device = next(model.parameters()).device
+            assert isinstance(shape, (tuple, list))
+            img = noise if noise is not None else th.randn(*shape, device=device)
+            img = img.to(device=device, dtype=th.float32).contiguous()
+            mk = model_kwargs or {}
+            if mk.get("xf_proj") is None or mk.get("xf_out") is None:
+                mk = dict(mk)
+                mk["xf_proj"], mk["xf_out"] = model.encode_music(mk["text"], device)
+            nat = model.set_conditioning(mk["xf_proj"], mk["xf_out"], mk.get("length"))
+            snap = sorted(int(i) for i in set(idxs) if 0 <= int(i) < self.num_timesteps)
+            out, snaps = nat.ddim_loop(img, self.native_coefficients(), snap)
+            if len(idxs) == 0:
+                return out
+            result = {it: snaps[k] for k, it in enumerate(snap)}
+            result[self.num_timesteps] = out
+            return result
+        final, i, result = None, 0, {}
+        for sample in self.ddim_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
+                                                        denoised_fn=denoised_fn, cond_fn=cond_fn,
+                                                        model_kwargs=model_kwargs, device=device,
+                                                        progress=progress, eta=eta):
+            final = sample
+            if i in idxs:
+                result[i] = sample["sample"]
+            i += 1
+        result[i] = final["sample"]
+        if len(idxs) == 0:
+            return final["sample"]
+        return result
+
+    # the north-star wording calls the entry point `GaussianDiffusion.sample`
+    sample = ddim_sample_loop
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                     cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0):
+        """gaussian_diffusion.py:917-965: yields {"sample","pred_xstart"} after every step."""
+        if device is None:
+            device = next(model.parameters()).device
+        assert isinstance(shape, (tuple, list))
+        img = noise if noise is not None else th.randn(*shape, device=device)
+        indices = list(range(self.num_timesteps))[::-1]
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        for i in indices:
+            t = th.full((shape[0],), i, device=device, dtype=th.long)
+            with th.no_grad():
+                out = self.ddim_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
+                                       cond_fn=cond_fn, model_kwargs=model_kwargs, eta=eta)
+                yield out
+                img = out["sample"]

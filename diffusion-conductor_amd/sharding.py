@@ -1,0 +1,50 @@
+"""Clip-level data parallelism: one process per GPU, contiguous clip shards, no data-path
+collective except ONE all-gather of the final poses.
+
+Clips are independent in eval mode (BatchNorm uses running stats, LayerNorm is per token, both
+softmaxes stay inside a clip), so shards never exchange anything during the DDIM loop.
+`torch.distributed` backend "nccl" is RCCL on ROCm; the CPU tests use "gloo".
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_clips: int, rank: int, world: int):
+    """Contiguous [lo, hi) block of clips for `rank`; sizes differ by at most one."""
+    base, rem = divmod(n_clips, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def dist_info(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def gather_poses(local: torch.Tensor, n_clips: int, group=None) -> torch.Tensor:
+    """All-gather per-rank results [b_local, T, P] into [n_clips, T, P] on every rank.
+    Ragged shards are padded to the largest shard for the collective."""
+    rank, world = dist_info(group)
+    if world == 1:
+        return local
+    sizes = [shard_bounds(n_clips, r, world) for r in range(world)]
+    bmax = max(hi - lo for lo, hi in sizes)
+    pad = local
+    if local.shape[0] < bmax:
+        pad = torch.cat([local, local.new_zeros((bmax - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
+    out = local.new_empty((world * bmax,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    return torch.cat([out[r * bmax: r * bmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)
+
+
+def sharded_sample(sample_fn, mel, noise=None, group=None):
+    """Run `sample_fn(mel_shard, noise_shard) -> [b_local,T,P]` on this rank's clips and gather.
+    mel: [B, Tm, 128]; noise: [B, T, P] or None."""
+    rank, world = dist_info(group)
+    B = mel.shape[0]
+    lo, hi = shard_bounds(B, rank, world)
+    local = sample_fn(mel[lo:hi], None if noise is None else noise[lo:hi])
+    return gather_poses(local, B, group)

@@ -148,6 +148,15 @@ int dc_sampler_profile_loop(dc_sampler* s, const float* d_noise, float* d_out, i
 const char* dc_kernel_name(int32_t kernel_id);
 int32_t dc_kernel_count(void);
 
+/* Test hooks (tests/ only).  dc_sampler_debug_denoise runs dc_sampler_denoise but stops after
+ * `n_layers` decoder layers, the last one cut after stage 1 = self-attention, 2 = cross-attention,
+ * 3 = FFN (0 = whole layer), leaving the residual stream in the internal buffer "h".
+ * dc_sampler_debug_read copies an internal device buffer to the host (synchronous); names:
+ * "h" "pp" "s_hi" "s_lo" "E" "recs" "a_sa" "a_ca" "temb" (layouts: DESIGN.md). */
+int dc_sampler_debug_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timesteps, float* d_out,
+                             int32_t n_layers, int32_t stage, void* stream);
+int dc_sampler_debug_read(dc_sampler* s, const char* what, void* h_out, int64_t nbytes);
+
 /* Introspection used by tests: bytes of device workspace currently held. */
 int64_t dc_sampler_workspace_bytes(const dc_sampler* s);
 

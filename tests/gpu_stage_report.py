@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""GPU bring-up report (not a pytest): compares every internal stage of the HIP denoiser with
+the oracle's taps and prints one rel-L2 line per stage, per precision mode.
+Usage on the GPU box:  python tests/gpu_stage_report.py [B T]"""
+import sys
+
+import numpy as np
+import torch
+
+from helpers import O, oracle_params, make_model, rel_l2, xf_pair, batch_noise  # noqa: E402
+from diffusion_conductor_amd import native
+
+
+def unpack_kmajor(raw, G, K8=32):
+    """[G][ks][64][8] operand image -> [32G tokens][16*K8... features]"""
+    raw = raw.reshape(G, K8, 64, 8)
+    out = np.empty((G, 32, K8, 2, 8), raw.dtype)
+    lane = np.arange(64)
+    out[:, lane & 31, :, lane >> 5, :] = raw.transpose(2, 0, 1, 3)
+    return out.reshape(G * 32, K8 * 16)
+
+
+def bf16_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def unpack_afrag(raw, nset, B):
+    """[nset][B][16 frags][64][8] bf16 (8 hi then 8 lo) -> A[nset][B][8 heads][16 d][16 l]"""
+    raw = bf16_to_f32(raw.reshape(nset, B, 2, 4, 2, 64, 8))
+    val = raw[:, :, 0] + raw[:, :, 1]            # [nset][B][oc][s][lane][j]
+    A = np.zeros((nset, B, 8, 16, 16), np.float32)
+    off = np.zeros((nset, B), np.float32)        # largest |cross-head| entry (must be 0)
+    for oc in range(4):
+        for s in range(2):
+            for lane in range(64):
+                c, hh = lane & 31, lane >> 5
+                for j in range(8):
+                    d = 8 * (j >> 2) + 4 * hh + (j & 3)
+                    v = val[:, :, oc, s, lane, j]
+                    if (c >> 4) == s:
+                        A[:, :, 2 * oc + s, d, c & 15] = v
+                    else:
+                        off = np.maximum(off, np.abs(v))
+    return A, off
+
+
+def oracle_attn_matrices(p, taps_h, xo, emb, mask, L=8, H=8):
+    """A_sa per layer (from the oracle's residual stream entering each layer) and A_ca per layer."""
+    F = torch.nn.functional
+    a_sa, a_ca = [], []
+    B, T, D = taps_h[0].shape
+    for i in range(L):
+        pre = f"temporal_decoder_blocks.{i}"
+        x = taps_h[i]
+        n = O._ln(x, p, pre + ".sa_block.norm")
+        key = F.linear(n, p[pre + ".sa_block.key.weight"], p[pre + ".sa_block.key.bias"]) + (1 - mask) * -1000000
+        key = F.softmax(key.view(B, T, H, -1), dim=1)
+        val = (F.linear(n, p[pre + ".sa_block.value.weight"], p[pre + ".sa_block.value.bias"]) * mask).view(B, T, H, -1)
+        a_sa.append(torch.einsum('bnhd,bnhl->bhdl', key, val))
+        tn = O._ln(xo, p, pre + ".ca_block.text_norm")
+        key = F.softmax(F.linear(tn, p[pre + ".ca_block.key.weight"], p[pre + ".ca_block.key.bias"]).view(B, T, H, -1), dim=1)
+        val = F.linear(tn, p[pre + ".ca_block.value.weight"], p[pre + ".ca_block.value.bias"]).view(B, T, H, -1)
+        a_ca.append(torch.einsum('bnhd,bnhl->bhdl', key, val))
+    return a_sa, a_ca
+
+
+def main():
+    B, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3, 100)
+    p = oracle_params()
+    xfp, xfo = xf_pair(B, T)
+    x = torch.from_numpy(batch_noise(B, T))
+    t = torch.tensor([(7 * b + 3) % 50 for b in range(B)])
+    length = [T if b % 2 == 0 else max(1, T - 17 - b) for b in range(B)]
+    taps = {}
+    with torch.no_grad():
+        ref = O.denoiser_forward(p, x, t, length, xfp, xfo, taps=taps)
+        xo = torch.nn.functional.linear(xfo, p["linear.weight"], p["linear.bias"])
+        mask = O.generate_src_mask(T, length).unsqueeze(-1)
+        h_in = [taps["h0"]] + [taps[f"ffn{i}"] for i in range(7)]
+        a_sa_ref, a_ca_ref = oracle_attn_matrices(p, h_in, xo, taps["emb"], mask)
+    M, G = B * T, (B * T + 31) // 32
+    print(f"B={B} T={T} M={M} G={G} length={length} t={t.tolist()}")
+    for prec in ("bf16x3", "mixed", "bf16"):
+        m = make_model(prec)
+        nat = m.set_conditioning(xfp.cuda(), xfo.cuda(), length)
+        xd = x.cuda()
+        print(f"--- precision {prec}  (workspace {nat.workspace_bytes()/2**20:.1f} MiB)")
+        temb = nat.debug_read("temb", np.float32, 1000 * 512).reshape(1000, 512)
+        te = O.timestep_embedding(torch.arange(1000), 128)
+        with torch.no_grad():
+            tref = torch.nn.functional.linear(torch.nn.functional.silu(torch.nn.functional.linear(
+                te, p["time_embed.0.weight"], p["time_embed.0.bias"])), p["time_embed.2.weight"], p["time_embed.2.bias"])
+        print(f"  temb table          {rel_l2(temb, tref):.3e}")
+        pp = unpack_kmajor(nat.debug_read("pp", np.float32, G * 32 * 64 * 8), G)[:M]
+        ppref = (taps["emb"] - tref[t][:, None, :]).reshape(M, 512)
+        print(f"  linear(xf_proj)     {rel_l2(pp, ppref):.3e}")
+        A, off = unpack_afrag(nat.debug_read("a_ca", np.uint16, 8 * B * 16 * 64 * 8), 8, B)
+        print(f"  A_cross (8 layers)  {rel_l2(A, torch.stack(a_ca_ref).numpy()):.3e}   cross-head leak {off.max():.1e}")
+        out = nat.debug_denoise(xd, t.numpy(), 0, 0)   # embed + front only
+        torch.cuda.synchronize()
+        h = nat.read_h()[:M].reshape(B, T, 128)
+        print(f"  h0 (joint_embed)    {rel_l2(h, taps['h0']):.3e}")
+        shi = unpack_kmajor(bf16_to_f32(nat.debug_read("s_hi", np.uint16, G * 32 * 64 * 8)), G)[:M]
+        print(f"  SiLU(emb) bf16      {rel_l2(shi, torch.nn.functional.silu(taps['emb']).reshape(M, 512)):.3e}")
+        E = native.unpack_ft(nat.debug_read("E", np.float16, G * 192 * 64 * 16).reshape(G, 192, 64, 16))[:M].astype(np.float32)
+        with torch.no_grad():
+            eref = []
+            for i in range(8):
+                for blk in ("sa_block", "ca_block", "ffn"):
+                    pre = f"temporal_decoder_blocks.{i}.{blk}.proj_out.emb_layers.1"
+                    eref.append(torch.nn.functional.linear(torch.nn.functional.silu(taps["emb"]), p[pre + ".weight"], p[pre + ".bias"]))
+            eref = torch.cat(eref, dim=-1).reshape(M, -1)
+        print(f"  FiLM scale|shift    {rel_l2(E, eref):.3e}")
+        for i in range(8):
+            row = []
+            for stage, tap in ((1, f"sa{i}"), (2, f"ca{i}"), (3, f"ffn{i}")):
+                nat.debug_denoise(xd, t.numpy(), i + 1, stage)
+                torch.cuda.synchronize()
+                h = nat.read_h()[:M].reshape(B, T, 128)
+                row.append(f"{tap} {rel_l2(h, taps[tap]):.2e}")
+                if stage == 1:
+                    As, off = unpack_afrag(nat.debug_read("a_sa", np.uint16, B * 16 * 64 * 8), 1, B)
+                    row.insert(0, f"A_sa {rel_l2(As[0], a_sa_ref[i].numpy()):.2e}")
+            print(f"  layer {i}: " + "   ".join(row))
+        out = nat.denoise(xd, t.numpy())
+        torch.cuda.synchronize()
+        print(f"  forward x0          {rel_l2(out, ref):.3e}   finite={bool(torch.isfinite(out).all())}")
+        m._native.close()
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, __file__.rsplit("/", 1)[0])
+    main()

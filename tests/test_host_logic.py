@@ -1,0 +1,170 @@
+"""Host-side logic and the C ABI surface, on a CPU-only box (no compute calls into the GPU path)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, golden, state_dict_np
+
+from diffusion_conductor_amd import native
+from diffusion_conductor_amd.param_spec import DenoiserConfig, param_shapes
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "dc_ddim.h")).read()
+    declared = set(re.findall(r"\b(dc_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"dc_sampler", "dc_config", "dc_status", "dc_precision"}
+    assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
+    L = native.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.dc_version()
+
+
+def test_schedule_and_coefficients_match_reference_tables():
+    g = golden("g1_schedule.npz")
+    for S in (50, 1000):
+        tab = native.linear_beta_schedule(S)
+        for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+                  "sqrt_recipm1_alphas_cumprod"):
+            np.testing.assert_allclose(tab[k], g[f"S{S}_{k}"], rtol=1e-14, atol=0, err_msg=f"{S} {k}")
+        co = native.ddim_coefficients(g[f"S{S}_alphas_cumprod"])
+        np.testing.assert_allclose(co, g[f"S{S}_step_coeff"][:, :4], rtol=2e-7, atol=0)
+        assert co[0, 2] == 1.0 and co[0, 3] == 0.0
+
+
+def test_gaussian_diffusion_tables_and_enums():
+    from diffusion_conductor_amd.sampler import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,
+                                                 get_named_beta_schedule)
+    g = golden("g1_schedule.npz")
+    gd = GaussianDiffusion(betas=get_named_beta_schedule("linear", 50), model_mean_type=ModelMeanType.START_X,
+                           model_var_type=ModelVarType.FIXED_SMALL, loss_type=LossType.MSE)
+    assert gd.num_timesteps == 50
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+              "sqrt_recipm1_alphas_cumprod"):
+        assert np.array_equal(getattr(gd, k), g[f"S50_{k}"])
+    assert gd.sample.__func__ is gd.ddim_sample_loop.__func__
+    with pytest.raises(NotImplementedError):
+        get_named_beta_schedule("quadratic", 10)
+    with pytest.raises(AssertionError):
+        GaussianDiffusion(betas=np.array([0.0, 0.5]), model_mean_type=ModelMeanType.START_X,
+                          model_var_type=ModelVarType.FIXED_SMALL, loss_type=LossType.MSE)
+
+
+def _bf16_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def _tile_row(r, hh):
+    return (r & 3) + 8 * (r >> 2) + 4 * hh
+
+
+def _mfma_32x32x16(a_frag, b_frag):
+    """Reference semantics of v_mfma_f32_32x32x16_bf16 on lane-major fragments [64][8]:
+    A[row = l&31][k = 8*(l>>5)+j], B[k = 8*(l>>5)+j][col = l&31]; returns D[32][32]."""
+    A = np.zeros((32, 16), np.float64)
+    Bm = np.zeros((16, 32), np.float64)
+    for l in range(64):
+        for j in range(8):
+            A[l & 31, 8 * (l >> 5) + j] = a_frag[l, j]
+            Bm[8 * (l >> 5) + j, l & 31] = b_frag[l, j]
+    return A @ Bm
+
+
+def _acc_to_frag(tile, s):
+    """An accumulator tile D[32 rows][32 cols] as the next MFMA's operand fragment for k-step s:
+    lane (c, hh) element j = register 8s+j = D[tile_row(8s+j, hh)][c]."""
+    f = np.zeros((64, 8), np.float64)
+    for l in range(64):
+        for j in range(8):
+            f[l, j] = tile[_tile_row(8 * s + j, l >> 5), l & 31]
+    return f
+
+
+@pytest.mark.parametrize("n_out,k_in", [(128, 128), (64, 128), (128, 64), (26, 128), (128, 26)])
+def test_chained_weight_image_reproduces_matmul(n_out, k_in):
+    """The packed weight image, consumed as the A operand against an activation that arrives as an
+    accumulator tile (the in-register chaining the kernels rely on), reproduces W @ X exactly
+    (integer-valued data, so bf16 and fp32 accumulation are exact)."""
+    rng = np.random.default_rng(0)
+    W = rng.integers(-8, 9, (n_out, k_in)).astype(np.float32)
+    X = rng.integers(-8, 9, (k_in, 32)).astype(np.float32)          # [features][32 tokens]
+    hi, lo = native.pack_weight(W, chained=True)
+    OT, KT = (n_out + 31) // 32, (k_in + 31) // 32
+    hi = _bf16_to_f32(hi).reshape(OT, KT, 2, 64, 8)
+    assert not _bf16_to_f32(lo).any()                                  # small integers are exact in bf16
+    Xp = np.zeros((KT * 32, 32), np.float32)
+    Xp[:k_in] = X
+    Y = np.zeros((OT * 32, 32))
+    for ot in range(OT):
+        for kt in range(KT):
+            for s in range(2):
+                Y[32 * ot:32 * ot + 32] += _mfma_32x32x16(hi[ot, kt, s], _acc_to_frag(Xp[32 * kt:32 * kt + 32], s))
+    np.testing.assert_array_equal(Y[:n_out], W.astype(np.float64) @ X)
+    # ... and as the B operand it yields X^T W^T (tokens on rows), the orientation K and V use
+    Yt = np.zeros((32, OT * 32))
+    for oc in range(OT):
+        for kt in range(KT):
+            for s in range(2):
+                Yt[:, 32 * oc:32 * oc + 32] += _mfma_32x32x16(_acc_to_frag(Xp[32 * kt:32 * kt + 32], s), hi[oc, kt, s])
+    np.testing.assert_array_equal(Yt[:, :n_out], (W.astype(np.float64) @ X).T)
+
+
+def test_natural_weight_image_and_split_precision():
+    rng = np.random.default_rng(1)
+    W = rng.standard_normal((64, 512)).astype(np.float32)
+    hi, lo = native.pack_weight(W, chained=False)
+    hi = _bf16_to_f32(hi).reshape(2, 16, 2, 64, 8)
+    lo = _bf16_to_f32(lo).reshape(2, 16, 2, 64, 8)
+    for (ot, kt, s, l, j) in [(0, 0, 0, 0, 0), (1, 7, 1, 45, 3), (1, 15, 1, 63, 7), (0, 9, 0, 32, 5)]:
+        w = W[32 * ot + (l & 31), 32 * kt + 16 * s + 8 * (l >> 5) + j]
+        assert abs(hi[ot, kt, s, l, j] - w) <= abs(w) * 2.0 ** -8
+        assert abs(hi[ot, kt, s, l, j] + lo[ot, kt, s, l, j] - w) <= abs(w) * 2.0 ** -16
+
+
+def test_param_spec_matches_reference_state_dict_layout():
+    shapes = param_shapes(DenoiserConfig())
+    sd = state_dict_np()
+    assert len(shapes) == 396 and list(shapes) == list(sd)
+    assert sum(int(np.prod(s)) for n, s in shapes.items() if not n.endswith("num_batches_tracked")
+               and "running_" not in n) == 5952666          # parameter count of the reference model
+    from diffusion_conductor_amd import MotionTransformer
+    m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cpu", no_clip=True)
+    assert list(m.state_dict()) == list(shapes)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    assert torch.equal(m.generate_src_mask(5, torch.tensor([5, 2])), torch.tensor([[1., 1, 1, 1, 1], [1, 1, 0, 0, 0]]))
+
+
+def test_no_gpu_fails_loudly_not_silently():
+    """On a box without an MI355X the product refuses to run; it never falls back to CPU."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(native.DcError, match="no HIP device|no CPU fallback"):
+        native.NativeSampler(DenoiserConfig())
+    from diffusion_conductor_amd import MotionTransformer
+    m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(torch.zeros(1, 64, 26), torch.zeros(1, dtype=torch.long), length=[64],
+          xf_proj=torch.zeros(1, 64, 64), xf_out=torch.zeros(1, 64, 64))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "diffusion-conductor_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "/root/reference" not in src, f
+
+
+def test_shard_bounds_partition():
+    from diffusion_conductor_amd.sharding import shard_bounds
+    for n in (1, 7, 32, 256, 294):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1

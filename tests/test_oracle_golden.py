@@ -1,0 +1,107 @@
+"""The oracle against the committed golden fixtures (which were produced by the imported reference,
+see oracle/make_golden.py and tests/golden/PINNING.txt).  CPU only."""
+import numpy as np
+import torch
+
+from helpers import O, batch_mel, batch_noise, golden, oracle_params, rel_l2, xf_pair
+
+
+def test_schedule_tables_g1():
+    g = golden("g1_schedule.npz")
+    for S in (50, 1000):
+        tab = O.ddim_tables(O.linear_beta_schedule(S))
+        for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+                  "sqrt_recipm1_alphas_cumprod"):
+            assert np.array_equal(tab[k], g[f"S{S}_{k}"]), (S, k)
+        co = O.ddim_step_coefficients(tab)
+        assert np.allclose(co, g[f"S{S}_step_coeff"], rtol=2e-7, atol=0)
+        assert co[0, 2] == 1.0 and co[0, 3] == 0.0        # t=0: x_{-1} == pred_xstart
+
+
+def test_time_embed_table_g2():
+    g = golden("g2_time_embed.npz")
+    p = oracle_params()
+    F = torch.nn.functional
+    te = O.timestep_embedding(torch.arange(1000), 128)
+    table = F.linear(F.silu(F.linear(te, p["time_embed.0.weight"], p["time_embed.0.bias"])),
+                     p["time_embed.2.weight"], p["time_embed.2.bias"]).numpy()
+    assert np.array_equal(table[g["rows"]], g["table_rows"])
+    assert abs(table.astype(np.float64).sum() - float(g["table_sum"])) < 1e-6 * float(g["table_abs_sum"])
+
+
+def test_blocks_g3():
+    g = golden("g3_blocks.npz")
+    p = oracle_params()
+    h, emb = torch.from_numpy(g["h"]), torch.from_numpy(g["emb"])
+    xo = torch.nn.functional.linear(torch.from_numpy(g["xf_out"]), p["linear.weight"], p["linear.bias"])
+    mask = O.generate_src_mask(64, g["length"]).unsqueeze(-1)
+    pre = "temporal_decoder_blocks.2"
+    with torch.no_grad():
+        got = {
+            "styl": O.stylization(p, pre + ".sa_block.proj_out", h, emb),
+            "sa": O.linear_self_attention(p, pre + ".sa_block", h, emb, mask, 8),
+            "ca": O.linear_cross_attention(p, pre + ".ca_block", h, xo, emb, 8),
+            "ffn": O.ffn(p, pre + ".ffn", h, emb),
+            "full_sa": O.full_self_attention(p, pre + ".sa_block", h, emb, mask, 8),
+            "full_ca": O.full_cross_attention(p, pre + ".ca_block", h, xo, emb, 8),
+        }
+        x, t, ln = torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), g["length"]
+        xfp, xfo = torch.from_numpy(g["xf_proj"]), torch.from_numpy(g["xf_out"])
+        got["forward"] = O.denoiser_forward(p, x, t, ln, xfp, xfo)
+        got["forward_no_eff"] = O.denoiser_forward(p, x, t, ln, xfp, xfo, no_eff=True)
+    for k, v in got.items():
+        assert rel_l2(v, g[k]) < 1e-6, k
+    # the ragged clip really exercises the mask: masked tokens change the answer
+    with torch.no_grad():
+        unmasked = O.linear_self_attention(p, pre + ".sa_block", h, emb, torch.ones_like(mask), 8)
+    assert rel_l2(unmasked[1], g["sa"][1]) > 1e-3
+
+
+def test_encode_music_g4():
+    g = golden("g4_encode_music.npz")
+    p = oracle_params()
+    with torch.no_grad():
+        xp, x = O.encode_music(p, torch.from_numpy(batch_mel(1, 270)))
+    assert tuple(x.shape) == (1, 90, 64)
+    assert rel_l2(xp, g["small_x_proj"]) < 1e-6 and rel_l2(x, g["small_x"]) < 1e-6
+
+
+def test_ddim50_config1_g5():
+    g = golden("g5_ddim50_b1.npz")
+    p = oracle_params()
+    xfp, xfo = xf_pair(1, 1800)
+    noise = torch.from_numpy(batch_noise(1, 1800))
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        res = O.ddim_sample_loop(p, noise, xfp, xfo, [1800], 50, idxs=(0, 24))
+    assert set(res) == {0, 24, 50}
+    assert rel_l2(res[50], g["x0"]) < 1e-5
+    assert rel_l2(res[0][:, ::20], g["idx0_sub"]) < 1e-5 and rel_l2(res[24][:, ::20], g["idx24_sub"]) < 1e-5
+
+
+def test_ddim50_t900_ragged_and_no_eff_g6():
+    g = golden("g6_variants.npz")
+    p = oracle_params()
+    xfp, xfo = xf_pair(2, 900, first=10)
+    with torch.no_grad():
+        out = O.ddim_sample_loop(p, torch.from_numpy(batch_noise(2, 900, first=10)), xfp, xfo, [900, 700], 50)
+    assert rel_l2(out, g["t900_x0"]) < 1e-5
+    xfp, xfo = xf_pair(2, 96, first=20)
+    with torch.no_grad():
+        out = O.ddim_sample_loop(p, torch.from_numpy(batch_noise(2, 96, first=20)), xfp, xfo, [96, 70], 50, no_eff=True)
+    assert rel_l2(out, golden("g6b_no_eff.npz")["x0"]) < 1e-5
+
+
+def test_precision_emulation_budget():
+    """Error budget of the HIP precision modes, emulated on CPU at a small size (one forward):
+    split-bf16 is ~fp32-accurate, the default mixed mode is O(1e-3), plain bf16 is several times worse."""
+    g = golden("g3_blocks.npz")
+    p = oracle_params()
+    args = (torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), g["length"], torch.from_numpy(g["xf_proj"]),
+            torch.from_numpy(g["xf_out"]))
+    err = {}
+    with torch.no_grad():
+        for mode in ("x3", "mixed", "bf16", "fp16"):
+            err[mode] = rel_l2(O.denoiser_forward(p, *args, emu=O.Emu(mode)), g["forward"])
+    print(err)
+    assert err["x3"] < 3e-4 and err["mixed"] < 3e-3 and err["fp16"] < err["mixed"] < err["bf16"] < 2e-2
