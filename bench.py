@@ -40,7 +40,11 @@ def cpu_baseline(steps_sample=6):
     import torch
     from diffusion_conductor_amd.synthetic import batch_music_features, batch_noise, synthetic_state_dict
     from oracle import ddim_oracle as O
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))      # cores this process may actually run on
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("DC_CPU_BASELINE_THREADS", "64"))))
     torch.set_num_threads(cores)
     p = O.to_torch_params(synthetic_state_dict())
     xf = torch.from_numpy(batch_music_features(1, 1800))
@@ -55,6 +59,11 @@ def cpu_baseline(steps_sample=6):
         dt = (time.perf_counter() - t0) / steps_sample
     return {"value": round(1800 / (50 * dt), 1), "unit": "frames/s", "cores": int(torch.get_num_threads()),
             "kind": "port", "sample": f"bs=1 T=1800: {steps_sample} denoiser steps timed ({dt*1e3:.0f} ms/step), x50 for DDIM-50"}
+
+
+def log(msg):
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -101,8 +110,11 @@ def main():
     xf = torch.from_numpy(batch_music_features(B, T, first=rank * B)).to(dev)
     xfp = torch.nn.functional.linear(xf, model.proj.weight, model.proj.bias).contiguous()
     noise = torch.from_numpy(batch_noise(B, T, first=rank * B)).to(dev)
+    log("inputs resident; building native sampler + conditioning")
     nat = model.set_conditioning(xfp, xf, [T] * B)
+    torch.cuda.synchronize()
     coef = gd.native_coefficients()
+    log(f"conditioning done, workspace {nat.workspace_bytes() / 2**20:.0f} MiB")
 
     def step():
         out, _ = nat.ddim_loop(noise, coef)
@@ -113,8 +125,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        log(f"warmup {i} done")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -126,6 +140,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     assert torch.isfinite(out).all()
+    log(f"timed region: {dt:.3f} s for {args.steps} steps")
 
     frames = world * B * T * args.steps
     value = frames / dt
@@ -133,7 +148,7 @@ def main():
         "metric": "motion frames/sec (DDIM-50, 60s clip, bs=32 per GPU)", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if args.precision != "bf16x3" else "bf16x3", "data": "synthetic",
+        "dtype": {"mixed": "bf16 (split-bf16 MFMA; FiLM GEMM f16 MFMA), fp32 accumulate", "bf16": "bf16", "bf16x3": "bf16x3"}[args.precision], "data": "synthetic",
         "config": {"workload": f"configs[1]: DDIM-{S} sampling loop, bs={B} clips/GPU x {T} frames (60 s), linear attention, "
                                f"precision={args.precision}, conditioning + x_T resident in HBM (loop-only)",
                    "clips_per_gpu": B, "frames_per_clip": T, "ddim_steps": S, "parallelism": f"clip-dp{world}"},
@@ -142,6 +157,7 @@ def main():
     if rank == 0:
         # roofline of the dominant kernel: separate eager pass with per-launch HIP events
         prof, _ = nat.profile_loop(noise, coef)
+        log("profile pass done: " + ", ".join(f"{k} {v[0]:.2f}ms/{v[1]}" for k, v in prof.items()))
         tot = sum(ms for ms, _ in prof.values())
         ms, cnt = prof["k_film_gemm"]
         per_launch = ms / cnt * 1e-3
@@ -151,6 +167,7 @@ def main():
                             "avg_launch_us": round(per_launch * 1e6, 1), "launches": cnt,
                             "time_share_by_kernel": {k: round(v[0] / tot, 3) for k, v in prof.items()}}
         if not args.no_cpu_baseline:
+            log("cpu baseline (oracle on host cores) ...")
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)

@@ -50,6 +50,18 @@ inline float bf2f(uint16_t h) {
     return f;
 }
 
+inline uint16_t f2h(float f) {   // fp32 -> fp16 bits, round to nearest even (compiler's conversion)
+    const _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+inline float h2f(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
+}
+
 inline int tile_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -57,7 +69,7 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 //   = W[32ot + i][32kt + 16s + 8(j>>2) + 4hh + (j&3)]
 // i.e. the k order in which an accumulator tile, converted in registers, presents its rows.
 // "natural" k order: frag (ot, ks): element j = W[32ot + i][16ks + 8hh + j].
-void pack_weight(const float* w, int n_out, int k_in, bool chained, uint16_t* hi, uint16_t* lo) {
+void pack_weight(const float* w, int n_out, int k_in, bool chained, uint16_t* hi, uint16_t* lo, bool f16 = false) {
     const int OT = cdiv(n_out, 32), KT = cdiv(k_in, 32);
     for (int ot = 0; ot < OT; ++ot)
         for (int kt = 0; kt < KT; ++kt)
@@ -70,9 +82,9 @@ void pack_weight(const float* w, int n_out, int k_in, bool chained, uint16_t* hi
                                                 : 32 * kt + 16 * s + 8 * hh + j;
                         const float v = (row < n_out && col < k_in) ? w[(size_t)row * k_in + col] : 0.f;
                         const size_t o = ((((size_t)ot * KT + kt) * 2 + s) * 64 + l) * 8 + j;
-                        const uint16_t h = f2bf(v);
+                        const uint16_t h = f16 ? f2h(v) : f2bf(v);
                         hi[o] = h;
-                        lo[o] = f2bf(v - bf2f(h));
+                        lo[o] = f16 ? f2h(v - h2f(h)) : f2bf(v - bf2f(h));
                     }
 }
 size_t packed_elems(int n_out, int k_in) { return (size_t)cdiv(n_out, 32) * cdiv(k_in, 32) * 2 * 64 * 8; }
@@ -111,7 +123,8 @@ struct Prof {
 
 struct dc_sampler {
     dc_config cfg{};
-    bool split_small = false, split_film = false;
+    bool split_small = false;
+    int film_mode = 0;   // FiLM GEMM operands: 0 = bf16, 1 = split bf16, 2 = f16
     std::map<std::string, std::vector<float>> params;
     bool finalized = false;
 
@@ -255,10 +268,10 @@ int build_model(dc_sampler* s) {
     memset(&m, 0, sizeof m);
     auto P_ = [&](const std::string& n) -> const float* { return find(s, n)->data(); };
 
-    auto add_packed = [&](const bf16x8** dst, const float* w, int n_out, int k_in, bool chained) {
+    auto add_packed = [&](const bf16x8** dst, const float* w, int n_out, int k_in, bool chained, bool f16 = false) {
         const size_t ne = packed_elems(n_out, k_in);
         std::vector<uint16_t> buf(2 * ne);
-        pack_weight(w, n_out, k_in, chained, buf.data(), buf.data() + ne);
+        pack_weight(w, n_out, k_in, chained, buf.data(), buf.data() + ne, f16);
         O.fix.push_back({(const void**)dst, A.add(buf.data(), buf.size() * 2)});
     };
     auto add_ft = [&](const float** dst, const float* v, int n, int NT) {
@@ -331,7 +344,7 @@ int build_model(dc_sampler* s) {
             memcpy(&film_b[row0], P_(p + blk[j] + ".emb_layers.1.bias"), 256 * 4);
         }
     }
-    add_packed(&m.film_w, film_w.data(), NT * 32, DC_E, false);
+    add_packed(&m.film_w, film_w.data(), NT * 32, DC_E, false, s->film_mode == 2);
     add_ft(&m.film_b, film_b.data(), NT * 32, NT);
     add_packed(&m.je_w, P_("joint_embed.weight"), D, P, true);
     add_ft(&m.je_b, P_("joint_embed.bias"), D, 4);
@@ -470,7 +483,8 @@ struct Timed {   // RAII-less helper: wraps a launch with events when profiling
 // One denoiser evaluation (+ DDIM update when loop_mode) enqueued on st.
 int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_src, float* x_dst) {
     const int B = s->B, T = s->T, M = s->M, G = s->G, L = s->cfg.num_layers;
-    const bool ss = s->split_small, sf = s->split_film;
+    const bool ss = s->split_small;
+    const int sf = s->film_mode;
     if (loop_mode)
         LAUNCH(K_BEGIN, dc_launch_begin_step(st, s->d_iter, s->d_t_of_iter, s->d_coef_of_t, s->d_snap_of_iter,
                                              s->d_t_clip, s->d_coef_cur, s->d_snap_cur, B));
@@ -639,7 +653,7 @@ int dc_sampler_create(const dc_config* cfg, dc_sampler** out) {
     dc_sampler* s = new dc_sampler();
     s->cfg = *cfg;
     s->split_small = cfg->precision != DC_PREC_BF16;
-    s->split_film = cfg->precision == DC_PREC_BF16X3;
+    s->film_mode = cfg->precision == DC_PREC_BF16X3 ? 1 : (cfg->precision == DC_PREC_MIXED ? 2 : 0);
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming) != hipSuccess) {

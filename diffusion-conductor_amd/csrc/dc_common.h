@@ -34,6 +34,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) _Float16 f16x16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 #else
 struct bf16x8 { uint16_t v[8]; };
 #endif
@@ -71,7 +72,7 @@ struct DcModel {
     const float* seq_emb;    // row-major [num_frames][128]
     const bf16x8* out_w;     // chained pack OT=1 KT=4
     const float* out_b;      // ftvec (1 tile)
-    const bf16x8* film_w;    // natural-k pack [24*L/8... = 3*L*8 tiles][32 ks]; hi then lo
+    const bf16x8* film_w;    // natural-k pack [3*L*8 tiles][32 ks], hi then lo; bf16 or f16 bits (film format)
     const float* film_b;     // ftvec [3*L*8 tiles]
     const float* lin_wt;     // `linear` weight transposed [64][512]
     const float* lin_b;      // [512]

@@ -14,6 +14,7 @@
 //     K^T V of the linear attention) is a two-phase reduction: per-group partial
 //     records (k_embed_front / k_layer) -> k_attn_combine.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "dc_common.h"
 
 #define DEV __device__ __forceinline__
@@ -23,9 +24,20 @@ namespace dc {
 DEV f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+DEV f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
-DEV float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
-DEV float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+// value of the partner lane (lane ^ 32) combined with this lane's: one v_permlane32_swap, no LDS
+DEV float xhalf_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+DEV float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // row (feature in FT, token in TF) held by register r of lane-half hh
 DEV int tile_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
@@ -162,13 +174,13 @@ DEV void softmax_heads_ft(f32x16 (&q)[4]) {
                 q[t][8 * p + j] = e;
                 s += e;
             }
-            const float inv = 1.f / xhalf_sum(s);
+            const float inv = fast_rcp(xhalf_sum(s));
 #pragma unroll
             for (int j = 0; j < 8; ++j) q[t][8 * p + j] *= inv;
         }
 }
 
-DEV float silu(float z) { return z / (1.f + __expf(-z)); }
+DEV float silu(float z) { return z * fast_rcp(1.f + __expf(-z)); }
 DEV float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 // y = softmax(Q) . A per head, i.e. FT tile oc of y = A_frag[oc]^T-as-A-operand * Q tile oc.
@@ -541,42 +553,72 @@ __global__ __launch_bounds__(256) void k_cond_ca_partials(const DcModel* __restr
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ recs, bf16x8* __restrict__ afrag,
                                                       int T, int G, int B) {
-    extern __shared__ float sm[];   // w[ng][32] then z[32]
+    extern __shared__ float sm[];   // w[ng][32], z[32], red[8][32]
     const int b = blockIdx.x, oc = blockIdx.y, set = blockIdx.z;
     const int g_lo = (b * T) / 32, g_hi = ((b + 1) * T - 1) / 32;
     const int ng = g_hi - g_lo + 1;
     const float* base = recs + (size_t)set * G * 2 * DC_REC_FLOATS;
     float* w = sm;
     float* z = sm + ng * 32;
+    float* red = z + 32;
     const int tid = threadIdx.x;
     auto rec_of = [&](int gi) -> const float* {
         const int g = g_lo + gi;
         const int slot = ((32 * g) / T == b) ? 0 : 1;
         return base + ((size_t)g * 2 + slot) * DC_REC_FLOATS;
     };
+    // phase 1: column max over the clip's groups; 8 groups in flight per feature
+    const int f = tid & 31, part = tid >> 5;
+    {
+        float mloc = -INFINITY;
+        for (int gi = part; gi < ng; gi += 8) {
+            const float* R = rec_of(gi);
+            const float ss = R[128 + 32 * oc + f], mm = R[32 * oc + f];
+            if (ss > 0.f) mloc = fmaxf(mloc, mm);
+        }
+        red[part * 32 + f] = mloc;
+    }
+    __syncthreads();
+    float mstar = red[f];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) mstar = fmaxf(mstar, red[k * 32 + f]);
+    __syncthreads();
+    // phase 2: weights w_g = exp(m_g - m*) and the normaliser
+    {
+        float zloc = 0.f;
+        for (int gi = part; gi < ng; gi += 8) {
+            const float* R = rec_of(gi);
+            const float ss = R[128 + 32 * oc + f];
+            const float ww = ss > 0.f ? __expf(R[32 * oc + f] - mstar) : 0.f;
+            w[gi * 32 + f] = ww;
+            zloc += ww * ss;
+        }
+        red[part * 32 + f] = zloc;
+    }
+    __syncthreads();
     if (tid < 32) {
-        const int f = 32 * oc + tid;
-        float mstar = -INFINITY;
-        for (int gi = 0; gi < ng; ++gi) {
-            const float* R = rec_of(gi);
-            if (R[128 + f] > 0.f) mstar = fmaxf(mstar, R[f]);
-        }
         float zz = 0.f;
-        for (int gi = 0; gi < ng; ++gi) {
-            const float* R = rec_of(gi);
-            const float ss = R[128 + f];
-            const float ww = ss > 0.f ? __expf(R[f] - mstar) : 0.f;
-            w[gi * 32 + tid] = ww;
-            zz += ww * ss;
-        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) zz += red[k * 32 + tid];   // fixed order: deterministic
         z[tid] = zz;
     }
     __syncthreads();
+    // phase 3: weighted sum of the partial K^T V tiles, groups in order (deterministic)
     const int lane = tid & 63, rq = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const int row0 = 8 * rq + 4 * hh;   // tile_row(4rq + i, hh) = i + 8rq + 4hh
-    for (int gi = 0; gi < ng; ++gi) {
+    int gi = 0;
+    for (; gi + 4 <= ng; gi += 4) {
+        f32x4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = reinterpret_cast<const f32x4*>(rec_of(gi + u) + 256)[(oc * 64 + lane) * 4 + rq];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[(gi + u) * 32 + row0 + i], p[u][i], acc[i]);
+    }
+    for (; gi < ng; ++gi) {
         const f32x4 p = reinterpret_cast<const f32x4*>(rec_of(gi) + 256)[(oc * 64 + lane) * 4 + rq];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[gi * 32 + row0 + i], p[i], acc[i]);
@@ -601,7 +643,8 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
 // per step: S = SiLU(time_embed[t] + xf_proj')  (transformer.py:482 + StylizationBlock's nn.SiLU, :57-58)
 // as the bf16 B-operand image of the FiLM GEMM, [G][32 ks][64 lanes][8]
 // ------------------------------------------------------------------------------------
-template <bool SPLIT>
+// FMODE: 0 = bf16, 1 = split bf16 (hi + lo images), 2 = f16
+template <int FMODE>
 __global__ void k_silu_emb(const float* __restrict__ pp /*frag-major fp32*/, const float* __restrict__ temb,
                            const int* __restrict__ t_clip, bf16x8* __restrict__ s_hi, bf16x8* __restrict__ s_lo,
                            int G, int T, int B) {
@@ -614,15 +657,22 @@ __global__ void k_silu_emb(const float* __restrict__ pp /*frag-major fp32*/, con
     const float* te = temb + (size_t)t_clip[b] * 512 + 16 * ks + 8 * (lane >> 5);
     const f32x8 p = reinterpret_cast<const f32x8*>(pp)[idx];
     const f32x8 tv = *reinterpret_cast<const f32x8*>(te);
-    bf16x8 hi, lo;
+    if constexpr (FMODE == 2) {
+        f16x8 h;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float v = silu(p[j] + tv[j]);
-        hi[j] = (__bf16)v;
-        if constexpr (SPLIT) lo[j] = (__bf16)(v - (float)hi[j]);
+        for (int j = 0; j < 8; ++j) h[j] = (_Float16)silu(p[j] + tv[j]);
+        reinterpret_cast<f16x8*>(s_hi)[idx] = h;
+    } else {
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = silu(p[j] + tv[j]);
+            hi[j] = (__bf16)v;
+            if constexpr (FMODE == 1) lo[j] = (__bf16)(v - (float)hi[j]);
+        }
+        s_hi[idx] = hi;
+        if constexpr (FMODE == 1) s_lo[idx] = lo;
     }
-    s_hi[idx] = hi;
-    if constexpr (SPLIT) s_lo[idx] = lo;
 }
 
 // ------------------------------------------------------------------------------------
@@ -631,10 +681,15 @@ __global__ void k_silu_emb(const float* __restrict__ pp /*frag-major fp32*/, con
 // v1: operands straight from L2 into registers; wave tile 4 feature tiles x 2 groups.
 // grid (NT/8, ceil(G/4)), 256 threads = 2x2 waves.
 // ------------------------------------------------------------------------------------
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void k_film_gemm(const bf16x8* __restrict__ W, const float* __restrict__ bias_ft,
-                                                   const bf16x8* __restrict__ S_hi, const bf16x8* __restrict__ S_lo,
+template <int FMODE>
+__global__ __launch_bounds__(256) void k_film_gemm(const void* __restrict__ Wv, const float* __restrict__ bias_ft,
+                                                   const void* __restrict__ S_hiv, const void* __restrict__ S_lov,
                                                    f16x16* __restrict__ E, int G, int NT) {
+    using OP = typename std::conditional<FMODE == 2, f16x8, bf16x8>::type;
+    constexpr bool SPLIT = FMODE == 1;
+    const OP* __restrict__ W = reinterpret_cast<const OP*>(Wv);
+    const OP* __restrict__ S_hi = reinterpret_cast<const OP*>(S_hiv);
+    const OP* __restrict__ S_lo = reinterpret_cast<const OP*>(S_lov);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ot0 = (blockIdx.x * 2 + (wave >> 1)) * 4;
     const int g0 = (blockIdx.y * 2 + (wave & 1)) * 2;
@@ -647,7 +702,7 @@ __global__ __launch_bounds__(256) void k_film_gemm(const bf16x8* __restrict__ W,
     const size_t nfw = (size_t)NT * DC_KS_E;
 #pragma unroll 2
     for (int ks = 0; ks < DC_KS_E; ++ks) {
-        bf16x8 a[4], al[4], b[2], bl[2];
+        OP a[4], al[4], b[2], bl[2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             a[i] = W[((size_t)(ot0 + i) * DC_KS_E + ks) * 64 + lane];
@@ -949,31 +1004,33 @@ hipError_t dc_launch_ca_partials(hipStream_t st, bool split, const DcModel* dm, 
 
 hipError_t dc_launch_attn_combine(hipStream_t st, const float* recs, void* afrag, int T, int G, int B, int nset) {
     const int ng_max = T / 32 + 2;
-    const size_t shm = (size_t)(ng_max * 32 + 32) * sizeof(float);
+    const size_t shm = (size_t)(ng_max * 32 + 32 + 256) * sizeof(float);
     hipLaunchKernelGGL(k_attn_combine, dim3(B, 4, nset), dim3(256), shm, st, recs, (bf16x8*)afrag, T, G, B);
     return LAUNCH_CHECK();
 }
 
-hipError_t dc_launch_silu_emb(hipStream_t st, bool split, const float* pp, const float* temb, const int* t_clip,
+hipError_t dc_launch_silu_emb(hipStream_t st, int fmode, const float* pp, const float* temb, const int* t_clip,
                               void* s_hi, void* s_lo, int G, int T, int B) {
     const size_t n = (size_t)G * 32 * 64;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (split)
-        hipLaunchKernelGGL(k_silu_emb<true>, grid, dim3(256), 0, st, pp, temb, t_clip, (bf16x8*)s_hi, (bf16x8*)s_lo, G, T, B);
+    if (fmode == 1)
+        hipLaunchKernelGGL(k_silu_emb<1>, grid, dim3(256), 0, st, pp, temb, t_clip, (bf16x8*)s_hi, (bf16x8*)s_lo, G, T, B);
+    else if (fmode == 2)
+        hipLaunchKernelGGL(k_silu_emb<2>, grid, dim3(256), 0, st, pp, temb, t_clip, (bf16x8*)s_hi, (bf16x8*)s_lo, G, T, B);
     else
-        hipLaunchKernelGGL(k_silu_emb<false>, grid, dim3(256), 0, st, pp, temb, t_clip, (bf16x8*)s_hi, (bf16x8*)s_lo, G, T, B);
+        hipLaunchKernelGGL(k_silu_emb<0>, grid, dim3(256), 0, st, pp, temb, t_clip, (bf16x8*)s_hi, (bf16x8*)s_lo, G, T, B);
     return LAUNCH_CHECK();
 }
 
-hipError_t dc_launch_film_gemm(hipStream_t st, bool split, const void* W, const float* bias_ft, const void* s_hi,
+hipError_t dc_launch_film_gemm(hipStream_t st, int fmode, const void* W, const float* bias_ft, const void* s_hi,
                                const void* s_lo, void* E, int G, int NT) {
     const dim3 grid(NT / 8, (G + 3) / 4);
-    if (split)
-        hipLaunchKernelGGL(k_film_gemm<true>, grid, dim3(256), 0, st, (const bf16x8*)W, bias_ft, (const bf16x8*)s_hi,
-                           (const bf16x8*)s_lo, (f16x16*)E, G, NT);
+    if (fmode == 1)
+        hipLaunchKernelGGL(k_film_gemm<1>, grid, dim3(256), 0, st, W, bias_ft, s_hi, s_lo, (f16x16*)E, G, NT);
+    else if (fmode == 2)
+        hipLaunchKernelGGL(k_film_gemm<2>, grid, dim3(256), 0, st, W, bias_ft, s_hi, s_lo, (f16x16*)E, G, NT);
     else
-        hipLaunchKernelGGL(k_film_gemm<false>, grid, dim3(256), 0, st, (const bf16x8*)W, bias_ft, (const bf16x8*)s_hi,
-                           (const bf16x8*)s_lo, (f16x16*)E, G, NT);
+        hipLaunchKernelGGL(k_film_gemm<0>, grid, dim3(256), 0, st, W, bias_ft, s_hi, s_lo, (f16x16*)E, G, NT);
     return LAUNCH_CHECK();
 }
 

@@ -14,9 +14,9 @@ hipError_t dc_launch_cond_pack(hipStream_t st, int mode, const float* y, const f
 hipError_t dc_launch_ca_partials(hipStream_t st, bool split, const DcModel* dm, const void* nh_hi, const void* nh_lo,
                                  float* recs, int M, int T, int G, int L);
 hipError_t dc_launch_attn_combine(hipStream_t st, const float* recs, void* afrag, int T, int G, int B, int nset);
-hipError_t dc_launch_silu_emb(hipStream_t st, bool split, const float* pp, const float* temb, const int* t_clip,
+hipError_t dc_launch_silu_emb(hipStream_t st, int fmode, const float* pp, const float* temb, const int* t_clip,
                               void* s_hi, void* s_lo, int G, int T, int B);
-hipError_t dc_launch_film_gemm(hipStream_t st, bool split, const void* W, const float* bias_ft, const void* s_hi,
+hipError_t dc_launch_film_gemm(hipStream_t st, int fmode, const void* W, const float* bias_ft, const void* s_hi,
                                const void* s_lo, void* E, int G, int NT);
 hipError_t dc_launch_embed_front(hipStream_t st, bool split, const DcModel* dm, const float* x, float* hbuf, float* recs,
                                  const int* length, int M, int T, int G);

@@ -41,7 +41,8 @@ typedef enum dc_status {
 /* GEMM operand precision of the denoiser (accumulation is always fp32). */
 typedef enum dc_precision {
     DC_PREC_BF16 = 0,   /* every MFMA operand plain bf16                                      */
-    DC_PREC_MIXED = 1,  /* K=512 FiLM GEMM plain bf16; all 128-wide GEMMs split-bf16 (3 MFMA) */
+    DC_PREC_MIXED = 1,  /* default: K=512 FiLM GEMM on f16 MFMA operands (same rate as bf16, 3 more
+                           mantissa bits); all 128-wide GEMMs (Q/K/V, attention, out-proj, FFN) split-bf16 */
     DC_PREC_BF16X3 = 2  /* split-bf16 everywhere (validation mode, ~fp32 accuracy)            */
 } dc_precision;
 

@@ -87,8 +87,8 @@ class Emu:
 
     mode "fp32":  no rounding (the oracle proper).
     mode "bf16":  every GEMM a·w -> bf16(a)·bf16(w).
-    mode "mixed": K=512 GEMMs (FiLM emb_layers, cross-attention K/V) plain bf16; all
-                  other GEMMs split-bf16 (a_hi·w_hi + a_lo·w_hi + a_hi·w_lo).
+    mode "mixed": the K=512 FiLM GEMM (emb_layers) on fp16 operands; all other GEMMs
+                  split-bf16 (a_hi·w_hi + a_lo·w_hi + a_hi·w_lo) - the HIP default.
     mode "x3":    split-bf16 everywhere.
     mode "fp16":  every GEMM fp16 operands.
     FiLM outputs (scale|shift) are additionally rounded to fp16 when `film_store_f16`
@@ -103,7 +103,7 @@ class Emu:
     def _kind(self, big):
         if self.mode in ("fp32", "bf16", "x3", "fp16"):
             return self.mode
-        return "bf16" if big else "x3"
+        return "fp16" if big else "x3"
 
     def matmul(self, a, w_t, big=False):
         """a [..., K] @ w_t [K, N] with emulated operand rounding."""

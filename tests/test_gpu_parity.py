@@ -39,12 +39,12 @@ def _ddim(model, S, noise, xfp, xfo, length, idxs=()):
 
 def test_native_library_is_loaded(models):
     """The product path must be the HIP library, not an eager fallback."""
-    maps = open("/proc/self/maps").read()
-    assert "libdc_ddim.so" in maps
-    assert models["mixed"]._native is None or models["mixed"]._native.workspace_bytes() >= 0
+    from diffusion_conductor_amd import native
+    assert native.lib().dc_kernel_count() >= 5
+    assert "libdc_ddim.so" in open("/proc/self/maps").read()
 
 
-@pytest.mark.parametrize("prec,tol", [("bf16x3", TOL_X3), ("mixed", 2 * TOL_PARITY), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("prec,tol", [("bf16x3", TOL_X3), ("mixed", TOL_PARITY), ("bf16", TOL_BF16)])
 def test_forward_golden_blocks(models, prec, tol):
     """G3: one MotionTransformer.forward at B=2, T=64, ragged length, per-clip timesteps."""
     g = golden("g3_blocks.npz")

@@ -94,7 +94,8 @@ def test_ddim50_t900_ragged_and_no_eff_g6():
 
 def test_precision_emulation_budget():
     """Error budget of the HIP precision modes, emulated on CPU at a small size (one forward):
-    split-bf16 is ~fp32-accurate, the default mixed mode is O(1e-3), plain bf16 is several times worse."""
+    split-bf16 is ~fp32-accurate, the default mixed mode (f16 FiLM GEMM + split-bf16 elsewhere) sits well
+    under the 1e-3 bound, fp16-everywhere is a few times worse, plain bf16 is several times over it."""
     g = golden("g3_blocks.npz")
     p = oracle_params()
     args = (torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), g["length"], torch.from_numpy(g["xf_proj"]),
@@ -104,4 +105,4 @@ def test_precision_emulation_budget():
         for mode in ("x3", "mixed", "bf16", "fp16"):
             err[mode] = rel_l2(O.denoiser_forward(p, *args, emu=O.Emu(mode)), g["forward"])
     print(err)
-    assert err["x3"] < 3e-4 and err["mixed"] < 3e-3 and err["fp16"] < err["mixed"] < err["bf16"] < 2e-2
+    assert err["x3"] < 1e-4 and err["mixed"] < 5e-4 and err["mixed"] < err["fp16"] < 1e-3 < err["bf16"] < 2e-2
