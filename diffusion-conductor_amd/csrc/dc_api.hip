@@ -65,7 +65,7 @@ inline float h2f(uint16_t u) {
 inline int tile_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// Weight image, "chained" k order: frag (ot, kt, s), lane (i = l&31, hh = l>>5), element j
+// Weight image [kt][ot][s][64][8] (kt-major).  "chained" k order: frag (ot, kt, s), lane (i = l&31, hh = l>>5), element j
 //   = W[32ot + i][32kt + 16s + 8(j>>2) + 4hh + (j&3)]
 // i.e. the k order in which an accumulator tile, converted in registers, presents its rows.
 // "natural" k order: frag (ot, ks): element j = W[32ot + i][16ks + 8hh + j].
@@ -81,7 +81,7 @@ void pack_weight(const float* w, int n_out, int k_in, bool chained, uint16_t* hi
                         const int col = chained ? 32 * kt + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)
                                                 : 32 * kt + 16 * s + 8 * hh + j;
                         const float v = (row < n_out && col < k_in) ? w[(size_t)row * k_in + col] : 0.f;
-                        const size_t o = ((((size_t)ot * KT + kt) * 2 + s) * 64 + l) * 8 + j;
+                        const size_t o = ((((size_t)kt * OT + ot) * 2 + s) * 64 + l) * 8 + j;
                         const uint16_t h = f16 ? f2h(v) : f2bf(v);
                         hi[o] = h;
                         lo[o] = f16 ? f2h(v - h2f(h)) : f2bf(v - bf2f(h));
@@ -123,8 +123,9 @@ struct Prof {
 
 struct dc_sampler {
     dc_config cfg{};
-    bool split_small = false;
-    int film_mode = 0;   // FiLM GEMM operands: 0 = bf16, 1 = split bf16, 2 = f16
+    // operand formats (0 = bf16, 1 = f16) and split flags of the 128-wide GEMMs and of the FiLM GEMM
+    int small_fmt = 0, film_fmt = 0;
+    bool split_small = false, split_film = false;
     std::map<std::string, std::vector<float>> params;
     bool finalized = false;
 
@@ -268,7 +269,8 @@ int build_model(dc_sampler* s) {
     memset(&m, 0, sizeof m);
     auto P_ = [&](const std::string& n) -> const float* { return find(s, n)->data(); };
 
-    auto add_packed = [&](const bf16x8** dst, const float* w, int n_out, int k_in, bool chained, bool f16 = false) {
+    const bool sf16 = s->small_fmt == 1;
+    auto add_packed = [&](const bf16x8** dst, const float* w, int n_out, int k_in, bool chained, bool f16) {
         const size_t ne = packed_elems(n_out, k_in);
         std::vector<uint16_t> buf(2 * ne);
         pack_weight(w, n_out, k_in, chained, buf.data(), buf.data() + ne, f16);
@@ -283,32 +285,49 @@ int build_model(dc_sampler* s) {
         O.fix.push_back({(const void**)dst, A.add(v, n * 4)});
     };
     auto add_styl = [&](DcStyl& st, const std::string& p) {
-        add_ft(&st.ln_g, P_(p + ".norm.weight"), D, 4);
-        add_ft(&st.ln_b, P_(p + ".norm.bias"), D, 4);
-        add_packed(&st.wo, P_(p + ".out_layers.2.weight"), D, D, true);
+        add_packed(&st.wo, P_(p + ".out_layers.2.weight"), D, D, true, sf16);
         add_ft(&st.bo, P_(p + ".out_layers.2.bias"), D, 4);
     };
 
-    // FiLM: all 3L blocks stacked along the output axis -> one [3L*256][512] GEMM operand
+    // W' = W diag(g), c' = c + W b  (LayerNorm affine folded into the projection that consumes it)
+    auto fold_ln = [&](const float* w, const float* c, const float* g, const float* b, int n_out, int k,
+                       std::vector<float>& wf, std::vector<float>& cf) {
+        wf.resize((size_t)n_out * k);
+        cf.resize(n_out);
+        for (int o = 0; o < n_out; ++o) {
+            double acc = c[o];
+            for (int i = 0; i < k; ++i) {
+                wf[(size_t)o * k + i] = w[(size_t)o * k + i] * g[i];
+                acc += (double)w[(size_t)o * k + i] * b[i];
+            }
+            cf[o] = (float)acc;
+        }
+    };
+    // FiLM: all 3L blocks stacked along the output axis -> one [3L*256][512] GEMM operand; inside a block the
+    // 32-row tiles are interleaved (scale0, shift0, scale1, shift1, ...) so one wave holds matching pairs
     const int NT = 3 * L * DC_FILM_TILES_PER_BLOCK;
     s->NT = NT;
-    std::vector<float> film_w((size_t)NT * 32 * DC_E), film_b((size_t)NT * 32);
+    std::vector<float> film_w((size_t)NT * 32 * DC_E), film_b((size_t)NT * 32), film_g((size_t)3 * L * 128), film_beta((size_t)3 * L * 128);
     for (int i = 0; i < L; ++i) {
         const std::string p = "temporal_decoder_blocks." + std::to_string(i);
         DcLayer& y = m.layer[i];
-        add_ft(&y.sa_ln_g, P_(p + ".sa_block.norm.weight"), D, 4);
-        add_ft(&y.sa_ln_b, P_(p + ".sa_block.norm.bias"), D, 4);
-        add_packed(&y.sa_wq, P_(p + ".sa_block.query.weight"), D, D, true);
-        add_packed(&y.sa_wk, P_(p + ".sa_block.key.weight"), D, D, true);
-        add_packed(&y.sa_wv, P_(p + ".sa_block.value.weight"), D, D, true);
-        add_ft(&y.sa_bq, P_(p + ".sa_block.query.bias"), D, 4);
-        add_raw(&y.sa_bk, P_(p + ".sa_block.key.bias"), D);
-        add_raw(&y.sa_bv, P_(p + ".sa_block.value.bias"), D);
+        std::vector<float> wf, cf;
+        const float* sg = P_(p + ".sa_block.norm.weight");
+        const float* sb = P_(p + ".sa_block.norm.bias");
+        fold_ln(P_(p + ".sa_block.query.weight"), P_(p + ".sa_block.query.bias"), sg, sb, D, D, wf, cf);
+        add_packed(&y.sa_wq, wf.data(), D, D, true, sf16);
+        add_ft(&y.sa_bq, cf.data(), D, 4);
+        fold_ln(P_(p + ".sa_block.key.weight"), P_(p + ".sa_block.key.bias"), sg, sb, D, D, wf, cf);
+        add_packed(&y.sa_wk, wf.data(), D, D, true, sf16);
+        add_raw(&y.sa_bk, cf.data(), D);
+        fold_ln(P_(p + ".sa_block.value.weight"), P_(p + ".sa_block.value.bias"), sg, sb, D, D, wf, cf);
+        add_packed(&y.sa_wv, wf.data(), D, D, true, sf16);
+        add_raw(&y.sa_bv, cf.data(), D);
         add_styl(y.sa_styl, p + ".sa_block.proj_out");
-        add_ft(&y.ca_ln_g, P_(p + ".ca_block.norm.weight"), D, 4);
-        add_ft(&y.ca_ln_b, P_(p + ".ca_block.norm.bias"), D, 4);
-        add_packed(&y.ca_wq, P_(p + ".ca_block.query.weight"), D, D, true);
-        add_ft(&y.ca_bq, P_(p + ".ca_block.query.bias"), D, 4);
+        fold_ln(P_(p + ".ca_block.query.weight"), P_(p + ".ca_block.query.bias"), P_(p + ".ca_block.norm.weight"),
+                P_(p + ".ca_block.norm.bias"), D, D, wf, cf);
+        add_packed(&y.ca_wq, wf.data(), D, D, true, sf16);
+        add_ft(&y.ca_bq, cf.data(), D, 4);
         // fold text_norm's affine (transformer.py:149,153) into the K/V projections:
         //   W (g*n + b) + c = (W*g) n + (W b + c)
         {
@@ -327,29 +346,39 @@ int build_model(dc_sampler* s) {
                     }
                     bf[o] = (float)acc;
                 }
-                add_packed(kv ? &y.ca_wv : &y.ca_wk, wf.data(), D, DC_E, false);
+                add_packed(kv ? &y.ca_wv : &y.ca_wk, wf.data(), D, DC_E, false, false);   // conditioning pre-pass is always split-bf16
                 add_raw(kv ? &y.ca_bv : &y.ca_bk, bf.data(), D);
             }
         }
         add_styl(y.ca_styl, p + ".ca_block.proj_out");
-        add_packed(&y.ffn_w1, P_(p + ".ffn.linear1.weight"), DC_F, D, true);
-        add_packed(&y.ffn_w2, P_(p + ".ffn.linear2.weight"), D, DC_F, true);
+        add_packed(&y.ffn_w1, P_(p + ".ffn.linear1.weight"), DC_F, D, true, sf16);
+        add_packed(&y.ffn_w2, P_(p + ".ffn.linear2.weight"), D, DC_F, true, sf16);
         add_ft(&y.ffn_b1, P_(p + ".ffn.linear1.bias"), DC_F, 2);
         add_ft(&y.ffn_b2, P_(p + ".ffn.linear2.bias"), D, 4);
         add_styl(y.ffn_styl, p + ".ffn.proj_out");
         const char* blk[3] = {".sa_block.proj_out", ".ca_block.proj_out", ".ffn.proj_out"};
         for (int j = 0; j < 3; ++j) {
             const size_t row0 = (size_t)(3 * i + j) * 256;
-            memcpy(&film_w[row0 * DC_E], P_(p + blk[j] + ".emb_layers.1.weight"), (size_t)256 * DC_E * 4);
-            memcpy(&film_b[row0], P_(p + blk[j] + ".emb_layers.1.bias"), 256 * 4);
+            const float* w = P_(p + blk[j] + ".emb_layers.1.weight");   // rows 0..127 scale, 128..255 shift
+            const float* bb = P_(p + blk[j] + ".emb_layers.1.bias");
+            for (int t = 0; t < 4; ++t)
+                for (int half = 0; half < 2; ++half) {       // interleave: tile 2t = scale tile t, 2t+1 = shift tile t
+                    const size_t dst = row0 + (size_t)(2 * t + half) * 32, src = (size_t)half * 128 + 32 * t;
+                    memcpy(&film_w[dst * DC_E], &w[src * DC_E], (size_t)32 * DC_E * 4);
+                    memcpy(&film_b[dst], &bb[src], 32 * 4);
+                }
+            memcpy(&film_g[(size_t)(3 * i + j) * 128], P_(p + blk[j] + ".norm.weight"), 128 * 4);
+            memcpy(&film_beta[(size_t)(3 * i + j) * 128], P_(p + blk[j] + ".norm.bias"), 128 * 4);
         }
     }
-    add_packed(&m.film_w, film_w.data(), NT * 32, DC_E, false, s->film_mode == 2);
+    add_packed(&m.film_w, film_w.data(), NT * 32, DC_E, false, s->film_fmt == 1);
     add_ft(&m.film_b, film_b.data(), NT * 32, NT);
-    add_packed(&m.je_w, P_("joint_embed.weight"), D, P, true);
+    add_ft(&m.film_g, film_g.data(), 3 * L * 128, 3 * L * 4);
+    add_ft(&m.film_beta, film_beta.data(), 3 * L * 128, 3 * L * 4);
+    add_packed(&m.je_w, P_("joint_embed.weight"), D, P, true, sf16);
     add_ft(&m.je_b, P_("joint_embed.bias"), D, 4);
     add_raw(&m.seq_emb, P_("sequence_embedding"), (size_t)c.num_frames * D);
-    add_packed(&m.out_w, P_("out.weight"), P, D, true);
+    add_packed(&m.out_w, P_("out.weight"), P, D, true, sf16);
     add_ft(&m.out_b, P_("out.bias"), P, 1);
     {
         const float* w = P_("linear.weight");   // [512][64] -> transposed [64][512]
@@ -483,19 +512,19 @@ struct Timed {   // RAII-less helper: wraps a launch with events when profiling
 // One denoiser evaluation (+ DDIM update when loop_mode) enqueued on st.
 int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_src, float* x_dst) {
     const int B = s->B, T = s->T, M = s->M, G = s->G, L = s->cfg.num_layers;
-    const bool ss = s->split_small;
-    const int sf = s->film_mode;
+    const bool ss = s->split_small, sf = s->split_film;
+    const int fs = s->small_fmt, ff = s->film_fmt;
     if (loop_mode)
         LAUNCH(K_BEGIN, dc_launch_begin_step(st, s->d_iter, s->d_t_of_iter, s->d_coef_of_t, s->d_snap_of_iter,
                                              s->d_t_clip, s->d_coef_cur, s->d_snap_cur, B));
-    LAUNCH(K_SILU, dc_launch_silu_emb(st, sf, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, G, T, B));
-    LAUNCH(K_FILM, dc_launch_film_gemm(st, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT));
-    LAUNCH(K_EMBED, dc_launch_embed_front(st, ss, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G));
+    LAUNCH(K_SILU, dc_launch_silu_emb(st, ff, sf, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, G, T, B));
+    LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->h_model.film_g, s->h_model.film_beta, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT));
+    LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G));
     const int nl_run = (s->dbg_layers >= 0 && s->dbg_layers < L) ? s->dbg_layers : L;
     for (int l = 0; l < nl_run; ++l) {
         const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
-        LAUNCH(K_COMBINE, dc_launch_attn_combine(st, s->d_recs, s->d_a_sa, T, G, B, 1));
-        LAUNCH(K_LAYER, dc_launch_layer(st, ss, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
+        LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, G, B, 1));
+        LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur,
                                         s->d_snaps, M, T, G, B, dbg));
     }
@@ -640,7 +669,7 @@ int dc_sampler_create(const dc_config* cfg, dc_sampler** out) {
     if (cfg->input_feats < 1 || cfg->input_feats > DC_PMAX) return fail(DC_ERR_UNSUPPORTED, "input_feats must be in [1,32]");
     if (cfg->num_layers < 1 || cfg->num_layers > DC_MAX_LAYERS) return fail(DC_ERR_UNSUPPORTED, "num_layers must be in [1,%d]", DC_MAX_LAYERS);
     if (cfg->no_eff) return fail(DC_ERR_UNSUPPORTED, "no_eff (full T x T attention) is not built yet");
-    if (cfg->precision < DC_PREC_BF16 || cfg->precision > DC_PREC_BF16X3) return fail(DC_ERR_INVALID, "unknown precision %d", cfg->precision);
+    if (cfg->precision < DC_PREC_BF16 || cfg->precision > DC_PREC_FP16) return fail(DC_ERR_INVALID, "unknown precision %d", cfg->precision);
     if (cfg->max_timesteps < 1) return fail(DC_ERR_INVALID, "max_timesteps must be >= 1");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(DC_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
@@ -652,8 +681,10 @@ int dc_sampler_create(const dc_config* cfg, dc_sampler** out) {
         return fail(DC_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", cfg->device, prop.gcnArchName);
     dc_sampler* s = new dc_sampler();
     s->cfg = *cfg;
-    s->split_small = cfg->precision != DC_PREC_BF16;
-    s->film_mode = cfg->precision == DC_PREC_BF16X3 ? 1 : (cfg->precision == DC_PREC_MIXED ? 2 : 0);
+    s->split_small = cfg->precision == DC_PREC_MIXED || cfg->precision == DC_PREC_BF16X3;
+    s->split_film = cfg->precision == DC_PREC_BF16X3;
+    s->small_fmt = cfg->precision == DC_PREC_FP16 ? 1 : 0;
+    s->film_fmt = (cfg->precision == DC_PREC_FP16 || cfg->precision == DC_PREC_MIXED) ? 1 : 0;
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming) != hipSuccess) {
@@ -734,8 +765,8 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
     HIP_TRY(dc_launch_row_stats(st, s->d_y, s->d_mean, s->d_rstd, Mpad));
     HIP_TRY(dc_launch_cond_pack(st, 1, s->d_y, s->d_mean, s->d_rstd, nullptr, s->d_nh_hi, s->d_nh_lo, G));
     // one-time cost: always split precision (plain bf16 here alone costs ~2e-3 on A_cross)
-    HIP_TRY(dc_launch_ca_partials(st, true, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_recs_ca, M, T, G, L));
-    HIP_TRY(dc_launch_attn_combine(st, s->d_recs_ca, s->d_a_ca, T, G, B, L));
+    HIP_TRY(dc_launch_ca_partials(st, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_recs_ca, M, T, G, L));
+    HIP_TRY(dc_launch_attn_combine(st, s->small_fmt, s->d_recs_ca, s->d_a_ca, T, G, B, L));
     HIP_TRY(hipStreamSynchronize(st));   // `len` is host memory
     s->cond_set = true;
     return sync_out(s, user);

@@ -39,25 +39,24 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 struct bf16x8 { uint16_t v[8]; };
 #endif
 
-// Device pointers to the packed weight image of one StylizationBlock
+// Device pointers to the packed weight image of one StylizationBlock.  Its LayerNorm affine is folded
+// into the FiLM GEMM's epilogue (E holds G' = g*(1+scale) and H' = b*(1+scale)+shift).
 struct DcStyl {
-    const float* ln_g;   // ftvec [4][2][16]
-    const float* ln_b;
     const bf16x8* wo;    // chained pack, OT=4 KT=4 (hi frags then lo frags)
     const float* bo;     // ftvec
 };
 
+// LayerNorm affines preceding a projection are folded into it on the host:
+//   W (g*n + b) + c = (W diag(g)) n + (W b + c),  n = (x - mean) * rstd
 struct DcLayer {
-    const float *sa_ln_g, *sa_ln_b;            // ftvec
-    const bf16x8 *sa_wq, *sa_wk, *sa_wv;       // chained pack 4x4
+    const bf16x8 *sa_wq, *sa_wk, *sa_wv;       // chained pack 4x4 (sa_block.norm folded in)
     const float *sa_bq;                        // ftvec
     const float *sa_bk, *sa_bv;                // plain [128]
     DcStyl sa_styl;
-    const float *ca_ln_g, *ca_ln_b;            // ftvec
-    const bf16x8* ca_wq;
+    const bf16x8* ca_wq;                       // (ca_block.norm folded in)
     const float* ca_bq;                        // ftvec
-    const bf16x8 *ca_wk, *ca_wv;               // natural-k pack, OT=4, KS=32 (text_norm folded in)
-    const float *ca_bk, *ca_bv;                // plain [128] (text_norm bias folded in)
+    const bf16x8 *ca_wk, *ca_wv;               // natural-k pack, OT=4, KS=32 (text_norm folded in), bf16
+    const float *ca_bk, *ca_bv;                // plain [128]
     DcStyl ca_styl;
     const bf16x8 *ffn_w1;                      // chained pack OT=2 KT=4
     const bf16x8 *ffn_w2;                      // chained pack OT=4 KT=2
@@ -74,6 +73,8 @@ struct DcModel {
     const float* out_b;      // ftvec (1 tile)
     const bf16x8* film_w;    // natural-k pack [3*L*8 tiles][32 ks], hi then lo; bf16 or f16 bits (film format)
     const float* film_b;     // ftvec [3*L*8 tiles]
+    const float* film_g;     // ftvec [3*L*4 tiles]: StylizationBlock.norm weight per block
+    const float* film_beta;  // ftvec [3*L*4 tiles]: StylizationBlock.norm bias per block
     const float* lin_wt;     // `linear` weight transposed [64][512]
     const float* lin_b;      // [512]
     const float* temb;       // [max_timesteps][512]

@@ -1,18 +1,21 @@
 // dc_kernels.hip - hand-written gfx950 (CDNA4) kernels of the DDIM denoising step.
 //
 // Design: every activation lives in "FT" form - a stack of 32x32 fp32
-// tiles in the v_mfma_f32_32x32x16_bf16 accumulator layout with the TOKEN on the lane
-// and the FEATURES in registers.  Consequences:
+// tiles in the v_mfma_f32_32x32x16 accumulator layout with the TOKEN on the lane and the
+// FEATURES in registers.  Consequences:
 //   * per-token reductions over features (LayerNorm, softmax over head_dim, FiLM) are
-//     in-lane register reductions plus ONE exchange with lane^32;
-//   * an accumulator tile converts in registers (v_cvt_pk_bf16_f32) into the B operand
-//     of the next MFMA (W * X) or the A operand (X^T * W), so the whole
+//     in-lane register reductions plus ONE v_permlane32_swap with lane^32;
+//   * an accumulator tile converts in registers (v_cvt_pk) into the B operand of the next
+//     MFMA (W * X) or the A operand (X^T * W), so the whole
 //     LN -> QKV -> softmax -> attention -> FiLM -> out-proj -> FFN chain of one token
 //     group never leaves the register file; weights are pre-packed host-side in the
-//     matching fragment order so each operand is one coalesced 16-B-per-lane load;
+//     matching fragment order so each operand is one 16-B-per-lane access;
 //   * the only cross-token dependency per layer (softmax over the sequence of K and
 //     K^T V of the linear attention) is a two-phase reduction: per-group partial
 //     records (k_embed_front / k_layer) -> k_attn_combine.
+//
+// Operand formats: T16 = __bf16 or _Float16 (same MFMA rate on gfx950), optionally SPLIT
+// (x = hi + lo, three MFMAs per product: hi*hi + lo*hi + hi*lo) for ~fp32 accuracy.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "dc_common.h"
@@ -21,12 +24,18 @@
 
 namespace dc {
 
-DEV f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-DEV f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
+template <class T> struct V8;
+template <> struct V8<__bf16> { using type = bf16x8; };
+template <> struct V8<_Float16> { using type = f16x8; };
+template <class T> using v8 = typename V8<T>::type;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+template <class T> struct V4;
+template <> struct V4<__bf16> { using type = bf16x4; };
+template <> struct V4<_Float16> { using type = f16x4; };
+template <class T> using v4 = typename V4<T>::type;
+
+DEV f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+DEV f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 // value of the partner lane (lane ^ 32) combined with this lane's: one v_permlane32_swap, no LDS
 DEV float xhalf_sum(float v) {
@@ -50,78 +59,81 @@ DEV f32x16 splat(float v) {
 }
 
 // One 32-row tile as MFMA operand fragments for its two 16-deep k-steps (hi [+ lo]).
-template <bool SPLIT>
+template <class T16, bool SPLIT>
 struct XFrag {
-    bf16x8 hi[2];
-    bf16x8 lo[SPLIT ? 2 : 1];
+    v8<T16> hi[2];
+    v8<T16> lo[SPLIT ? 2 : 1];
 };
 
-template <bool SPLIT>
-DEV void make_frag(const f32x16& x, XFrag<SPLIT>& f) {
+template <class T16, bool SPLIT>
+DEV void make_frag(const f32x16& x, XFrag<T16, SPLIT>& f) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float v = x[8 * s + j];
-            const __bf16 h = (__bf16)v;
+            const T16 h = (T16)v;
             f.hi[s][j] = h;
-            if constexpr (SPLIT) f.lo[s][j] = (__bf16)(v - (float)h);
+            if constexpr (SPLIT) f.lo[s][j] = (T16)(v - (float)h);
         }
 }
 
-template <bool SPLIT>
-DEV void mask_frag(XFrag<SPLIT>& f, bool keep) {
+template <class T16, bool SPLIT>
+DEV void mask_frag(XFrag<T16, SPLIT>& f, bool keep) {
     if (!keep) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                f.hi[s][j] = (__bf16)0.f;
-                if constexpr (SPLIT) f.lo[s][j] = (__bf16)0.f;
+                f.hi[s][j] = (T16)0.f;
+                if constexpr (SPLIT) f.lo[s][j] = (T16)0.f;
             }
     }
 }
 
-// acc[ot] (rows = output features, cols = tokens) += W[ot][kt] * X[kt]; weights are the A operand.
-template <int OT, int KT, bool SPLIT>
-DEV void gemm_wa(f32x16 (&acc)[OT], const bf16x8* __restrict__ w, const XFrag<SPLIT> (&x)[KT], int lane) {
+// Weight image order (chained pack): [hi | lo][kt][ot][s][64 lanes][8]  (kt-major).  NF = OT*KT*2 frags per half.
+//
+// acc[ot] (rows = output features, cols = tokens) += W[ot][kt] * X[kt] for ONE k-tile; weights are the A operand.
+template <int OT, int KT, class T16, bool SPLIT>
+DEV void mma_kt(f32x16 (&acc)[OT], const v8<T16>* __restrict__ w, int kt, const XFrag<T16, SPLIT>& x, int lane) {
     constexpr int NF = OT * KT * 2;
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int fi = (ot * KT + kt) * 2 + s;
-                const bf16x8 a = w[fi * 64 + lane];
-                acc[ot] = mfma(a, x[kt].hi[s], acc[ot]);
-                if constexpr (SPLIT) {
-                    acc[ot] = mfma(a, x[kt].lo[s], acc[ot]);
-                    const bf16x8 al = w[(NF + fi) * 64 + lane];
-                    acc[ot] = mfma(al, x[kt].hi[s], acc[ot]);
-                }
+        for (int s = 0; s < 2; ++s) {
+            const int fi = (kt * OT + ot) * 2 + s;
+            const v8<T16> a = w[fi * 64 + lane];
+            acc[ot] = mfma(a, x.hi[s], acc[ot]);
+            if constexpr (SPLIT) {
+                acc[ot] = mfma(a, x.lo[s], acc[ot]);
+                const v8<T16> al = w[(NF + fi) * 64 + lane];
+                acc[ot] = mfma(al, x.hi[s], acc[ot]);
             }
+        }
+}
+template <int OT, int KT, class T16, bool SPLIT>
+DEV void gemm_wa(f32x16 (&acc)[OT], const v8<T16>* __restrict__ w, const XFrag<T16, SPLIT> (&x)[KT], int lane) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) mma_kt<OT, KT, T16, SPLIT>(acc, w, kt, x[kt], lane);
 }
 
-// acc[oc] (rows = tokens, cols = output features) += X^T[kt] * W[oc][kt]; weights are the B operand.
-template <int OC, int KT, bool SPLIT>
-DEV void gemm_wb(f32x16 (&acc)[OC], const bf16x8* __restrict__ w, const XFrag<SPLIT> (&x)[KT], int lane) {
+// acc (rows = tokens, cols = output features of tile oc) += X^T * W[oc] over all k-tiles; weights are the B operand.
+template <int OC, int KT, class T16, bool SPLIT>
+DEV void mmb_oc(f32x16& acc, const v8<T16>* __restrict__ w, int oc, const XFrag<T16, SPLIT> (&x)[KT], int lane) {
     constexpr int NF = OC * KT * 2;
 #pragma unroll
-    for (int oc = 0; oc < OC; ++oc)
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int fi = (oc * KT + kt) * 2 + s;
-                const bf16x8 b = w[fi * 64 + lane];
-                acc[oc] = mfma(x[kt].hi[s], b, acc[oc]);
-                if constexpr (SPLIT) {
-                    acc[oc] = mfma(x[kt].lo[s], b, acc[oc]);
-                    const bf16x8 bl = w[(NF + fi) * 64 + lane];
-                    acc[oc] = mfma(x[kt].hi[s], bl, acc[oc]);
-                }
+        for (int s = 0; s < 2; ++s) {
+            const int fi = (kt * OC + oc) * 2 + s;
+            const v8<T16> b = w[fi * 64 + lane];
+            acc = mfma(x[kt].hi[s], b, acc);
+            if constexpr (SPLIT) {
+                acc = mfma(x[kt].lo[s], b, acc);
+                const v8<T16> bl = w[(NF + fi) * 64 + lane];
+                acc = mfma(x[kt].hi[s], bl, acc);
             }
+        }
 }
 
 // per-feature vector stored as [tile][lane-half][16] so a lane reads its 16 values with one 64-B load
@@ -131,14 +143,13 @@ DEV f32x16 ld_ft(const float* __restrict__ p, int tile, int hh) {
 
 // nn.LayerNorm(128) over the feature axis of an FT activation (transformer.py:79,104,147)
 template <int NT>
-DEV void layernorm_ft(const f32x16 (&x)[NT], f32x16 (&y)[NT], const float* __restrict__ g,
-                      const float* __restrict__ b, int hh) {
+DEV void ln_stats(const f32x16 (&x)[NT], float& mean, float& rstd) {
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += x[t][r];
-    const float mean = xhalf_sum(s) * (1.f / (32 * NT));
+    mean = xhalf_sum(s) * (1.f / (32 * NT));
     float q = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -147,12 +158,20 @@ DEV void layernorm_ft(const f32x16 (&x)[NT], f32x16 (&y)[NT], const float* __res
             const float d = x[t][r] - mean;
             q += d * d;
         }
-    const float rstd = rsqrtf(xhalf_sum(q) * (1.f / (32 * NT)) + 1e-5f);
+    rstd = rsqrtf(xhalf_sum(q) * (1.f / (32 * NT)) + 1e-5f);
+}
+// operand fragments of the normalised x (the LayerNorm affine is folded into the projection that follows)
+template <class T16, bool SPLIT>
+DEV void ln_frags(XFrag<T16, SPLIT> (&nf)[4], const f32x16 (&x)[4]) {
+    float mean, rstd;
+    ln_stats<4>(x, mean, rstd);
+    const float shift = -mean * rstd;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const f32x16 gg = ld_ft(g, t, hh), bb = ld_ft(b, t, hh);
+    for (int kt = 0; kt < 4; ++kt) {
+        f32x16 n;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[t][r] = (x[t][r] - mean) * rstd * gg[r] + bb[r];
+        for (int r = 0; r < 16; ++r) n[r] = fmaf(x[kt][r], rstd, shift);
+        make_frag<T16, SPLIT>(n, nf[kt]);
     }
 }
 
@@ -181,24 +200,17 @@ DEV void softmax_heads_ft(f32x16 (&q)[4]) {
 }
 
 DEV float silu(float z) { return z * fast_rcp(1.f + __expf(-z)); }
-DEV float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-
-// y = softmax(Q) . A per head, i.e. FT tile oc of y = A_frag[oc]^T-as-A-operand * Q tile oc.
-// afrag: [4 oc][2 s][64 lanes] hi frags, followed by the same count of lo frags.
-template <bool SPLIT>
-DEV void attn_apply(f32x16 (&y)[4], const bf16x8* __restrict__ afrag, const XFrag<SPLIT> (&q)[4], int lane) {
-#pragma unroll
-    for (int oc = 0; oc < 4; ++oc)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const bf16x8 a = afrag[(oc * 2 + s) * 64 + lane];
-            y[oc] = mfma(a, q[oc].hi[s], y[oc]);
-            if constexpr (SPLIT) {
-                y[oc] = mfma(a, q[oc].lo[s], y[oc]);
-                const bf16x8 al = afrag[(8 + oc * 2 + s) * 64 + lane];
-                y[oc] = mfma(al, q[oc].hi[s], y[oc]);
-            }
-        }
+// nn.GELU() (exact-erf form).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 noise of the
+// surrounding GEMMs): erf(a) = 1 - (a1 t + ... + a5 t^5) exp(-a^2), t = 1/(1 + p a), a >= 0.
+DEV float gelu_erf(float x) {
+    const float a = fabsf(x) * 0.70710678118654752440f;
+    const float t = fast_rcp(fmaf(0.3275911f, a, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erfa = 1.f - poly * t * __expf(-a * a);
+    return 0.5f * x * (1.f + copysignf(erfa, x));
 }
 
 // token group geometry shared by the per-group kernels
@@ -228,100 +240,64 @@ DEV GroupCtx make_ctx(int g, int lane, int M, int T) {
     return x;
 }
 
-// StylizationBlock.forward (transformer.py:68-81) given the precomputed FiLM tiles
-// E (fp16 FT tiles: 4 scale tiles then 4 shift tiles for this block and group):
-//   o = W_o * SiLU( LN(y) * (1 + scale) + shift ) + b_o
-template <bool SPLIT>
-DEV void stylization(f32x16 (&o)[4], const f32x16 (&y)[4], const f16x16* __restrict__ E,
-                     const DcStyl& w, int lane, int hh) {
-    f32x16 n[4];
-    layernorm_ft<4>(y, n, w.ln_g, w.ln_b, hh);
-    XFrag<SPLIT> a[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const f16x16 sc = E[t * 64 + lane];
-        const f16x16 sh = E[(4 + t) * 64 + lane];
-        f32x16 z;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = silu(n[t][r] * (1.f + (float)sc[r]) + (float)sh[r]);
-        make_frag<SPLIT>(z, a[t]);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) o[t] = ld_ft(w.bo, t, hh);
-    gemm_wa<4, 4, SPLIT>(o, w.wo, a, lane);
+// Rows (tokens, TF layout) of a group that belong to the slot's clip and are unmasked form one interval
+// [lo, lo + span) of group-local row indices (src_mask of transformer.py:107,114; `length` == nullptr means no
+// mask, as in cross-attention).  Stored per lane with the lane-half offset folded in: register r is valid
+// iff (unsigned)(crow(r) - lo) < span, crow(r) = (r&3) + 8*(r>>2).
+struct RowRange {
+    int lo;
+    unsigned span;
+};
+DEV RowRange valid_rows(const GroupCtx& cx, int slot, int M, int T, const int* __restrict__ length) {
+    const int bs = slot == 0 ? cx.b0 : cx.b1;
+    const int len = length ? length[bs] : T;
+    const int first = max(bs * T, 32 * cx.g);                         // first valid token
+    const int end = min(min(bs * T + min(len, T), M), 32 * cx.g + 32);   // one past the last valid token
+    RowRange rr;
+    rr.lo = first - 32 * cx.g - 4 * cx.hh;
+    rr.span = end > first ? (unsigned)(end - first) : 0u;
+    return rr;
 }
+DEV bool row_ok(const RowRange& rr, int r) { return (unsigned)(((r & 3) + 8 * (r >> 2)) - rr.lo) < rr.span; }
 
-// "Front half" of LinearTemporalSelfAttention (transformer.py:104-117) for one group:
-// n = LN(h); K = Wk n + bk; V = Wv n + bv in TF form; then the group's partial record
-// of softmax_T(K + mask) and K^T V, one record per clip the group touches.
-template <bool SPLIT>
-DEV void sa_front(const f32x16 (&h)[4], const DcLayer& L, const GroupCtx& cx, int M, int T,
-                  const int* __restrict__ length, float* __restrict__ rec /* this group's 2 records */) {
-    f32x16 n[4];
-    layernorm_ft<4>(h, n, L.sa_ln_g, L.sa_ln_b, cx.hh);
-    XFrag<SPLIT> nf[4];
+// One 32-feature tile of a group's partial record: column max m, column sum of exp(K-m), and
+// exp(K-m)^T V (32x32, of which the two diagonal 16x16 head blocks are used by the combine).
+template <class T16, bool SPLIT>
+DEV void emit_partial(const f32x16& K, const f32x16& V, int oc, const RowRange& rr, float* __restrict__ R,
+                      const GroupCtx& cx) {
+    float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) make_frag<SPLIT>(n[t], nf[t]);
-    f32x16 K[4], V[4];
+    for (int r = 0; r < 16; ++r) m = row_ok(rr, r) ? fmaxf(m, K[r]) : m;
+    m = xhalf_max(m);
+    if (m == -INFINITY) m = 0.f;
+    f32x16 Ee, Vm;
+    float ssum = 0.f;
 #pragma unroll
-    for (int oc = 0; oc < 4; ++oc) {
-        K[oc] = splat(L.sa_bk[32 * oc + cx.c]);
-        V[oc] = splat(L.sa_bv[32 * oc + cx.c]);
+    for (int r = 0; r < 16; ++r) {
+        const bool ok = row_ok(rr, r);
+        const float e = ok ? __expf(K[r] - m) : 0.f;
+        Ee[r] = e;
+        ssum += e;
+        Vm[r] = ok ? V[r] : 0.f;
     }
-    gemm_wb<4, 4, SPLIT>(K, L.sa_wk, nf, cx.lane);
-    gemm_wb<4, 4, SPLIT>(V, L.sa_wv, nf, cx.lane);
-
-    const int nslot = cx.straddle ? 2 : 1;
-    for (int slot = 0; slot < nslot; ++slot) {
-        const int bs = slot == 0 ? cx.b0 : cx.b1;
-        const int len = length[bs];
-        const int base = bs * T;
-        unsigned valid = 0;   // bit r: token of register r belongs to clip bs and is unmasked
+    ssum = xhalf_sum(ssum);
+    XFrag<T16, SPLIT> ef, vf;
+    make_frag<T16, SPLIT>(Ee, ef);
+    make_frag<T16, SPLIT>(Vm, vf);
+    f32x16 P = splat(0.f);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tk = 32 * cx.g + tile_row(r, cx.hh);
-            const int nn = tk - base;
-            if (tk < M && nn >= 0 && nn < T && nn < len) valid |= 1u << r;
-        }
-        float* R = rec + (size_t)slot * DC_REC_FLOATS;
-#pragma unroll
-        for (int oc = 0; oc < 4; ++oc) {
-            float m = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (valid & (1u << r)) m = fmaxf(m, K[oc][r]);
-            m = xhalf_max(m);
-            if (m == -INFINITY) m = 0.f;
-            f32x16 Ee, Vm;
-            float ssum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool ok = valid & (1u << r);
-                const float e = ok ? __expf(K[oc][r] - m) : 0.f;
-                Ee[r] = e;
-                ssum += e;
-                Vm[r] = ok ? V[oc][r] : 0.f;
-            }
-            ssum = xhalf_sum(ssum);
-            XFrag<SPLIT> ef, vf;
-            make_frag<SPLIT>(Ee, ef);
-            make_frag<SPLIT>(Vm, vf);
-            f32x16 P = splat(0.f);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                P = mfma(ef.hi[s], vf.hi[s], P);
-                if constexpr (SPLIT) {
-                    P = mfma(ef.lo[s], vf.hi[s], P);
-                    P = mfma(ef.hi[s], vf.lo[s], P);
-                }
-            }
-            if (cx.hh == 0) {
-                R[32 * oc + cx.c] = m;
-                R[128 + 32 * oc + cx.c] = ssum;
-            }
-            reinterpret_cast<f32x16*>(R + 256)[oc * 64 + cx.lane] = P;
+    for (int s = 0; s < 2; ++s) {
+        P = mfma(ef.hi[s], vf.hi[s], P);
+        if constexpr (SPLIT) {
+            P = mfma(ef.lo[s], vf.hi[s], P);
+            P = mfma(ef.hi[s], vf.lo[s], P);
         }
     }
+    if (cx.hh == 0) {
+        R[32 * oc + cx.c] = m;
+        R[128 + 32 * oc + cx.c] = ssum;
+    }
+    reinterpret_cast<f32x16*>(R + 256)[oc * 64 + cx.lane] = P;
 }
 
 DEV void load_h(f32x16 (&h)[4], const float* __restrict__ hbuf, int g, int lane) {
@@ -333,6 +309,29 @@ DEV void store_h(const f32x16 (&h)[4], float* __restrict__ hbuf, int g, int lane
     f32x16* p = reinterpret_cast<f32x16*>(hbuf) + (size_t)g * 256 + lane;
 #pragma unroll
     for (int t = 0; t < 4; ++t) p[t * 64] = h[t];
+}
+
+// "Front half" of LinearTemporalSelfAttention (transformer.py:104-117) for one group, given the
+// operand fragments nf of n = LN(h): K = Wk n + bk, V = Wv n + bv in TF form, then the group's
+// partial record(s) of softmax_T(K + mask) and K^T V - one per clip the group touches.
+template <class T16, bool SPLIT>
+DEV void sa_front(const XFrag<T16, SPLIT> (&nf)[4], const v8<T16>* __restrict__ wk, const v8<T16>* __restrict__ wv,
+                  const float* __restrict__ bk, const float* __restrict__ bv, const GroupCtx& cx, int M, int T,
+                  const int* __restrict__ length, float* __restrict__ rec, bool active) {
+    const RowRange valid0 = valid_rows(cx, 0, M, T, length);
+    const RowRange valid1 = valid_rows(cx, cx.straddle ? 1 : 0, M, T, length);
+#pragma unroll
+    for (int oc = 0; oc < 4; ++oc) {
+        f32x16 K = splat(bk[32 * oc + cx.c]);
+        f32x16 V = splat(bv[32 * oc + cx.c]);
+        mmb_oc<4, 4, T16, SPLIT>(K, wk, oc, nf, cx.lane);
+        mmb_oc<4, 4, T16, SPLIT>(V, wv, oc, nf, cx.lane);
+        if (active) {
+            emit_partial<T16, SPLIT>(K, V, oc, valid0, rec, cx);
+            if (cx.straddle) emit_partial<T16, SPLIT>(K, V, oc, valid1, rec + DC_REC_FLOATS, cx);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the four feature tiles sequential: bounds register pressure
+    }
 }
 
 }  // namespace dc
@@ -428,7 +427,7 @@ __global__ void k_row_stats512(const float* __restrict__ y, float* __restrict__ 
 }
 
 // row-major [Mpad][512] fp32 -> fragment-major: element (g, ks, lane, j) = y[32g + (lane&31)][16ks + 8(lane>>5) + j]
-// MODE 0: fp32 image (the xf_proj' term of emb);  MODE 1: normalised, bf16 hi (+lo) operand image.
+// MODE 0: fp32 image (the xf_proj' term of emb);  MODE 1: normalised, bf16 hi + lo operand images.
 template <int MODE>
 __global__ void k_cond_pack(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ rstd,
                             float* __restrict__ out_f32, bf16x8* __restrict__ out_hi, bf16x8* __restrict__ out_lo, int G) {
@@ -451,14 +450,14 @@ __global__ void k_cond_pack(const float* __restrict__ y, const float* __restrict
             lo[j] = (__bf16)(n - (float)hi[j]);
         }
         out_hi[idx] = hi;
-        if (out_lo) out_lo[idx] = lo;
+        out_lo[idx] = lo;
     }
 }
 
 // Cross-attention K/V for every layer + their partial records (transformer.py:149-155):
 // K = Wk' nhat + bk', V = Wv' nhat + bv' with text_norm's affine folded into Wk'/Wv'.
 // grid (ceil(G/4), L); one wave per (group, layer).  CA has no mask: every real token is valid.
-template <bool SPLIT>
+// One-time cost per batch, so always split-bf16 (plain bf16 here alone costs ~2e-3 on the matrices).
 __global__ __launch_bounds__(256) void k_cond_ca_partials(const DcModel* __restrict__ dm, const bf16x8* __restrict__ nh_hi,
                                                           const bf16x8* __restrict__ nh_lo, float* __restrict__ recs,
                                                           int M, int T, int G) {
@@ -477,81 +476,39 @@ __global__ __launch_bounds__(256) void k_cond_ca_partials(const DcModel* __restr
     constexpr int NF = 4 * DC_KS_E;
     for (int ks = 0; ks < DC_KS_E; ++ks) {
         const bf16x8 a = nh_hi[((size_t)g * DC_KS_E + ks) * 64 + lane];
-        bf16x8 al;
-        if constexpr (SPLIT) al = nh_lo[((size_t)g * DC_KS_E + ks) * 64 + lane];
+        const bf16x8 al = nh_lo[((size_t)g * DC_KS_E + ks) * 64 + lane];
 #pragma unroll
         for (int oc = 0; oc < 4; ++oc) {
-            const bf16x8 bk = L.ca_wk[(oc * DC_KS_E + ks) * 64 + lane];
-            const bf16x8 bv = L.ca_wv[(oc * DC_KS_E + ks) * 64 + lane];
+            const int fi = ((ks >> 1) * 4 + oc) * 2 + (ks & 1);   // kt-major image
+            const bf16x8 bk = L.ca_wk[fi * 64 + lane];
+            const bf16x8 bv = L.ca_wv[fi * 64 + lane];
             K[oc] = mfma(a, bk, K[oc]);
             V[oc] = mfma(a, bv, V[oc]);
-            if constexpr (SPLIT) {
-                K[oc] = mfma(al, bk, K[oc]);
-                V[oc] = mfma(al, bv, V[oc]);
-                K[oc] = mfma(a, L.ca_wk[((NF + oc * DC_KS_E + ks)) * 64 + lane], K[oc]);
-                V[oc] = mfma(a, L.ca_wv[((NF + oc * DC_KS_E + ks)) * 64 + lane], V[oc]);
-            }
+            K[oc] = mfma(al, bk, K[oc]);
+            V[oc] = mfma(al, bv, V[oc]);
+            K[oc] = mfma(a, L.ca_wk[(NF + fi) * 64 + lane], K[oc]);
+            V[oc] = mfma(a, L.ca_wv[(NF + fi) * 64 + lane], V[oc]);
         }
     }
     float* rec = recs + ((size_t)l * G + g) * 2 * DC_REC_FLOATS;
     const int nslot = cx.straddle ? 2 : 1;
     for (int slot = 0; slot < nslot; ++slot) {
-        const int bs = slot == 0 ? cx.b0 : cx.b1;
-        const int base = bs * T;
-        unsigned valid = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tk = 32 * g + tile_row(r, cx.hh);
-            const int nn = tk - base;
-            if (tk < M && nn >= 0 && nn < T) valid |= 1u << r;
-        }
+        const RowRange valid = valid_rows(cx, slot, M, T, nullptr);
         float* R = rec + (size_t)slot * DC_REC_FLOATS;
 #pragma unroll
-        for (int oc = 0; oc < 4; ++oc) {
-            float m = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (valid & (1u << r)) m = fmaxf(m, K[oc][r]);
-            m = xhalf_max(m);
-            if (m == -INFINITY) m = 0.f;
-            f32x16 Ee, Vm;
-            float ssum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool ok = valid & (1u << r);
-                const float e = ok ? __expf(K[oc][r] - m) : 0.f;
-                Ee[r] = e;
-                ssum += e;
-                Vm[r] = ok ? V[oc][r] : 0.f;
-            }
-            ssum = xhalf_sum(ssum);
-            // cross-attention K^T V always in split precision: it is step-invariant (one-time cost)
-            XFrag<true> ef, vf;
-            make_frag<true>(Ee, ef);
-            make_frag<true>(Vm, vf);
-            f32x16 P = splat(0.f);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                P = mfma(ef.hi[s], vf.hi[s], P);
-                P = mfma(ef.lo[s], vf.hi[s], P);
-                P = mfma(ef.hi[s], vf.lo[s], P);
-            }
-            if (cx.hh == 0) {
-                R[32 * oc + cx.c] = m;
-                R[128 + 32 * oc + cx.c] = ssum;
-            }
-            reinterpret_cast<f32x16*>(R + 256)[oc * 64 + lane] = P;
-        }
+        for (int oc = 0; oc < 4; ++oc) emit_partial<__bf16, true>(K[oc], V[oc], oc, valid, R, cx);
     }
 }
 
 // ------------------------------------------------------------------------------------
 // combine partial records of one (set, clip, 32-feature tile) into attention operand frags
 //   A[d][l] = sum_g w_g[d] P_g[d][l] / sum_g w_g[d] ssum_g[d],   w_g = exp(m_g - max_g m_g)
-// recs: [nset][G][2][DC_REC_FLOATS]; afrag out: [nset][B][16 frags (8 hi, 8 lo)][64] bf16x8.
+// recs: [nset][G][2][DC_REC_FLOATS]; afrag out: [nset][B][16 frags (8 hi, 8 lo)][64 lanes][8] T16.
 // grid (B, 4, nset), 256 threads: thread (lane, rq) owns registers 4rq..4rq+3 of the tile.
+// All sums run in a fixed order: re-running is bit-identical.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ recs, bf16x8* __restrict__ afrag,
+template <class T16>
+__global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ recs, v8<T16>* __restrict__ afrag,
                                                       int T, int G, int B) {
     extern __shared__ float sm[];   // w[ng][32], z[32], red[8][32]
     const int b = blockIdx.x, oc = blockIdx.y, set = blockIdx.z;
@@ -599,11 +556,11 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
     if (tid < 32) {
         float zz = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) zz += red[k * 32 + tid];   // fixed order: deterministic
+        for (int k = 0; k < 8; ++k) zz += red[k * 32 + tid];
         z[tid] = zz;
     }
     __syncthreads();
-    // phase 3: weighted sum of the partial K^T V tiles, groups in order (deterministic)
+    // phase 3: weighted sum of the partial K^T V tiles, groups in order
     const int lane = tid & 63, rq = tid >> 6;
     const int c = lane & 31, hh = lane >> 5;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -624,29 +581,28 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
         for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[gi * 32 + row0 + i], p[i], acc[i]);
     }
     const bool keep = (rq >> 1) == (c >> 4);   // same head on both sides
-    bf16x4 hi, lo;
+    v4<T16> hi, lo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float zz = z[row0 + i];
         const float a = (keep && zz > 0.f) ? acc[i] / zz : 0.f;
-        hi[i] = (__bf16)a;
-        lo[i] = (__bf16)(a - (float)hi[i]);
+        hi[i] = (T16)a;
+        lo[i] = (T16)(a - (float)hi[i]);
     }
     // register r = 4rq+i of the tile  ->  k-step s = r>>3, element j = r&7 of the A-operand frag
-    bf16x8* out = afrag + ((size_t)set * B + b) * 16 * 64;
+    v8<T16>* out = afrag + ((size_t)set * B + b) * 16 * 64;
     const int s = rq >> 1, j0 = (rq & 1) * 4;
-    reinterpret_cast<bf16x4*>(out + ((oc * 2 + s) * 64 + lane))[j0 >> 2] = hi;
-    reinterpret_cast<bf16x4*>(out + ((8 + oc * 2 + s) * 64 + lane))[j0 >> 2] = lo;
+    reinterpret_cast<v4<T16>*>(out + ((oc * 2 + s) * 64 + lane))[j0 >> 2] = hi;
+    reinterpret_cast<v4<T16>*>(out + ((8 + oc * 2 + s) * 64 + lane))[j0 >> 2] = lo;
 }
 
 // ------------------------------------------------------------------------------------
 // per step: S = SiLU(time_embed[t] + xf_proj')  (transformer.py:482 + StylizationBlock's nn.SiLU, :57-58)
-// as the bf16 B-operand image of the FiLM GEMM, [G][32 ks][64 lanes][8]
+// as the 16-bit B-operand image of the FiLM GEMM, [G][32 ks][64 lanes][8]
 // ------------------------------------------------------------------------------------
-// FMODE: 0 = bf16, 1 = split bf16 (hi + lo images), 2 = f16
-template <int FMODE>
+template <class T16, bool SPLIT>
 __global__ void k_silu_emb(const float* __restrict__ pp /*frag-major fp32*/, const float* __restrict__ temb,
-                           const int* __restrict__ t_clip, bf16x8* __restrict__ s_hi, bf16x8* __restrict__ s_lo,
+                           const int* __restrict__ t_clip, v8<T16>* __restrict__ s_hi, v8<T16>* __restrict__ s_lo,
                            int G, int T, int B) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)G * 32 * 64) return;
@@ -657,41 +613,34 @@ __global__ void k_silu_emb(const float* __restrict__ pp /*frag-major fp32*/, con
     const float* te = temb + (size_t)t_clip[b] * 512 + 16 * ks + 8 * (lane >> 5);
     const f32x8 p = reinterpret_cast<const f32x8*>(pp)[idx];
     const f32x8 tv = *reinterpret_cast<const f32x8*>(te);
-    if constexpr (FMODE == 2) {
-        f16x8 h;
+    v8<T16> hi, lo;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = (_Float16)silu(p[j] + tv[j]);
-        reinterpret_cast<f16x8*>(s_hi)[idx] = h;
-    } else {
-        bf16x8 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = silu(p[j] + tv[j]);
-            hi[j] = (__bf16)v;
-            if constexpr (FMODE == 1) lo[j] = (__bf16)(v - (float)hi[j]);
-        }
-        s_hi[idx] = hi;
-        if constexpr (FMODE == 1) s_lo[idx] = lo;
+    for (int j = 0; j < 8; ++j) {
+        const float v = silu(p[j] + tv[j]);
+        hi[j] = (T16)v;
+        if constexpr (SPLIT) lo[j] = (T16)(v - (float)hi[j]);
     }
+    s_hi[idx] = hi;
+    if constexpr (SPLIT) s_lo[idx] = lo;
 }
 
 // ------------------------------------------------------------------------------------
-// FiLM GEMM: E[g][ot] = Wf[ot] * S[g] + bf  for all 3*L StylizationBlocks at once
-// (StylizationBlock.emb_layers, transformer.py:57-60,74), output fp16 FT tiles.
+// FiLM GEMM: [scale|shift] = Wf * S + bf for all 3*L StylizationBlocks at once
+// (StylizationBlock.emb_layers, transformer.py:57-60,74), with the block's LayerNorm affine folded into
+// the epilogue: it stores G' = g*(1+scale) and H' = b*(1+scale)+shift as fp16 FT tiles,
+// E[g][blk][G'0..3, H'0..3][64][16].  The weight image interleaves each block's tiles as
+// (scale0, shift0, scale1, shift1, ...) so that a wave holds matching scale/shift tiles.
 // v1: operands straight from L2 into registers; wave tile 4 feature tiles x 2 groups.
 // grid (NT/8, ceil(G/4)), 256 threads = 2x2 waves.
 // ------------------------------------------------------------------------------------
-template <int FMODE>
-__global__ __launch_bounds__(256) void k_film_gemm(const void* __restrict__ Wv, const float* __restrict__ bias_ft,
-                                                   const void* __restrict__ S_hiv, const void* __restrict__ S_lov,
+template <class T16, bool SPLIT>
+__global__ __launch_bounds__(256) void k_film_gemm(const v8<T16>* __restrict__ W, const float* __restrict__ bias_ft,
+                                                   const float* __restrict__ g_ft, const float* __restrict__ beta_ft,
+                                                   const v8<T16>* __restrict__ S_hi, const v8<T16>* __restrict__ S_lo,
                                                    f16x16* __restrict__ E, int G, int NT) {
-    using OP = typename std::conditional<FMODE == 2, f16x8, bf16x8>::type;
-    constexpr bool SPLIT = FMODE == 1;
-    const OP* __restrict__ W = reinterpret_cast<const OP*>(Wv);
-    const OP* __restrict__ S_hi = reinterpret_cast<const OP*>(S_hiv);
-    const OP* __restrict__ S_lo = reinterpret_cast<const OP*>(S_lov);
+    using OP = v8<T16>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ot0 = (blockIdx.x * 2 + (wave >> 1)) * 4;
+    const int ot0 = (blockIdx.x * 2 + (wave >> 1)) * 4;   // interleaved order: (s_j, h_j, s_j+1, h_j+1)
     const int g0 = (blockIdx.y * 2 + (wave & 1)) * 2;
     if (g0 >= G) return;
     const bool two = g0 + 1 < G;
@@ -705,8 +654,9 @@ __global__ __launch_bounds__(256) void k_film_gemm(const void* __restrict__ Wv, 
         OP a[4], al[4], b[2], bl[2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            a[i] = W[((size_t)(ot0 + i) * DC_KS_E + ks) * 64 + lane];
-            if constexpr (SPLIT) al[i] = W[(nfw + (size_t)(ot0 + i) * DC_KS_E + ks) * 64 + lane];
+            const size_t fi = ((size_t)(ks >> 1) * NT + ot0 + i) * 2 + (ks & 1);   // kt-major image
+            a[i] = W[fi * 64 + lane];
+            if constexpr (SPLIT) al[i] = W[(nfw + fi) * 64 + lane];
         }
         b[0] = S_hi[((size_t)g0 * DC_KS_E + ks) * 64 + lane];
         b[1] = S_hi[((size_t)g1 * DC_KS_E + ks) * 64 + lane];
@@ -726,16 +676,24 @@ __global__ __launch_bounds__(256) void k_film_gemm(const void* __restrict__ Wv, 
             }
     }
     const int hh = lane >> 5;
+    const int blk = ot0 >> 3, pair0 = (ot0 & 7) >> 1;       // this wave holds feature tiles pair0, pair0+1 of block blk
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const f32x16 bb = ld_ft(bias_ft, ot0 + i, hh);
+    for (int p = 0; p < 2; ++p) {
+        const f32x16 bs = ld_ft(bias_ft, ot0 + 2 * p, hh), bh = ld_ft(bias_ft, ot0 + 2 * p + 1, hh);
+        const f32x16 gg = ld_ft(g_ft, blk * 4 + pair0 + p, hh), be = ld_ft(beta_ft, blk * 4 + pair0 + p, hh);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && !two) continue;
-            f16x16 o;
+            f16x16 og, oh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = (_Float16)(acc[i][j][r] + bb[r]);
-            E[((size_t)(g0 + j) * NT + ot0 + i) * 64 + lane] = o;
+            for (int r = 0; r < 16; ++r) {
+                const float sc1 = 1.f + acc[2 * p][j][r] + bs[r];
+                og[r] = (_Float16)(gg[r] * sc1);
+                oh[r] = (_Float16)(fmaf(be[r], sc1, acc[2 * p + 1][j][r] + bh[r]));
+            }
+            f16x16* Eb = E + ((size_t)(g0 + j) * NT + blk * 8) * 64 + lane;
+            Eb[(pair0 + p) * 64] = og;
+            Eb[(4 + pair0 + p) * 64] = oh;
         }
     }
 }
@@ -743,8 +701,10 @@ __global__ __launch_bounds__(256) void k_film_gemm(const void* __restrict__ Wv, 
 // ------------------------------------------------------------------------------------
 // step prologue: h = joint_embed(x) + sequence_embedding[:T] (transformer.py:488-490),
 // then layer 0's self-attention front half.  One wave per group.
+// The K=26 input projection always runs split: rounding x_t itself to 8/11 mantissa bits is the
+// single largest error source otherwise, and the GEMM is tiny.
 // ------------------------------------------------------------------------------------
-template <bool SPLIT>
+template <class T16, bool SPLIT>
 __global__ __launch_bounds__(256) void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /*[M][P]*/,
                                                      float* __restrict__ hbuf, float* __restrict__ recs,
                                                      const int* __restrict__ length, int M, int T, int G) {
@@ -756,20 +716,20 @@ __global__ __launch_bounds__(256) void k_embed_front(const DcModel* __restrict__
     const bool live = cx.tok < M;
     const int n = live ? cx.tok % T : 0;
     // x as chained-order operand: element j of k-step s <-> pose feature 16s + 8(j>>2) + 4hh + (j&3)
-    XFrag<SPLIT> xf[1];
+    f32x16 h[4];
     {
+        XFrag<T16, true> xf[1];
         f32x16 xv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = tile_row(r, cx.hh);
             xv[r] = (live && f < P) ? x[(size_t)cx.tok * P + f] : 0.f;
         }
-        make_frag<SPLIT>(xv, xf[0]);
-    }
-    f32x16 h[4];
+        make_frag<T16, true>(xv, xf[0]);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) h[t] = ld_ft(dm->je_b, t, cx.hh);
-    gemm_wa<4, 1, SPLIT>(h, dm->je_w, xf, lane);
+        for (int t = 0; t < 4; ++t) h[t] = ld_ft(dm->je_b, t, cx.hh);
+        gemm_wa<4, 1, T16, true>(h, reinterpret_cast<const v8<T16>*>(dm->je_w), xf, lane);
+    }
     const float* se = dm->seq_emb + (size_t)n * DC_D;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -780,151 +740,227 @@ __global__ __launch_bounds__(256) void k_embed_front(const DcModel* __restrict__
             for (int i = 0; i < 4; ++i) h[t][4 * q + i] += v[i];
         }
     store_h(h, hbuf, g, lane);
-    sa_front<SPLIT>(h, dm->layer[0], cx, M, T, length, recs + (size_t)g * 2 * DC_REC_FLOATS);
+    const DcLayer& L = dm->layer[0];
+    XFrag<T16, SPLIT> nf[4];
+    ln_frags<T16, SPLIT>(nf, h);
+    sa_front<T16, SPLIT>(nf, reinterpret_cast<const v8<T16>*>(L.sa_wk), reinterpret_cast<const v8<T16>*>(L.sa_wv), L.sa_bk,
+                         L.sa_bv, cx, M, T, length, recs + (size_t)g * 2 * DC_REC_FLOATS, true);
 }
 
 // ------------------------------------------------------------------------------------
-// one decoder layer for one token group, from the attention matrices onward:
+// one decoder layer for NW token groups (one per wave), from the attention matrices onward:
 //   SA back half (transformer.py:104,109,119-121) -> CA (:147,150,156-157) -> FFN (:170-173)
 //   then either the next layer's SA front half, or the output projection (:496) fused with the
 //   DDIM update (gaussian_diffusion.py:812-830).
 // out_mode 0: write pred_xstart to xout;  1: DDIM update of xio in place (+ snapshot).
+//
+// Structure: NW waves per workgroup (8 = 256 tokens, 2 waves per SIMD; 4 in the split modes, whose
+// doubled fragments need the 512-register budget).  The weight images of the GEMM stages stream
+// L2 -> LDS by LDS-DMA (global_load_lds, 16 B/lane) one stage ahead into two buffers shared by the
+// waves; each stage ends with vmcnt(0) + barrier.  All activations stay in registers, and the
+// residual stream h IS the accumulator of the three out-projections (h += W_o * a + b_o).
 // ------------------------------------------------------------------------------------
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf,
-                                               const f16x16* __restrict__ E, int NT,
-                                               const bf16x8* __restrict__ a_sa /*[B][16][64]*/,
-                                               const bf16x8* __restrict__ a_ca /*[L][B][16][64]*/,
-                                               float* __restrict__ recs, const int* __restrict__ length,
-                                               const float* __restrict__ xin, float* __restrict__ xout, int out_mode,
-                                               const float* __restrict__ coef_cur, const int* __restrict__ snap_cur,
-                                               float* __restrict__ snaps, int M, int T, int G, int B, int dbg) {
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= G) return;
-    const int lane = threadIdx.x & 63;
+template <int NW>
+DEV void stage_frags(const void* __restrict__ src, char* dst, int nfrags, int wave, int lane) {
+    const bf16x8* s = reinterpret_cast<const bf16x8*>(src);
+    for (int f = wave; f < nfrags; f += NW)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + (size_t)f * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+}
+DEV void stage_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+template <class T16, bool SPLIT>
+DEV void attn_apply_tile(f32x16& y, const v8<T16>* __restrict__ afrag, int oc, const XFrag<T16, SPLIT>& q, int lane) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const v8<T16> a = afrag[(oc * 2 + s) * 64 + lane];
+        y = mfma(a, q.hi[s], y);
+        if constexpr (SPLIT) {
+            y = mfma(a, q.lo[s], y);
+            const v8<T16> al = afrag[(8 + oc * 2 + s) * 64 + lane];
+            y = mfma(al, q.hi[s], y);
+        }
+    }
+}
+
+// q = softmax_heads(Wq LN(h) + bq);  y = q . A per head  (weights image `w` in LDS)
+template <class T16, bool SPLIT>
+DEV void query_attend(f32x16 (&y)[4], const f32x16 (&h)[4], const float* bq,
+                      const v8<T16>* w, const v8<T16>* __restrict__ a0, const v8<T16>* __restrict__ a1,
+                      const GroupCtx& cx) {
+    f32x16 q[4];
+    {
+        XFrag<T16, SPLIT> nf[4];
+        ln_frags<T16, SPLIT>(nf, h);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q[t] = ld_ft(bq, t, cx.hh);
+        gemm_wa<4, 4, T16, SPLIT>(q, w, nf, cx.lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    softmax_heads_ft(q);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int oc = 0; oc < 4; ++oc) {
+        y[oc] = splat(0.f);
+        XFrag<T16, SPLIT> qf;
+        make_frag<T16, SPLIT>(q[oc], qf);
+        if (!cx.straddle) {
+            attn_apply_tile<T16, SPLIT>(y[oc], a0, oc, qf, cx.lane);
+        } else {   // the group spans two clips: apply each clip's matrix to its own tokens (lanes)
+            XFrag<T16, SPLIT> qm = qf;
+            mask_frag<T16, SPLIT>(qm, cx.lane_in_b0);
+            attn_apply_tile<T16, SPLIT>(y[oc], a0, oc, qm, cx.lane);
+            mask_frag<T16, SPLIT>(qf, !cx.lane_in_b0);
+            attn_apply_tile<T16, SPLIT>(y[oc], a1, oc, qf, cx.lane);
+        }
+    }
+}
+
+// StylizationBlock (transformer.py:68-81) accumulated straight into the residual stream:
+//   h += W_o * SiLU( LN(y) * (1 + scale) + shift ) + b_o          (weights image `w` in LDS)
+// with LN(y)*(1+scale)+shift = nhat*G' + H', nhat = (y-mean)*rstd, and G' = g*(1+scale), H' = b*(1+scale)+shift
+// delivered by the FiLM GEMM (E: 4 G' tiles then 4 H' tiles for this block and group).
+template <class T16, bool SPLIT>
+DEV void styl_accumulate(f32x16 (&h)[4], const f32x16 (&y)[4], const f16x16* __restrict__ E, const DcStyl& st,
+                         const v8<T16>* w, int lane, int hh) {
+    XFrag<T16, SPLIT> zf[4];
+    {
+        float mean, rstd;
+        ln_stats<4>(y, mean, rstd);
+        const float shift = -mean * rstd;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const f16x16 gp = E[kt * 64 + lane], hp = E[(4 + kt) * 64 + lane];
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = silu(fmaf(fmaf(y[kt][r], rstd, shift), (float)gp[r], (float)hp[r]));
+            make_frag<T16, SPLIT>(z, zf[kt]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const f32x16 bb = ld_ft(st.bo, t, hh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[t][r] += bb[r];
+    }
+    gemm_wa<4, 4, T16, SPLIT>(h, w, zf, lane);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <class T16, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
+void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
+             const v8<T16>* __restrict__ a_sa /*[B][16][64]*/, const v8<T16>* __restrict__ a_ca /*[L][B][16][64]*/,
+             float* __restrict__ recs, const int* __restrict__ length, const float* __restrict__ xin,
+             float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur, const int* __restrict__ snap_cur,
+             float* __restrict__ snaps, int M, int T, int G, int B, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int NW = SPLIT ? 4 : 8;
+    constexpr int WM = SPLIT ? 2 : 1;            // operand images per matrix (hi [+ lo])
+    constexpr int WBUF = 32768 * WM;             // one 128x128 matrix
+    using W = v8<T16>;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int g = blockIdx.x * NW + wave;
+    const bool active = g < G;                   // idle waves still take part in the staging and barriers
+    if (!active) g = G - 1;
     const GroupCtx cx = make_ctx(g, lane, M, T);
     const DcLayer& L = dm->layer[l];
     const int nl = dm->num_layers;
+    const bool last = l + 1 >= nl;
     const f16x16* Eg = E + ((size_t)g * NT + (size_t)l * 24) * 64;   // this layer's 3 blocks x 8 tiles
+    char* buf0 = lds;
+    char* buf1 = lds + WBUF;
+    const W* w0 = reinterpret_cast<const W*>(buf0);
+    const W* w1 = reinterpret_cast<const W*>(buf1);
 
+    stage_frags<NW>(L.sa_wq, buf0, 32 * WM, wave, lane);
     f32x16 h[4];
     load_h(h, hbuf, g, lane);
+    stage_sync();
 
-    // ---------------- self-attention, back half ----------------
+    // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
+    stage_frags<NW>(L.sa_styl.wo, buf1, 32 * WM, wave, lane);
+    f32x16 y[4];
+    query_attend<T16, SPLIT>(y, h, L.sa_bq, w0, a_sa + (size_t)cx.b0 * 16 * 64,
+                             a_sa + (size_t)cx.b1 * 16 * 64, cx);
+    stage_sync();
+    // ---- stage 2: SA stylization [buf1]; prefetch CA query -> buf0
+    stage_frags<NW>(L.ca_wq, buf0, 32 * WM, wave, lane);
+    styl_accumulate<T16, SPLIT>(h, y, Eg, L.sa_styl, w1, lane, cx.hh);
+    if (dbg == 1) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after self-attention
+    stage_sync();
+    // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
+    stage_frags<NW>(L.ca_styl.wo, buf1, 32 * WM, wave, lane);
     {
-        f32x16 q[4];
-        {
-            f32x16 n[4];
-            layernorm_ft<4>(h, n, L.sa_ln_g, L.sa_ln_b, cx.hh);
-            XFrag<SPLIT> nf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) make_frag<SPLIT>(n[t], nf[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) q[t] = ld_ft(L.sa_bq, t, cx.hh);
-            gemm_wa<4, 4, SPLIT>(q, L.sa_wq, nf, lane);
-        }
-        softmax_heads_ft(q);
-        XFrag<SPLIT> qf[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) make_frag<SPLIT>(q[t], qf[t]);
-        f32x16 y[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) y[t] = splat(0.f);
-        if (!cx.straddle) {
-            attn_apply<SPLIT>(y, a_sa + (size_t)cx.b0 * 16 * 64, qf, lane);
-        } else {
-            XFrag<SPLIT> qm[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { qm[t] = qf[t]; mask_frag<SPLIT>(qm[t], cx.lane_in_b0); }
-            attn_apply<SPLIT>(y, a_sa + (size_t)cx.b0 * 16 * 64, qm, lane);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { qm[t] = qf[t]; mask_frag<SPLIT>(qm[t], !cx.lane_in_b0); }
-            attn_apply<SPLIT>(y, a_sa + (size_t)cx.b1 * 16 * 64, qm, lane);
-        }
-        f32x16 o[4];
-        stylization<SPLIT>(o, y, Eg, L.sa_styl, lane, cx.hh);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) h[t] += o[t];
+        const W* acl = a_ca + (size_t)l * B * 16 * 64;
+        query_attend<T16, SPLIT>(y, h, L.ca_bq, w0, acl + (size_t)cx.b0 * 16 * 64,
+                                 acl + (size_t)cx.b1 * 16 * 64, cx);
     }
-    if (dbg == 1) { store_h(h, hbuf, g, lane); return; }   // test hook: stop after self-attention
-    // ---------------- cross-attention ----------------
+    stage_sync();
+    // ---- stage 4: CA stylization [buf1]; prefetch FFN W1|W2 -> buf0
+    stage_frags<NW>(L.ffn_w1, buf0, 16 * WM, wave, lane);
+    stage_frags<NW>(L.ffn_w2, buf0 + 16 * WM * 1024, 16 * WM, wave, lane);
+    styl_accumulate<T16, SPLIT>(h, y, Eg + 8 * 64, L.ca_styl, w1, lane, cx.hh);
+    if (dbg == 2) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after cross-attention
+    stage_sync();
+    // ---- stage 5: FFN [buf0]; prefetch FFN out-proj -> buf1
+    stage_frags<NW>(L.ffn_styl.wo, buf1, 32 * WM, wave, lane);
     {
-        f32x16 q[4];
-        {
-            f32x16 n[4];
-            layernorm_ft<4>(h, n, L.ca_ln_g, L.ca_ln_b, cx.hh);
-            XFrag<SPLIT> nf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) make_frag<SPLIT>(n[t], nf[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) q[t] = ld_ft(L.ca_bq, t, cx.hh);
-            gemm_wa<4, 4, SPLIT>(q, L.ca_wq, nf, lane);
-        }
-        softmax_heads_ft(q);
-        XFrag<SPLIT> qf[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) make_frag<SPLIT>(q[t], qf[t]);
-        f32x16 y[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) y[t] = splat(0.f);
-        const bf16x8* acl = a_ca + (size_t)l * B * 16 * 64;
-        if (!cx.straddle) {
-            attn_apply<SPLIT>(y, acl + (size_t)cx.b0 * 16 * 64, qf, lane);
-        } else {
-            XFrag<SPLIT> qm[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { qm[t] = qf[t]; mask_frag<SPLIT>(qm[t], cx.lane_in_b0); }
-            attn_apply<SPLIT>(y, acl + (size_t)cx.b0 * 16 * 64, qm, lane);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { qm[t] = qf[t]; mask_frag<SPLIT>(qm[t], !cx.lane_in_b0); }
-            attn_apply<SPLIT>(y, acl + (size_t)cx.b1 * 16 * 64, qm, lane);
-        }
-        f32x16 o[4];
-        stylization<SPLIT>(o, y, Eg + 8 * 64, L.ca_styl, lane, cx.hh);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) h[t] += o[t];
-    }
-    if (dbg == 2) { store_h(h, hbuf, g, lane); return; }   // test hook: stop after cross-attention
-    // ---------------- FFN ----------------
-    {
-        XFrag<SPLIT> hf[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) make_frag<SPLIT>(h[t], hf[t]);
         f32x16 u[2];
+        {
+            XFrag<T16, SPLIT> hf[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) u[t] = ld_ft(L.ffn_b1, t, cx.hh);
-        gemm_wa<2, 4, SPLIT>(u, L.ffn_w1, hf, lane);
-        XFrag<SPLIT> uf[2];
+            for (int kt = 0; kt < 4; ++kt) make_frag<T16, SPLIT>(h[kt], hf[kt]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) u[t][r] = gelu_erf(u[t][r]);
-            make_frag<SPLIT>(u[t], uf[t]);
+            for (int t = 0; t < 2; ++t) u[t] = ld_ft(L.ffn_b1, t, cx.hh);
+            gemm_wa<2, 4, T16, SPLIT>(u, w0, hf, lane);
         }
-        f32x16 y[4];
+        XFrag<T16, SPLIT> uf[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[kt][r] = gelu_erf(u[kt][r]);
+            make_frag<T16, SPLIT>(u[kt], uf[kt]);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) y[t] = ld_ft(L.ffn_b2, t, cx.hh);
-        gemm_wa<4, 2, SPLIT>(y, L.ffn_w2, uf, lane);
-        f32x16 o[4];
-        stylization<SPLIT>(o, y, Eg + 16 * 64, L.ffn_styl, lane, cx.hh);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) h[t] += o[t];
+        gemm_wa<4, 2, T16, SPLIT>(y, w0 + 16 * WM * 64, uf, lane);
     }
+    stage_sync();
+    // ---- stage 6: FFN stylization [buf1]; prefetch next layer's key projection (or the output projection) -> buf0
+    if (!last)
+        stage_frags<NW>(dm->layer[l + 1].sa_wk, buf0, 32 * WM, wave, lane);
+    else
+        stage_frags<NW>(dm->out_w, buf0, 16, wave, lane);       // 8 hi + 8 lo frags: the output projection always runs split
+    styl_accumulate<T16, SPLIT>(h, y, Eg + 16 * 64, L.ffn_styl, w1, lane, cx.hh);
+    if (dbg == 3) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
+    stage_sync();
 
-    if (dbg == 3) { store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
-    if (l + 1 < nl) {
-        store_h(h, hbuf, g, lane);
-        sa_front<SPLIT>(h, dm->layer[l + 1], cx, M, T, length, recs + (size_t)g * 2 * DC_REC_FLOATS);
+    if (!last) {
+        // ---- stage 7: next layer's SA front half: K [buf0] and V [buf1], partial records
+        const DcLayer& N = dm->layer[l + 1];
+        stage_frags<NW>(N.sa_wv, buf1, 32 * WM, wave, lane);
+        if (active) store_h(h, hbuf, g, lane);
+        XFrag<T16, SPLIT> nf[4];
+        ln_frags<T16, SPLIT>(nf, h);
+        stage_sync();
+        sa_front<T16, SPLIT>(nf, w0, w1, N.sa_bk, N.sa_bv, cx, M, T, length, recs + (size_t)g * 2 * DC_REC_FLOATS, active);
         return;
     }
-    // ---------------- output projection + DDIM update ----------------
-    XFrag<SPLIT> hf[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) make_frag<SPLIT>(h[t], hf[t]);
+    // ---- output projection [buf0, split] + DDIM update
     f32x16 x0[1];
-    x0[0] = ld_ft(dm->out_b, 0, cx.hh);
-    gemm_wa<1, 4, SPLIT>(x0, dm->out_w, hf, lane);
-    if (cx.tok >= M) return;
+    {
+        XFrag<T16, true> hf[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) make_frag<T16, true>(h[kt], hf[kt]);
+        x0[0] = ld_ft(dm->out_b, 0, cx.hh);
+        gemm_wa<1, 4, T16, true>(x0, w0, hf, lane);
+    }
+    if (!active || cx.tok >= M) return;
     const int P = dm->input_feats;
     if (out_mode == 0) {
 #pragma unroll
@@ -951,11 +987,21 @@ __global__ __launch_bounds__(256) void k_layer(const DcModel* __restrict__ dm, i
 }
 
 // ------------------------------------------------------------------------------------
-// host-callable launchers (declared in dc_launch.h)
+// host-callable launchers (declared in dc_launch.h).  fmt: 0 = bf16, 1 = f16.
 // ------------------------------------------------------------------------------------
 #include "dc_launch.h"
 
 #define LAUNCH_CHECK() (hipGetLastError())
+#define DISPATCH(fmt, split, CALL)                       \
+    do {                                                 \
+        if ((fmt) == 1) {                                \
+            using T16 = _Float16;                        \
+            if (split) { constexpr bool SP = true; CALL; } else { constexpr bool SP = false; CALL; } \
+        } else {                                         \
+            using T16 = __bf16;                          \
+            if (split) { constexpr bool SP = true; CALL; } else { constexpr bool SP = false; CALL; } \
+        }                                                \
+    } while (0)
 
 hipError_t dc_launch_begin_step(hipStream_t st, int* iter, const int* t_of_iter, const float* coef_of_t,
                                 const int* snap_of_iter, int* t_clip, float* coef_cur, int* snap_cur, int B) {
@@ -992,68 +1038,85 @@ hipError_t dc_launch_cond_pack(hipStream_t st, int mode, const float* y, const f
     return LAUNCH_CHECK();
 }
 
-hipError_t dc_launch_ca_partials(hipStream_t st, bool split, const DcModel* dm, const void* nh_hi, const void* nh_lo,
+hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* nh_hi, const void* nh_lo,
                                  float* recs, int M, int T, int G, int L) {
-    const dim3 grid((G + 3) / 4, L);
-    if (split)
-        hipLaunchKernelGGL(k_cond_ca_partials<true>, grid, dim3(256), 0, st, dm, (const bf16x8*)nh_hi, (const bf16x8*)nh_lo, recs, M, T, G);
-    else
-        hipLaunchKernelGGL(k_cond_ca_partials<false>, grid, dim3(256), 0, st, dm, (const bf16x8*)nh_hi, (const bf16x8*)nh_lo, recs, M, T, G);
+    hipLaunchKernelGGL(k_cond_ca_partials, dim3((G + 3) / 4, L), dim3(256), 0, st, dm, (const bf16x8*)nh_hi,
+                       (const bf16x8*)nh_lo, recs, M, T, G);
     return LAUNCH_CHECK();
 }
 
-hipError_t dc_launch_attn_combine(hipStream_t st, const float* recs, void* afrag, int T, int G, int B, int nset) {
+hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, void* afrag, int T, int G, int B, int nset) {
     const int ng_max = T / 32 + 2;
     const size_t shm = (size_t)(ng_max * 32 + 32 + 256) * sizeof(float);
-    hipLaunchKernelGGL(k_attn_combine, dim3(B, 4, nset), dim3(256), shm, st, recs, (bf16x8*)afrag, T, G, B);
+    if (fmt == 1)
+        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(B, 4, nset), dim3(256), shm, st, recs, (f16x8*)afrag, T, G, B);
+    else
+        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(B, 4, nset), dim3(256), shm, st, recs, (bf16x8*)afrag, T, G, B);
     return LAUNCH_CHECK();
 }
 
-hipError_t dc_launch_silu_emb(hipStream_t st, int fmode, const float* pp, const float* temb, const int* t_clip,
-                              void* s_hi, void* s_lo, int G, int T, int B) {
+template <class T16, bool SP>
+static void launch_silu_t(hipStream_t st, const float* pp, const float* temb, const int* t_clip, void* s_hi, void* s_lo,
+                          int G, int T, int B) {
     const size_t n = (size_t)G * 32 * 64;
-    const dim3 grid((unsigned)((n + 255) / 256));
-    if (fmode == 1)
-        hipLaunchKernelGGL(k_silu_emb<1>, grid, dim3(256), 0, st, pp, temb, t_clip, (bf16x8*)s_hi, (bf16x8*)s_lo, G, T, B);
-    else if (fmode == 2)
-        hipLaunchKernelGGL(k_silu_emb<2>, grid, dim3(256), 0, st, pp, temb, t_clip, (bf16x8*)s_hi, (bf16x8*)s_lo, G, T, B);
-    else
-        hipLaunchKernelGGL(k_silu_emb<0>, grid, dim3(256), 0, st, pp, temb, t_clip, (bf16x8*)s_hi, (bf16x8*)s_lo, G, T, B);
+    k_silu_emb<T16, SP><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(pp, temb, t_clip, (v8<T16>*)s_hi,
+                                                                                 (v8<T16>*)s_lo, G, T, B);
+}
+hipError_t dc_launch_silu_emb(hipStream_t st, int fmt, bool split, const float* pp, const float* temb, const int* t_clip,
+                              void* s_hi, void* s_lo, int G, int T, int B) {
+    DISPATCH(fmt, split, (launch_silu_t<T16, SP>(st, pp, temb, t_clip, s_hi, s_lo, G, T, B)));
     return LAUNCH_CHECK();
 }
 
-hipError_t dc_launch_film_gemm(hipStream_t st, int fmode, const void* W, const float* bias_ft, const void* s_hi,
-                               const void* s_lo, void* E, int G, int NT) {
-    const dim3 grid(NT / 8, (G + 3) / 4);
-    if (fmode == 1)
-        hipLaunchKernelGGL(k_film_gemm<1>, grid, dim3(256), 0, st, W, bias_ft, s_hi, s_lo, (f16x16*)E, G, NT);
-    else if (fmode == 2)
-        hipLaunchKernelGGL(k_film_gemm<2>, grid, dim3(256), 0, st, W, bias_ft, s_hi, s_lo, (f16x16*)E, G, NT);
-    else
-        hipLaunchKernelGGL(k_film_gemm<0>, grid, dim3(256), 0, st, W, bias_ft, s_hi, s_lo, (f16x16*)E, G, NT);
+template <class T16, bool SP>
+static void launch_film_t(hipStream_t st, const void* W, const float* bias_ft, const float* g_ft, const float* beta_ft,
+                          const void* s_hi, const void* s_lo, void* E, int G, int NT) {
+    k_film_gemm<T16, SP><<<dim3(NT / 8, (G + 3) / 4), dim3(256), 0, st>>>((const v8<T16>*)W, bias_ft, g_ft, beta_ft,
+                                                                         (const v8<T16>*)s_hi, (const v8<T16>*)s_lo,
+                                                                         (f16x16*)E, G, NT);
+}
+hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const float* g_ft,
+                               const float* beta_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT) {
+    DISPATCH(fmt, split, (launch_film_t<T16, SP>(st, W, bias_ft, g_ft, beta_ft, s_hi, s_lo, E, G, NT)));
     return LAUNCH_CHECK();
 }
 
-hipError_t dc_launch_embed_front(hipStream_t st, bool split, const DcModel* dm, const float* x, float* hbuf, float* recs,
-                                 const int* length, int M, int T, int G) {
-    const dim3 grid((G + 3) / 4);
-    if (split)
-        hipLaunchKernelGGL(k_embed_front<true>, grid, dim3(256), 0, st, dm, x, hbuf, recs, length, M, T, G);
-    else
-        hipLaunchKernelGGL(k_embed_front<false>, grid, dim3(256), 0, st, dm, x, hbuf, recs, length, M, T, G);
+template <class T16, bool SP>
+static void launch_embed_t(hipStream_t st, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
+                           int M, int T, int G) {
+    k_embed_front<T16, SP><<<dim3((G + 3) / 4), dim3(256), 0, st>>>(dm, x, hbuf, recs, length, M, T, G);
+}
+hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, const DcModel* dm, const float* x, float* hbuf,
+                                 float* recs, const int* length, int M, int T, int G) {
+    DISPATCH(fmt, split, (launch_embed_t<T16, SP>(st, dm, x, hbuf, recs, length, M, T, G)));
     return LAUNCH_CHECK();
 }
 
-hipError_t dc_launch_layer(hipStream_t st, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
+template <class T16, bool SP>
+static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
+                                 const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
+                                 float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
+                                 int M, int T, int G, int B, int dbg) {
+    constexpr int NW = SP ? 4 : 8;
+    const size_t shm = 2 * 32768 * (SP ? 2 : 1);
+    static bool attr_set = false;
+    if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
+        hipError_t e = hipFuncSetAttribute((const void*)k_layer<T16, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    k_layer<T16, SP><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
+                       (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
+                       snaps, M, T, G, B, dbg);
+    return hipGetLastError();
+}
+
+hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg) {
-    const dim3 grid((G + 3) / 4);
-    if (split)
-        hipLaunchKernelGGL(k_layer<true>, grid, dim3(256), 0, st, dm, l, hbuf, (const f16x16*)E, NT, (const bf16x8*)a_sa,
-                           (const bf16x8*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg);
-    else
-        hipLaunchKernelGGL(k_layer<false>, grid, dim3(256), 0, st, dm, l, hbuf, (const f16x16*)E, NT, (const bf16x8*)a_sa,
-                           (const bf16x8*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg);
-    return LAUNCH_CHECK();
+    hipError_t e = hipSuccess;
+    DISPATCH(fmt, split, (e = launch_layer_t<T16, SP>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode,
+                                                       coef_cur, snap_cur, snaps, M, T, G, B, dbg)));
+    return e;
 }

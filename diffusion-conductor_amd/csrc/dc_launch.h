@@ -1,4 +1,4 @@
-// dc_launch.h - host-callable launchers implemented in dc_kernels.hip
+// dc_launch.h - host-callable launchers implemented in dc_kernels.hip.  fmt: 0 = bf16 operands, 1 = f16.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dc_common.h"
@@ -11,16 +11,16 @@ hipError_t dc_launch_cond_linear(hipStream_t st, const float* xf, const float* w
 hipError_t dc_launch_row_stats(hipStream_t st, const float* y, float* mean, float* rstd, int Mpad);
 hipError_t dc_launch_cond_pack(hipStream_t st, int mode, const float* y, const float* mean, const float* rstd,
                                float* out_f32, void* out_hi, void* out_lo, int G);
-hipError_t dc_launch_ca_partials(hipStream_t st, bool split, const DcModel* dm, const void* nh_hi, const void* nh_lo,
+hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* nh_hi, const void* nh_lo,
                                  float* recs, int M, int T, int G, int L);
-hipError_t dc_launch_attn_combine(hipStream_t st, const float* recs, void* afrag, int T, int G, int B, int nset);
-hipError_t dc_launch_silu_emb(hipStream_t st, int fmode, const float* pp, const float* temb, const int* t_clip,
+hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, void* afrag, int T, int G, int B, int nset);
+hipError_t dc_launch_silu_emb(hipStream_t st, int fmt, bool split, const float* pp, const float* temb, const int* t_clip,
                               void* s_hi, void* s_lo, int G, int T, int B);
-hipError_t dc_launch_film_gemm(hipStream_t st, int fmode, const void* W, const float* bias_ft, const void* s_hi,
-                               const void* s_lo, void* E, int G, int NT);
-hipError_t dc_launch_embed_front(hipStream_t st, bool split, const DcModel* dm, const float* x, float* hbuf, float* recs,
+hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const float* g_ft,
+                               const float* beta_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT);
+hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, const DcModel* dm, const float* x, float* hbuf, float* recs,
                                  const int* length, int M, int T, int G);
-hipError_t dc_launch_layer(hipStream_t st, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
+hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg);

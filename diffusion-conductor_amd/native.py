@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdc_ddim.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-DC_PREC = {"bf16": 0, "mixed": 1, "bf16x3": 2}
+DC_PREC = {"bf16": 0, "mixed": 1, "bf16x3": 2, "fp16": 3}
 
 EXPORTS = [
     "dc_last_error", "dc_version", "dc_linear_beta_schedule", "dc_ddim_coefficients", "dc_pack_weight",
@@ -154,7 +154,7 @@ class NativeSampler:
     """Owns one dc_sampler.  Tensors are torch CUDA(ROCm) tensors; only their data_ptr()
     crosses the ABI."""
 
-    def __init__(self, cfg, precision="mixed", max_timesteps=1000, device=0):
+    def __init__(self, cfg, precision="fp16", max_timesteps=1000, device=0):
         self._h = C.c_void_p()
         c = DcConfig(cfg.input_feats, cfg.num_frames, cfg.latent_dim, cfg.ff_size, cfg.num_layers, cfg.num_heads,
                      int(bool(cfg.no_eff)), DC_PREC[precision], int(max_timesteps), int(device))

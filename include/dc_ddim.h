@@ -38,12 +38,16 @@ typedef enum dc_status {
     DC_ERR_UNSUPPORTED = -5   /* configuration outside the built path     */
 } dc_status;
 
-/* GEMM operand precision of the denoiser (accumulation is always fp32). */
+/* MFMA operand precision of the denoiser (accumulation is always fp32; LayerNorm, softmax, SiLU/GELU,
+ * FiLM and the DDIM update are fp32).  f16 and bf16 MFMA run at the same rate on gfx950; "split" means
+ * x = hi + lo and three MFMAs per product (hi*hi + lo*hi + hi*lo), ~fp32 accurate.  In every mode the
+ * two tiny pose projections (joint_embed 26->128, out 128->26) run split, and the one-time
+ * cross-attention pre-pass runs split-bf16.  Measured rel-L2 on x0, DDIM-50: see DESIGN.md. */
 typedef enum dc_precision {
-    DC_PREC_BF16 = 0,   /* every MFMA operand plain bf16                                      */
-    DC_PREC_MIXED = 1,  /* default: K=512 FiLM GEMM on f16 MFMA operands (same rate as bf16, 3 more
-                           mantissa bits); all 128-wide GEMMs (Q/K/V, attention, out-proj, FFN) split-bf16 */
-    DC_PREC_BF16X3 = 2  /* split-bf16 everywhere (validation mode, ~fp32 accuracy)            */
+    DC_PREC_BF16 = 0,   /* every GEMM plain bf16 (does NOT meet the 1e-3 parity bound)              */
+    DC_PREC_MIXED = 1,  /* 128-wide GEMMs (Q/K/V, attention, out-proj, FFN) split-bf16; FiLM GEMM f16 */
+    DC_PREC_BF16X3 = 2, /* split-bf16 everywhere (validation mode)                                   */
+    DC_PREC_FP16 = 3    /* default: every GEMM plain f16, one MFMA per product                       */
 } dc_precision;
 
 /* Mirrors the constructor arguments the sampler path consumes:

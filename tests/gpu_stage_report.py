@@ -24,9 +24,10 @@ def bf16_to_f32(u16):
     return (u16.astype(np.uint32) << 16).view(np.float32)
 
 
-def unpack_afrag(raw, nset, B):
-    """[nset][B][16 frags][64][8] bf16 (8 hi then 8 lo) -> A[nset][B][8 heads][16 d][16 l]"""
-    raw = bf16_to_f32(raw.reshape(nset, B, 2, 4, 2, 64, 8))
+def unpack_afrag(raw, nset, B, f16=False):
+    """[nset][B][16 frags][64][8] bf16|f16 (8 hi then 8 lo) -> A[nset][B][8 heads][16 d][16 l]"""
+    raw = raw.reshape(nset, B, 2, 4, 2, 64, 8)
+    raw = raw.view(np.float16).astype(np.float32) if f16 else bf16_to_f32(raw)
     val = raw[:, :, 0] + raw[:, :, 1]            # [nset][B][oc][s][lane][j]
     A = np.zeros((nset, B, 8, 16, 16), np.float32)
     off = np.zeros((nset, B), np.float32)        # largest |cross-head| entry (must be 0)
@@ -80,7 +81,7 @@ def main():
         a_sa_ref, a_ca_ref = oracle_attn_matrices(p, h_in, xo, taps["emb"], mask)
     M, G = B * T, (B * T + 31) // 32
     print(f"B={B} T={T} M={M} G={G} length={length} t={t.tolist()}")
-    for prec in ("bf16x3", "mixed", "bf16"):
+    for prec in ("bf16x3", "fp16", "mixed", "bf16"):
         m = make_model(prec)
         nat = m.set_conditioning(xfp.cuda(), xfo.cuda(), length)
         xd = x.cuda()
@@ -94,13 +95,14 @@ def main():
         pp = unpack_kmajor(nat.debug_read("pp", np.float32, G * 32 * 64 * 8), G)[:M]
         ppref = (taps["emb"] - tref[t][:, None, :]).reshape(M, 512)
         print(f"  linear(xf_proj)     {rel_l2(pp, ppref):.3e}")
-        A, off = unpack_afrag(nat.debug_read("a_ca", np.uint16, 8 * B * 16 * 64 * 8), 8, B)
+        A, off = unpack_afrag(nat.debug_read("a_ca", np.uint16, 8 * B * 16 * 64 * 8), 8, B, prec == "fp16")
         print(f"  A_cross (8 layers)  {rel_l2(A, torch.stack(a_ca_ref).numpy()):.3e}   cross-head leak {off.max():.1e}")
         out = nat.debug_denoise(xd, t.numpy(), 0, 0)   # embed + front only
         torch.cuda.synchronize()
         h = nat.read_h()[:M].reshape(B, T, 128)
         print(f"  h0 (joint_embed)    {rel_l2(h, taps['h0']):.3e}")
-        shi = unpack_kmajor(bf16_to_f32(nat.debug_read("s_hi", np.uint16, G * 32 * 64 * 8)), G)[:M]
+        raw = nat.debug_read("s_hi", np.uint16, G * 32 * 64 * 8)
+        shi = unpack_kmajor(raw.view(np.float16).astype(np.float32) if prec in ("fp16", "mixed") else bf16_to_f32(raw), G)[:M]
         print(f"  SiLU(emb) bf16      {rel_l2(shi, torch.nn.functional.silu(taps['emb']).reshape(M, 512)):.3e}")
         E = native.unpack_ft(nat.debug_read("E", np.float16, G * 192 * 64 * 16).reshape(G, 192, 64, 16))[:M].astype(np.float32)
         with torch.no_grad():
@@ -108,9 +110,13 @@ def main():
             for i in range(8):
                 for blk in ("sa_block", "ca_block", "ffn"):
                     pre = f"temporal_decoder_blocks.{i}.{blk}.proj_out.emb_layers.1"
-                    eref.append(torch.nn.functional.linear(torch.nn.functional.silu(taps["emb"]), p[pre + ".weight"], p[pre + ".bias"]))
+                    e = torch.nn.functional.linear(torch.nn.functional.silu(taps["emb"]), p[pre + ".weight"], p[pre + ".bias"])
+                    sc, sh = torch.chunk(e, 2, dim=-1)
+                    npre = f"temporal_decoder_blocks.{i}.{blk}.proj_out.norm"
+                    g_, b_ = p[npre + ".weight"], p[npre + ".bias"]
+                    eref.append(torch.cat([g_ * (1 + sc), b_ * (1 + sc) + sh], dim=-1))   # the folded G' | H' image
             eref = torch.cat(eref, dim=-1).reshape(M, -1)
-        print(f"  FiLM scale|shift    {rel_l2(E, eref):.3e}")
+        print(f"  FiLM G'|H'          {rel_l2(E, eref):.3e}")
         for i in range(8):
             row = []
             for stage, tap in ((1, f"sa{i}"), (2, f"ca{i}"), (3, f"ffn{i}")):
@@ -119,7 +125,7 @@ def main():
                 h = nat.read_h()[:M].reshape(B, T, 128)
                 row.append(f"{tap} {rel_l2(h, taps[tap]):.2e}")
                 if stage == 1:
-                    As, off = unpack_afrag(nat.debug_read("a_sa", np.uint16, B * 16 * 64 * 8), 1, B)
+                    As, off = unpack_afrag(nat.debug_read("a_sa", np.uint16, B * 16 * 64 * 8), 1, B, prec == "fp16")
                     row.insert(0, f"A_sa {rel_l2(As[0], a_sa_ref[i].numpy()):.2e}")
             print(f"  layer {i}: " + "   ".join(row))
         out = nat.denoise(xd, t.numpy())

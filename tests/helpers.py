@@ -48,7 +48,7 @@ def xf_pair(B, T, first=0):
     return torch.nn.functional.linear(xf, p["proj.weight"], p["proj.bias"]), xf
 
 
-def make_model(precision="mixed", device="cuda"):
+def make_model(precision="fp16", device="cuda"):
     from diffusion_conductor_amd import MotionTransformer
     m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device=device,
                           no_clip=True, precision=precision)

@@ -93,7 +93,7 @@ def test_chained_weight_image_reproduces_matmul(n_out, k_in):
     X = rng.integers(-8, 9, (k_in, 32)).astype(np.float32)          # [features][32 tokens]
     hi, lo = native.pack_weight(W, chained=True)
     OT, KT = (n_out + 31) // 32, (k_in + 31) // 32
-    hi = _bf16_to_f32(hi).reshape(OT, KT, 2, 64, 8)
+    hi = _bf16_to_f32(hi).reshape(KT, OT, 2, 64, 8).transpose(1, 0, 2, 3, 4)     # image is kt-major
     assert not _bf16_to_f32(lo).any()                                  # small integers are exact in bf16
     Xp = np.zeros((KT * 32, 32), np.float32)
     Xp[:k_in] = X
@@ -116,8 +116,8 @@ def test_natural_weight_image_and_split_precision():
     rng = np.random.default_rng(1)
     W = rng.standard_normal((64, 512)).astype(np.float32)
     hi, lo = native.pack_weight(W, chained=False)
-    hi = _bf16_to_f32(hi).reshape(2, 16, 2, 64, 8)
-    lo = _bf16_to_f32(lo).reshape(2, 16, 2, 64, 8)
+    hi = _bf16_to_f32(hi).reshape(16, 2, 2, 64, 8).transpose(1, 0, 2, 3, 4)     # image is kt-major
+    lo = _bf16_to_f32(lo).reshape(16, 2, 2, 64, 8).transpose(1, 0, 2, 3, 4)
     for (ot, kt, s, l, j) in [(0, 0, 0, 0, 0), (1, 7, 1, 45, 3), (1, 15, 1, 63, 7), (0, 9, 0, 32, 5)]:
         w = W[32 * ot + (l & 31), 32 * kt + 16 * s + 8 * (l >> 5) + j]
         assert abs(hi[ot, kt, s, l, j] - w) <= abs(w) * 2.0 ** -8
