@@ -81,7 +81,8 @@ void pack_weight(const float* w, int n_out, int k_in, bool chained, uint16_t* hi
                         const int col = chained ? 32 * kt + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)
                                                 : 32 * kt + 16 * s + 8 * hh + j;
                         const float v = (row < n_out && col < k_in) ? w[(size_t)row * k_in + col] : 0.f;
-                        const size_t o = ((((size_t)kt * OT + ot) * 2 + s) * 64 + l) * 8 + j;
+                        const size_t o = chained ? ((((size_t)kt * OT + ot) * 2 + s) * 64 + l) * 8 + j     // [kt][ot][s]: k-outer sweeps
+                                                 : ((((size_t)ot * KT + kt) * 2 + s) * 64 + l) * 8 + j;    // [ot][ks]: streamed per tile
                         const uint16_t h = f16 ? f2h(v) : f2bf(v);
                         hi[o] = h;
                         lo[o] = f16 ? f2h(v - h2f(h)) : f2bf(v - bf2f(h));

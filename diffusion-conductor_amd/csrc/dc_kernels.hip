@@ -17,6 +17,7 @@
 // Operand formats: T16 = __bf16 or _Float16 (same MFMA rate on gfx950), optionally SPLIT
 // (x = hi + lo, three MFMAs per product: hi*hi + lo*hi + hi*lo) for ~fp32 accuracy.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 #include "dc_common.h"
 
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(256) void k_cond_ca_partials(const DcModel* __restr
         const bf16x8 al = nh_lo[((size_t)g * DC_KS_E + ks) * 64 + lane];
 #pragma unroll
         for (int oc = 0; oc < 4; ++oc) {
-            const int fi = ((ks >> 1) * 4 + oc) * 2 + (ks & 1);   // kt-major image
+            const int fi = oc * DC_KS_E + ks;                      // natural pack: [ot][ks]
             const bf16x8 bk = L.ca_wk[fi * 64 + lane];
             const bf16x8 bv = L.ca_wv[fi * 64 + lane];
             K[oc] = mfma(a, bk, K[oc]);
@@ -627,7 +628,8 @@ __global__ void k_silu_emb(const float* __restrict__ pp /*frag-major fp32*/, con
 // ------------------------------------------------------------------------------------
 // FiLM GEMM: [scale|shift] = Wf * S + bf for all 3*L StylizationBlocks at once
 // (StylizationBlock.emb_layers, transformer.py:57-60,74), with the block's LayerNorm affine folded into
-// the epilogue: it stores G' = g*(1+scale) and H' = b*(1+scale)+shift as fp16 FT tiles,
+// the epilogue: it stores G'-1 = g*(1+scale)-1 and H' = b*(1+scale)+shift as fp16 FT tiles (the
+// "-1" keeps the fp16 rounding on the small modulation, not on the ~1 multiplier),
 // E[g][blk][G'0..3, H'0..3][64][16].  The weight image interleaves each block's tiles as
 // (scale0, shift0, scale1, shift1, ...) so that a wave holds matching scale/shift tiles.
 // v1: operands straight from L2 into registers; wave tile 4 feature tiles x 2 groups.
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(256) void k_film_gemm(const v8<T16>* __restrict__ W
         OP a[4], al[4], b[2], bl[2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const size_t fi = ((size_t)(ks >> 1) * NT + ot0 + i) * 2 + (ks & 1);   // kt-major image
+            const size_t fi = (size_t)(ot0 + i) * DC_KS_E + ks;                      // natural pack: [ot][ks]
             a[i] = W[fi * 64 + lane];
             if constexpr (SPLIT) al[i] = W[(nfw + fi) * 64 + lane];
         }
@@ -688,12 +690,97 @@ __global__ __launch_bounds__(256) void k_film_gemm(const v8<T16>* __restrict__ W
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float sc1 = 1.f + acc[2 * p][j][r] + bs[r];
-                og[r] = (_Float16)(gg[r] * sc1);
+                og[r] = (_Float16)(fmaf(gg[r], sc1, -1.f));
                 oh[r] = (_Float16)(fmaf(be[r], sc1, acc[2 * p + 1][j][r] + bh[r]));
             }
             f16x16* Eb = E + ((size_t)(g0 + j) * NT + blk * 8) * 64 + lane;
             Eb[(pair0 + p) * 64] = og;
             Eb[(4 + pair0 + p) * 64] = oh;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// FiLM GEMM v2 (non-split formats): S-stationary.  One workgroup = 8 waves = 4 token groups (128 tokens):
+// its operand slab S[4 g][32 ks] (128 KiB) is copied once into LDS by LDS-DMA and stays there while the
+// waves sweep all 3L*4*... feature-tile PAIRS (scale tile, shift tile): wave w takes pairs w, w+8, ...
+// Weight fragments stream L2 -> registers through a PF-deep software prefetch ring (each fragment is used
+// by exactly one wave, so LDS staging would buy nothing); there is no barrier in the sweep.
+// Per k-step and wave: 2 weight loads + 4 LDS reads feed 8 MFMAs (accumulators 2 x 4 tiles = 128 VGPRs).
+// ------------------------------------------------------------------------------------
+template <class T16>
+__global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict__ W, const float* __restrict__ bias_ft,
+                                                       const float* __restrict__ g_ft, const float* __restrict__ beta_ft,
+                                                       const v8<T16>* __restrict__ S, f16x16* __restrict__ E, int G, int NT) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using OP = v8<T16>;
+    constexpr int PF = 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g0 = blockIdx.x * 4;
+    // slab: frag (g, ks) at [(g*32 + ks)]; groups past the end alias the last one (their stores are skipped)
+    for (int f = wave; f < 4 * DC_KS_E; f += 8) {
+        const int gg = min(g0 + (f >> 5), G - 1);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(S + ((size_t)gg * DC_KS_E + (f & 31)) * 64 + lane),
+            (__attribute__((address_space(3))) void*)(lds + f * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const OP* slab = reinterpret_cast<const OP*>(lds);
+    const int hh = lane >> 5;
+    const int npair = NT / 2;
+    OP a0[PF], a1[PF];
+    {
+        const OP* w0 = W + (size_t)(2 * wave) * DC_KS_E * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            a0[i] = w0[i * 64];
+            a1[i] = w0[(DC_KS_E + i) * 64];
+        }
+    }
+    for (int p = wave; p < npair; p += 8) {
+        const OP* w0 = W + (size_t)(2 * p) * DC_KS_E * 64 + lane;          // scale tile of the pair; shift tile follows
+        const int pn = p + 8 < npair ? p + 8 : p;                           // next pair (prefetch target)
+        const OP* wn = W + (size_t)(2 * pn) * DC_KS_E * 64 + lane;
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[i][g] = splat(0.f);
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < DC_KS_E; ks0 += PF) {
+            const bool tail = ks0 + PF >= DC_KS_E;                          // ring rolls over into the next pair
+            const OP* wsrc = tail ? wn + (size_t)(ks0 + PF - DC_KS_E) * 64 : w0 + (size_t)(ks0 + PF) * 64;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const OP x0 = a0[u], x1 = a1[u];
+                a0[u] = wsrc[u * 64];
+                a1[u] = wsrc[(DC_KS_E + u) * 64];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const OP b = slab[(g * DC_KS_E + ks0 + u) * 64 + lane];
+                    acc[0][g] = mfma(x0, b, acc[0][g]);
+                    acc[1][g] = mfma(x1, b, acc[1][g]);
+                }
+            }
+        }
+        // epilogue: fold the block's LayerNorm affine, fp16, store
+        const int blk = p >> 2, t = p & 3;
+        const f32x16 bs = ld_ft(bias_ft, 2 * p, hh), bh = ld_ft(bias_ft, 2 * p + 1, hh);
+        const f32x16 gg = ld_ft(g_ft, blk * 4 + t, hh), be = ld_ft(beta_ft, blk * 4 + t, hh);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g0 + g >= G) continue;
+            f16x16 og, oh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sc1 = 1.f + acc[0][g][r] + bs[r];
+                og[r] = (_Float16)(fmaf(gg[r], sc1, -1.f));
+                oh[r] = (_Float16)(fmaf(be[r], sc1, acc[1][g][r] + bh[r]));
+            }
+            f16x16* Eb = E + ((size_t)(g0 + g) * NT + blk * 8) * 64 + lane;
+            Eb[t * 64] = og;
+            Eb[(4 + t) * 64] = oh;
         }
     }
 }
@@ -822,7 +909,7 @@ DEV void query_attend(f32x16 (&y)[4], const f32x16 (&h)[4], const float* bq,
 // StylizationBlock (transformer.py:68-81) accumulated straight into the residual stream:
 //   h += W_o * SiLU( LN(y) * (1 + scale) + shift ) + b_o          (weights image `w` in LDS)
 // with LN(y)*(1+scale)+shift = nhat*G' + H', nhat = (y-mean)*rstd, and G' = g*(1+scale), H' = b*(1+scale)+shift
-// delivered by the FiLM GEMM (E: 4 G' tiles then 4 H' tiles for this block and group).
+// delivered by the FiLM GEMM (E: 4 (G'-1) tiles then 4 H' tiles for this block and group).
 template <class T16, bool SPLIT>
 DEV void styl_accumulate(f32x16 (&h)[4], const f32x16 (&y)[4], const f16x16* __restrict__ E, const DcStyl& st,
                          const v8<T16>* w, int lane, int hh) {
@@ -836,7 +923,10 @@ DEV void styl_accumulate(f32x16 (&h)[4], const f32x16 (&y)[4], const f16x16* __r
             const f16x16 gp = E[kt * 64 + lane], hp = E[(4 + kt) * 64 + lane];
             f32x16 z;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = silu(fmaf(fmaf(y[kt][r], rstd, shift), (float)gp[r], (float)hp[r]));
+            for (int r = 0; r < 16; ++r) {
+                const float n = fmaf(y[kt][r], rstd, shift);
+                z[r] = silu(fmaf(n, (float)gp[r], n + (float)hp[r]));      // n*G' + H',  gp = G' - 1
+            }
             make_frag<T16, SPLIT>(z, zf[kt]);
         }
     }
@@ -1075,8 +1165,26 @@ static void launch_film_t(hipStream_t st, const void* W, const float* bias_ft, c
                                                                          (const v8<T16>*)s_hi, (const v8<T16>*)s_lo,
                                                                          (f16x16*)E, G, NT);
 }
+template <class T16>
+static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bias_ft, const float* g_ft, const float* beta_ft,
+                                 const void* s_hi, void* E, int G, int NT) {
+    const size_t shm = 4 * DC_KS_E * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_film_gemm2<T16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    k_film_gemm2<T16><<<dim3((G + 3) / 4), dim3(512), shm, st>>>((const v8<T16>*)W, bias_ft, g_ft, beta_ft,
+                                                                (const v8<T16>*)s_hi, (f16x16*)E, G, NT);
+    return hipGetLastError();
+}
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const float* g_ft,
                                const float* beta_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT) {
+    static const bool use_v1 = getenv("DC_FILM_V1") != nullptr;
+    if (!split && !use_v1)
+        return fmt == 1 ? launch_film2_t<_Float16>(st, W, bias_ft, g_ft, beta_ft, s_hi, E, G, NT)
+                        : launch_film2_t<__bf16>(st, W, bias_ft, g_ft, beta_ft, s_hi, E, G, NT);
     DISPATCH(fmt, split, (launch_film_t<T16, SP>(st, W, bias_ft, g_ft, beta_ft, s_hi, s_lo, E, G, NT)));
     return LAUNCH_CHECK();
 }

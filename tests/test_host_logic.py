@@ -116,8 +116,8 @@ def test_natural_weight_image_and_split_precision():
     rng = np.random.default_rng(1)
     W = rng.standard_normal((64, 512)).astype(np.float32)
     hi, lo = native.pack_weight(W, chained=False)
-    hi = _bf16_to_f32(hi).reshape(16, 2, 2, 64, 8).transpose(1, 0, 2, 3, 4)     # image is kt-major
-    lo = _bf16_to_f32(lo).reshape(16, 2, 2, 64, 8).transpose(1, 0, 2, 3, 4)
+    hi = _bf16_to_f32(hi).reshape(2, 16, 2, 64, 8)          # natural-k images are [ot][ks]
+    lo = _bf16_to_f32(lo).reshape(2, 16, 2, 64, 8)
     for (ot, kt, s, l, j) in [(0, 0, 0, 0, 0), (1, 7, 1, 45, 3), (1, 15, 1, 63, 7), (0, 9, 0, 32, 5)]:
         w = W[32 * ot + (l & 31), 32 * kt + 16 * s + 8 * (l >> 5) + j]
         assert abs(hi[ot, kt, s, l, j] - w) <= abs(w) * 2.0 ** -8
