@@ -523,7 +523,8 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G));
     const int nl_run = (s->dbg_layers >= 0 && s->dbg_layers < L) ? s->dbg_layers : L;
     for (int l = 0; l < nl_run; ++l) {
-        const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
+        static const int ablate = getenv("DC_ABLATE") ? (int)strtol(getenv("DC_ABLATE"), nullptr, 0) : 0;   // timing experiments
+        const int dbg = ((l == nl_run - 1) ? s->dbg_stage : 0) | ablate;
         LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, G, B, 1));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur,
@@ -744,6 +745,7 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
                                 int32_t B, int32_t T, void* stream) {
     if (!s || !s->finalized) return fail(DC_ERR_INVALID, "sampler not finalized");
     if (!d_xf_proj || !d_xf_out || B < 1 || T < 32) return fail(DC_ERR_INVALID, "bad conditioning arguments (need B >= 1, T >= 32)");
+    if (T / 32 + 2 > 128) return fail(DC_ERR_UNSUPPORTED, "T=%d: the attention combine holds at most 128 token groups per clip (T <= 4032)", T);
     if (T > s->cfg.num_frames) return fail(DC_ERR_INVALID, "T=%d exceeds num_frames=%d rows of sequence_embedding", T, s->cfg.num_frames);
     HIP_TRY(hipSetDevice(s->cfg.device));
     int rc;

@@ -505,13 +505,13 @@ __global__ __launch_bounds__(256) void k_cond_ca_partials(const DcModel* __restr
 // combine partial records of one (set, clip, 32-feature tile) into attention operand frags
 //   A[d][l] = sum_g w_g[d] P_g[d][l] / sum_g w_g[d] ssum_g[d],   w_g = exp(m_g - max_g m_g)
 // recs: [nset][G][2][DC_REC_FLOATS]; afrag out: [nset][B][16 frags (8 hi, 8 lo)][64 lanes][8] T16.
-// grid (B, 4, nset), 256 threads: thread (lane, rq) owns registers 4rq..4rq+3 of the tile.
+// grid (B, 4, nset), 1024 threads: thread (q4, lane, rq) sums group-quarter q4 of registers 4rq..4rq+3 of the tile.
 // All sums run in a fixed order: re-running is bit-identical.
 // ------------------------------------------------------------------------------------
 template <class T16>
-__global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ recs, v8<T16>* __restrict__ afrag,
-                                                      int T, int G, int B) {
-    extern __shared__ float sm[];   // w[ng][32], z[32], red[8][32]
+__global__ __launch_bounds__(1024) void k_attn_combine(const float* __restrict__ recs, v8<T16>* __restrict__ afrag,
+                                                       int T, int G, int B) {
+    extern __shared__ float sm[];   // w[ng][32], z[32], red[32][32], pacc[4][256][4]
     const int b = blockIdx.x, oc = blockIdx.y, set = blockIdx.z;
     const int g_lo = (b * T) / 32, g_hi = ((b + 1) * T - 1) / 32;
     const int ng = g_hi - g_lo + 1;
@@ -519,74 +519,90 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
     float* w = sm;
     float* z = sm + ng * 32;
     float* red = z + 32;
+    float* pacc = red + 1024;
     const int tid = threadIdx.x;
     auto rec_of = [&](int gi) -> const float* {
         const int g = g_lo + gi;
         const int slot = ((32 * g) / T == b) ? 0 : 1;
         return base + ((size_t)g * 2 + slot) * DC_REC_FLOATS;
     };
-    // phase 1: column max over the clip's groups; 8 groups in flight per feature
-    const int f = tid & 31, part = tid >> 5;
-    {
-        float mloc = -INFINITY;
-        for (int gi = part; gi < ng; gi += 8) {
+    // phase 1: every (group, feature) pair read once: m and ssum to registers, column max over groups
+    const int f = tid & 31, part = tid >> 5;          // 32 features x 32 group-parts
+    float mreg[4], sreg[4];                            // this thread's groups: part, part+32, ...  (ng <= 128)
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int gi = part + 32 * k;
+        mreg[k] = 0.f;
+        sreg[k] = 0.f;
+        if (gi < ng) {
             const float* R = rec_of(gi);
-            const float ss = R[128 + 32 * oc + f], mm = R[32 * oc + f];
-            if (ss > 0.f) mloc = fmaxf(mloc, mm);
+            sreg[k] = R[128 + 32 * oc + f];
+            mreg[k] = R[32 * oc + f];
+            if (sreg[k] > 0.f) mloc = fmaxf(mloc, mreg[k]);
         }
-        red[part * 32 + f] = mloc;
     }
+    red[part * 32 + f] = mloc;
     __syncthreads();
     float mstar = red[f];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) mstar = fmaxf(mstar, red[k * 32 + f]);
+#pragma unroll 8
+    for (int k = 1; k < 32; ++k) mstar = fmaxf(mstar, red[k * 32 + f]);
     __syncthreads();
-    // phase 2: weights w_g = exp(m_g - m*) and the normaliser
-    {
-        float zloc = 0.f;
-        for (int gi = part; gi < ng; gi += 8) {
-            const float* R = rec_of(gi);
-            const float ss = R[128 + 32 * oc + f];
-            const float ww = ss > 0.f ? __expf(R[32 * oc + f] - mstar) : 0.f;
+    // phase 2: weights w_g = exp(m_g - m*) and the normaliser (fixed summation order)
+    float zloc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int gi = part + 32 * k;
+        if (gi < ng) {
+            const float ww = sreg[k] > 0.f ? __expf(mreg[k] - mstar) : 0.f;
             w[gi * 32 + f] = ww;
-            zloc += ww * ss;
+            zloc += ww * sreg[k];
         }
-        red[part * 32 + f] = zloc;
     }
+    red[part * 32 + f] = zloc;
     __syncthreads();
     if (tid < 32) {
         float zz = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) zz += red[k * 32 + tid];
+        for (int k = 0; k < 32; ++k) zz += red[k * 32 + tid];
         z[tid] = zz;
     }
-    __syncthreads();
-    // phase 3: weighted sum of the partial K^T V tiles, groups in order
-    const int lane = tid & 63, rq = tid >> 6;
+    // phase 3: weighted sum of the partial K^T V tiles; 4 group-quarters in parallel, each in group order
+    const int q4 = tid >> 8, t8 = tid & 255;
+    const int lane = t8 & 63, rq = t8 >> 6;
     const int c = lane & 31, hh = lane >> 5;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const int row0 = 8 * rq + 4 * hh;   // tile_row(4rq + i, hh) = i + 8rq + 4hh
-    int gi = 0;
-    for (; gi + 4 <= ng; gi += 4) {
-        f32x4 p[4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int per = (ng + 3) / 4, gb = q4 * per, ge = min(gb + per, ng);
+        int gi = gb;
+        for (; gi + 8 <= ge; gi += 8) {
+            f32x4 p[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] = reinterpret_cast<const f32x4*>(rec_of(gi + u) + 256)[(oc * 64 + lane) * 4 + rq];
+            for (int u = 0; u < 8; ++u) p[u] = reinterpret_cast<const f32x4*>(rec_of(gi + u) + 256)[(oc * 64 + lane) * 4 + rq];
+            if (gi == gb) __syncthreads();          // w[] (phase 2) is needed from here on; loads are already in flight
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 8; ++u)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[(gi + u) * 32 + row0 + i], p[u][i], acc[i]);
+                for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[(gi + u) * 32 + row0 + i], p[u][i], acc[i]);
+        }
+        if (gi == gb) __syncthreads();
+        for (; gi < ge; ++gi) {
+            const f32x4 p = reinterpret_cast<const f32x4*>(rec_of(gi) + 256)[(oc * 64 + lane) * 4 + rq];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[gi * 32 + row0 + i], p[i], acc[i]);
+        }
     }
-    for (; gi < ng; ++gi) {
-        const f32x4 p = reinterpret_cast<const f32x4*>(rec_of(gi) + 256)[(oc * 64 + lane) * 4 + rq];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[gi * 32 + row0 + i], p[i], acc[i]);
-    }
+    for (int i = 0; i < 4; ++i) pacc[(q4 * 256 + t8) * 4 + i] = acc[i];
+    __syncthreads();
+    if (q4 != 0) return;
     const bool keep = (rq >> 1) == (c >> 4);   // same head on both sides
     v4<T16> hi, lo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        const float tot = ((pacc[t8 * 4 + i] + pacc[(256 + t8) * 4 + i]) + pacc[(512 + t8) * 4 + i]) + pacc[(768 + t8) * 4 + i];
         const float zz = z[row0 + i];
-        const float a = (keep && zz > 0.f) ? acc[i] / zz : 0.f;
+        const float a = (keep && zz > 0.f) ? tot / zz : 0.f;
         hi[i] = (T16)a;
         lo[i] = (T16)(a - (float)hi[i]);
     }
@@ -912,7 +928,7 @@ DEV void query_attend(f32x16 (&y)[4], const f32x16 (&h)[4], const float* bq,
 // delivered by the FiLM GEMM (E: 4 (G'-1) tiles then 4 H' tiles for this block and group).
 template <class T16, bool SPLIT>
 DEV void styl_accumulate(f32x16 (&h)[4], const f32x16 (&y)[4], const f16x16* __restrict__ E, const DcStyl& st,
-                         const v8<T16>* w, int lane, int hh) {
+                         const v8<T16>* w, int lane, int hh, int abl = 0) {
     XFrag<T16, SPLIT> zf[4];
     {
         float mean, rstd;
@@ -920,7 +936,14 @@ DEV void styl_accumulate(f32x16 (&h)[4], const f32x16 (&y)[4], const f16x16* __r
         const float shift = -mean * rstd;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            const f16x16 gp = E[kt * 64 + lane], hp = E[(4 + kt) * 64 + lane];
+            f16x16 gp, hp;
+            if (abl & 0x100) {            // timing experiment: no FiLM tile loads
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gp[r] = hp[r] = (_Float16)0.f;
+            } else {
+                gp = E[kt * 64 + lane];
+                hp = E[(4 + kt) * 64 + lane];
+            }
             f32x16 z;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -980,8 +1003,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     stage_sync();
     // ---- stage 2: SA stylization [buf1]; prefetch CA query -> buf0
     stage_frags<NW>(L.ca_wq, buf0, 32 * WM, wave, lane);
-    styl_accumulate<T16, SPLIT>(h, y, Eg, L.sa_styl, w1, lane, cx.hh);
-    if (dbg == 1) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after self-attention
+    styl_accumulate<T16, SPLIT>(h, y, Eg, L.sa_styl, w1, lane, cx.hh, dbg);
+    if ((dbg & 0xff) == 1) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after self-attention
     stage_sync();
     // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
     stage_frags<NW>(L.ca_styl.wo, buf1, 32 * WM, wave, lane);
@@ -994,8 +1017,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     // ---- stage 4: CA stylization [buf1]; prefetch FFN W1|W2 -> buf0
     stage_frags<NW>(L.ffn_w1, buf0, 16 * WM, wave, lane);
     stage_frags<NW>(L.ffn_w2, buf0 + 16 * WM * 1024, 16 * WM, wave, lane);
-    styl_accumulate<T16, SPLIT>(h, y, Eg + 8 * 64, L.ca_styl, w1, lane, cx.hh);
-    if (dbg == 2) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after cross-attention
+    styl_accumulate<T16, SPLIT>(h, y, Eg + 8 * 64, L.ca_styl, w1, lane, cx.hh, dbg);
+    if ((dbg & 0xff) == 2) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after cross-attention
     stage_sync();
     // ---- stage 5: FFN [buf0]; prefetch FFN out-proj -> buf1
     stage_frags<NW>(L.ffn_styl.wo, buf1, 32 * WM, wave, lane);
@@ -1026,8 +1049,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         stage_frags<NW>(dm->layer[l + 1].sa_wk, buf0, 32 * WM, wave, lane);
     else
         stage_frags<NW>(dm->out_w, buf0, 16, wave, lane);       // 8 hi + 8 lo frags: the output projection always runs split
-    styl_accumulate<T16, SPLIT>(h, y, Eg + 16 * 64, L.ffn_styl, w1, lane, cx.hh);
-    if (dbg == 3) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
+    styl_accumulate<T16, SPLIT>(h, y, Eg + 16 * 64, L.ffn_styl, w1, lane, cx.hh, dbg);
+    if ((dbg & 0xff) == 3) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
     stage_sync();
 
     if (!last) {
@@ -1038,6 +1061,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         XFrag<T16, SPLIT> nf[4];
         ln_frags<T16, SPLIT>(nf, h);
         stage_sync();
+        if (dbg & 0x400) return;      // timing experiment: no front stage
         sa_front<T16, SPLIT>(nf, w0, w1, N.sa_bk, N.sa_bv, cx, M, T, length, recs + (size_t)g * 2 * DC_REC_FLOATS, active);
         return;
     }
@@ -1137,11 +1161,12 @@ hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* 
 
 hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, void* afrag, int T, int G, int B, int nset) {
     const int ng_max = T / 32 + 2;
-    const size_t shm = (size_t)(ng_max * 32 + 32 + 256) * sizeof(float);
+    if (ng_max > 128) return hipErrorInvalidValue;    // combine holds <= 4 groups per thread (T <= 4032)
+    const size_t shm = (size_t)(ng_max * 32 + 32 + 1024 + 4096) * sizeof(float);
     if (fmt == 1)
-        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(B, 4, nset), dim3(256), shm, st, recs, (f16x8*)afrag, T, G, B);
+        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(B, 4, nset), dim3(1024), shm, st, recs, (f16x8*)afrag, T, G, B);
     else
-        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(B, 4, nset), dim3(256), shm, st, recs, (bf16x8*)afrag, T, G, B);
+        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(B, 4, nset), dim3(1024), shm, st, recs, (bf16x8*)afrag, T, G, B);
     return LAUNCH_CHECK();
 }
 
