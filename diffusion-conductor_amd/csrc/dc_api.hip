@@ -135,6 +135,7 @@ struct dc_sampler {
     DcModel* d_model = nullptr;
     DcModel h_model{};
     int NT = 0;   // FiLM feature tiles = 3 * L * 8
+    int gran = 32;   // tokens per partial-record unit: 32 (per group) or waves-per-workgroup * 32 (T permitting)
 
     hipStream_t stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -285,11 +286,28 @@ int build_model(dc_sampler* s) {
     auto add_raw = [&](const float** dst, const float* v, size_t n) {
         O.fix.push_back({(const void**)dst, A.add(v, n * 4)});
     };
-    auto add_styl = [&](DcStyl& st, const std::string& p) {
-        add_packed(&st.wo, P_(p + ".out_layers.2.weight"), D, D, true, sf16);
-        add_ft(&st.bo, P_(p + ".out_layers.2.bias"), D, 4);
+    // stage image: [hi frags][lo frags if `with_lo`][1 KiB of fp32 constants if `consts`] (dc_common.h)
+    auto add_image = [&](const bf16x8** dst, const float* w, int n_out, int k_in, bool with_lo, const float* consts,
+                         size_t n_consts) {
+        const size_t ne = packed_elems(n_out, k_in);
+        std::vector<uint16_t> hi(ne), lo(ne);
+        pack_weight(w, n_out, k_in, true, hi.data(), lo.data(), sf16);
+        std::vector<uint8_t> blob(ne * 2 * (with_lo ? 2 : 1) + (consts ? 1024 : 0), 0);
+        memcpy(blob.data(), hi.data(), ne * 2);
+        if (with_lo) memcpy(blob.data() + ne * 2, lo.data(), ne * 2);
+        if (consts) memcpy(blob.data() + ne * 2 * (with_lo ? 2 : 1), consts, n_consts * 4);
+        O.fix.push_back({(const void**)dst, A.add(blob.data(), blob.size())});
     };
-
+    auto ftvec = [&](const float* v, int n, int NT_) {
+        std::vector<float> buf((size_t)NT_ * 32);
+        pack_ftvec(v, n, NT_, buf.data());
+        return buf;
+    };
+    const bool ssp = s->split_small;
+    auto add_styl = [&](const bf16x8** dst, const std::string& p) {
+        const std::vector<float> bo = ftvec(P_(p + ".out_layers.2.bias"), D, 4);
+        add_image(dst, P_(p + ".out_layers.2.weight"), D, D, ssp, bo.data(), bo.size());
+    };
     // W' = W diag(g), c' = c + W b  (LayerNorm affine folded into the projection that consumes it)
     auto fold_ln = [&](const float* w, const float* c, const float* g, const float* b, int n_out, int k,
                        std::vector<float>& wf, std::vector<float>& cf) {
@@ -316,19 +334,21 @@ int build_model(dc_sampler* s) {
         const float* sg = P_(p + ".sa_block.norm.weight");
         const float* sb = P_(p + ".sa_block.norm.bias");
         fold_ln(P_(p + ".sa_block.query.weight"), P_(p + ".sa_block.query.bias"), sg, sb, D, D, wf, cf);
-        add_packed(&y.sa_wq, wf.data(), D, D, true, sf16);
-        add_ft(&y.sa_bq, cf.data(), D, 4);
+        {
+            const std::vector<float> c = ftvec(cf.data(), D, 4);
+            add_image(&y.img_sa_q, wf.data(), D, D, ssp, c.data(), c.size());
+        }
         fold_ln(P_(p + ".sa_block.key.weight"), P_(p + ".sa_block.key.bias"), sg, sb, D, D, wf, cf);
-        add_packed(&y.sa_wk, wf.data(), D, D, true, sf16);
-        add_raw(&y.sa_bk, cf.data(), D);
+        add_image(&y.img_sa_k, wf.data(), D, D, ssp, cf.data(), cf.size());          // plain bias[128]
         fold_ln(P_(p + ".sa_block.value.weight"), P_(p + ".sa_block.value.bias"), sg, sb, D, D, wf, cf);
-        add_packed(&y.sa_wv, wf.data(), D, D, true, sf16);
-        add_raw(&y.sa_bv, cf.data(), D);
-        add_styl(y.sa_styl, p + ".sa_block.proj_out");
+        add_image(&y.img_sa_v, wf.data(), D, D, ssp, cf.data(), cf.size());
+        add_styl(&y.img_sa_o, p + ".sa_block.proj_out");
         fold_ln(P_(p + ".ca_block.query.weight"), P_(p + ".ca_block.query.bias"), P_(p + ".ca_block.norm.weight"),
                 P_(p + ".ca_block.norm.bias"), D, D, wf, cf);
-        add_packed(&y.ca_wq, wf.data(), D, D, true, sf16);
-        add_ft(&y.ca_bq, cf.data(), D, 4);
+        {
+            const std::vector<float> c = ftvec(cf.data(), D, 4);
+            add_image(&y.img_ca_q, wf.data(), D, D, ssp, c.data(), c.size());
+        }
         // fold text_norm's affine (transformer.py:149,153) into the K/V projections:
         //   W (g*n + b) + c = (W*g) n + (W b + c)
         {
@@ -351,12 +371,15 @@ int build_model(dc_sampler* s) {
                 add_raw(kv ? &y.ca_bv : &y.ca_bk, bf.data(), D);
             }
         }
-        add_styl(y.ca_styl, p + ".ca_block.proj_out");
-        add_packed(&y.ffn_w1, P_(p + ".ffn.linear1.weight"), DC_F, D, true, sf16);
-        add_packed(&y.ffn_w2, P_(p + ".ffn.linear2.weight"), D, DC_F, true, sf16);
-        add_ft(&y.ffn_b1, P_(p + ".ffn.linear1.bias"), DC_F, 2);
-        add_ft(&y.ffn_b2, P_(p + ".ffn.linear2.bias"), D, 4);
-        add_styl(y.ffn_styl, p + ".ffn.proj_out");
+        add_styl(&y.img_ca_o, p + ".ca_block.proj_out");
+        add_image(&y.img_ffn_w1, P_(p + ".ffn.linear1.weight"), DC_F, D, ssp, nullptr, 0);
+        {
+            std::vector<float> c = ftvec(P_(p + ".ffn.linear1.bias"), DC_F, 2);       // 64 floats, then b2
+            const std::vector<float> c2 = ftvec(P_(p + ".ffn.linear2.bias"), D, 4);
+            c.insert(c.end(), c2.begin(), c2.end());
+            add_image(&y.img_ffn_w2, P_(p + ".ffn.linear2.weight"), D, DC_F, ssp, c.data(), c.size());
+        }
+        add_styl(&y.img_ffn_o, p + ".ffn.proj_out");
         const char* blk[3] = {".sa_block.proj_out", ".ca_block.proj_out", ".ffn.proj_out"};
         for (int j = 0; j < 3; ++j) {
             const size_t row0 = (size_t)(3 * i + j) * 256;
@@ -376,11 +399,13 @@ int build_model(dc_sampler* s) {
     add_ft(&m.film_b, film_b.data(), NT * 32, NT);
     add_ft(&m.film_g, film_g.data(), 3 * L * 128, 3 * L * 4);
     add_ft(&m.film_beta, film_beta.data(), 3 * L * 128, 3 * L * 4);
-    add_packed(&m.je_w, P_("joint_embed.weight"), D, P, true, sf16);
-    add_ft(&m.je_b, P_("joint_embed.bias"), D, 4);
+    {   // the two pose projections always run split: [hi][lo][bias]
+        const std::vector<float> jb = ftvec(P_("joint_embed.bias"), D, 4);
+        add_image(&m.img_je, P_("joint_embed.weight"), D, P, true, jb.data(), jb.size());
+        const std::vector<float> ob = ftvec(P_("out.bias"), P, 1);
+        add_image(&m.img_out, P_("out.weight"), P, D, true, ob.data(), ob.size());
+    }
     add_raw(&m.seq_emb, P_("sequence_embedding"), (size_t)c.num_frames * D);
-    add_packed(&m.out_w, P_("out.weight"), P, D, true, sf16);
-    add_ft(&m.out_b, P_("out.bias"), P, 1);
     {
         const float* w = P_("linear.weight");   // [512][64] -> transposed [64][512]
         std::vector<float> wt((size_t)64 * 512);
@@ -473,6 +498,10 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
     s->T = T;
     s->M = M;
     s->G = G;
+    {   // per-workgroup partial records when a workgroup (NW groups) cannot span more than two clips
+        const int nw = s->split_small ? 4 : 8;
+        s->gran = T >= nw * 32 ? nw * 32 : 32;
+    }
     return DC_OK;
 }
 
@@ -520,15 +549,15 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
                                              s->d_t_clip, s->d_coef_cur, s->d_snap_cur, B));
     LAUNCH(K_SILU, dc_launch_silu_emb(st, ff, sf, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, G, T, B));
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->h_model.film_g, s->h_model.film_beta, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT));
-    LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G));
+    LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, s->gran));
     const int nl_run = (s->dbg_layers >= 0 && s->dbg_layers < L) ? s->dbg_layers : L;
     for (int l = 0; l < nl_run; ++l) {
         static const int ablate = getenv("DC_ABLATE") ? (int)strtol(getenv("DC_ABLATE"), nullptr, 0) : 0;   // timing experiments
         const int dbg = ((l == nl_run - 1) ? s->dbg_stage : 0) | ablate;
-        LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, G, B, 1));
+        LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur,
-                                        s->d_snaps, M, T, G, B, dbg));
+                                        s->d_snaps, M, T, G, B, s->gran, dbg));
     }
     return DC_OK;
 }
@@ -769,7 +798,7 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
     HIP_TRY(dc_launch_cond_pack(st, 1, s->d_y, s->d_mean, s->d_rstd, nullptr, s->d_nh_hi, s->d_nh_lo, G));
     // one-time cost: always split precision (plain bf16 here alone costs ~2e-3 on A_cross)
     HIP_TRY(dc_launch_ca_partials(st, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_recs_ca, M, T, G, L));
-    HIP_TRY(dc_launch_attn_combine(st, s->small_fmt, s->d_recs_ca, s->d_a_ca, T, G, B, L));
+    HIP_TRY(dc_launch_attn_combine(st, s->small_fmt, s->d_recs_ca, s->d_a_ca, T, G, B, L, 32));
     HIP_TRY(hipStreamSynchronize(st));   // `len` is host memory
     s->cond_set = true;
     return sync_out(s, user);

@@ -39,38 +39,26 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 struct bf16x8 { uint16_t v[8]; };
 #endif
 
-// Device pointers to the packed weight image of one StylizationBlock.  Its LayerNorm affine is folded
-// into the FiLM GEMM's epilogue (E holds G' = g*(1+scale) and H' = b*(1+scale)+shift).
-struct DcStyl {
-    const bf16x8* wo;    // chained pack, OT=4 KT=4 (hi frags then lo frags)
-    const float* bo;     // ftvec
-};
-
+// Stage images: what one GEMM stage of k_layer consumes, laid out exactly as it sits in LDS so that one
+// run of LDS-DMA copies brings it in: operand fragments ([hi frags][lo frags], lo always present in the
+// file, staged only in split modes) followed by ONE 1-KiB block of fp32 constants (biases).
+//   128x128 projection: 32 frags per half, chained pack [kt][ot][s];   constants: bias as ftvec [4][2][16]
+//   (K/V projections: plain bias[128], indexed by output feature);    ffn: W1 (16 frags/half) | W2 (16) | b1 ftvec[2], b2 ftvec[4]
 // LayerNorm affines preceding a projection are folded into it on the host:
 //   W (g*n + b) + c = (W diag(g)) n + (W b + c),  n = (x - mean) * rstd
+// and each StylizationBlock's LayerNorm affine is folded into the FiLM GEMM's epilogue.
 struct DcLayer {
-    const bf16x8 *sa_wq, *sa_wk, *sa_wv;       // chained pack 4x4 (sa_block.norm folded in)
-    const float *sa_bq;                        // ftvec
-    const float *sa_bk, *sa_bv;                // plain [128]
-    DcStyl sa_styl;
-    const bf16x8* ca_wq;                       // (ca_block.norm folded in)
-    const float* ca_bq;                        // ftvec
-    const bf16x8 *ca_wk, *ca_wv;               // natural-k pack, OT=4, KS=32 (text_norm folded in), bf16
+    const bf16x8 *img_sa_q, *img_sa_o, *img_ca_q, *img_ca_o, *img_ffn_o, *img_sa_k, *img_sa_v;   // 32 frags/half + consts
+    const bf16x8 *img_ffn_w1, *img_ffn_w2;     // 16 frags/half each; consts (b1 | b2) follow img_ffn_w2
+    const bf16x8 *ca_wk, *ca_wv;               // conditioning pre-pass: natural-k pack [ot][ks], bf16 hi+lo (text_norm folded in)
     const float *ca_bk, *ca_bv;                // plain [128]
-    DcStyl ca_styl;
-    const bf16x8 *ffn_w1;                      // chained pack OT=2 KT=4
-    const bf16x8 *ffn_w2;                      // chained pack OT=4 KT=2
-    const float *ffn_b1, *ffn_b2;              // ftvec (2 tiles / 4 tiles)
-    DcStyl ffn_styl;
 };
 
 struct DcModel {
     DcLayer layer[DC_MAX_LAYERS];
-    const bf16x8* je_w;      // joint_embed, chained pack OT=4 KT=1
-    const float* je_b;       // ftvec
+    const bf16x8* img_je;    // joint_embed: chained pack OT=4 KT=1 (8 frags/half, always used split) + bias ftvec[4]
     const float* seq_emb;    // row-major [num_frames][128]
-    const bf16x8* out_w;     // chained pack OT=1 KT=4
-    const float* out_b;      // ftvec (1 tile)
+    const bf16x8* img_out;   // out: chained pack OT=1 KT=4 (8 frags/half, always used split) + bias ftvec[1]
     const bf16x8* film_w;    // natural-k pack [3*L*8 tiles][32 ks], hi then lo; bf16 or f16 bits (film format)
     const float* film_b;     // ftvec [3*L*8 tiles]
     const float* film_g;     // ftvec [3*L*4 tiles]: StylizationBlock.norm weight per block

@@ -301,6 +301,30 @@ DEV void emit_partial(const f32x16& K, const f32x16& V, int oc, const RowRange& 
     reinterpret_cast<f32x16*>(R + 256)[oc * 64 + cx.lane] = P;
 }
 
+// FiLM tile image: [2 halves][64 lanes][8 fp16] - registers 0..7 then 8..15 of each lane, so that both a
+// register load and an LDS-DMA copy of the tile are lane-linear 16-B accesses.
+DEV void store_etile(f16x16* __restrict__ E, size_t tile, int lane, const f16x16& v) {
+    f16x8* p = reinterpret_cast<f16x8*>(E) + tile * 128 + lane;
+    f16x8 lo8, hi8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        lo8[i] = v[i];
+        hi8[i] = v[8 + i];
+    }
+    p[0] = lo8;
+    p[64] = hi8;
+}
+DEV f16x16 load_etile(const f16x8* __restrict__ p /* tile base + lane; global or LDS */) {
+    const f16x8 lo8 = p[0], hi8 = p[64];
+    f16x16 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v[i] = lo8[i];
+        v[8 + i] = hi8[i];
+    }
+    return v;
+}
+
 DEV void load_h(f32x16 (&h)[4], const float* __restrict__ hbuf, int g, int lane) {
     const f32x16* p = reinterpret_cast<const f32x16*>(hbuf) + (size_t)g * 256 + lane;
 #pragma unroll
@@ -312,26 +336,124 @@ DEV void store_h(const f32x16 (&h)[4], float* __restrict__ hbuf, int g, int lane
     for (int t = 0; t < 4; ++t) p[t * 64] = h[t];
 }
 
-// "Front half" of LinearTemporalSelfAttention (transformer.py:104-117) for one group, given the
-// operand fragments nf of n = LN(h): K = Wk n + bk, V = Wv n + bv in TF form, then the group's
-// partial record(s) of softmax_T(K + mask) and K^T V - one per clip the group touches.
-template <class T16, bool SPLIT>
-DEV void sa_front(const XFrag<T16, SPLIT> (&nf)[4], const v8<T16>* __restrict__ wk, const v8<T16>* __restrict__ wv,
-                  const float* __restrict__ bk, const float* __restrict__ bv, const GroupCtx& cx, int M, int T,
-                  const int* __restrict__ length, float* __restrict__ rec, bool active) {
-    const RowRange valid0 = valid_rows(cx, 0, M, T, length);
-    const RowRange valid1 = valid_rows(cx, cx.straddle ? 1 : 0, M, T, length);
+// "Front half" of LinearTemporalSelfAttention (transformer.py:104-117) for the NW token groups of a workgroup,
+// given each wave's operand fragments nf of n = LN(h): K = Wk n + bk, V = Wv n + bv in TF form, then the partial
+// record(s) of softmax_T(K + mask) and K^T V.
+//   gran == 32    : one record per group and clip slot (small-T fallback: a workgroup may touch many clips)
+//   gran == NW*32 : the NW waves' partials are reduced through LDS (common column max, ordered sums) into ONE
+//                   record per workgroup and clip slot - 8x less record traffic and an 8x shorter combine.
+// `scratch` is the workgroup's LDS (NW*16 KiB + NW*1 KiB used); a barrier is taken before it is overwritten, so
+// the weight images may live in the same LDS.  bk/bv: plain bias[128] (any address space).
+template <class T16, bool SPLIT, int NW>
+DEV void front_stage(const XFrag<T16, SPLIT> (&nf)[4], const v8<T16>* wk, const v8<T16>* wv, const float* bk,
+                     const float* bv, const GroupCtx& cx, int M, int T, const int* __restrict__ length,
+                     float* __restrict__ recs, bool active, int gran, char* scratch, int wave) {
+    if (gran == 32) {
+        float* rec = recs + (size_t)cx.g * 2 * DC_REC_FLOATS;
+        const RowRange valid0 = valid_rows(cx, 0, M, T, length);
+        const RowRange valid1 = valid_rows(cx, cx.straddle ? 1 : 0, M, T, length);
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc) {
+            f32x16 K = splat(bk[32 * oc + cx.c]);
+            f32x16 V = splat(bv[32 * oc + cx.c]);
+            mmb_oc<4, 4, T16, SPLIT>(K, wk, oc, nf, cx.lane);
+            mmb_oc<4, 4, T16, SPLIT>(V, wv, oc, nf, cx.lane);
+            if (active) {
+                emit_partial<T16, SPLIT>(K, V, oc, valid0, rec, cx);
+                if (cx.straddle) emit_partial<T16, SPLIT>(K, V, oc, valid1, rec + DC_REC_FLOATS, cx);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the four feature tiles sequential: bounds register pressure
+        }
+        return;
+    }
+    f32x16 K[4], V[4];
 #pragma unroll
     for (int oc = 0; oc < 4; ++oc) {
-        f32x16 K = splat(bk[32 * oc + cx.c]);
-        f32x16 V = splat(bv[32 * oc + cx.c]);
-        mmb_oc<4, 4, T16, SPLIT>(K, wk, oc, nf, cx.lane);
-        mmb_oc<4, 4, T16, SPLIT>(V, wv, oc, nf, cx.lane);
-        if (active) {
-            emit_partial<T16, SPLIT>(K, V, oc, valid0, rec, cx);
-            if (cx.straddle) emit_partial<T16, SPLIT>(K, V, oc, valid1, rec + DC_REC_FLOATS, cx);
+        K[oc] = splat(bk[32 * oc + cx.c]);
+        V[oc] = splat(bv[32 * oc + cx.c]);
+        mmb_oc<4, 4, T16, SPLIT>(K[oc], wk, oc, nf, cx.lane);
+        mmb_oc<4, 4, T16, SPLIT>(V[oc], wv, oc, nf, cx.lane);
+    }
+    __syncthreads();                                  // every wave is done with the weight images
+    float* P_lds = reinterpret_cast<float*>(scratch);                 // [NW][4 oc][64 lanes][16]
+    float* red_m = reinterpret_cast<float*>(scratch + NW * 16384);    // [NW][128]
+    float* red_s = red_m + NW * 128;                                  // [NW][128]
+    const int u = blockIdx.x;
+    const int ufirst = u * gran, ulast = min(ufirst + gran - 1, M - 1);
+    const int ub0 = ufirst / T, ub1 = ulast / T;
+    const int nslot = ub1 != ub0 ? 2 : 1;
+    const int tid = wave * 64 + cx.lane;
+    for (int slot = 0; slot < nslot; ++slot) {
+        const int bs = slot ? ub1 : ub0;
+        RowRange rr;                                   // this group's rows inside clip bs, unmasked
+        {
+            const int len = length ? length[bs] : T;
+            const int first = max(bs * T, 32 * cx.g);
+            const int end = min(min(bs * T + min(len, T), M), 32 * cx.g + 32);
+            rr.lo = first - 32 * cx.g - 4 * cx.hh;
+            rr.span = (active && end > first) ? (unsigned)(end - first) : 0u;
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the four feature tiles sequential: bounds register pressure
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = row_ok(rr, r) ? fmaxf(m, K[oc][r]) : m;
+            m = xhalf_max(m);
+            if (cx.hh == 0) red_m[wave * 128 + 32 * oc + cx.c] = m;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc) {
+            float mw = red_m[32 * oc + cx.c];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) mw = fmaxf(mw, red_m[w * 128 + 32 * oc + cx.c]);
+            if (mw == -INFINITY) mw = 0.f;
+            f32x16 Ee, Vm;
+            float ssum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = row_ok(rr, r);
+                const float e = ok ? __expf(K[oc][r] - mw) : 0.f;
+                Ee[r] = e;
+                ssum += e;
+                Vm[r] = ok ? V[oc][r] : 0.f;
+            }
+            ssum = xhalf_sum(ssum);
+            XFrag<T16, SPLIT> ef, vf;
+            make_frag<T16, SPLIT>(Ee, ef);
+            make_frag<T16, SPLIT>(Vm, vf);
+            f32x16 P = splat(0.f);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                P = mfma(ef.hi[s], vf.hi[s], P);
+                if constexpr (SPLIT) {
+                    P = mfma(ef.lo[s], vf.hi[s], P);
+                    P = mfma(ef.hi[s], vf.lo[s], P);
+                }
+            }
+            reinterpret_cast<f32x16*>(P_lds)[(wave * 4 + oc) * 64 + cx.lane] = P;
+            if (cx.hh == 0) red_s[wave * 128 + 32 * oc + cx.c] = ssum;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        float* R = recs + ((size_t)u * 2 + slot) * DC_REC_FLOATS;
+        for (int e = tid * 4; e < 4096; e += NW * 64 * 4) {      // ordered sum over the waves
+            f32x4 acc = *reinterpret_cast<const f32x4*>(P_lds + e);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) acc += *reinterpret_cast<const f32x4*>(P_lds + w * 4096 + e);
+            *reinterpret_cast<f32x4*>(R + 256 + e) = acc;
+        }
+        if (tid < 128) {
+            float mw = red_m[tid], ss = red_s[tid];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                mw = fmaxf(mw, red_m[w * 128 + tid]);
+                ss += red_s[w * 128 + tid];
+            }
+            R[tid] = mw == -INFINITY ? 0.f : mw;
+            R[128 + tid] = ss;
+        }
+        __syncthreads();                              // scratch is reused by the next slot
     }
 }
 
@@ -504,18 +626,18 @@ __global__ __launch_bounds__(256) void k_cond_ca_partials(const DcModel* __restr
 // ------------------------------------------------------------------------------------
 // combine partial records of one (set, clip, 32-feature tile) into attention operand frags
 //   A[d][l] = sum_g w_g[d] P_g[d][l] / sum_g w_g[d] ssum_g[d],   w_g = exp(m_g - max_g m_g)
-// recs: [nset][G][2][DC_REC_FLOATS]; afrag out: [nset][B][16 frags (8 hi, 8 lo)][64 lanes][8] T16.
+// recs: [nset][NU units][2][DC_REC_FLOATS] (a unit = `gran` consecutive tokens); afrag out: [nset][B][16 frags (8 hi, 8 lo)][64 lanes][8] T16.
 // grid (B, 4, nset), 1024 threads: thread (q4, lane, rq) sums group-quarter q4 of registers 4rq..4rq+3 of the tile.
 // All sums run in a fixed order: re-running is bit-identical.
 // ------------------------------------------------------------------------------------
 template <class T16>
 __global__ __launch_bounds__(1024) void k_attn_combine(const float* __restrict__ recs, v8<T16>* __restrict__ afrag,
-                                                       int T, int G, int B) {
+                                                       int T, int NU, int B, int gran) {
     extern __shared__ float sm[];   // w[ng][32], z[32], red[32][32], pacc[4][256][4]
     const int b = blockIdx.x, oc = blockIdx.y, set = blockIdx.z;
-    const int g_lo = (b * T) / 32, g_hi = ((b + 1) * T - 1) / 32;
+    const int g_lo = (b * T) / gran, g_hi = ((b + 1) * T - 1) / gran;     // record units (gran tokens each) of this clip
     const int ng = g_hi - g_lo + 1;
-    const float* base = recs + (size_t)set * G * 2 * DC_REC_FLOATS;
+    const float* base = recs + (size_t)set * NU * 2 * DC_REC_FLOATS;
     float* w = sm;
     float* z = sm + ng * 32;
     float* red = z + 32;
@@ -523,7 +645,7 @@ __global__ __launch_bounds__(1024) void k_attn_combine(const float* __restrict__
     const int tid = threadIdx.x;
     auto rec_of = [&](int gi) -> const float* {
         const int g = g_lo + gi;
-        const int slot = ((32 * g) / T == b) ? 0 : 1;
+        const int slot = ((gran * g) / T == b) ? 0 : 1;
         return base + ((size_t)g * 2 + slot) * DC_REC_FLOATS;
     };
     // phase 1: every (group, feature) pair read once: m and ssum to registers, column max over groups
@@ -709,9 +831,8 @@ __global__ __launch_bounds__(256) void k_film_gemm(const v8<T16>* __restrict__ W
                 og[r] = (_Float16)(fmaf(gg[r], sc1, -1.f));
                 oh[r] = (_Float16)(fmaf(be[r], sc1, acc[2 * p + 1][j][r] + bh[r]));
             }
-            f16x16* Eb = E + ((size_t)(g0 + j) * NT + blk * 8) * 64 + lane;
-            Eb[(pair0 + p) * 64] = og;
-            Eb[(4 + pair0 + p) * 64] = oh;
+            store_etile(E, (size_t)(g0 + j) * NT + blk * 8 + pair0 + p, lane, og);
+            store_etile(E, (size_t)(g0 + j) * NT + blk * 8 + 4 + pair0 + p, lane, oh);
         }
     }
 }
@@ -794,9 +915,8 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
                 og[r] = (_Float16)(fmaf(gg[r], sc1, -1.f));
                 oh[r] = (_Float16)(fmaf(be[r], sc1, acc[1][g][r] + bh[r]));
             }
-            f16x16* Eb = E + ((size_t)(g0 + g) * NT + blk * 8) * 64 + lane;
-            Eb[t * 64] = og;
-            Eb[(4 + t) * 64] = oh;
+            store_etile(E, (size_t)(g0 + g) * NT + blk * 8 + t, lane, og);
+            store_etile(E, (size_t)(g0 + g) * NT + blk * 8 + 4 + t, lane, oh);
         }
     }
 }
@@ -808,12 +928,17 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
 // single largest error source otherwise, and the GEMM is tiny.
 // ------------------------------------------------------------------------------------
 template <class T16, bool SPLIT>
-__global__ __launch_bounds__(256) void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /*[M][P]*/,
-                                                     float* __restrict__ hbuf, float* __restrict__ recs,
-                                                     const int* __restrict__ length, int M, int T, int G) {
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= G) return;
-    const int lane = threadIdx.x & 63;
+__global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
+void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /*[M][P]*/, float* __restrict__ hbuf,
+                   float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G, int gran) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int NW = SPLIT ? 4 : 8;
+    constexpr int WM = SPLIT ? 2 : 1;
+    using W = v8<T16>;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int g = blockIdx.x * NW + wave;
+    const bool active = g < G;
+    if (!active) g = G - 1;
     const GroupCtx cx = make_ctx(g, lane, M, T);
     const int P = dm->input_feats;
     const bool live = cx.tok < M;
@@ -829,9 +954,11 @@ __global__ __launch_bounds__(256) void k_embed_front(const DcModel* __restrict__
             xv[r] = (live && f < P) ? x[(size_t)cx.tok * P + f] : 0.f;
         }
         make_frag<T16, true>(xv, xf[0]);
+        const W* img = reinterpret_cast<const W*>(dm->img_je);
+        const float* je_b = reinterpret_cast<const float*>(img + 16 * 64);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) h[t] = ld_ft(dm->je_b, t, cx.hh);
-        gemm_wa<4, 1, T16, true>(h, reinterpret_cast<const v8<T16>*>(dm->je_w), xf, lane);
+        for (int t = 0; t < 4; ++t) h[t] = ld_ft(je_b, t, cx.hh);
+        gemm_wa<4, 1, T16, true>(h, img, xf, lane);
     }
     const float* se = dm->seq_emb + (size_t)n * DC_D;
 #pragma unroll
@@ -842,12 +969,14 @@ __global__ __launch_bounds__(256) void k_embed_front(const DcModel* __restrict__
 #pragma unroll
             for (int i = 0; i < 4; ++i) h[t][4 * q + i] += v[i];
         }
-    store_h(h, hbuf, g, lane);
+    if (active) store_h(h, hbuf, g, lane);
     const DcLayer& L = dm->layer[0];
     XFrag<T16, SPLIT> nf[4];
     ln_frags<T16, SPLIT>(nf, h);
-    sa_front<T16, SPLIT>(nf, reinterpret_cast<const v8<T16>*>(L.sa_wk), reinterpret_cast<const v8<T16>*>(L.sa_wv), L.sa_bk,
-                         L.sa_bv, cx, M, T, length, recs + (size_t)g * 2 * DC_REC_FLOATS, true);
+    const W* wk = reinterpret_cast<const W*>(L.img_sa_k);
+    const W* wv = reinterpret_cast<const W*>(L.img_sa_v);
+    front_stage<T16, SPLIT, NW>(nf, wk, wv, reinterpret_cast<const float*>(wk + 32 * WM * 64),
+                                reinterpret_cast<const float*>(wv + 32 * WM * 64), cx, M, T, length, recs, active, gran, lds, wave);
 }
 
 // ------------------------------------------------------------------------------------
@@ -889,11 +1018,10 @@ DEV void attn_apply_tile(f32x16& y, const v8<T16>* __restrict__ afrag, int oc, c
     }
 }
 
-// q = softmax_heads(Wq LN(h) + bq);  y = q . A per head  (weights image `w` in LDS)
+// q = softmax_heads(Wq LN(h) + bq);  y = q . A per head  (weights image `w` in LDS, bias block behind it)
 template <class T16, bool SPLIT>
-DEV void query_attend(f32x16 (&y)[4], const f32x16 (&h)[4], const float* bq,
-                      const v8<T16>* w, const v8<T16>* __restrict__ a0, const v8<T16>* __restrict__ a1,
-                      const GroupCtx& cx) {
+DEV void query_attend(f32x16 (&y)[4], const f32x16 (&h)[4], const float* bq, const v8<T16>* w, const v8<T16>* a0,
+                      const v8<T16>* a1, const GroupCtx& cx) {
     f32x16 q[4];
     {
         XFrag<T16, SPLIT> nf[4];
@@ -922,13 +1050,25 @@ DEV void query_attend(f32x16 (&y)[4], const f32x16 (&h)[4], const float* bq,
     }
 }
 
-// StylizationBlock (transformer.py:68-81) accumulated straight into the residual stream:
-//   h += W_o * SiLU( LN(y) * (1 + scale) + shift ) + b_o          (weights image `w` in LDS)
-// with LN(y)*(1+scale)+shift = nhat*G' + H', nhat = (y-mean)*rstd, and G' = g*(1+scale), H' = b*(1+scale)+shift
-// delivered by the FiLM GEMM (E: 4 (G'-1) tiles then 4 H' tiles for this block and group).
+// one k-tile of the FiLM-modulated, SiLU'ed operand: z = SiLU(nhat*G' + H'), gp = G' - 1
 template <class T16, bool SPLIT>
-DEV void styl_accumulate(f32x16 (&h)[4], const f32x16 (&y)[4], const f16x16* __restrict__ E, const DcStyl& st,
-                         const v8<T16>* w, int lane, int hh, int abl = 0) {
+DEV void styl_tile(XFrag<T16, SPLIT>& zf, const f32x16& y, float rstd, float shift, const f16x16& gp, const f16x16& hp) {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float n = fmaf(y[r], rstd, shift);
+        z[r] = silu(fmaf(n, (float)gp[r], n + (float)hp[r]));
+    }
+    make_frag<T16, SPLIT>(z, zf);
+}
+
+// StylizationBlock (transformer.py:68-81) accumulated straight into the residual stream:
+//   h += W_o * SiLU( LN(y) * (1 + scale) + shift ) + b_o          (weights image `w` in LDS, b_o behind it)
+// with LN(y)*(1+scale)+shift = nhat*G' + H', nhat = (y-mean)*rstd; the FiLM GEMM delivers G'-1 and H' tiles.
+// E tiles come straight from global memory (Eg: this block's 8 tiles for this group).
+template <class T16, bool SPLIT>
+DEV void styl_accumulate(f32x16 (&h)[4], const f32x16 (&y)[4], const f16x8* __restrict__ Eg, const float* bo,
+                         const v8<T16>* w, int lane, int hh, int abl) {
     XFrag<T16, SPLIT> zf[4];
     {
         float mean, rstd;
@@ -941,22 +1081,67 @@ DEV void styl_accumulate(f32x16 (&h)[4], const f32x16 (&y)[4], const f16x16* __r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gp[r] = hp[r] = (_Float16)0.f;
             } else {
-                gp = E[kt * 64 + lane];
-                hp = E[(4 + kt) * 64 + lane];
+                gp = load_etile(Eg + kt * 128 + lane);
+                hp = load_etile(Eg + (4 + kt) * 128 + lane);
             }
-            f32x16 z;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float n = fmaf(y[kt][r], rstd, shift);
-                z[r] = silu(fmaf(n, (float)gp[r], n + (float)hp[r]));      // n*G' + H',  gp = G' - 1
-            }
-            make_frag<T16, SPLIT>(z, zf[kt]);
+            styl_tile<T16, SPLIT>(zf[kt], y[kt], rstd, shift, gp, hp);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const f32x16 bb = ld_ft(st.bo, t, hh);
+        const f32x16 bb = ld_ft(bo, t, hh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[t][r] += bb[r];
+    }
+    gemm_wa<4, 4, T16, SPLIT>(h, w, zf, lane);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Per-wave FiLM tile ring in LDS: two 4-KiB slots, each holding one k-tile's (G'-1, H') tile pair.
+DEV void ering_issue(const f16x8* __restrict__ Eg, int kt, char* slot, int lane) {
+    const f16x8* gsrc = Eg + kt * 128 + lane;
+    const f16x8* hsrc = Eg + (4 + kt) * 128 + lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc), (__attribute__((address_space(3))) void*)(slot), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + 64), (__attribute__((address_space(3))) void*)(slot + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hsrc), (__attribute__((address_space(3))) void*)(slot + 2048), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hsrc + 64), (__attribute__((address_space(3))) void*)(slot + 3072), 16, 0, 0);
+}
+// same StylizationBlock with the FiLM tiles arriving through the ring: k-tiles 0,1 were issued a stage ago;
+// k-tiles 2,3 are issued as soon as 0,1 sit in registers and land behind the first half's VALU work.
+template <class T16, bool SPLIT>
+DEV void styl_accumulate_ring(f32x16 (&h)[4], const f32x16 (&y)[4], const f16x8* __restrict__ Eg, char* ring,
+                              const float* bo, const v8<T16>* w, int lane, int hh) {
+    XFrag<T16, SPLIT> zf[4];
+    float mean, rstd;
+    ln_stats<4>(y, mean, rstd);
+    const float shift = -mean * rstd;
+    const f16x8* s0 = reinterpret_cast<const f16x8*>(ring) + lane;
+    const f16x8* s1 = reinterpret_cast<const f16x8*>(ring + 4096) + lane;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        const f16x16 g0 = load_etile(s0), h0 = load_etile(s0 + 128);
+        const f16x16 g1 = load_etile(s1), h1 = load_etile(s1 + 128);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ering_issue(Eg, 2, ring, lane);
+        ering_issue(Eg, 3, ring + 4096, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        styl_tile<T16, SPLIT>(zf[0], y[0], rstd, shift, g0, h0);
+        styl_tile<T16, SPLIT>(zf[1], y[1], rstd, shift, g1, h1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        const f16x16 g2 = load_etile(s0), h2 = load_etile(s0 + 128);
+        const f16x16 g3 = load_etile(s1), h3 = load_etile(s1 + 128);
+        styl_tile<T16, SPLIT>(zf[2], y[2], rstd, shift, g2, h2);
+        styl_tile<T16, SPLIT>(zf[3], y[3], rstd, shift, g3, h3);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the ring slots are free again
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const f32x16 bb = ld_ft(bo, t, hh);
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[t][r] += bb[r];
     }
@@ -970,11 +1155,14 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
              const v8<T16>* __restrict__ a_sa /*[B][16][64]*/, const v8<T16>* __restrict__ a_ca /*[L][B][16][64]*/,
              float* __restrict__ recs, const int* __restrict__ length, const float* __restrict__ xin,
              float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur, const int* __restrict__ snap_cur,
-             float* __restrict__ snaps, int M, int T, int G, int B, int dbg) {
+             float* __restrict__ snaps, int M, int T, int G, int B, int gran, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int NW = SPLIT ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;            // operand images per matrix (hi [+ lo])
-    constexpr int WBUF = 32768 * WM;             // one 128x128 matrix
+    constexpr int NFW = 32 * WM;                 // frags of one 128x128 stage image (constants block follows)
+    constexpr int WSZ = (NFW + 1) * 1024;
+    constexpr int OFF_AF = 2 * WSZ;              // non-split: attention frags of the workgroup's <= 2 clips (16 KiB)
+    constexpr int OFF_ER = OFF_AF + 16384;       // non-split: per-wave FiLM tile rings (8 KiB each)
     using W = v8<T16>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int g = blockIdx.x * NW + wave;
@@ -984,44 +1172,78 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const DcLayer& L = dm->layer[l];
     const int nl = dm->num_layers;
     const bool last = l + 1 >= nl;
-    const f16x16* Eg = E + ((size_t)g * NT + (size_t)l * 24) * 64;   // this layer's 3 blocks x 8 tiles
+    const f16x8* Eg = reinterpret_cast<const f16x8*>(E) + ((size_t)g * NT + (size_t)l * 24) * 128;   // 3 blocks x 8 tiles
     char* buf0 = lds;
-    char* buf1 = lds + WBUF;
+    char* buf1 = lds + WSZ;
     const W* w0 = reinterpret_cast<const W*>(buf0);
     const W* w1 = reinterpret_cast<const W*>(buf1);
+    const float* c0 = reinterpret_cast<const float*>(buf0 + NFW * 1024);    // constants block of the image in buf0
+    const float* c1 = reinterpret_cast<const float*>(buf1 + NFW * 1024);
+    // LDS paths for attention frags / FiLM ring need the workgroup to span <= 2 clips (true when gran == NW*32)
+    const bool wg_lds = !SPLIT && gran != 32;
+    const int ub0 = (blockIdx.x * NW * 32) / T;
+    char* ring = lds + OFF_ER + wave * 8192;
+    auto stage_attn = [&](const W* a) {          // frags of clips ub0, ub0+1 -> AF region
+        const int c1i = min(ub0 + 1, B - 1);
+        stage_frags<NW>(a + (size_t)ub0 * 16 * 64, lds + OFF_AF, 8, wave, lane);
+        stage_frags<NW>(a + (size_t)c1i * 16 * 64, lds + OFF_AF + 8192, 8, wave, lane);
+    };
+    const W* af = reinterpret_cast<const W*>(lds + OFF_AF);
 
-    stage_frags<NW>(L.sa_wq, buf0, 32 * WM, wave, lane);
+    stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
+    if (wg_lds) {
+        stage_attn(a_sa);
+        ering_issue(Eg, 0, ring, lane);
+        ering_issue(Eg, 1, ring + 4096, lane);
+    }
     f32x16 h[4];
     load_h(h, hbuf, g, lane);
     stage_sync();
 
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
-    stage_frags<NW>(L.sa_styl.wo, buf1, 32 * WM, wave, lane);
+    stage_frags<NW>(L.img_sa_o, buf1, NFW + 1, wave, lane);
     f32x16 y[4];
-    query_attend<T16, SPLIT>(y, h, L.sa_bq, w0, a_sa + (size_t)cx.b0 * 16 * 64,
-                             a_sa + (size_t)cx.b1 * 16 * 64, cx);
+    if (wg_lds)
+        query_attend<T16, SPLIT>(y, h, c0, w0, af + (size_t)(cx.b0 - ub0) * 8 * 64, af + (size_t)(cx.b1 - ub0) * 8 * 64, cx);
+    else
+        query_attend<T16, SPLIT>(y, h, c0, w0, a_sa + (size_t)cx.b0 * 16 * 64, a_sa + (size_t)cx.b1 * 16 * 64, cx);
     stage_sync();
-    // ---- stage 2: SA stylization [buf1]; prefetch CA query -> buf0
-    stage_frags<NW>(L.ca_wq, buf0, 32 * WM, wave, lane);
-    styl_accumulate<T16, SPLIT>(h, y, Eg, L.sa_styl, w1, lane, cx.hh, dbg);
+    // ---- stage 2: SA stylization [buf1]; prefetch CA query -> buf0 (+ cross-attention frags)
+    stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
+    if (wg_lds) {
+        stage_attn(a_ca + (size_t)l * B * 16 * 64);
+        styl_accumulate_ring<T16, SPLIT>(h, y, Eg, ring, c1, w1, lane, cx.hh);
+    } else {
+        styl_accumulate<T16, SPLIT>(h, y, Eg, c1, w1, lane, cx.hh, dbg);
+    }
     if ((dbg & 0xff) == 1) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after self-attention
     stage_sync();
     // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
-    stage_frags<NW>(L.ca_styl.wo, buf1, 32 * WM, wave, lane);
-    {
+    stage_frags<NW>(L.img_ca_o, buf1, NFW + 1, wave, lane);
+    if (wg_lds) {
+        ering_issue(Eg + 8 * 128, 0, ring, lane);
+        ering_issue(Eg + 8 * 128, 1, ring + 4096, lane);
+        query_attend<T16, SPLIT>(y, h, c0, w0, af + (size_t)(cx.b0 - ub0) * 8 * 64, af + (size_t)(cx.b1 - ub0) * 8 * 64, cx);
+    } else {
         const W* acl = a_ca + (size_t)l * B * 16 * 64;
-        query_attend<T16, SPLIT>(y, h, L.ca_bq, w0, acl + (size_t)cx.b0 * 16 * 64,
-                                 acl + (size_t)cx.b1 * 16 * 64, cx);
+        query_attend<T16, SPLIT>(y, h, c0, w0, acl + (size_t)cx.b0 * 16 * 64, acl + (size_t)cx.b1 * 16 * 64, cx);
     }
     stage_sync();
-    // ---- stage 4: CA stylization [buf1]; prefetch FFN W1|W2 -> buf0
-    stage_frags<NW>(L.ffn_w1, buf0, 16 * WM, wave, lane);
-    stage_frags<NW>(L.ffn_w2, buf0 + 16 * WM * 1024, 16 * WM, wave, lane);
-    styl_accumulate<T16, SPLIT>(h, y, Eg + 8 * 64, L.ca_styl, w1, lane, cx.hh, dbg);
+    // ---- stage 4: CA stylization [buf1]; prefetch FFN W1|W2 (+ b1|b2) -> buf0
+    stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
+    stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
+    if (wg_lds)
+        styl_accumulate_ring<T16, SPLIT>(h, y, Eg + 8 * 128, ring, c1, w1, lane, cx.hh);
+    else
+        styl_accumulate<T16, SPLIT>(h, y, Eg + 8 * 128, c1, w1, lane, cx.hh, dbg);
     if ((dbg & 0xff) == 2) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after cross-attention
     stage_sync();
     // ---- stage 5: FFN [buf0]; prefetch FFN out-proj -> buf1
-    stage_frags<NW>(L.ffn_styl.wo, buf1, 32 * WM, wave, lane);
+    stage_frags<NW>(L.img_ffn_o, buf1, NFW + 1, wave, lane);
+    if (wg_lds) {
+        ering_issue(Eg + 16 * 128, 0, ring, lane);
+        ering_issue(Eg + 16 * 128, 1, ring + 4096, lane);
+    }
     {
         f32x16 u[2];
         {
@@ -1029,7 +1251,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) make_frag<T16, SPLIT>(h[kt], hf[kt]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) u[t] = ld_ft(L.ffn_b1, t, cx.hh);
+            for (int t = 0; t < 2; ++t) u[t] = ld_ft(c0, t, cx.hh);                 // b1
             gemm_wa<2, 4, T16, SPLIT>(u, w0, hf, lane);
         }
         XFrag<T16, SPLIT> uf[2];
@@ -1040,29 +1262,31 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             make_frag<T16, SPLIT>(u[kt], uf[kt]);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) y[t] = ld_ft(L.ffn_b2, t, cx.hh);
+        for (int t = 0; t < 4; ++t) y[t] = ld_ft(c0 + 64, t, cx.hh);               // b2
         gemm_wa<4, 2, T16, SPLIT>(y, w0 + 16 * WM * 64, uf, lane);
     }
     stage_sync();
     // ---- stage 6: FFN stylization [buf1]; prefetch next layer's key projection (or the output projection) -> buf0
     if (!last)
-        stage_frags<NW>(dm->layer[l + 1].sa_wk, buf0, 32 * WM, wave, lane);
+        stage_frags<NW>(dm->layer[l + 1].img_sa_k, buf0, NFW + 1, wave, lane);
     else
-        stage_frags<NW>(dm->out_w, buf0, 16, wave, lane);       // 8 hi + 8 lo frags: the output projection always runs split
-    styl_accumulate<T16, SPLIT>(h, y, Eg + 16 * 64, L.ffn_styl, w1, lane, cx.hh, dbg);
+        stage_frags<NW>(dm->img_out, buf0, 17, wave, lane);      // 8 hi + 8 lo frags + bias: always runs split
+    if (wg_lds)
+        styl_accumulate_ring<T16, SPLIT>(h, y, Eg + 16 * 128, ring, c1, w1, lane, cx.hh);
+    else
+        styl_accumulate<T16, SPLIT>(h, y, Eg + 16 * 128, c1, w1, lane, cx.hh, dbg);
     if ((dbg & 0xff) == 3) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
     stage_sync();
 
     if (!last) {
         // ---- stage 7: next layer's SA front half: K [buf0] and V [buf1], partial records
-        const DcLayer& N = dm->layer[l + 1];
-        stage_frags<NW>(N.sa_wv, buf1, 32 * WM, wave, lane);
+        stage_frags<NW>(dm->layer[l + 1].img_sa_v, buf1, NFW + 1, wave, lane);
         if (active) store_h(h, hbuf, g, lane);
         XFrag<T16, SPLIT> nf[4];
         ln_frags<T16, SPLIT>(nf, h);
         stage_sync();
         if (dbg & 0x400) return;      // timing experiment: no front stage
-        sa_front<T16, SPLIT>(nf, w0, w1, N.sa_bk, N.sa_bv, cx, M, T, length, recs + (size_t)g * 2 * DC_REC_FLOATS, active);
+        front_stage<T16, SPLIT, NW>(nf, w0, w1, c0, c1, cx, M, T, length, recs, active, gran, lds, wave);
         return;
     }
     // ---- output projection [buf0, split] + DDIM update
@@ -1071,7 +1295,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         XFrag<T16, true> hf[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) make_frag<T16, true>(h[kt], hf[kt]);
-        x0[0] = ld_ft(dm->out_b, 0, cx.hh);
+        x0[0] = ld_ft(reinterpret_cast<const float*>(buf0 + 16 * 1024), 0, cx.hh);
         gemm_wa<1, 4, T16, true>(x0, w0, hf, lane);
     }
     if (!active || cx.tok >= M) return;
@@ -1159,14 +1383,15 @@ hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* 
     return LAUNCH_CHECK();
 }
 
-hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, void* afrag, int T, int G, int B, int nset) {
-    const int ng_max = T / 32 + 2;
+hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, void* afrag, int T, int NU, int B, int nset,
+                                  int gran) {
+    const int ng_max = T / gran + 2;
     if (ng_max > 128) return hipErrorInvalidValue;    // combine holds <= 4 groups per thread (T <= 4032)
     const size_t shm = (size_t)(ng_max * 32 + 32 + 1024 + 4096) * sizeof(float);
     if (fmt == 1)
-        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(B, 4, nset), dim3(1024), shm, st, recs, (f16x8*)afrag, T, G, B);
+        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(B, 4, nset), dim3(1024), shm, st, recs, (f16x8*)afrag, T, NU, B, gran);
     else
-        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(B, 4, nset), dim3(1024), shm, st, recs, (bf16x8*)afrag, T, G, B);
+        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(B, 4, nset), dim3(1024), shm, st, recs, (bf16x8*)afrag, T, NU, B, gran);
     return LAUNCH_CHECK();
 }
 
@@ -1215,23 +1440,34 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
 }
 
 template <class T16, bool SP>
-static void launch_embed_t(hipStream_t st, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
-                           int M, int T, int G) {
-    k_embed_front<T16, SP><<<dim3((G + 3) / 4), dim3(256), 0, st>>>(dm, x, hbuf, recs, length, M, T, G);
+static hipError_t launch_embed_t(hipStream_t st, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
+                                 int M, int T, int G, int gran) {
+    constexpr int NW = SP ? 4 : 8;
+    const size_t shm = (size_t)NW * 17408;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_embed_front<T16, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    k_embed_front<T16, SP><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, gran);
+    return hipGetLastError();
 }
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, const DcModel* dm, const float* x, float* hbuf,
-                                 float* recs, const int* length, int M, int T, int G) {
-    DISPATCH(fmt, split, (launch_embed_t<T16, SP>(st, dm, x, hbuf, recs, length, M, T, G)));
-    return LAUNCH_CHECK();
+                                 float* recs, const int* length, int M, int T, int G, int gran) {
+    hipError_t e = hipSuccess;
+    DISPATCH(fmt, split, (e = launch_embed_t<T16, SP>(st, dm, x, hbuf, recs, length, M, T, G, gran)));
+    return e;
 }
 
 template <class T16, bool SP>
 static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                                 int M, int T, int G, int B, int dbg) {
+                                 int M, int T, int G, int B, int gran, int dbg) {
     constexpr int NW = SP ? 4 : 8;
-    const size_t shm = 2 * 32768 * (SP ? 2 : 1);
+    // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
+    const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192;
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
         hipError_t e = hipFuncSetAttribute((const void*)k_layer<T16, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -1240,16 +1476,16 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
     }
     k_layer<T16, SP><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
                        (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
-                       snaps, M, T, G, B, dbg);
+                       snaps, M, T, G, B, gran, dbg);
     return hipGetLastError();
 }
 
 hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                           int M, int T, int G, int B, int dbg) {
+                           int M, int T, int G, int B, int gran, int dbg) {
     hipError_t e = hipSuccess;
     DISPATCH(fmt, split, (e = launch_layer_t<T16, SP>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode,
-                                                       coef_cur, snap_cur, snaps, M, T, G, B, dbg)));
+                                                       coef_cur, snap_cur, snaps, M, T, G, B, gran, dbg)));
     return e;
 }

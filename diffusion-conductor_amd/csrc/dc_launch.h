@@ -13,14 +13,15 @@ hipError_t dc_launch_cond_pack(hipStream_t st, int mode, const float* y, const f
                                float* out_f32, void* out_hi, void* out_lo, int G);
 hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* nh_hi, const void* nh_lo,
                                  float* recs, int M, int T, int G, int L);
-hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, void* afrag, int T, int G, int B, int nset);
+hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, void* afrag, int T, int NU, int B, int nset,
+                                  int gran);
 hipError_t dc_launch_silu_emb(hipStream_t st, int fmt, bool split, const float* pp, const float* temb, const int* t_clip,
                               void* s_hi, void* s_lo, int G, int T, int B);
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const float* g_ft,
                                const float* beta_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT);
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, const DcModel* dm, const float* x, float* hbuf, float* recs,
-                                 const int* length, int M, int T, int G);
+                                 const int* length, int M, int T, int G, int gran);
 hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                           int M, int T, int G, int B, int dbg);
+                           int M, int T, int G, int B, int gran, int dbg);

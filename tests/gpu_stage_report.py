@@ -104,7 +104,8 @@ def main():
         raw = nat.debug_read("s_hi", np.uint16, G * 32 * 64 * 8)
         shi = unpack_kmajor(raw.view(np.float16).astype(np.float32) if prec in ("fp16", "mixed") else bf16_to_f32(raw), G)[:M]
         print(f"  SiLU(emb) bf16      {rel_l2(shi, torch.nn.functional.silu(taps['emb']).reshape(M, 512)):.3e}")
-        E = native.unpack_ft(nat.debug_read("E", np.float16, G * 192 * 64 * 16).reshape(G, 192, 64, 16))[:M].astype(np.float32)
+        Eraw = nat.debug_read("E", np.float16, G * 192 * 64 * 16).reshape(G, 192, 2, 64, 8)    # tile image [2 halves][64 lanes][8]
+        E = native.unpack_ft(Eraw.transpose(0, 1, 3, 2, 4).reshape(G, 192, 64, 16))[:M].astype(np.float32)
         with torch.no_grad():
             eref = []
             for i in range(8):
