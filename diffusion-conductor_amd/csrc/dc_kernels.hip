@@ -1108,44 +1108,55 @@ DEV void ering_issue(const f16x8* __restrict__ Eg, int kt, char* slot, int lane)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hsrc + 64), (__attribute__((address_space(3))) void*)(slot + 3072), 16, 0, 0);
 }
 // same StylizationBlock with the FiLM tiles arriving through the ring: k-tiles 0,1 were issued a stage ago;
-// k-tiles 2,3 are issued as soon as 0,1 sit in registers and land behind the first half's VALU work.
-template <class T16, bool SPLIT>
+// k-tiles 2,3 are issued as soon as 0,1 sit in registers and land behind the first half's VALU + MFMA work.
+// `prefetch_next` (the next stage's weight image) is issued only after that wait, so the wait covers just 8 KiB.
+template <class T16, bool SPLIT, class F>
 DEV void styl_accumulate_ring(f32x16 (&h)[4], const f32x16 (&y)[4], const f16x8* __restrict__ Eg, char* ring,
-                              const float* bo, const v8<T16>* w, int lane, int hh) {
-    XFrag<T16, SPLIT> zf[4];
+                              const float* bo, const v8<T16>* w, int lane, int hh, F&& prefetch_next) {
     float mean, rstd;
     ln_stats<4>(y, mean, rstd);
     const float shift = -mean * rstd;
     const f16x8* s0 = reinterpret_cast<const f16x8*>(ring) + lane;
     const f16x8* s1 = reinterpret_cast<const f16x8*>(ring + 4096) + lane;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    {
-        const f16x16 g0 = load_etile(s0), h0 = load_etile(s0 + 128);
-        const f16x16 g1 = load_etile(s1), h1 = load_etile(s1 + 128);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        ering_issue(Eg, 2, ring, lane);
-        ering_issue(Eg, 3, ring + 4096, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        styl_tile<T16, SPLIT>(zf[0], y[0], rstd, shift, g0, h0);
-        styl_tile<T16, SPLIT>(zf[1], y[1], rstd, shift, g1, h1);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    {
-        const f16x16 g2 = load_etile(s0), h2 = load_etile(s0 + 128);
-        const f16x16 g3 = load_etile(s1), h3 = load_etile(s1 + 128);
-        styl_tile<T16, SPLIT>(zf[2], y[2], rstd, shift, g2, h2);
-        styl_tile<T16, SPLIT>(zf[3], y[3], rstd, shift, g3, h3);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the ring slots are free again
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const f32x16 bb = ld_ft(bo, t, hh);
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[t][r] += bb[r];
     }
-    gemm_wa<4, 4, T16, SPLIT>(h, w, zf, lane);
+    {
+        XFrag<T16, SPLIT> zf0, zf1;
+        {
+            const f16x16 g0 = load_etile(s0), h0 = load_etile(s0 + 128);
+            const f16x16 g1 = load_etile(s1), h1 = load_etile(s1 + 128);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            ering_issue(Eg, 2, ring, lane);
+            ering_issue(Eg, 3, ring + 4096, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            styl_tile<T16, SPLIT>(zf0, y[0], rstd, shift, g0, h0);
+            styl_tile<T16, SPLIT>(zf1, y[1], rstd, shift, g1, h1);
+        }
+        mma_kt<4, 4, T16, SPLIT>(h, w, 0, zf0, lane);
+        mma_kt<4, 4, T16, SPLIT>(h, w, 1, zf1, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        XFrag<T16, SPLIT> zf2, zf3;
+        {
+            const f16x16 g2 = load_etile(s0), h2 = load_etile(s0 + 128);
+            const f16x16 g3 = load_etile(s1), h3 = load_etile(s1 + 128);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the ring slots are free again
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch_next();
+            __builtin_amdgcn_sched_barrier(0);
+            styl_tile<T16, SPLIT>(zf2, y[2], rstd, shift, g2, h2);
+            styl_tile<T16, SPLIT>(zf3, y[3], rstd, shift, g3, h3);
+        }
+        mma_kt<4, 4, T16, SPLIT>(h, w, 2, zf2, lane);
+        mma_kt<4, 4, T16, SPLIT>(h, w, 3, zf3, lane);
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -1179,7 +1190,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const W* w1 = reinterpret_cast<const W*>(buf1);
     const float* c0 = reinterpret_cast<const float*>(buf0 + NFW * 1024);    // constants block of the image in buf0
     const float* c1 = reinterpret_cast<const float*>(buf1 + NFW * 1024);
-    // LDS paths for attention frags / FiLM ring need the workgroup to span <= 2 clips (true when gran == NW*32)
+    // attention frags come through LDS when the workgroup spans <= 2 clips (true when gran == NW*32), else from L2
     const bool wg_lds = !SPLIT && gran != 32;
     const int ub0 = (blockIdx.x * NW * 32) / T;
     char* ring = lds + OFF_ER + wave * 8192;
@@ -1189,10 +1200,11 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         stage_frags<NW>(a + (size_t)c1i * 16 * 64, lds + OFF_AF + 8192, 8, wave, lane);
     };
     const W* af = reinterpret_cast<const W*>(lds + OFF_AF);
+    const W* acl = a_ca + (size_t)l * B * 16 * 64;
 
     stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
-    if (wg_lds) {
-        stage_attn(a_sa);
+    if (wg_lds) stage_attn(a_sa);
+    if constexpr (!SPLIT) {
         ering_issue(Eg, 0, ring, lane);
         ering_issue(Eg, 1, ring + 4096, lane);
     }
@@ -1203,47 +1215,51 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
     stage_frags<NW>(L.img_sa_o, buf1, NFW + 1, wave, lane);
     f32x16 y[4];
-    if (wg_lds)
-        query_attend<T16, SPLIT>(y, h, c0, w0, af + (size_t)(cx.b0 - ub0) * 8 * 64, af + (size_t)(cx.b1 - ub0) * 8 * 64, cx);
-    else
-        query_attend<T16, SPLIT>(y, h, c0, w0, a_sa + (size_t)cx.b0 * 16 * 64, a_sa + (size_t)cx.b1 * 16 * 64, cx);
+    {
+        const W* a0 = wg_lds ? af + (size_t)(cx.b0 - ub0) * 8 * 64 : a_sa + (size_t)cx.b0 * 16 * 64;
+        const W* a1 = wg_lds ? af + (size_t)(cx.b1 - ub0) * 8 * 64 : a_sa + (size_t)cx.b1 * 16 * 64;
+        query_attend<T16, SPLIT>(y, h, c0, w0, a0, a1, cx);
+    }
     stage_sync();
     // ---- stage 2: SA stylization [buf1]; prefetch CA query -> buf0 (+ cross-attention frags)
-    stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
-    if (wg_lds) {
-        stage_attn(a_ca + (size_t)l * B * 16 * 64);
-        styl_accumulate_ring<T16, SPLIT>(h, y, Eg, ring, c1, w1, lane, cx.hh);
-    } else {
+    if constexpr (SPLIT) {
+        stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
         styl_accumulate<T16, SPLIT>(h, y, Eg, c1, w1, lane, cx.hh, dbg);
+    } else {
+        styl_accumulate_ring<T16, SPLIT>(h, y, Eg, ring, c1, w1, lane, cx.hh, [&]() {
+            stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
+            if (wg_lds) stage_attn(acl);
+            ering_issue(Eg + 8 * 128, 0, ring, lane);
+            ering_issue(Eg + 8 * 128, 1, ring + 4096, lane);
+        });
     }
     if ((dbg & 0xff) == 1) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after self-attention
     stage_sync();
     // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
     stage_frags<NW>(L.img_ca_o, buf1, NFW + 1, wave, lane);
-    if (wg_lds) {
-        ering_issue(Eg + 8 * 128, 0, ring, lane);
-        ering_issue(Eg + 8 * 128, 1, ring + 4096, lane);
-        query_attend<T16, SPLIT>(y, h, c0, w0, af + (size_t)(cx.b0 - ub0) * 8 * 64, af + (size_t)(cx.b1 - ub0) * 8 * 64, cx);
-    } else {
-        const W* acl = a_ca + (size_t)l * B * 16 * 64;
-        query_attend<T16, SPLIT>(y, h, c0, w0, acl + (size_t)cx.b0 * 16 * 64, acl + (size_t)cx.b1 * 16 * 64, cx);
+    {
+        const W* a0 = wg_lds ? af + (size_t)(cx.b0 - ub0) * 8 * 64 : acl + (size_t)cx.b0 * 16 * 64;
+        const W* a1 = wg_lds ? af + (size_t)(cx.b1 - ub0) * 8 * 64 : acl + (size_t)cx.b1 * 16 * 64;
+        query_attend<T16, SPLIT>(y, h, c0, w0, a0, a1, cx);
     }
     stage_sync();
     // ---- stage 4: CA stylization [buf1]; prefetch FFN W1|W2 (+ b1|b2) -> buf0
-    stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
-    stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
-    if (wg_lds)
-        styl_accumulate_ring<T16, SPLIT>(h, y, Eg + 8 * 128, ring, c1, w1, lane, cx.hh);
-    else
+    if constexpr (SPLIT) {
+        stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
+        stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
         styl_accumulate<T16, SPLIT>(h, y, Eg + 8 * 128, c1, w1, lane, cx.hh, dbg);
+    } else {
+        styl_accumulate_ring<T16, SPLIT>(h, y, Eg + 8 * 128, ring, c1, w1, lane, cx.hh, [&]() {
+            stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
+            stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
+            ering_issue(Eg + 16 * 128, 0, ring, lane);
+            ering_issue(Eg + 16 * 128, 1, ring + 4096, lane);
+        });
+    }
     if ((dbg & 0xff) == 2) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after cross-attention
     stage_sync();
     // ---- stage 5: FFN [buf0]; prefetch FFN out-proj -> buf1
     stage_frags<NW>(L.img_ffn_o, buf1, NFW + 1, wave, lane);
-    if (wg_lds) {
-        ering_issue(Eg + 16 * 128, 0, ring, lane);
-        ering_issue(Eg + 16 * 128, 1, ring + 4096, lane);
-    }
     {
         f32x16 u[2];
         {
@@ -1267,14 +1283,20 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     }
     stage_sync();
     // ---- stage 6: FFN stylization [buf1]; prefetch next layer's key projection (or the output projection) -> buf0
-    if (!last)
-        stage_frags<NW>(dm->layer[l + 1].img_sa_k, buf0, NFW + 1, wave, lane);
-    else
-        stage_frags<NW>(dm->img_out, buf0, 17, wave, lane);      // 8 hi + 8 lo frags + bias: always runs split
-    if (wg_lds)
-        styl_accumulate_ring<T16, SPLIT>(h, y, Eg + 16 * 128, ring, c1, w1, lane, cx.hh);
-    else
-        styl_accumulate<T16, SPLIT>(h, y, Eg + 16 * 128, c1, w1, lane, cx.hh, dbg);
+    {
+        auto next_w = [&]() {
+            if (!last)
+                stage_frags<NW>(dm->layer[l + 1].img_sa_k, buf0, NFW + 1, wave, lane);
+            else
+                stage_frags<NW>(dm->img_out, buf0, 17, wave, lane);      // 8 hi + 8 lo frags + bias: always runs split
+        };
+        if constexpr (SPLIT) {
+            next_w();
+            styl_accumulate<T16, SPLIT>(h, y, Eg + 16 * 128, c1, w1, lane, cx.hh, dbg);
+        } else {
+            styl_accumulate_ring<T16, SPLIT>(h, y, Eg + 16 * 128, ring, c1, w1, lane, cx.hh, next_w);
+        }
+    }
     if ((dbg & 0xff) == 3) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
     stage_sync();
 
