@@ -156,6 +156,7 @@ struct dc_sampler {
     float *d_y = nullptr, *d_mean = nullptr, *d_rstd = nullptr, *d_recs_ca = nullptr;
     void *d_nh_hi = nullptr, *d_nh_lo = nullptr;
     // step state
+    unsigned long long* d_stamps = nullptr;
     int *d_iter = nullptr, *d_t_clip = nullptr, *d_snap_cur = nullptr, *d_t_of_iter = nullptr, *d_snap_of_iter = nullptr;
     float *d_coef_cur = nullptr, *d_coef_of_t = nullptr;
     bool cond_set = false;
@@ -489,6 +490,7 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
     }
     if (!s->d_iter) {
         int rc;
+        if ((rc = dev_alloc(s, s->d_stamps, 8 * 16 * 8))) return rc;
         if ((rc = dev_alloc(s, s->d_iter, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_snap_cur, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_coef_cur, 16))) return rc;
@@ -500,7 +502,8 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
     s->G = G;
     {   // per-workgroup partial records when a workgroup (NW groups) cannot span more than two clips
         const int nw = s->split_small ? 4 : 8;
-        s->gran = T >= nw * 32 ? nw * 32 : 32;
+        (void)nw;
+        s->gran = 32;   // per-group records (a workgroup-level LDS pre-reduction was measured slower overall)
     }
     return DC_OK;
 }
@@ -549,7 +552,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
                                              s->d_t_clip, s->d_coef_cur, s->d_snap_cur, B));
     LAUNCH(K_SILU, dc_launch_silu_emb(st, ff, sf, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, G, T, B));
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->h_model.film_g, s->h_model.film_beta, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT));
-    LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, s->gran));
+    LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G));
     const int nl_run = (s->dbg_layers >= 0 && s->dbg_layers < L) ? s->dbg_layers : L;
     for (int l = 0; l < nl_run; ++l) {
         static const int ablate = getenv("DC_ABLATE") ? (int)strtol(getenv("DC_ABLATE"), nullptr, 0) : 0;   // timing experiments
@@ -557,7 +560,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur,
-                                        s->d_snaps, M, T, G, B, s->gran, dbg));
+                                        s->d_snaps, M, T, G, B, dbg, (l == 3 && getenv("DC_STAMPS")) ? s->d_stamps : nullptr));
     }
     return DC_OK;
 }
@@ -883,6 +886,7 @@ int dc_sampler_debug_read(dc_sampler* s, const char* what, void* h_out, int64_t 
     else if (w == "recs") { src = s->d_recs; have = g * 2 * DC_REC_FLOATS * 4; }
     else if (w == "a_sa") { src = s->d_a_sa; have = (size_t)s->B * 16 * 1024; }
     else if (w == "a_ca") { src = s->d_a_ca; have = (size_t)s->cfg.num_layers * s->B * 16 * 1024; }
+    else if (w == "stamps") { src = s->d_stamps; have = 8 * 16 * 8; }
     else if (w == "temb") { src = s->h_model.temb; have = (size_t)s->cfg.max_timesteps * 512 * 4; }
     else return fail(DC_ERR_INVALID, "unknown debug buffer '%s'", what);
     if (!src) return fail(DC_ERR_INVALID, "buffer '%s' not allocated yet", what);

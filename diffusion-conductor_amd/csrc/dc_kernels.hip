@@ -336,124 +336,29 @@ DEV void store_h(const f32x16 (&h)[4], float* __restrict__ hbuf, int g, int lane
     for (int t = 0; t < 4; ++t) p[t * 64] = h[t];
 }
 
-// "Front half" of LinearTemporalSelfAttention (transformer.py:104-117) for the NW token groups of a workgroup,
-// given each wave's operand fragments nf of n = LN(h): K = Wk n + bk, V = Wv n + bv in TF form, then the partial
-// record(s) of softmax_T(K + mask) and K^T V.
-//   gran == 32    : one record per group and clip slot (small-T fallback: a workgroup may touch many clips)
-//   gran == NW*32 : the NW waves' partials are reduced through LDS (common column max, ordered sums) into ONE
-//                   record per workgroup and clip slot - 8x less record traffic and an 8x shorter combine.
-// `scratch` is the workgroup's LDS (NW*16 KiB + NW*1 KiB used); a barrier is taken before it is overwritten, so
-// the weight images may live in the same LDS.  bk/bv: plain bias[128] (any address space).
-template <class T16, bool SPLIT, int NW>
+// "Front half" of LinearTemporalSelfAttention (transformer.py:104-117) for one token group, given the operand
+// fragments nf of n = LN(h): K = Wk n + bk, V = Wv n + bv in TF form, then the group's partial record(s) of
+// softmax_T(K + mask) and K^T V - one per clip the group touches.  bk/bv: plain bias[128] (any address space).
+// (A workgroup-level pre-reduction of these records through LDS was measured: it shortened the combine by 30 %
+// but cost 2x that in this kernel - 8 waves x 128 live K/V registers - so records stay per group.)
+template <class T16, bool SPLIT>
 DEV void front_stage(const XFrag<T16, SPLIT> (&nf)[4], const v8<T16>* wk, const v8<T16>* wv, const float* bk,
                      const float* bv, const GroupCtx& cx, int M, int T, const int* __restrict__ length,
-                     float* __restrict__ recs, bool active, int gran, char* scratch, int wave) {
-    if (gran == 32) {
-        float* rec = recs + (size_t)cx.g * 2 * DC_REC_FLOATS;
-        const RowRange valid0 = valid_rows(cx, 0, M, T, length);
-        const RowRange valid1 = valid_rows(cx, cx.straddle ? 1 : 0, M, T, length);
-#pragma unroll
-        for (int oc = 0; oc < 4; ++oc) {
-            f32x16 K = splat(bk[32 * oc + cx.c]);
-            f32x16 V = splat(bv[32 * oc + cx.c]);
-            mmb_oc<4, 4, T16, SPLIT>(K, wk, oc, nf, cx.lane);
-            mmb_oc<4, 4, T16, SPLIT>(V, wv, oc, nf, cx.lane);
-            if (active) {
-                emit_partial<T16, SPLIT>(K, V, oc, valid0, rec, cx);
-                if (cx.straddle) emit_partial<T16, SPLIT>(K, V, oc, valid1, rec + DC_REC_FLOATS, cx);
-            }
-            __builtin_amdgcn_sched_barrier(0);   // keep the four feature tiles sequential: bounds register pressure
-        }
-        return;
-    }
-    f32x16 K[4], V[4];
+                     float* __restrict__ recs, bool active) {
+    float* rec = recs + (size_t)cx.g * 2 * DC_REC_FLOATS;
+    const RowRange valid0 = valid_rows(cx, 0, M, T, length);
+    const RowRange valid1 = valid_rows(cx, cx.straddle ? 1 : 0, M, T, length);
 #pragma unroll
     for (int oc = 0; oc < 4; ++oc) {
-        K[oc] = splat(bk[32 * oc + cx.c]);
-        V[oc] = splat(bv[32 * oc + cx.c]);
-        mmb_oc<4, 4, T16, SPLIT>(K[oc], wk, oc, nf, cx.lane);
-        mmb_oc<4, 4, T16, SPLIT>(V[oc], wv, oc, nf, cx.lane);
-    }
-    __syncthreads();                                  // every wave is done with the weight images
-    float* P_lds = reinterpret_cast<float*>(scratch);                 // [NW][4 oc][64 lanes][16]
-    float* red_m = reinterpret_cast<float*>(scratch + NW * 16384);    // [NW][128]
-    float* red_s = red_m + NW * 128;                                  // [NW][128]
-    const int u = blockIdx.x;
-    const int ufirst = u * gran, ulast = min(ufirst + gran - 1, M - 1);
-    const int ub0 = ufirst / T, ub1 = ulast / T;
-    const int nslot = ub1 != ub0 ? 2 : 1;
-    const int tid = wave * 64 + cx.lane;
-    for (int slot = 0; slot < nslot; ++slot) {
-        const int bs = slot ? ub1 : ub0;
-        RowRange rr;                                   // this group's rows inside clip bs, unmasked
-        {
-            const int len = length ? length[bs] : T;
-            const int first = max(bs * T, 32 * cx.g);
-            const int end = min(min(bs * T + min(len, T), M), 32 * cx.g + 32);
-            rr.lo = first - 32 * cx.g - 4 * cx.hh;
-            rr.span = (active && end > first) ? (unsigned)(end - first) : 0u;
+        f32x16 K = splat(bk[32 * oc + cx.c]);
+        f32x16 V = splat(bv[32 * oc + cx.c]);
+        mmb_oc<4, 4, T16, SPLIT>(K, wk, oc, nf, cx.lane);
+        mmb_oc<4, 4, T16, SPLIT>(V, wv, oc, nf, cx.lane);
+        if (active) {
+            emit_partial<T16, SPLIT>(K, V, oc, valid0, rec, cx);
+            if (cx.straddle) emit_partial<T16, SPLIT>(K, V, oc, valid1, rec + DC_REC_FLOATS, cx);
         }
-#pragma unroll
-        for (int oc = 0; oc < 4; ++oc) {
-            float m = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m = row_ok(rr, r) ? fmaxf(m, K[oc][r]) : m;
-            m = xhalf_max(m);
-            if (cx.hh == 0) red_m[wave * 128 + 32 * oc + cx.c] = m;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int oc = 0; oc < 4; ++oc) {
-            float mw = red_m[32 * oc + cx.c];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) mw = fmaxf(mw, red_m[w * 128 + 32 * oc + cx.c]);
-            if (mw == -INFINITY) mw = 0.f;
-            f32x16 Ee, Vm;
-            float ssum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool ok = row_ok(rr, r);
-                const float e = ok ? __expf(K[oc][r] - mw) : 0.f;
-                Ee[r] = e;
-                ssum += e;
-                Vm[r] = ok ? V[oc][r] : 0.f;
-            }
-            ssum = xhalf_sum(ssum);
-            XFrag<T16, SPLIT> ef, vf;
-            make_frag<T16, SPLIT>(Ee, ef);
-            make_frag<T16, SPLIT>(Vm, vf);
-            f32x16 P = splat(0.f);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                P = mfma(ef.hi[s], vf.hi[s], P);
-                if constexpr (SPLIT) {
-                    P = mfma(ef.lo[s], vf.hi[s], P);
-                    P = mfma(ef.hi[s], vf.lo[s], P);
-                }
-            }
-            reinterpret_cast<f32x16*>(P_lds)[(wave * 4 + oc) * 64 + cx.lane] = P;
-            if (cx.hh == 0) red_s[wave * 128 + 32 * oc + cx.c] = ssum;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-        float* R = recs + ((size_t)u * 2 + slot) * DC_REC_FLOATS;
-        for (int e = tid * 4; e < 4096; e += NW * 64 * 4) {      // ordered sum over the waves
-            f32x4 acc = *reinterpret_cast<const f32x4*>(P_lds + e);
-#pragma unroll
-            for (int w = 1; w < NW; ++w) acc += *reinterpret_cast<const f32x4*>(P_lds + w * 4096 + e);
-            *reinterpret_cast<f32x4*>(R + 256 + e) = acc;
-        }
-        if (tid < 128) {
-            float mw = red_m[tid], ss = red_s[tid];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) {
-                mw = fmaxf(mw, red_m[w * 128 + tid]);
-                ss += red_s[w * 128 + tid];
-            }
-            R[tid] = mw == -INFINITY ? 0.f : mw;
-            R[128 + tid] = ss;
-        }
-        __syncthreads();                              // scratch is reused by the next slot
+        __builtin_amdgcn_sched_barrier(0);   // keep the four feature tiles sequential: bounds register pressure
     }
 }
 
@@ -648,8 +553,18 @@ __global__ __launch_bounds__(1024) void k_attn_combine(const float* __restrict__
         const int slot = ((gran * g) / T == b) ? 0 : 1;
         return base + ((size_t)g * 2 + slot) * DC_REC_FLOATS;
     };
-    // phase 1: every (group, feature) pair read once: m and ssum to registers, column max over groups
-    const int f = tid & 31, part = tid >> 5;          // 32 features x 32 group-parts
+    // every load of the block is issued before the first dependent use: one memory round trip in all.
+    const int f = tid & 31, part = tid >> 5;          // phases 1-2: 32 features x 32 group-parts
+    const int q4 = tid >> 8, t8 = tid & 255;          // phase 3: 4 group-quarters x (lane, rq)
+    const int lane = t8 & 63, rq = t8 >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const int row0 = 8 * rq + 4 * hh;                 // tile_row(4rq + i, hh) = i + 8rq + 4hh
+    const int per = (ng + 3) / 4, gb = q4 * per, ge = min(gb + per, ng);
+    constexpr int PMAX = 16;                          // records preloaded per thread (covers T <= 1984; longer clips loop)
+    f32x4 p[PMAX];
+#pragma unroll
+    for (int u = 0; u < PMAX; ++u)
+        if (gb + u < ge) p[u] = reinterpret_cast<const f32x4*>(rec_of(gb + u) + 256)[(oc * 64 + lane) * 4 + rq];
     float mreg[4], sreg[4];                            // this thread's groups: part, part+32, ...  (ng <= 128)
     float mloc = -INFINITY;
 #pragma unroll
@@ -689,30 +604,17 @@ __global__ __launch_bounds__(1024) void k_attn_combine(const float* __restrict__
         z[tid] = zz;
     }
     // phase 3: weighted sum of the partial K^T V tiles; 4 group-quarters in parallel, each in group order
-    const int q4 = tid >> 8, t8 = tid & 255;
-    const int lane = t8 & 63, rq = t8 >> 6;
-    const int c = lane & 31, hh = lane >> 5;
-    const int row0 = 8 * rq + 4 * hh;   // tile_row(4rq + i, hh) = i + 8rq + 4hh
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    {
-        const int per = (ng + 3) / 4, gb = q4 * per, ge = min(gb + per, ng);
-        int gi = gb;
-        for (; gi + 8 <= ge; gi += 8) {
-            f32x4 p[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) p[u] = reinterpret_cast<const f32x4*>(rec_of(gi + u) + 256)[(oc * 64 + lane) * 4 + rq];
-            if (gi == gb) __syncthreads();          // w[] (phase 2) is needed from here on; loads are already in flight
+    for (int u = 0; u < PMAX; ++u)
+        if (gb + u < ge) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[(gi + u) * 32 + row0 + i], p[u][i], acc[i]);
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[(gb + u) * 32 + row0 + i], p[u][i], acc[i]);
         }
-        if (gi == gb) __syncthreads();
-        for (; gi < ge; ++gi) {
-            const f32x4 p = reinterpret_cast<const f32x4*>(rec_of(gi) + 256)[(oc * 64 + lane) * 4 + rq];
+    for (int gi = gb + PMAX; gi < ge; ++gi) {          // clips longer than PMAX*4 groups
+        const f32x4 pp = reinterpret_cast<const f32x4*>(rec_of(gi) + 256)[(oc * 64 + lane) * 4 + rq];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[gi * 32 + row0 + i], p[i], acc[i]);
-        }
+        for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[gi * 32 + row0 + i], pp[i], acc[i]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) pacc[(q4 * 256 + t8) * 4 + i] = acc[i];
@@ -930,8 +832,7 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
 template <class T16, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
 void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /*[M][P]*/, float* __restrict__ hbuf,
-                   float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G, int gran) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+                   float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G) {
     constexpr int NW = SPLIT ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;
     using W = v8<T16>;
@@ -975,8 +876,8 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
     ln_frags<T16, SPLIT>(nf, h);
     const W* wk = reinterpret_cast<const W*>(L.img_sa_k);
     const W* wv = reinterpret_cast<const W*>(L.img_sa_v);
-    front_stage<T16, SPLIT, NW>(nf, wk, wv, reinterpret_cast<const float*>(wk + 32 * WM * 64),
-                                reinterpret_cast<const float*>(wv + 32 * WM * 64), cx, M, T, length, recs, active, gran, lds, wave);
+    front_stage<T16, SPLIT>(nf, wk, wv, reinterpret_cast<const float*>(wk + 32 * WM * 64),
+                            reinterpret_cast<const float*>(wv + 32 * WM * 64), cx, M, T, length, recs, active);
 }
 
 // ------------------------------------------------------------------------------------
@@ -999,9 +900,9 @@ DEV void stage_frags(const void* __restrict__ src, char* dst, int nfrags, int wa
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + (size_t)f * 64 + lane),
                                          (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
 }
-DEV void stage_sync() {
+DEV void stage_sync(int abl = 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!(abl & 0x1000)) __syncthreads();        // 0x1000: timing experiment only (results are garbage)
 }
 
 template <class T16, bool SPLIT>
@@ -1166,11 +1067,18 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
              const v8<T16>* __restrict__ a_sa /*[B][16][64]*/, const v8<T16>* __restrict__ a_ca /*[L][B][16][64]*/,
              float* __restrict__ recs, const int* __restrict__ length, const float* __restrict__ xin,
              float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur, const int* __restrict__ snap_cur,
-             float* __restrict__ snaps, int M, int T, int G, int B, int gran, int dbg) {
+             float* __restrict__ snaps, int M, int T, int G, int B, int dbg,
+             unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int NW = SPLIT ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;            // operand images per matrix (hi [+ lo])
-    constexpr int NFW = 32 * WM;                 // frags of one 128x128 stage image (constants block follows)
+    constexpr int NFW = 32 * WM;
+    // diagnostic build aid: 100 MHz timestamps per stage for the waves of workgroup 3 (stamps == nullptr normally)
+#define DC_STAMP(k)                                                                                        \
+    do {                                                                                                   \
+        if (stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0)                                          \
+            stamps[(threadIdx.x >> 6) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                      \
+    } while (0)                 // frags of one 128x128 stage image (constants block follows)
     constexpr int WSZ = (NFW + 1) * 1024;
     constexpr int OFF_AF = 2 * WSZ;              // non-split: attention frags of the workgroup's <= 2 clips (16 KiB)
     constexpr int OFF_ER = OFF_AF + 16384;       // non-split: per-wave FiLM tile rings (8 KiB each)
@@ -1190,8 +1098,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const W* w1 = reinterpret_cast<const W*>(buf1);
     const float* c0 = reinterpret_cast<const float*>(buf0 + NFW * 1024);    // constants block of the image in buf0
     const float* c1 = reinterpret_cast<const float*>(buf1 + NFW * 1024);
-    // attention frags come through LDS when the workgroup spans <= 2 clips (true when gran == NW*32), else from L2
-    const bool wg_lds = !SPLIT && gran != 32;
+    // attention frags come through LDS when the workgroup can span at most 2 clips, else straight from L2
+    const bool wg_lds = !SPLIT && T >= NW * 32;
     const int ub0 = (blockIdx.x * NW * 32) / T;
     char* ring = lds + OFF_ER + wave * 8192;
     auto stage_attn = [&](const W* a) {          // frags of clips ub0, ub0+1 -> AF region
@@ -1204,13 +1112,16 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
 
     stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
     if (wg_lds) stage_attn(a_sa);
-    if constexpr (!SPLIT) {
+    constexpr bool use_ring = !SPLIT;             // FiLM tiles through the per-wave LDS ring (else: registers)
+    if constexpr (use_ring) {
         ering_issue(Eg, 0, ring, lane);
         ering_issue(Eg, 1, ring + 4096, lane);
     }
     f32x16 h[4];
+    DC_STAMP(0);
     load_h(h, hbuf, g, lane);
-    stage_sync();
+    stage_sync(dbg);
+    DC_STAMP(1);
 
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
     stage_frags<NW>(L.img_sa_o, buf1, NFW + 1, wave, lane);
@@ -1220,10 +1131,13 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         const W* a1 = wg_lds ? af + (size_t)(cx.b1 - ub0) * 8 * 64 : a_sa + (size_t)cx.b1 * 16 * 64;
         query_attend<T16, SPLIT>(y, h, c0, w0, a0, a1, cx);
     }
-    stage_sync();
+    DC_STAMP(2);
+    stage_sync(dbg);
+    DC_STAMP(3);
     // ---- stage 2: SA stylization [buf1]; prefetch CA query -> buf0 (+ cross-attention frags)
-    if constexpr (SPLIT) {
+    if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
+        if (wg_lds) stage_attn(acl);
         styl_accumulate<T16, SPLIT>(h, y, Eg, c1, w1, lane, cx.hh, dbg);
     } else {
         styl_accumulate_ring<T16, SPLIT>(h, y, Eg, ring, c1, w1, lane, cx.hh, [&]() {
@@ -1234,7 +1148,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         });
     }
     if ((dbg & 0xff) == 1) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after self-attention
-    stage_sync();
+    DC_STAMP(4);
+    stage_sync(dbg);
+    DC_STAMP(5);
     // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
     stage_frags<NW>(L.img_ca_o, buf1, NFW + 1, wave, lane);
     {
@@ -1242,9 +1158,10 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         const W* a1 = wg_lds ? af + (size_t)(cx.b1 - ub0) * 8 * 64 : acl + (size_t)cx.b1 * 16 * 64;
         query_attend<T16, SPLIT>(y, h, c0, w0, a0, a1, cx);
     }
-    stage_sync();
+    DC_STAMP(6);
+    stage_sync(dbg);
     // ---- stage 4: CA stylization [buf1]; prefetch FFN W1|W2 (+ b1|b2) -> buf0
-    if constexpr (SPLIT) {
+    if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
         stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
         styl_accumulate<T16, SPLIT>(h, y, Eg + 8 * 128, c1, w1, lane, cx.hh, dbg);
@@ -1257,7 +1174,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         });
     }
     if ((dbg & 0xff) == 2) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after cross-attention
-    stage_sync();
+    DC_STAMP(7);
+    stage_sync(dbg);
+    DC_STAMP(8);
     // ---- stage 5: FFN [buf0]; prefetch FFN out-proj -> buf1
     stage_frags<NW>(L.img_ffn_o, buf1, NFW + 1, wave, lane);
     {
@@ -1281,7 +1200,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         for (int t = 0; t < 4; ++t) y[t] = ld_ft(c0 + 64, t, cx.hh);               // b2
         gemm_wa<4, 2, T16, SPLIT>(y, w0 + 16 * WM * 64, uf, lane);
     }
-    stage_sync();
+    DC_STAMP(9);
+    stage_sync(dbg);
     // ---- stage 6: FFN stylization [buf1]; prefetch next layer's key projection (or the output projection) -> buf0
     {
         auto next_w = [&]() {
@@ -1290,7 +1210,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             else
                 stage_frags<NW>(dm->img_out, buf0, 17, wave, lane);      // 8 hi + 8 lo frags + bias: always runs split
         };
-        if constexpr (SPLIT) {
+        if constexpr (!use_ring) {
             next_w();
             styl_accumulate<T16, SPLIT>(h, y, Eg + 16 * 128, c1, w1, lane, cx.hh, dbg);
         } else {
@@ -1298,17 +1218,21 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         }
     }
     if ((dbg & 0xff) == 3) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
-    stage_sync();
+    DC_STAMP(10);
+    stage_sync(dbg);
+    DC_STAMP(11);
 
     if (!last) {
         // ---- stage 7: next layer's SA front half: K [buf0] and V [buf1], partial records
         stage_frags<NW>(dm->layer[l + 1].img_sa_v, buf1, NFW + 1, wave, lane);
-        if (active) store_h(h, hbuf, g, lane);
         XFrag<T16, SPLIT> nf[4];
         ln_frags<T16, SPLIT>(nf, h);
-        stage_sync();
+        stage_sync(dbg);
+        DC_STAMP(12);
+        if (active) store_h(h, hbuf, g, lane);      // after the vmcnt(0): nothing waits on these stores
         if (dbg & 0x400) return;      // timing experiment: no front stage
-        front_stage<T16, SPLIT, NW>(nf, w0, w1, c0, c1, cx, M, T, length, recs, active, gran, lds, wave);
+        front_stage<T16, SPLIT>(nf, w0, w1, c0, c1, cx, M, T, length, recs, active);
+        DC_STAMP(13);
         return;
     }
     // ---- output projection [buf0, split] + DDIM update
@@ -1463,22 +1387,15 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
 
 template <class T16, bool SP>
 static hipError_t launch_embed_t(hipStream_t st, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
-                                 int M, int T, int G, int gran) {
+                                 int M, int T, int G) {
     constexpr int NW = SP ? 4 : 8;
-    const size_t shm = (size_t)NW * 17408;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_embed_front<T16, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    k_embed_front<T16, SP><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, gran);
+    k_embed_front<T16, SP><<<dim3((G + NW - 1) / NW), dim3(NW * 64), 0, st>>>(dm, x, hbuf, recs, length, M, T, G);
     return hipGetLastError();
 }
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, const DcModel* dm, const float* x, float* hbuf,
-                                 float* recs, const int* length, int M, int T, int G, int gran) {
+                                 float* recs, const int* length, int M, int T, int G) {
     hipError_t e = hipSuccess;
-    DISPATCH(fmt, split, (e = launch_embed_t<T16, SP>(st, dm, x, hbuf, recs, length, M, T, G, gran)));
+    DISPATCH(fmt, split, (e = launch_embed_t<T16, SP>(st, dm, x, hbuf, recs, length, M, T, G)));
     return e;
 }
 
@@ -1486,7 +1403,7 @@ template <class T16, bool SP>
 static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                                 int M, int T, int G, int B, int gran, int dbg) {
+                                 int M, int T, int G, int B, int dbg, unsigned long long* stamps) {
     constexpr int NW = SP ? 4 : 8;
     // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
     const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192;
@@ -1498,16 +1415,16 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
     }
     k_layer<T16, SP><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
                        (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
-                       snaps, M, T, G, B, gran, dbg);
+                       snaps, M, T, G, B, dbg, stamps);
     return hipGetLastError();
 }
 
 hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                           int M, int T, int G, int B, int gran, int dbg) {
+                           int M, int T, int G, int B, int dbg, unsigned long long* stamps) {
     hipError_t e = hipSuccess;
     DISPATCH(fmt, split, (e = launch_layer_t<T16, SP>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode,
-                                                       coef_cur, snap_cur, snaps, M, T, G, B, gran, dbg)));
+                                                       coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps)));
     return e;
 }

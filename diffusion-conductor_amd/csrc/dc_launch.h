@@ -20,8 +20,8 @@ hipError_t dc_launch_silu_emb(hipStream_t st, int fmt, bool split, const float* 
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const float* g_ft,
                                const float* beta_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT);
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, const DcModel* dm, const float* x, float* hbuf, float* recs,
-                                 const int* length, int M, int T, int G, int gran);
+                                 const int* length, int M, int T, int G);
 hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                           int M, int T, int G, int B, int gran, int dbg);
+                           int M, int T, int G, int B, int dbg, unsigned long long* stamps);

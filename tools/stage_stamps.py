@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-stage time (us) of the 8 waves of one k_layer workgroup (layer 3), from s_memrealtime stamps.
+Run on the GPU box:  DC_STAMPS=1 DC_DISABLE_GRAPH=1 python tools/stage_stamps.py"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from helpers import make_model, make_diffusion, xf_pair, batch_noise
+B, T = 32, 1800
+m = make_model("fp16")
+xfp, xfo = xf_pair(B, T); noise = torch.from_numpy(batch_noise(B, T)).cuda()
+nat = m.set_conditioning(xfp.cuda(), xfo.cuda(), [T] * B)
+gd = make_diffusion(50)
+for _ in range(2):
+    nat.ddim_loop(noise, gd.native_coefficients())
+torch.cuda.synchronize()
+st = nat.debug_read("stamps", np.uint64, 8 * 16).reshape(8, 16).astype(np.int64)
+names = ["load_h+W0", "Q+attn SA", "sync", "styl SA", "sync", "Q+attn CA", "sync+(7)styl CA", "", "sync", "FFN", "sync+styl FFN", "sync", "ln+sync", "front"]
+t0 = st[:, 0].min()
+print("wave:      " + "".join(f"{w:8d}" for w in range(8)))
+for k in range(1, 14):
+    print(f"{k:2d} {names[k-1][:16]:16s}" + "".join(f"{(st[w, k] - st[w, k-1]) / 100.0:8.2f}" for w in range(8)))
+print("total (us) " + "".join(f"{(st[w, 13] - st[w, 0]) / 100.0:8.2f}" for w in range(8)))
