@@ -310,19 +310,22 @@ int build_model(dc_sampler* s) {
         add_image(dst, P_(p + ".out_layers.2.weight"), D, D, ssp, bo.data(), bo.size());
     };
     // W' = W diag(g), c' = c + W b  (LayerNorm affine folded into the projection that consumes it)
+    // `scale` additionally multiplies the whole projection: log2(e) for the query / key projections, whose
+    // outputs only ever feed exp() (softmax), so the kernels can use the native exp2.
     auto fold_ln = [&](const float* w, const float* c, const float* g, const float* b, int n_out, int k,
-                       std::vector<float>& wf, std::vector<float>& cf) {
+                       std::vector<float>& wf, std::vector<float>& cf, double scale = 1.0) {
         wf.resize((size_t)n_out * k);
         cf.resize(n_out);
         for (int o = 0; o < n_out; ++o) {
             double acc = c[o];
             for (int i = 0; i < k; ++i) {
-                wf[(size_t)o * k + i] = w[(size_t)o * k + i] * g[i];
+                wf[(size_t)o * k + i] = (float)((double)w[(size_t)o * k + i] * g[i] * scale);
                 acc += (double)w[(size_t)o * k + i] * b[i];
             }
-            cf[o] = (float)acc;
+            cf[o] = (float)(acc * scale);
         }
     };
+    const double LOG2E = 1.4426950408889634;
     // FiLM: all 3L blocks stacked along the output axis -> one [3L*256][512] GEMM operand; inside a block the
     // 32-row tiles are interleaved (scale0, shift0, scale1, shift1, ...) so one wave holds matching pairs
     const int NT = 3 * L * DC_FILM_TILES_PER_BLOCK;
@@ -334,18 +337,18 @@ int build_model(dc_sampler* s) {
         std::vector<float> wf, cf;
         const float* sg = P_(p + ".sa_block.norm.weight");
         const float* sb = P_(p + ".sa_block.norm.bias");
-        fold_ln(P_(p + ".sa_block.query.weight"), P_(p + ".sa_block.query.bias"), sg, sb, D, D, wf, cf);
+        fold_ln(P_(p + ".sa_block.query.weight"), P_(p + ".sa_block.query.bias"), sg, sb, D, D, wf, cf, LOG2E);
         {
             const std::vector<float> c = ftvec(cf.data(), D, 4);
             add_image(&y.img_sa_q, wf.data(), D, D, ssp, c.data(), c.size());
         }
-        fold_ln(P_(p + ".sa_block.key.weight"), P_(p + ".sa_block.key.bias"), sg, sb, D, D, wf, cf);
+        fold_ln(P_(p + ".sa_block.key.weight"), P_(p + ".sa_block.key.bias"), sg, sb, D, D, wf, cf, LOG2E);
         add_image(&y.img_sa_k, wf.data(), D, D, ssp, cf.data(), cf.size());          // plain bias[128]
         fold_ln(P_(p + ".sa_block.value.weight"), P_(p + ".sa_block.value.bias"), sg, sb, D, D, wf, cf);
         add_image(&y.img_sa_v, wf.data(), D, D, ssp, cf.data(), cf.size());
         add_styl(&y.img_sa_o, p + ".sa_block.proj_out");
         fold_ln(P_(p + ".ca_block.query.weight"), P_(p + ".ca_block.query.bias"), P_(p + ".ca_block.norm.weight"),
-                P_(p + ".ca_block.norm.bias"), D, D, wf, cf);
+                P_(p + ".ca_block.norm.bias"), D, D, wf, cf, LOG2E);
         {
             const std::vector<float> c = ftvec(cf.data(), D, 4);
             add_image(&y.img_ca_q, wf.data(), D, D, ssp, c.data(), c.size());
@@ -360,13 +363,14 @@ int build_model(dc_sampler* s) {
                 const float* w = P_(nm + ".weight");
                 const float* bb = P_(nm + ".bias");
                 std::vector<float> wf((size_t)D * DC_E), bf(D);
+                const double sc = kv ? 1.0 : LOG2E;      // keys feed exp2 in the partial records
                 for (int o = 0; o < D; ++o) {
                     double acc = bb[o];
                     for (int k = 0; k < DC_E; ++k) {
-                        wf[(size_t)o * DC_E + k] = w[(size_t)o * DC_E + k] * g[k];
+                        wf[(size_t)o * DC_E + k] = (float)((double)w[(size_t)o * DC_E + k] * g[k] * sc);
                         acc += (double)w[(size_t)o * DC_E + k] * bt[k];
                     }
-                    bf[o] = (float)acc;
+                    bf[o] = (float)(acc * sc);
                 }
                 add_packed(kv ? &y.ca_wv : &y.ca_wk, wf.data(), D, DC_E, false, false);   // conditioning pre-pass is always split-bf16
                 add_raw(kv ? &y.ca_bv : &y.ca_bk, bf.data(), D);

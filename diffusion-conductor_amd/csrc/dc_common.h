@@ -23,9 +23,10 @@
 #define DC_KS_E (DC_E / 16)         // 32 k-steps of 16 over the 512-wide embedding
 
 // one partial record of the linear-attention K-softmax / K^T V reduction
-// (per group, per clip slot): column max, column sum of exp, and the 4 diagonal
-// 32x32 blocks of exp(K-m)^T V in accumulator layout.
-#define DC_REC_FLOATS (128 + 128 + 4 * 64 * 16)
+// (per group, per clip slot): column max (log2 units), column sum of exp2, and for each of the 4 feature
+// tiles the two diagonal 16x16 head blocks of exp(K-m)^T V: lane (c, hh) keeps the 8 accumulator registers
+// 8*(c>>4) .. +7 of the 32x32 tile (the other 8 are cross-head products nobody reads).
+#define DC_REC_FLOATS (128 + 128 + 4 * 64 * 8)
 
 #ifdef __HIPCC__
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -48,6 +48,7 @@ DEV float xhalf_max(float v) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+DEV float exp2f_fast(float x) { return __builtin_amdgcn_exp2f(x); }     // v_exp_f32
 
 // row (feature in FT, token in TF) held by register r of lane-half hh
 DEV int tile_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
@@ -145,21 +146,20 @@ DEV f32x16 ld_ft(const float* __restrict__ p, int tile, int hh) {
 // nn.LayerNorm(128) over the feature axis of an FT activation (transformer.py:79,104,147)
 template <int NT>
 DEV void ln_stats(const f32x16 (&x)[NT], float& mean, float& rstd) {
-    float s = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += x[t][r];
-    mean = xhalf_sum(s) * (1.f / (32 * NT));
-    float q = 0.f;
+    // one pass: sum and sum of squares (fp32, 128 terms: the cancellation in E[x^2]-mean^2 stays ~1e-7*mean^2/var)
+    float s = 0.f, q = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float d = x[t][r] - mean;
-            q += d * d;
+            s += x[t][r];
+            q = fmaf(x[t][r], x[t][r], q);
         }
-    rstd = rsqrtf(xhalf_sum(q) * (1.f / (32 * NT)) + 1e-5f);
+    s = xhalf_sum(s);
+    q = xhalf_sum(q);
+    mean = s * (1.f / (32 * NT));
+    const float var = fmaxf(fmaf(-mean, mean, q * (1.f / (32 * NT))), 0.f);
+    rstd = rsqrtf(var + 1e-5f);
 }
 // operand fragments of the normalised x (the LayerNorm affine is folded into the projection that follows)
 template <class T16, bool SPLIT>
@@ -190,7 +190,7 @@ DEV void softmax_heads_ft(f32x16 (&q)[4]) {
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float e = __expf(q[t][8 * p + j] - m);
+                const float e = exp2f_fast(q[t][8 * p + j] - m);     // q carries log2(e): folded into Wq, bq
                 q[t][8 * p + j] = e;
                 s += e;
             }
@@ -200,7 +200,7 @@ DEV void softmax_heads_ft(f32x16 (&q)[4]) {
         }
 }
 
-DEV float silu(float z) { return z * fast_rcp(1.f + __expf(-z)); }
+DEV float silu(float z) { return z * fast_rcp(1.f + exp2f_fast(-1.4426950408889634f * z)); }
 // nn.GELU() (exact-erf form).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 noise of the
 // surrounding GEMMs): erf(a) = 1 - (a1 t + ... + a5 t^5) exp(-a^2), t = 1/(1 + p a), a >= 0.
 DEV float gelu_erf(float x) {
@@ -262,7 +262,7 @@ DEV RowRange valid_rows(const GroupCtx& cx, int slot, int M, int T, const int* _
 DEV bool row_ok(const RowRange& rr, int r) { return (unsigned)(((r & 3) + 8 * (r >> 2)) - rr.lo) < rr.span; }
 
 // One 32-feature tile of a group's partial record: column max m, column sum of exp(K-m), and
-// exp(K-m)^T V (32x32, of which the two diagonal 16x16 head blocks are used by the combine).
+// exp2(K-m)^T V (32x32; only the two diagonal 16x16 head blocks are stored).
 template <class T16, bool SPLIT>
 DEV void emit_partial(const f32x16& K, const f32x16& V, int oc, const RowRange& rr, float* __restrict__ R,
                       const GroupCtx& cx) {
@@ -276,7 +276,7 @@ DEV void emit_partial(const f32x16& K, const f32x16& V, int oc, const RowRange& 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const bool ok = row_ok(rr, r);
-        const float e = ok ? __expf(K[r] - m) : 0.f;
+        const float e = ok ? exp2f_fast(K[r] - m) : 0.f;       // K carries log2(e): folded into Wk, bk
         Ee[r] = e;
         ssum += e;
         Vm[r] = ok ? V[r] : 0.f;
@@ -298,7 +298,11 @@ DEV void emit_partial(const f32x16& K, const f32x16& V, int oc, const RowRange& 
         R[32 * oc + cx.c] = m;
         R[128 + 32 * oc + cx.c] = ssum;
     }
-    reinterpret_cast<f32x16*>(R + 256)[oc * 64 + cx.lane] = P;
+    // keep the diagonal head blocks only: rows 16*(c>>4) .. +15 of this lane's column = registers 8*(c>>4) .. +7
+    f32x8 keep;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) keep[i] = (cx.c >> 4) ? P[8 + i] : P[i];
+    reinterpret_cast<f32x8*>(R + 256)[oc * 64 + cx.lane] = keep;
 }
 
 // FiLM tile image: [2 halves][64 lanes][8 fp16] - registers 0..7 then 8..15 of each lane, so that both a
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(256) void k_cond_ca_partials(const DcModel* __restr
 // combine partial records of one (set, clip, 32-feature tile) into attention operand frags
 //   A[d][l] = sum_g w_g[d] P_g[d][l] / sum_g w_g[d] ssum_g[d],   w_g = exp(m_g - max_g m_g)
 // recs: [nset][NU units][2][DC_REC_FLOATS] (a unit = `gran` consecutive tokens); afrag out: [nset][B][16 frags (8 hi, 8 lo)][64 lanes][8] T16.
-// grid (B, 4, nset), 1024 threads: thread (q4, lane, rq) sums group-quarter q4 of registers 4rq..4rq+3 of the tile.
+// grid (B, 4, nset), 1024 threads: thread (q8, lane, hq) sums group-eighth q8 of kept values 4hq..4hq+3 of its lane.
 // All sums run in a fixed order: re-running is bit-identical.
 // ------------------------------------------------------------------------------------
 template <class T16>
@@ -555,16 +559,18 @@ __global__ __launch_bounds__(1024) void k_attn_combine(const float* __restrict__
     };
     // every load of the block is issued before the first dependent use: one memory round trip in all.
     const int f = tid & 31, part = tid >> 5;          // phases 1-2: 32 features x 32 group-parts
-    const int q4 = tid >> 8, t8 = tid & 255;          // phase 3: 4 group-quarters x (lane, rq)
-    const int lane = t8 & 63, rq = t8 >> 6;
+    const int q8 = tid >> 7, t7 = tid & 127;          // phase 3: 8 group-eighths x (lane, half)
+    const int lane = t7 & 63, hq = t7 >> 6;           // this thread: kept values 4hq..4hq+3 of the lane
     const int c = lane & 31, hh = lane >> 5;
-    const int row0 = 8 * rq + 4 * hh;                 // tile_row(4rq + i, hh) = i + 8rq + 4hh
-    const int per = (ng + 3) / 4, gb = q4 * per, ge = min(gb + per, ng);
-    constexpr int PMAX = 16;                          // records preloaded per thread (covers T <= 1984; longer clips loop)
+    // kept value j of lane (c,hh) = tile register r = 8*(c>>4) + j -> E-feature row tile_row(r, hh)
+    const int r0 = 8 * (c >> 4) + 4 * hq;
+    const int row0 = tile_row(r0, hh);                // rows row0 .. row0+3 (r0 is a multiple of 4)
+    const int per = (ng + 7) / 8, gb = q8 * per, ge = min(gb + per, ng);
+    constexpr int PMAX = 8;                           // records preloaded per thread (covers T <= 1984; longer clips loop)
     f32x4 p[PMAX];
 #pragma unroll
     for (int u = 0; u < PMAX; ++u)
-        if (gb + u < ge) p[u] = reinterpret_cast<const f32x4*>(rec_of(gb + u) + 256)[(oc * 64 + lane) * 4 + rq];
+        if (gb + u < ge) p[u] = reinterpret_cast<const f32x4*>(rec_of(gb + u) + 256)[(oc * 64 + lane) * 2 + hq];
     float mreg[4], sreg[4];                            // this thread's groups: part, part+32, ...  (ng <= 128)
     float mloc = -INFINITY;
 #pragma unroll
@@ -585,13 +591,13 @@ __global__ __launch_bounds__(1024) void k_attn_combine(const float* __restrict__
 #pragma unroll 8
     for (int k = 1; k < 32; ++k) mstar = fmaxf(mstar, red[k * 32 + f]);
     __syncthreads();
-    // phase 2: weights w_g = exp(m_g - m*) and the normaliser (fixed summation order)
+    // phase 2: weights w_g = exp2(m_g - m*) and the normaliser (fixed summation order)
     float zloc = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int gi = part + 32 * k;
         if (gi < ng) {
-            const float ww = sreg[k] > 0.f ? __expf(mreg[k] - mstar) : 0.f;
+            const float ww = sreg[k] > 0.f ? exp2f_fast(mreg[k] - mstar) : 0.f;
             w[gi * 32 + f] = ww;
             zloc += ww * sreg[k];
         }
@@ -603,7 +609,7 @@ __global__ __launch_bounds__(1024) void k_attn_combine(const float* __restrict__
         for (int k = 0; k < 32; ++k) zz += red[k * 32 + tid];
         z[tid] = zz;
     }
-    // phase 3: weighted sum of the partial K^T V tiles; 4 group-quarters in parallel, each in group order
+    // phase 3: weighted sum of the partial K^T V blocks; 8 group-eighths in parallel, each in group order
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < PMAX; ++u)
@@ -611,30 +617,36 @@ __global__ __launch_bounds__(1024) void k_attn_combine(const float* __restrict__
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[(gb + u) * 32 + row0 + i], p[u][i], acc[i]);
         }
-    for (int gi = gb + PMAX; gi < ge; ++gi) {          // clips longer than PMAX*4 groups
-        const f32x4 pp = reinterpret_cast<const f32x4*>(rec_of(gi) + 256)[(oc * 64 + lane) * 4 + rq];
+    for (int gi = gb + PMAX; gi < ge; ++gi) {          // clips longer than PMAX*8 groups
+        const f32x4 pp = reinterpret_cast<const f32x4*>(rec_of(gi) + 256)[(oc * 64 + lane) * 2 + hq];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[gi * 32 + row0 + i], pp[i], acc[i]);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pacc[(q4 * 256 + t8) * 4 + i] = acc[i];
+    for (int i = 0; i < 4; ++i) pacc[(q8 * 128 + t7) * 4 + i] = acc[i];
     __syncthreads();
-    if (q4 != 0) return;
-    const bool keep = (rq >> 1) == (c >> 4);   // same head on both sides
-    v4<T16> hi, lo;
+    if (q8 != 0) return;
+    // thread (lane, hq) writes registers r0..r0+3 of the operand tile; the other 8 registers of the lane are
+    // cross-head entries = 0 (written by the same thread: its partner half)
+    v4<T16> hi, lo, zero;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float tot = ((pacc[t8 * 4 + i] + pacc[(256 + t8) * 4 + i]) + pacc[(512 + t8) * 4 + i]) + pacc[(768 + t8) * 4 + i];
+        float tot = pacc[t7 * 4 + i];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) tot += pacc[(k * 128 + t7) * 4 + i];
         const float zz = z[row0 + i];
-        const float a = (keep && zz > 0.f) ? tot / zz : 0.f;
+        const float a = zz > 0.f ? tot / zz : 0.f;
         hi[i] = (T16)a;
         lo[i] = (T16)(a - (float)hi[i]);
+        zero[i] = (T16)0.f;
     }
-    // register r = 4rq+i of the tile  ->  k-step s = r>>3, element j = r&7 of the A-operand frag
+    // register r of the tile  ->  k-step s = r>>3, element j = r&7 of the A-operand frag
     v8<T16>* out = afrag + ((size_t)set * B + b) * 16 * 64;
-    const int s = rq >> 1, j0 = (rq & 1) * 4;
+    const int s = r0 >> 3, j0 = r0 & 7;               // kept block: s == c>>4
     reinterpret_cast<v4<T16>*>(out + ((oc * 2 + s) * 64 + lane))[j0 >> 2] = hi;
     reinterpret_cast<v4<T16>*>(out + ((8 + oc * 2 + s) * 64 + lane))[j0 >> 2] = lo;
+    reinterpret_cast<v4<T16>*>(out + ((oc * 2 + (s ^ 1)) * 64 + lane))[j0 >> 2] = zero;
+    reinterpret_cast<v4<T16>*>(out + ((8 + oc * 2 + (s ^ 1)) * 64 + lane))[j0 >> 2] = zero;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1227,11 +1239,31 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         stage_frags<NW>(dm->layer[l + 1].img_sa_v, buf1, NFW + 1, wave, lane);
         XFrag<T16, SPLIT> nf[4];
         ln_frags<T16, SPLIT>(nf, h);
+        if (dbg & 0x400) return;      // timing experiment: no front stage
+        f32x16 K[4];                  // keys from buf0 while the value image lands in buf1
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc) {
+            K[oc] = splat(c0[32 * oc + cx.c]);
+            mmb_oc<4, 4, T16, SPLIT>(K[oc], w0, oc, nf, lane);
+        }
         stage_sync(dbg);
         DC_STAMP(12);
         if (active) store_h(h, hbuf, g, lane);      // after the vmcnt(0): nothing waits on these stores
-        if (dbg & 0x400) return;      // timing experiment: no front stage
-        front_stage<T16, SPLIT>(nf, w0, w1, c0, c1, cx, M, T, length, recs, active);
+        {
+            float* rec = recs + (size_t)cx.g * 2 * DC_REC_FLOATS;
+            const RowRange valid0 = valid_rows(cx, 0, M, T, length);
+            const RowRange valid1 = valid_rows(cx, cx.straddle ? 1 : 0, M, T, length);
+#pragma unroll
+            for (int oc = 0; oc < 4; ++oc) {
+                f32x16 V = splat(c1[32 * oc + cx.c]);
+                mmb_oc<4, 4, T16, SPLIT>(V, w1, oc, nf, lane);
+                if (active) {
+                    emit_partial<T16, SPLIT>(K[oc], V, oc, valid0, rec, cx);
+                    if (cx.straddle) emit_partial<T16, SPLIT>(K[oc], V, oc, valid1, rec + DC_REC_FLOATS, cx);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         DC_STAMP(13);
         return;
     }
@@ -1333,7 +1365,7 @@ hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, vo
                                   int gran) {
     const int ng_max = T / gran + 2;
     if (ng_max > 128) return hipErrorInvalidValue;    // combine holds <= 4 groups per thread (T <= 4032)
-    const size_t shm = (size_t)(ng_max * 32 + 32 + 1024 + 4096) * sizeof(float);
+    const size_t shm = (size_t)(ng_max * 32 + 32 + 1024 + 4096) * sizeof(float);   // w, z, red, pacc
     if (fmt == 1)
         hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(B, 4, nset), dim3(1024), shm, st, recs, (f16x8*)afrag, T, NU, B, gran);
     else
