@@ -116,7 +116,29 @@ DEV void mma_kt(f32x16 (&acc)[OT], const v8<T16>* __restrict__ w, int kt, const 
 template <int OT, int KT, class T16, bool SPLIT>
 DEV void gemm_wa(f32x16 (&acc)[OT], const v8<T16>* __restrict__ w, const XFrag<T16, SPLIT> (&x)[KT], int lane) {
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) mma_kt<OT, KT, T16, SPLIT>(acc, w, kt, x[kt], lane);
+    for (int kt = 0; kt < KT; ++kt) {
+        mma_kt<OT, KT, T16, SPLIT>(acc, w, kt, x[kt], lane);
+        __builtin_amdgcn_sched_barrier(0);      // bounds the operand-read lookahead to one k-tile (register pressure)
+    }
+}
+
+// one output tile: acc (rows = output features of tile ot) += sum_kt W[ot][kt] * X[kt]
+template <int OT, int KT, class T16, bool SPLIT>
+DEV void mma_ot(f32x16& acc, const v8<T16>* __restrict__ w, int ot, const XFrag<T16, SPLIT> (&x)[KT], int lane) {
+    constexpr int NF = OT * KT * 2;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int fi = (kt * OT + ot) * 2 + s;
+            const v8<T16> a = w[fi * 64 + lane];
+            acc = mfma(a, x[kt].hi[s], acc);
+            if constexpr (SPLIT) {
+                acc = mfma(a, x[kt].lo[s], acc);
+                const v8<T16> al = w[(NF + fi) * 64 + lane];
+                acc = mfma(al, x[kt].hi[s], acc);
+            }
+        }
 }
 
 // acc (rows = tokens, cols = output features of tile oc) += X^T * W[oc] over all k-tiles; weights are the B operand.
@@ -913,8 +935,10 @@ DEV void stage_frags(const void* __restrict__ src, char* dst, int nfrags, int wa
                                          (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
 }
 DEV void stage_sync(int abl = 0) {
+    __builtin_amdgcn_sched_barrier(0);           // stages do not interleave: keeps each stage's live set separate
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!(abl & 0x1000)) __syncthreads();        // 0x1000: timing experiment only (results are garbage)
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <class T16, bool SPLIT>
@@ -931,10 +955,44 @@ DEV void attn_apply_tile(f32x16& y, const v8<T16>* __restrict__ afrag, int oc, c
     }
 }
 
+// The attention / FFN output y that feeds a StylizationBlock: its LayerNorm statistics are taken from the exact
+// fp32 accumulators as the tiles are produced; the tiles themselves are then held as packed f16 in the
+// non-split modes (32 instead of 64 VGPRs - y only ever passes through LayerNorm -> FiLM -> SiLU -> f16 operand).
+template <bool SPLIT> struct YT { using tile = f16x16; };
+template <> struct YT<true> { using tile = f32x16; };
+template <bool SPLIT> using ytile = typename YT<SPLIT>::tile;
+
+struct RowStats {
+    float s = 0.f, q = 0.f;
+    DEV void add(const f32x16& x) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s += x[r];
+            q = fmaf(x[r], x[r], q);
+        }
+    }
+    DEV void finish(float& rstd, float& shift) {      // LayerNorm(128): n = x*rstd + shift
+        const float ss = xhalf_sum(s), qq = xhalf_sum(q);
+        const float mean = ss * (1.f / 128.f);
+        const float var = fmaxf(fmaf(-mean, mean, qq * (1.f / 128.f)), 0.f);
+        rstd = rsqrtf(var + 1e-5f);
+        shift = -mean * rstd;
+    }
+};
+template <bool SPLIT>
+DEV void put_y(ytile<SPLIT>& dst, const f32x16& x) {
+    if constexpr (SPLIT) {
+        dst = x;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[r] = (_Float16)x[r];
+    }
+}
+
 // q = softmax_heads(Wq LN(h) + bq);  y = q . A per head  (weights image `w` in LDS, bias block behind it)
 template <class T16, bool SPLIT>
-DEV void query_attend(f32x16 (&y)[4], const f32x16 (&h)[4], const float* bq, const v8<T16>* w, const v8<T16>* a0,
-                      const v8<T16>* a1, const GroupCtx& cx) {
+DEV void query_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const f32x16 (&h)[4], const float* bq,
+                      const v8<T16>* w, const v8<T16>* a0, const v8<T16>* a1, const GroupCtx& cx) {
     f32x16 q[4];
     {
         XFrag<T16, SPLIT> nf[4];
@@ -946,30 +1004,34 @@ DEV void query_attend(f32x16 (&y)[4], const f32x16 (&h)[4], const float* bq, con
     __builtin_amdgcn_sched_barrier(0);
     softmax_heads_ft(q);
     __builtin_amdgcn_sched_barrier(0);
+    RowStats st;
 #pragma unroll
     for (int oc = 0; oc < 4; ++oc) {
-        y[oc] = splat(0.f);
+        f32x16 acc = splat(0.f);
         XFrag<T16, SPLIT> qf;
         make_frag<T16, SPLIT>(q[oc], qf);
         if (!cx.straddle) {
-            attn_apply_tile<T16, SPLIT>(y[oc], a0, oc, qf, cx.lane);
+            attn_apply_tile<T16, SPLIT>(acc, a0, oc, qf, cx.lane);
         } else {   // the group spans two clips: apply each clip's matrix to its own tokens (lanes)
             XFrag<T16, SPLIT> qm = qf;
             mask_frag<T16, SPLIT>(qm, cx.lane_in_b0);
-            attn_apply_tile<T16, SPLIT>(y[oc], a0, oc, qm, cx.lane);
+            attn_apply_tile<T16, SPLIT>(acc, a0, oc, qm, cx.lane);
             mask_frag<T16, SPLIT>(qf, !cx.lane_in_b0);
-            attn_apply_tile<T16, SPLIT>(y[oc], a1, oc, qf, cx.lane);
+            attn_apply_tile<T16, SPLIT>(acc, a1, oc, qf, cx.lane);
         }
+        st.add(acc);
+        put_y<SPLIT>(y[oc], acc);
     }
+    st.finish(y_rstd, y_shift);
 }
 
 // one k-tile of the FiLM-modulated, SiLU'ed operand: z = SiLU(nhat*G' + H'), gp = G' - 1
-template <class T16, bool SPLIT>
-DEV void styl_tile(XFrag<T16, SPLIT>& zf, const f32x16& y, float rstd, float shift, const f16x16& gp, const f16x16& hp) {
+template <class T16, bool SPLIT, class YTile>
+DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shift, const f16x16& gp, const f16x16& hp) {
     f32x16 z;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float n = fmaf(y[r], rstd, shift);
+        const float n = fmaf((float)y[r], rstd, shift);
         z[r] = silu(fmaf(n, (float)gp[r], n + (float)hp[r]));
     }
     make_frag<T16, SPLIT>(z, zf);
@@ -980,13 +1042,10 @@ DEV void styl_tile(XFrag<T16, SPLIT>& zf, const f32x16& y, float rstd, float shi
 // with LN(y)*(1+scale)+shift = nhat*G' + H', nhat = (y-mean)*rstd; the FiLM GEMM delivers G'-1 and H' tiles.
 // E tiles come straight from global memory (Eg: this block's 8 tiles for this group).
 template <class T16, bool SPLIT>
-DEV void styl_accumulate(f32x16 (&h)[4], const f32x16 (&y)[4], const f16x8* __restrict__ Eg, const float* bo,
-                         const v8<T16>* w, int lane, int hh, int abl) {
+DEV void styl_accumulate(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd, float shift, const f16x8* __restrict__ Eg,
+                         const float* bo, const v8<T16>* w, int lane, int hh, int abl) {
     XFrag<T16, SPLIT> zf[4];
     {
-        float mean, rstd;
-        ln_stats<4>(y, mean, rstd);
-        const float shift = -mean * rstd;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             f16x16 gp, hp;
@@ -997,7 +1056,7 @@ DEV void styl_accumulate(f32x16 (&h)[4], const f32x16 (&y)[4], const f16x8* __re
                 gp = load_etile(Eg + kt * 128 + lane);
                 hp = load_etile(Eg + (4 + kt) * 128 + lane);
             }
-            styl_tile<T16, SPLIT>(zf[kt], y[kt], rstd, shift, gp, hp);
+            styl_tile<T16, SPLIT, ytile<SPLIT>>(zf[kt], y[kt], rstd, shift, gp, hp);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1024,53 +1083,34 @@ DEV void ering_issue(const f16x8* __restrict__ Eg, int kt, char* slot, int lane)
 // k-tiles 2,3 are issued as soon as 0,1 sit in registers and land behind the first half's VALU + MFMA work.
 // `prefetch_next` (the next stage's weight image) is issued only after that wait, so the wait covers just 8 KiB.
 template <class T16, bool SPLIT, class F>
-DEV void styl_accumulate_ring(f32x16 (&h)[4], const f32x16 (&y)[4], const f16x8* __restrict__ Eg, char* ring,
-                              const float* bo, const v8<T16>* w, int lane, int hh, F&& prefetch_next) {
-    float mean, rstd;
-    ln_stats<4>(y, mean, rstd);
-    const float shift = -mean * rstd;
-    const f16x8* s0 = reinterpret_cast<const f16x8*>(ring) + lane;
-    const f16x8* s1 = reinterpret_cast<const f16x8*>(ring + 4096) + lane;
+DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd, float shift,
+                              const f16x8* __restrict__ Eg, char* ring, const float* bo, const v8<T16>* w, int lane,
+                              int hh, F&& prefetch_next) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const f32x16 bb = ld_ft(bo, t, hh);
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[t][r] += bb[r];
     }
-    {
-        XFrag<T16, SPLIT> zf0, zf1;
-        {
-            const f16x16 g0 = load_etile(s0), h0 = load_etile(s0 + 128);
-            const f16x16 g1 = load_etile(s1), h1 = load_etile(s1 + 128);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            ering_issue(Eg, 2, ring, lane);
-            ering_issue(Eg, 3, ring + 4096, lane);
-            __builtin_amdgcn_sched_barrier(0);
-            styl_tile<T16, SPLIT>(zf0, y[0], rstd, shift, g0, h0);
-            styl_tile<T16, SPLIT>(zf1, y[1], rstd, shift, g1, h1);
-        }
-        mma_kt<4, 4, T16, SPLIT>(h, w, 0, zf0, lane);
-        mma_kt<4, 4, T16, SPLIT>(h, w, 1, zf1, lane);
-    }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    {
-        XFrag<T16, SPLIT> zf2, zf3;
-        {
-            const f16x16 g2 = load_etile(s0), h2 = load_etile(s0 + 128);
-            const f16x16 g3 = load_etile(s1), h3 = load_etile(s1 + 128);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the ring slots are free again
-            __builtin_amdgcn_sched_barrier(0);
-            prefetch_next();
-            __builtin_amdgcn_sched_barrier(0);
-            styl_tile<T16, SPLIT>(zf2, y[2], rstd, shift, g2, h2);
-            styl_tile<T16, SPLIT>(zf3, y[3], rstd, shift, g3, h3);
-        }
-        mma_kt<4, 4, T16, SPLIT>(h, w, 2, zf2, lane);
-        mma_kt<4, 4, T16, SPLIT>(h, w, 3, zf3, lane);
+    // one k-tile at a time (one (G'-1, H') pair = 16 registers live): read slot kt&1, hand the slot back to the
+    // DMA engine for k-tile kt+2, modulate, accumulate.
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        char* slot = ring + (kt & 1) * 4096;
+        if (kt == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // k-tiles 2,3 have landed
+        const f16x8* sp = reinterpret_cast<const f16x8*>(slot) + lane;
+        const f16x16 gp = load_etile(sp), hp = load_etile(sp + 128);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt < 2) ering_issue(Eg, kt + 2, slot, lane);
+        if (kt == 3) prefetch_next();                                       // both slots are free again
+        __builtin_amdgcn_sched_barrier(0);
+        XFrag<T16, SPLIT> zf;
+        styl_tile<T16, SPLIT, ytile<SPLIT>>(zf, y[kt], rstd, shift, gp, hp);
+        mma_kt<4, 4, T16, SPLIT>(h, w, kt, zf, lane);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <class T16, bool SPLIT>
@@ -1137,11 +1177,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
 
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
     stage_frags<NW>(L.img_sa_o, buf1, NFW + 1, wave, lane);
-    f32x16 y[4];
+    ytile<SPLIT> y[4];
+    float y_rstd, y_shift;
     {
         const W* a0 = wg_lds ? af + (size_t)(cx.b0 - ub0) * 8 * 64 : a_sa + (size_t)cx.b0 * 16 * 64;
         const W* a1 = wg_lds ? af + (size_t)(cx.b1 - ub0) * 8 * 64 : a_sa + (size_t)cx.b1 * 16 * 64;
-        query_attend<T16, SPLIT>(y, h, c0, w0, a0, a1, cx);
+        query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, a0, a1, cx);
     }
     DC_STAMP(2);
     stage_sync(dbg);
@@ -1150,9 +1191,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
         if (wg_lds) stage_attn(acl);
-        styl_accumulate<T16, SPLIT>(h, y, Eg, c1, w1, lane, cx.hh, dbg);
+        styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh, dbg);
     } else {
-        styl_accumulate_ring<T16, SPLIT>(h, y, Eg, ring, c1, w1, lane, cx.hh, [&]() {
+        styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, ring, c1, w1, lane, cx.hh, [&]() {
             stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
             if (wg_lds) stage_attn(acl);
             ering_issue(Eg + 8 * 128, 0, ring, lane);
@@ -1168,7 +1209,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     {
         const W* a0 = wg_lds ? af + (size_t)(cx.b0 - ub0) * 8 * 64 : acl + (size_t)cx.b0 * 16 * 64;
         const W* a1 = wg_lds ? af + (size_t)(cx.b1 - ub0) * 8 * 64 : acl + (size_t)cx.b1 * 16 * 64;
-        query_attend<T16, SPLIT>(y, h, c0, w0, a0, a1, cx);
+        query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, a0, a1, cx);
     }
     DC_STAMP(6);
     stage_sync(dbg);
@@ -1176,9 +1217,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
         stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
-        styl_accumulate<T16, SPLIT>(h, y, Eg + 8 * 128, c1, w1, lane, cx.hh, dbg);
+        styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh, dbg);
     } else {
-        styl_accumulate_ring<T16, SPLIT>(h, y, Eg + 8 * 128, ring, c1, w1, lane, cx.hh, [&]() {
+        styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, ring, c1, w1, lane, cx.hh, [&]() {
             stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
             stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
             ering_issue(Eg + 16 * 128, 0, ring, lane);
@@ -1208,9 +1249,15 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             for (int r = 0; r < 16; ++r) u[kt][r] = gelu_erf(u[kt][r]);
             make_frag<T16, SPLIT>(u[kt], uf[kt]);
         }
+        RowStats st;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) y[t] = ld_ft(c0 + 64, t, cx.hh);               // b2
-        gemm_wa<4, 2, T16, SPLIT>(y, w0 + 16 * WM * 64, uf, lane);
+        for (int t = 0; t < 4; ++t) {                                              // one output tile at a time
+            f32x16 yf = ld_ft(c0 + 64, t, cx.hh);                                  // b2
+            mma_ot<4, 2, T16, SPLIT>(yf, w0 + 16 * WM * 64, t, uf, lane);
+            st.add(yf);
+            put_y<SPLIT>(y[t], yf);
+        }
+        st.finish(y_rstd, y_shift);
     }
     DC_STAMP(9);
     stage_sync(dbg);
@@ -1224,9 +1271,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         };
         if constexpr (!use_ring) {
             next_w();
-            styl_accumulate<T16, SPLIT>(h, y, Eg + 16 * 128, c1, w1, lane, cx.hh, dbg);
+            styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, c1, w1, lane, cx.hh, dbg);
         } else {
-            styl_accumulate_ring<T16, SPLIT>(h, y, Eg + 16 * 128, ring, c1, w1, lane, cx.hh, next_w);
+            styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, ring, c1, w1, lane, cx.hh, next_w);
         }
     }
     if ((dbg & 0xff) == 3) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
