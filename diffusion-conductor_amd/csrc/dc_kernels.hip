@@ -1113,7 +1113,9 @@ DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float 
     }
 }
 
-template <class T16, bool SPLIT>
+// DBG = true builds the test-hook variant (early exits after a stage, ablation switches, stage stamps); the
+// production instantiation has none of them - the extra exits alone cost 160 spilled registers.
+template <class T16, bool SPLIT, bool DBG>
 __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
 void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
              const v8<T16>* __restrict__ a_sa /*[B][16][64]*/, const v8<T16>* __restrict__ a_ca /*[L][B][16][64]*/,
@@ -1128,7 +1130,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     // diagnostic build aid: 100 MHz timestamps per stage for the waves of workgroup 3 (stamps == nullptr normally)
 #define DC_STAMP(k)                                                                                        \
     do {                                                                                                   \
-        if (stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0)                                          \
+        if (DBG && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0)                                   \
             stamps[(threadIdx.x >> 6) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                      \
     } while (0)                 // frags of one 128x128 stage image (constants block follows)
     constexpr int WSZ = (NFW + 1) * 1024;
@@ -1172,7 +1174,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     f32x16 h[4];
     DC_STAMP(0);
     load_h(h, hbuf, g, lane);
-    stage_sync(dbg);
+    stage_sync(DBG ? dbg : 0);
     DC_STAMP(1);
 
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
@@ -1185,7 +1187,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, a0, a1, cx);
     }
     DC_STAMP(2);
-    stage_sync(dbg);
+    stage_sync(DBG ? dbg : 0);
     DC_STAMP(3);
     // ---- stage 2: SA stylization [buf1]; prefetch CA query -> buf0 (+ cross-attention frags)
     if constexpr (!use_ring) {
@@ -1200,9 +1202,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             ering_issue(Eg + 8 * 128, 1, ring + 4096, lane);
         });
     }
-    if ((dbg & 0xff) == 1) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after self-attention
+    if constexpr (DBG) if ((dbg & 0xff) == 1) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after self-attention
     DC_STAMP(4);
-    stage_sync(dbg);
+    stage_sync(DBG ? dbg : 0);
     DC_STAMP(5);
     // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
     stage_frags<NW>(L.img_ca_o, buf1, NFW + 1, wave, lane);
@@ -1212,7 +1214,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, a0, a1, cx);
     }
     DC_STAMP(6);
-    stage_sync(dbg);
+    stage_sync(DBG ? dbg : 0);
     // ---- stage 4: CA stylization [buf1]; prefetch FFN W1|W2 (+ b1|b2) -> buf0
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
@@ -1226,9 +1228,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             ering_issue(Eg + 16 * 128, 1, ring + 4096, lane);
         });
     }
-    if ((dbg & 0xff) == 2) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after cross-attention
+    if constexpr (DBG) if ((dbg & 0xff) == 2) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after cross-attention
     DC_STAMP(7);
-    stage_sync(dbg);
+    stage_sync(DBG ? dbg : 0);
     DC_STAMP(8);
     // ---- stage 5: FFN [buf0]; prefetch FFN out-proj -> buf1
     stage_frags<NW>(L.img_ffn_o, buf1, NFW + 1, wave, lane);
@@ -1260,7 +1262,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         st.finish(y_rstd, y_shift);
     }
     DC_STAMP(9);
-    stage_sync(dbg);
+    stage_sync(DBG ? dbg : 0);
     // ---- stage 6: FFN stylization [buf1]; prefetch next layer's key projection (or the output projection) -> buf0
     {
         auto next_w = [&]() {
@@ -1276,9 +1278,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, ring, c1, w1, lane, cx.hh, next_w);
         }
     }
-    if ((dbg & 0xff) == 3) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
+    if constexpr (DBG) if ((dbg & 0xff) == 3) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
     DC_STAMP(10);
-    stage_sync(dbg);
+    stage_sync(DBG ? dbg : 0);
     DC_STAMP(11);
 
     if (!last) {
@@ -1286,14 +1288,14 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         stage_frags<NW>(dm->layer[l + 1].img_sa_v, buf1, NFW + 1, wave, lane);
         XFrag<T16, SPLIT> nf[4];
         ln_frags<T16, SPLIT>(nf, h);
-        if (dbg & 0x400) return;      // timing experiment: no front stage
+        if constexpr (DBG) if (dbg & 0x400) return;      // timing experiment: no front stage
         f32x16 K[4];                  // keys from buf0 while the value image lands in buf1
 #pragma unroll
         for (int oc = 0; oc < 4; ++oc) {
             K[oc] = splat(c0[32 * oc + cx.c]);
             mmb_oc<4, 4, T16, SPLIT>(K[oc], w0, oc, nf, lane);
         }
-        stage_sync(dbg);
+        stage_sync(DBG ? dbg : 0);
         DC_STAMP(12);
         if (active) store_h(h, hbuf, g, lane);      // after the vmcnt(0): nothing waits on these stores
         {
@@ -1478,7 +1480,7 @@ hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, const DcMo
     return e;
 }
 
-template <class T16, bool SP>
+template <class T16, bool SP, bool DBG>
 static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
@@ -1488,11 +1490,11 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
     const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192;
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
-        hipError_t e = hipFuncSetAttribute((const void*)k_layer<T16, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipError_t e = hipFuncSetAttribute((const void*)k_layer<T16, SP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    k_layer<T16, SP><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
+    k_layer<T16, SP, DBG><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
                        (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
                        snaps, M, T, G, B, dbg, stamps);
     return hipGetLastError();
@@ -1503,7 +1505,12 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, const DcModel* d
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps) {
     hipError_t e = hipSuccess;
-    DISPATCH(fmt, split, (e = launch_layer_t<T16, SP>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode,
-                                                       coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps)));
+    if (dbg != 0 || stamps != nullptr) {
+        DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, true>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout,
+                                                                 out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps)));
+    } else {
+        DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, false>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout,
+                                                                  out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps)));
+    }
     return e;
 }
