@@ -8,6 +8,7 @@ import pandas as pd
 d = sys.argv[1]
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     df = pd.read_csv(f)
+    df = df[~df["Kernel_Name"].str.contains("rocclr|at::native|Cijk", regex=True)]
     df["k"] = df["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.slice(0, 40)
     t = df.pivot_table(index="k", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
     t["n"] = df.groupby("k")["Dispatch_Id"].nunique()
