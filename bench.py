@@ -172,8 +172,12 @@ def main():
         ms, cnt = prof["k_film_gemm"]
         per_launch = ms / cnt * 1e-3
         achieved = FILM_FLOP_PER_TOKEN * B * T / per_launch / 1e12
+        traffic = None       # HBM bytes per launch of this kernel from the committed PMC passes of this same command
+        tf = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tf) and (B, T, S, args.precision) == (32, 1800, 50, "fp16"):
+            traffic = json.load(open(tf)).get("k_film_gemm", {}).get("traffic_bytes")
         line["roofline"] = {"bound": "mfma", "kernel": "k_film_gemm", "achieved": round(achieved, 1), "peak": PEAK_BF16_FLOPS / 1e12,
-                            "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_FLOPS, 4), "traffic": None,
+                            "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_FLOPS, 4), "traffic": traffic,
                             "avg_launch_us": round(per_launch * 1e6, 1), "launches": cnt,
                             "time_share_by_kernel": {k: round(v[0] / tot, 3) for k, v in prof.items()}}
         if not args.no_cpu_baseline:
