@@ -774,7 +774,7 @@ __global__ __launch_bounds__(256) void k_film_gemm(const v8<T16>* __restrict__ W
 }
 
 // ------------------------------------------------------------------------------------
-// FiLM GEMM v2 (non-split formats): S-stationary.  One workgroup = 8 waves = 4 token groups (128 tokens):
+// FiLM GEMM v2 (non-split formats): S-stationary, persistent.  A workgroup = 8 waves works on 4 token groups (128 tokens):
 // its operand slab S[4 g][32 ks] (128 KiB) is copied once into LDS by LDS-DMA and stays there while the
 // waves sweep all 3L*4*... feature-tile PAIRS (scale tile, shift tile): wave w takes pairs w, w+8, ...
 // Weight fragments stream L2 -> registers through a PF-deep software prefetch ring (each fragment is used
@@ -789,32 +789,44 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
     using OP = v8<T16>;
     constexpr int PF = 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g0 = blockIdx.x * 4;
-    // slab: frag (g, ks) at [(g*32 + ks)]; groups past the end alias the last one (their stores are skipped)
-    for (int f = wave; f < 4 * DC_KS_E; f += 8) {
-        const int gg = min(g0 + (f >> 5), G - 1);
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(S + ((size_t)gg * DC_KS_E + (f & 31)) * 64 + lane),
-            (__attribute__((address_space(3))) void*)(lds + f * 1024), 16, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const OP* slab = reinterpret_cast<const OP*>(lds);
     const int hh = lane >> 5;
-    const int npair = NT / 2;
+    const OP* slab = reinterpret_cast<const OP*>(lds);
+    // Persistent workgroups: the work is (token block of 4 groups) x (round of 8 feature-tile pairs, one pair per
+    // wave); each workgroup owns a contiguous, equal share of those units so that all CUs finish together, and
+    // reloads its slab only when it crosses into the next token block.
+    const int nround = NT / 16;                                   // pairs / 8 waves
+    const int nblk = (G + 3) / 4;
+    const long long nunit = (long long)nblk * nround;
+    const int u0 = (int)(nunit * blockIdx.x / gridDim.x), u1 = (int)(nunit * (blockIdx.x + 1) / gridDim.x);
+    int cur_blk = -1;
     OP a0[PF], a1[PF];
-    {
-        const OP* w0 = W + (size_t)(2 * wave) * DC_KS_E * 64 + lane;
+    auto wbase = [&](int u) { return W + (size_t)(2 * ((u % nround) * 8 + wave)) * DC_KS_E * 64 + lane; };
+    if (u0 < u1) {
+        const OP* w0 = wbase(u0);
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             a0[i] = w0[i * 64];
             a1[i] = w0[(DC_KS_E + i) * 64];
         }
     }
-    for (int p = wave; p < npair; p += 8) {
-        const OP* w0 = W + (size_t)(2 * p) * DC_KS_E * 64 + lane;          // scale tile of the pair; shift tile follows
-        const int pn = p + 8 < npair ? p + 8 : p;                           // next pair (prefetch target)
-        const OP* wn = W + (size_t)(2 * pn) * DC_KS_E * 64 + lane;
+    for (int u = u0; u < u1; ++u) {
+        const int tb = u / nround, p = (u % nround) * 8 + wave;
+        const int g0 = tb * 4;
+        if (tb != cur_blk) {
+            __syncthreads();                                      // everyone is done with the previous slab
+            // slab: frag (g, ks) at [(g*32 + ks)]; groups past the end alias the last one (their stores are skipped)
+            for (int f = wave; f < 4 * DC_KS_E; f += 8) {
+                const int gg = min(g0 + (f >> 5), G - 1);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(S + ((size_t)gg * DC_KS_E + (f & 31)) * 64 + lane),
+                    (__attribute__((address_space(3))) void*)(lds + f * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur_blk = tb;
+        }
+        const OP* w0 = wbase(u);                                  // scale tile of the pair; the shift tile follows
+        const OP* wn = wbase(u + 1 < u1 ? u + 1 : u);             // next unit's pair (prefetch target)
         f32x16 acc[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -825,13 +837,13 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
             const bool tail = ks0 + PF >= DC_KS_E;                          // ring rolls over into the next pair
             const OP* wsrc = tail ? wn + (size_t)(ks0 + PF - DC_KS_E) * 64 : w0 + (size_t)(ks0 + PF) * 64;
 #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const OP x0 = a0[u], x1 = a1[u];
-                a0[u] = wsrc[u * 64];
-                a1[u] = wsrc[(DC_KS_E + u) * 64];
+            for (int q = 0; q < PF; ++q) {
+                const OP x0 = a0[q], x1 = a1[q];
+                a0[q] = wsrc[q * 64];
+                a1[q] = wsrc[(DC_KS_E + q) * 64];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const OP b = slab[(g * DC_KS_E + ks0 + u) * 64 + lane];
+                    const OP b = slab[(g * DC_KS_E + ks0 + q) * 64 + lane];
                     acc[0][g] = mfma(x0, b, acc[0][g]);
                     acc[1][g] = mfma(x1, b, acc[1][g]);
                 }
@@ -1452,7 +1464,9 @@ static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bia
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    k_film_gemm2<T16><<<dim3((G + 3) / 4), dim3(512), shm, st>>>((const v8<T16>*)W, bias_ft, g_ft, beta_ft,
+    static const int ncu = [] { hipDeviceProp_t p; int d = 0; hipGetDevice(&d); hipGetDeviceProperties(&p, d); return p.multiProcessorCount; }();
+    const int nblk = (G + 3) / 4;
+    k_film_gemm2<T16><<<dim3(nblk < ncu ? nblk : ncu), dim3(512), shm, st>>>((const v8<T16>*)W, bias_ft, g_ft, beta_ft,
                                                                 (const v8<T16>*)s_hi, (f16x16*)E, G, NT);
     return hipGetLastError();
 }
