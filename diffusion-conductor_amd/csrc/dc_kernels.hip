@@ -838,15 +838,18 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
             const OP* wsrc = tail ? wn + (size_t)(ks0 + PF - DC_KS_E) * 64 : w0 + (size_t)(ks0 + PF) * 64;
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
-                const OP x0 = a0[q], x1 = a1[q];
-                a0[q] = wsrc[q * 64];
-                a1[q] = wsrc[(DC_KS_E + q) * 64];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const OP b = slab[(g * DC_KS_E + ks0 + q) * 64 + lane];
-                    acc[0][g] = mfma(x0, b, acc[0][g]);
-                    acc[1][g] = mfma(x1, b, acc[1][g]);
+                    acc[0][g] = mfma(a0[q], b, acc[0][g]);
+                    acc[1][g] = mfma(a1[q], b, acc[1][g]);
                 }
+                // refill this ring slot for k-step +PF right after its last use; the fences keep the loads here
+                // (hipcc otherwise sinks all of them to the end of the body and waits vmcnt(0) on the spot)
+                __builtin_amdgcn_sched_barrier(0);
+                a0[q] = wsrc[q * 64];
+                a1[q] = wsrc[(DC_KS_E + q) * 64];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // epilogue: fold the block's LayerNorm affine, fp16, store
