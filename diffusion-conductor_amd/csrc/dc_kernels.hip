@@ -832,17 +832,33 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[i][g] = splat(0.f);
+        // slab operand fragments are read one k-step ahead (bA/bB alternate), weight fragments PF k-steps ahead
+        OP bA[4], bB[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bA[g] = slab[(g * DC_KS_E) * 64 + lane];
 #pragma unroll 1
         for (int ks0 = 0; ks0 < DC_KS_E; ks0 += PF) {
             const bool tail = ks0 + PF >= DC_KS_E;                          // ring rolls over into the next pair
             const OP* wsrc = tail ? wn + (size_t)(ks0 + PF - DC_KS_E) * 64 : w0 + (size_t)(ks0 + PF) * 64;
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
+                const int ksn = (ks0 + q + 1) & (DC_KS_E - 1);              // next k-step (wraps harmlessly at the end)
+                if ((q & 1) == 0) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const OP b = slab[(g * DC_KS_E + ks0 + q) * 64 + lane];
-                    acc[0][g] = mfma(a0[q], b, acc[0][g]);
-                    acc[1][g] = mfma(a1[q], b, acc[1][g]);
+                    for (int g = 0; g < 4; ++g) bB[g] = slab[(g * DC_KS_E + ksn) * 64 + lane];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[0][g] = mfma(a0[q], bA[g], acc[0][g]);
+                        acc[1][g] = mfma(a1[q], bA[g], acc[1][g]);
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bA[g] = slab[(g * DC_KS_E + ksn) * 64 + lane];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[0][g] = mfma(a0[q], bB[g], acc[0][g]);
+                        acc[1][g] = mfma(a1[q], bB[g], acc[1][g]);
+                    }
                 }
                 // refill this ring slot for k-step +PF right after its last use; the fences keep the loads here
                 // (hipcc otherwise sinks all of them to the end of the body and waits vmcnt(0) on the spot)
