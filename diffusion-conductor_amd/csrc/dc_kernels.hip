@@ -773,6 +773,20 @@ __global__ __launch_bounds__(256) void k_film_gemm(const v8<T16>* __restrict__ W
     }
 }
 
+
+// LDS-DMA of one 1-KiB fragment: lane i's 16 bytes at gsrc land at lds_dst + 16*i.  Issued through inline asm
+// on purpose: for the builtin form hipcc inserts `s_waitcnt vmcnt(0)` before the next LDS read of ANY address
+// (it assumes the DMA may alias), which would turn every "one stage ahead" prefetch into a synchronous copy.
+// All waits for these copies are explicit (stage_sync, the FiLM ring); M0 is saved/restored in the statement.
+DEV void lds_dma16(const void* gsrc /*per-lane*/, const char* lds_dst /*wave-uniform*/) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
 // ------------------------------------------------------------------------------------
 // FiLM GEMM v2 (non-split formats): S-stationary, persistent.  A workgroup = 8 waves works on 4 token groups (128 tokens):
 // its operand slab S[4 g][32 ks] (128 KiB) is copied once into LDS by LDS-DMA and stays there while the
@@ -787,7 +801,7 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
                                                        const v8<T16>* __restrict__ S, f16x16* __restrict__ E, int G, int NT) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using OP = v8<T16>;
-    constexpr int PF = 4;
+    constexpr int PF = 4;       // measured: 8 (with the 256-register budget it needs) is 25 % slower
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hh = lane >> 5;
     const OP* slab = reinterpret_cast<const OP*>(lds);
@@ -797,6 +811,8 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
     const int nround = NT / 16;                                   // pairs / 8 waves
     const int nblk = (G + 3) / 4;
     const long long nunit = (long long)nblk * nround;
+    // (whole token blocks per workgroup, all sweeping the weight rounds in lockstep for L2 locality, was measured:
+    // 5 % faster per sweep, but 450 blocks on 256 CUs need 2 full sweeps instead of 1.76 - slower overall)
     const int u0 = (int)(nunit * blockIdx.x / gridDim.x), u1 = (int)(nunit * (blockIdx.x + 1) / gridDim.x);
     int cur_blk = -1;
     OP a0[PF], a1[PF];
@@ -817,9 +833,7 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
             // slab: frag (g, ks) at [(g*32 + ks)]; groups past the end alias the last one (their stores are skipped)
             for (int f = wave; f < 4 * DC_KS_E; f += 8) {
                 const int gg = min(g0 + (f >> 5), G - 1);
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(S + ((size_t)gg * DC_KS_E + (f & 31)) * 64 + lane),
-                    (__attribute__((address_space(3))) void*)(lds + f * 1024), 16, 0, 0);
+                lds_dma16(S + ((size_t)gg * DC_KS_E + (f & 31)) * 64 + lane, lds + f * 1024);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -961,9 +975,7 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
 template <int NW>
 DEV void stage_frags(const void* __restrict__ src, char* dst, int nfrags, int wave, int lane) {
     const bf16x8* s = reinterpret_cast<const bf16x8*>(src);
-    for (int f = wave; f < nfrags; f += NW)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + (size_t)f * 64 + lane),
-                                         (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+    for (int f = wave; f < nfrags; f += NW) lds_dma16(s + (size_t)f * 64 + lane, dst + f * 1024);
 }
 DEV void stage_sync(int abl = 0) {
     __builtin_amdgcn_sched_barrier(0);           // stages do not interleave: keeps each stage's live set separate
@@ -1105,10 +1117,10 @@ DEV void styl_accumulate(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd,
 DEV void ering_issue(const f16x8* __restrict__ Eg, int kt, char* slot, int lane) {
     const f16x8* gsrc = Eg + kt * 128 + lane;
     const f16x8* hsrc = Eg + (4 + kt) * 128 + lane;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc), (__attribute__((address_space(3))) void*)(slot), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + 64), (__attribute__((address_space(3))) void*)(slot + 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hsrc), (__attribute__((address_space(3))) void*)(slot + 2048), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hsrc + 64), (__attribute__((address_space(3))) void*)(slot + 3072), 16, 0, 0);
+    lds_dma16(gsrc, slot);
+    lds_dma16(gsrc + 64, slot + 1024);
+    lds_dma16(hsrc, slot + 2048);
+    lds_dma16(hsrc + 64, slot + 3072);
 }
 // same StylizationBlock with the FiLM tiles arriving through the ring: k-tiles 0,1 were issued a stage ago;
 // k-tiles 2,3 are issued as soon as 0,1 sit in registers and land behind the first half's VALU + MFMA work.
@@ -1146,7 +1158,7 @@ DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float 
 
 // DBG = true builds the test-hook variant (early exits after a stage, ablation switches, stage stamps); the
 // production instantiation has none of them - the extra exits alone cost 160 spilled registers.
-template <class T16, bool SPLIT, bool DBG>
+template <class T16, bool SPLIT, bool DBG, bool STAMP>
 __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
 void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
              const v8<T16>* __restrict__ a_sa /*[B][16][64]*/, const v8<T16>* __restrict__ a_ca /*[L][B][16][64]*/,
@@ -1161,7 +1173,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     // diagnostic build aid: 100 MHz timestamps per stage for the waves of workgroup 3 (stamps == nullptr normally)
 #define DC_STAMP(k)                                                                                        \
     do {                                                                                                   \
-        if (DBG && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0)                                   \
+        if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0)                                 \
             stamps[(threadIdx.x >> 6) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                      \
     } while (0)                 // frags of one 128x128 stage image (constants block follows)
     constexpr int WSZ = (NFW + 1) * 1024;
@@ -1212,11 +1224,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     stage_frags<NW>(L.img_sa_o, buf1, NFW + 1, wave, lane);
     ytile<SPLIT> y[4];
     float y_rstd, y_shift;
-    {
-        const W* a0 = wg_lds ? af + (size_t)(cx.b0 - ub0) * 8 * 64 : a_sa + (size_t)cx.b0 * 16 * 64;
-        const W* a1 = wg_lds ? af + (size_t)(cx.b1 - ub0) * 8 * 64 : a_sa + (size_t)cx.b1 * 16 * 64;
-        query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, a0, a1, cx);
-    }
+    if (wg_lds)     // two instantiations so that each keeps its address space (a generic pointer means flat loads)
+        query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (size_t)(cx.b0 - ub0) * 8 * 64,
+                                 af + (size_t)(cx.b1 - ub0) * 8 * 64, cx);
+    else
+        query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, a_sa + (size_t)cx.b0 * 16 * 64,
+                                 a_sa + (size_t)cx.b1 * 16 * 64, cx);
     DC_STAMP(2);
     stage_sync(DBG ? dbg : 0);
     DC_STAMP(3);
@@ -1239,11 +1252,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(5);
     // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
     stage_frags<NW>(L.img_ca_o, buf1, NFW + 1, wave, lane);
-    {
-        const W* a0 = wg_lds ? af + (size_t)(cx.b0 - ub0) * 8 * 64 : acl + (size_t)cx.b0 * 16 * 64;
-        const W* a1 = wg_lds ? af + (size_t)(cx.b1 - ub0) * 8 * 64 : acl + (size_t)cx.b1 * 16 * 64;
-        query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, a0, a1, cx);
-    }
+    if (wg_lds)
+        query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (size_t)(cx.b0 - ub0) * 8 * 64,
+                                 af + (size_t)(cx.b1 - ub0) * 8 * 64, cx);
+    else
+        query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, acl + (size_t)cx.b0 * 16 * 64,
+                                 acl + (size_t)cx.b1 * 16 * 64, cx);
     DC_STAMP(6);
     stage_sync(DBG ? dbg : 0);
     // ---- stage 4: CA stylization [buf1]; prefetch FFN W1|W2 (+ b1|b2) -> buf0
@@ -1317,6 +1331,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if (!last) {
         // ---- stage 7: next layer's SA front half: K [buf0] and V [buf1], partial records
         stage_frags<NW>(dm->layer[l + 1].img_sa_v, buf1, NFW + 1, wave, lane);
+        // h goes out right behind the value-image DMA: vmcnt counts in issue order, so waiting until only the 16
+        // youngest operations (the 16 dwordx4 stores of h) are outstanding means "the image has landed" while the
+        // stores keep draining behind the K/V projections.
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) store_h(h, hbuf, g, lane);
+        __builtin_amdgcn_sched_barrier(0);
         XFrag<T16, SPLIT> nf[4];
         ln_frags<T16, SPLIT>(nf, h);
         if constexpr (DBG) if (dbg & 0x400) return;      // timing experiment: no front stage
@@ -1326,9 +1346,14 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             K[oc] = splat(c0[32 * oc + cx.c]);
             mmb_oc<4, 4, T16, SPLIT>(K[oc], w0, oc, nf, lane);
         }
-        stage_sync(DBG ? dbg : 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (active)
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
         DC_STAMP(12);
-        if (active) store_h(h, hbuf, g, lane);      // after the vmcnt(0): nothing waits on these stores
         {
             float* rec = recs + (size_t)cx.g * 2 * DC_REC_FLOATS;
             const RowRange valid0 = valid_rows(cx, 0, M, T, length);
@@ -1513,7 +1538,7 @@ hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, const DcMo
     return e;
 }
 
-template <class T16, bool SP, bool DBG>
+template <class T16, bool SP, bool DBG, bool STAMP>
 static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
@@ -1523,11 +1548,11 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
     const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192;
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
-        hipError_t e = hipFuncSetAttribute((const void*)k_layer<T16, SP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipError_t e = hipFuncSetAttribute((const void*)k_layer<T16, SP, DBG, STAMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    k_layer<T16, SP, DBG><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
+    k_layer<T16, SP, DBG, STAMP><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
                        (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
                        snaps, M, T, G, B, dbg, stamps);
     return hipGetLastError();
@@ -1538,12 +1563,15 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, const DcModel* d
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps) {
     hipError_t e = hipSuccess;
-    if (dbg != 0 || stamps != nullptr) {
-        DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, true>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout,
-                                                                 out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps)));
+    if (dbg != 0) {
+        DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, true, false>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout,
+                                                                        out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps)));
+    } else if (stamps != nullptr) {
+        DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, false, true>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout,
+                                                                        out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps)));
     } else {
-        DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, false>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout,
-                                                                  out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps)));
+        DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, false, false>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout,
+                                                                         out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps)));
     }
     return e;
 }

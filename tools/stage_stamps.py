@@ -14,7 +14,7 @@ for _ in range(2):
     nat.ddim_loop(noise, gd.native_coefficients())
 torch.cuda.synchronize()
 st = nat.debug_read("stamps", np.uint64, 8 * 16).reshape(8, 16).astype(np.int64)
-names = ["load_h+W0", "Q+attn SA", "sync", "styl SA", "sync", "Q+attn CA", "sync+(7)styl CA", "", "sync", "FFN", "sync+styl FFN", "sync", "ln+sync", "front"]
+names = ["load h + image 0", "Q + attend (SA)", "barrier", "stylize (SA)", "barrier", "Q + attend (CA)", "barrier + stylize (CA)", "barrier", "FFN", "barrier + stylize (FFN)", "barrier", "LN + K proj + barrier", "store h + V proj + partial records"]
 t0 = st[:, 0].min()
 print("wave:      " + "".join(f"{w:8d}" for w in range(8)))
 for k in range(1, 14):
