@@ -14,6 +14,7 @@
 #include "../../include/dc_ddim.h"
 #include "dc_common.h"
 #include "dc_launch.h"
+#include "dc_music.h"
 
 namespace {
 
@@ -166,6 +167,8 @@ struct dc_sampler {
     hipGraphExec_t graph = nullptr;
     int graph_B = 0, graph_T = 0, graph_K = 0;
 
+    dc_music* music = nullptr;   // MusicEncoder (built when its parameters were supplied)
+
     Prof prof;
     int dbg_layers = -1, dbg_stage = 0;   // test hooks (dc_sampler_debug_denoise)
 };
@@ -253,9 +256,9 @@ std::vector<ParamReq> required_params(const dc_config& c) {
     return r;
 }
 
-// true for reference keys the sampler path does not consume here (music encoder, proj):
-// accepted and ignored so a whole state_dict can be streamed in.
-bool ignorable_param(const std::string& n) {
+// MusicEncoder / proj entries are optional as a group: a sampler fed x_proj/x_out from elsewhere never needs them.
+// Entries of the group the kernels do not consume (num_batches_tracked counters) are accepted and dropped.
+bool music_param(const std::string& n) {
     return n.rfind("music_encoder.", 0) == 0 || n == "proj.weight" || n == "proj.bias";
 }
 
@@ -743,6 +746,7 @@ void dc_sampler_destroy(dc_sampler* s) {
                     s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    dc_music_destroy(s->music);
     if (s->ev_in) hipEventDestroy(s->ev_in);
     if (s->ev_out) hipEventDestroy(s->ev_out);
     if (s->stream) hipStreamDestroy(s->stream);
@@ -752,7 +756,16 @@ void dc_sampler_destroy(dc_sampler* s) {
 int dc_sampler_set_param(dc_sampler* s, const char* name, const float* data, int64_t numel) {
     if (!s || !name || !data || numel < 0) return fail(DC_ERR_INVALID, "null argument");
     const std::string n(name);
-    if (ignorable_param(n)) return DC_OK;
+    if (music_param(n)) {
+        for (const auto& r : dc_music_required(DC_C))
+            if (r.first == n) {
+                if ((size_t)numel != r.second) return fail(DC_ERR_PARAM, "parameter %s has %lld elements, expected %zu", name, (long long)numel, r.second);
+                s->params[n].assign(data, data + numel);
+                s->finalized = false;
+                return DC_OK;
+            }
+        return DC_OK;
+    }
     for (const auto& r : required_params(s->cfg))
         if (r.name == n) {
             if ((size_t)numel != r.numel) return fail(DC_ERR_PARAM, "parameter %s has %lld elements, expected %zu", name, (long long)numel, r.numel);
@@ -772,6 +785,17 @@ int dc_sampler_finalize_params(dc_sampler* s) {
     s->cap_G = 0;   // NT may have changed: force workspace rebuild
     int rc = build_model(s);
     if (rc) return rc;
+    if (s->music) {
+        dc_music_destroy(s->music);
+        s->music = nullptr;
+    }
+    bool any_music = false;
+    for (const auto& kv : s->params) any_music = any_music || music_param(kv.first);
+    if (any_music) {
+        std::string err;
+        s->music = dc_music_build(s->params, DC_C, &err);
+        if (!s->music) return fail(DC_ERR_PARAM, "music encoder: %s", err.c_str());
+    }
     s->finalized = true;
     s->cond_set = false;
     return DC_OK;
@@ -808,6 +832,23 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
     HIP_TRY(dc_launch_attn_combine(st, s->small_fmt, s->d_recs_ca, s->d_a_ca, T, G, B, L, 32));
     HIP_TRY(hipStreamSynchronize(st));   // `len` is host memory
     s->cond_set = true;
+    return sync_out(s, user);
+}
+
+int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t B, int32_t Tm, int32_t n_mels, float* d_xf_proj,
+                            float* d_xf_out, void* stream) {
+    if (!s || !s->finalized) return fail(DC_ERR_INVALID, "sampler not finalized");
+    if (!s->music) return fail(DC_ERR_PARAM, "music encoder parameters (music_encoder.*, proj.*) were not supplied");
+    if (!d_mel || !d_xf_proj || !d_xf_out || B < 1) return fail(DC_ERR_INVALID, "bad encode_music arguments");
+    if (n_mels != 128) return fail(DC_ERR_UNSUPPORTED, "mel spectrograms must have 128 bins (conv4 takes 32 channels x 16 bins), got %d", n_mels);
+    if (Tm < 2) return fail(DC_ERR_INVALID, "need at least 2 mel frames (reflect padding)");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    hipStream_t user = (hipStream_t)stream, st = s->stream;
+    int rc;
+    if ((rc = sync_in(s, user))) return rc;
+    std::string err;
+    const hipError_t e = dc_music_encode(s->music, d_mel, B, Tm, d_xf_proj, d_xf_out, st, &err);
+    if (e != hipSuccess) return fail(DC_ERR_HIP, "encode_music: %s %s", hipGetErrorString(e), err.c_str());
     return sync_out(s, user);
 }
 

@@ -1,0 +1,556 @@
+// dc_music.hip - MusicEncoder + encode_music on gfx950 (MI355X), hand-written MFMA kernels.
+//
+// Reference (restated, not translated): Diffusion_Stage/models/transformer.py
+//   :289-311 Conv2dResLayer   reflect-pad 3x3 conv -> BatchNorm2d(eval) -> ReLU, plus identity / 1x1-conv+BN residual
+//   :313-340 MusicEncoder     conv1 (1->16->16->16) pool(5,5)/(1,2); conv2 (16->32->32) pool(5,5)/(3,2);
+//                             conv3 (32->32->32) pool(3,3)/(1,2); [B,32,T,16] -> [B,512,T] -> Conv1d 512->64 + BatchNorm1d
+//   :447-459 encode_music     x = music_encoder(mel); x_proj = proj(x)   (eval mode: no token dropout)
+//
+// Layout.  mel is [B][Tm][128] fp32 = an image with H = time, W = mel bin, one channel.  Every activation lives in HBM
+// as TWO bf16 planes (hi, lo: x ~ hi + lo, 16 mantissa bits) in pixel-major order [b][y][x][c]; a pixel's 16 channels of
+// one plane are 32 contiguous bytes, i.e. exactly one k-step of a v_mfma_f32_32x32x16_bf16 B operand:
+//   lane (n = l & 31, kh = l >> 5) loads the 16 bytes of channels 8kh..8kh+7 of pixel x0 + n (+ tap offset)
+// so the implicit GEMM needs no staging or transposition: out[co][pixel] += W_tap[co][ci] * in[ci][pixel + tap] with the
+// folded weights as the A operand (LDS-resident, natural-k fragments) and 3 MFMAs per k-step (hi*hi + lo*hi + hi*lo,
+// "bf16x3": ~1e-5 relative, the conditioning must not cost the sampler its 1e-3 parity budget).
+// A wave owns 32 consecutive pixels of one image row; the accumulator tile has the output channels on registers
+// (row (r&3) + 8(r>>2) + 4(l>>5)) and those pixels on lanes, so bias / ReLU / residual / the hi-lo split are per-lane and
+// the stores are 8-byte pieces that tile the row's bytes without gaps.
+// Neighbouring taps re-read the same lines from L1/L2; HBM sees each plane about once per layer.
+#include "dc_music.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "dc_common.h"
+
+namespace {
+
+#define DEV __device__ __forceinline__
+
+DEV f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+DEV f32x16 mma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 acc) {
+    acc = mfma(ah, bh, acc);
+    acc = mfma(al, bh, acc);
+    return mfma(ah, bl, acc);
+}
+DEV int reflect(int i, int n) {        // torch 'reflect' padding of width 1 (no edge repeat)
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+DEV void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(v[j] - (float)h);
+    }
+}
+DEV f32x16 zero16() {
+    f32x16 x;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = 0.f;
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 3x3 reflect-padded convolution + folded BatchNorm + ReLU (+ residual).  RES: 0 none, 1 identity, 2 1x1 conv + BN.
+// Weight fragments (A operand, natural k = tap*CIN + ci): [hi: NKS][lo: NKS] then for RES == 2 [hi: KC][lo: KC].
+// CIN == 1 reads the fp32 mel directly: its single k-step holds the 9 taps (k = tap), split in registers.
+// ---------------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int RES>
+__global__ __launch_bounds__(256) void k_me_conv(const float* __restrict__ mel, const bf16x8* __restrict__ in_hi,
+                                                 const bf16x8* __restrict__ in_lo, __bf16* __restrict__ out_hi,
+                                                 __bf16* __restrict__ out_lo, const bf16x8* __restrict__ w,
+                                                 const float* __restrict__ bias_ft, const float* __restrict__ rbias_ft,
+                                                 int Bc, int H, int W, int tiles_per_wave) {
+    constexpr int KC = CIN >= 16 ? CIN / 16 : 1;
+    constexpr int NKS = CIN >= 16 ? 9 * KC : 1;
+    constexpr int NF = 2 * NKS + (RES == 2 ? 2 * KC : 0);
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    bf16x8* wl = reinterpret_cast<bf16x8*>(lds);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = lane & 31, kh = lane >> 5;
+    for (int f = wave; f < NF; f += 4) wl[f * 64 + lane] = w[f * 64 + lane];
+    __syncthreads();
+    f32x16 bias, rbias;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        bias[r] = bias_ft[kh * 16 + r];
+        rbias[r] = RES == 2 ? rbias_ft[kh * 16 + r] : 0.f;
+    }
+    const int xt_per_row = W / 32;
+    const long long total = (long long)Bc * H * xt_per_row;
+    const long long t0 = ((long long)blockIdx.x * 4 + wave) * tiles_per_wave;
+    for (int i = 0; i < tiles_per_wave; ++i) {
+        const long long tile = t0 + i;
+        if (tile >= total) break;
+        const int xt = (int)(tile % xt_per_row);
+        const int y = (int)((tile / xt_per_row) % H);
+        const int b = (int)(tile / ((long long)xt_per_row * H));
+        const int x = xt * 32 + n;
+        f32x16 acc = zero16();
+        if constexpr (CIN == 1) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = 8 * kh + j;
+                const int yy = reflect(y + t / 3 - 1, H), xx = reflect(x + t % 3 - 1, W);
+                v[j] = t < 9 ? mel[((size_t)b * H + yy) * W + xx] : 0.f;
+            }
+            bf16x8 bh, bl;
+            split8(v, bh, bl);
+            acc = mma3(wl[lane], wl[64 + lane], bh, bl, acc);
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = reflect(y + tap / 3 - 1, H), xx = reflect(x + tap % 3 - 1, W);
+                const size_t base = (((size_t)b * H + yy) * W + xx) * (CIN / 8) + kh;
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    const bf16x8 bh = in_hi[base + 2 * kc], bl = in_lo[base + 2 * kc];
+                    const int ks = tap * KC + kc;
+                    acc = mma3(wl[ks * 64 + lane], wl[(NKS + ks) * 64 + lane], bh, bl, acc);
+                }
+            }
+        }
+        const size_t pix = ((size_t)b * H + y) * W + x;
+        f32x16 res = zero16();
+        if constexpr (RES == 2) {
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const bf16x8 bh = in_hi[pix * (CIN / 8) + kh + 2 * kc], bl = in_lo[pix * (CIN / 8) + kh + 2 * kc];
+                res = mma3(wl[(2 * NKS + kc) * 64 + lane], wl[(2 * NKS + KC + kc) * 64 + lane], bh, bl, res);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < COUT / 8; ++q) {
+            const int c0 = 8 * q + 4 * kh;          // this lane's 4 consecutive output channels of register group q
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[4 * q + e] + bias[4 * q + e], 0.f);
+            if constexpr (RES == 1) {
+                const __bf16* ph = reinterpret_cast<const __bf16*>(in_hi) + pix * CIN + c0;
+                const __bf16* pl = reinterpret_cast<const __bf16*>(in_lo) + pix * CIN + c0;
+                const bf16x4 xh = *reinterpret_cast<const bf16x4*>(ph), xl = *reinterpret_cast<const bf16x4*>(pl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)xh[e] + (float)xl[e];
+            }
+            if constexpr (RES == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += res[4 * q + e] + rbias[4 * q + e];
+            }
+            bf16x4 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const __bf16 h = (__bf16)v[e];
+                oh[e] = h;
+                ol[e] = (__bf16)(v[e] - (float)h);
+            }
+            *reinterpret_cast<bf16x4*>(out_hi + pix * COUT + c0) = oh;
+            *reinterpret_cast<bf16x4*>(out_lo + pix * COUT + c0) = ol;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// max_pool2d on the plane pair; padding never wins (torch pads with -inf).  One thread per (pixel, 8 channels).
+// hi + lo is exact in fp32 (<= 17 significant bits), so the maximum re-splits into the very planes it came from.
+// ---------------------------------------------------------------------------------------------------------
+template <int KH, int KW, int SH, int SW, int PH, int PW>
+__global__ __launch_bounds__(256) void k_me_pool(const bf16x8* __restrict__ in_hi, const bf16x8* __restrict__ in_lo,
+                                                 bf16x8* __restrict__ out_hi, bf16x8* __restrict__ out_lo, int Bc, int H, int W,
+                                                 int C8, int Ho, int Wo) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)Bc * Ho * Wo * C8;
+    if (idx >= total) return;
+    const int c8 = (int)(idx % C8);
+    const int xo = (int)((idx / C8) % Wo);
+    const int yo = (int)((idx / ((long long)C8 * Wo)) % Ho);
+    const int b = (int)(idx / ((long long)C8 * Wo * Ho));
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky) {
+        const int yy = yo * SH - PH + ky;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const int xx = xo * SW - PW + kx;
+            if (xx < 0 || xx >= W) continue;
+            const size_t o = (((size_t)b * H + yy) * W + xx) * C8 + c8;
+            const bf16x8 h = in_hi[o], l = in_lo[o];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)h[j] + (float)l[j]);
+        }
+    }
+    bf16x8 oh, ol;
+    split8(m, oh, ol);
+    out_hi[idx] = oh;
+    out_lo[idx] = ol;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv4: Conv1d(512 -> 64, k=1) + BatchNorm1d over the flattened (channel, bin) axis.  The planes hold a frame's 512
+// features in (bin, channel) order, so the host permutes the weight columns instead of moving data.
+// One wave = 32 frames; weights (natural-k fragments [ot][ks], hi then lo) stream from L2.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_me_head(const bf16x8* __restrict__ in_hi, const bf16x8* __restrict__ in_lo,
+                                                 const bf16x8* __restrict__ w4, const float* __restrict__ bias_ft,
+                                                 float* __restrict__ xf_out, int M) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = lane & 31, kh = lane >> 5;
+    const int tok = (blockIdx.x * 4 + wave) * 32 + n;
+    const size_t t = tok < M ? tok : M - 1;
+    f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll 4
+    for (int ks = 0; ks < 32; ++ks) {
+        const bf16x8 bh = in_hi[t * 64 + 2 * ks + kh], bl = in_lo[t * 64 + 2 * ks + kh];
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+            acc[ot] = mma3(w4[(ot * 32 + ks) * 64 + lane], w4[(64 + ot * 32 + ks) * 64 + lane], bh, bl, acc[ot]);
+    }
+    if (tok >= M) return;
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[ot][4 * q + e] + bias_ft[(ot * 2 + kh) * 16 + 4 * q + e];
+            *reinterpret_cast<f32x4*>(xf_out + (size_t)tok * 64 + 32 * ot + 8 * q + 4 * kh) = v;
+        }
+}
+
+// proj: Linear(64 -> 64) on the fp32 features (transformer.py:457), operands split in registers.
+__global__ __launch_bounds__(256) void k_me_proj(const float* __restrict__ xf, const bf16x8* __restrict__ wp,
+                                                 const float* __restrict__ bias_ft, float* __restrict__ xf_proj, int M) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = lane & 31, kh = lane >> 5;
+    const int tok = (blockIdx.x * 4 + wave) * 32 + n;
+    const size_t t = tok < M ? tok : M - 1;
+    f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        float v[8];
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xf + t * 64 + 16 * ks + 8 * kh);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(xf + t * 64 + 16 * ks + 8 * kh + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = a[e];
+            v[4 + e] = c[e];
+        }
+        bf16x8 bh, bl;
+        split8(v, bh, bl);
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+            acc[ot] = mma3(wp[(ot * 4 + ks) * 64 + lane], wp[(8 + ot * 4 + ks) * 64 + lane], bh, bl, acc[ot]);
+    }
+    if (tok >= M) return;
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[ot][4 * q + e] + bias_ft[(ot * 2 + kh) * 16 + 4 * q + e];
+            *reinterpret_cast<f32x4*>(xf_proj + (size_t)tok * 64 + 32 * ot + 8 * q + 4 * kh) = v;
+        }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+inline uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf2f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+inline int tile_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// natural-k A fragments of Wm [n_out][k_in] (row-major): frag (ot, ks), lane (i = l & 31, hh = l >> 5), element j
+//   = Wm[32 ot + i][16 ks + 8 hh + j]; order [hi: ot][ks] then [lo: ot][ks]
+std::vector<uint16_t> pack_nat(const std::vector<float>& Wm, int n_out, int k_in, int OT, int KS) {
+    const size_t ne = (size_t)OT * KS * 512;
+    std::vector<uint16_t> out(2 * ne, 0);
+    for (int ot = 0; ot < OT; ++ot)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int row = 32 * ot + (l & 31), col = 16 * ks + 8 * (l >> 5) + j;
+                    const float v = (row < n_out && col < k_in) ? Wm[(size_t)row * k_in + col] : 0.f;
+                    const size_t o = (((size_t)ot * KS + ks) * 64 + l) * 8 + j;
+                    const uint16_t h = f2bf(v);
+                    out[o] = h;
+                    out[ne + o] = f2bf(v - bf2f(h));
+                }
+    return out;
+}
+std::vector<float> ftvec(const std::vector<float>& v, int NT) {
+    std::vector<float> out((size_t)NT * 32, 0.f);
+    for (int t = 0; t < NT; ++t)
+        for (int hh = 0; hh < 2; ++hh)
+            for (int r = 0; r < 16; ++r) {
+                const int f = 32 * t + tile_row(r, hh);
+                out[(t * 2 + hh) * 16 + r] = f < (int)v.size() ? v[f] : 0.f;
+            }
+    return out;
+}
+
+struct ConvDev {
+    const bf16x8* w = nullptr;
+    const float *bias = nullptr, *rbias = nullptr;
+};
+
+}  // namespace
+
+struct dc_music {
+    uint8_t* arena = nullptr;
+    ConvDev conv[7];
+    const bf16x8 *w4 = nullptr, *wp = nullptr;
+    const float *b4 = nullptr, *bp = nullptr;
+    // ping-pong plane pairs, sized for `cap` clips of `cap_tm` mel frames
+    bf16x8 *a_hi = nullptr, *a_lo = nullptr, *b_hi = nullptr, *b_lo = nullptr;
+    int cap = 0, cap_tm = 0;
+    long long ws_bytes = 0;
+};
+
+namespace {
+
+struct ConvSpec {
+    const char* name;
+    int cin, cout;
+    bool res_conv;
+};
+const ConvSpec kConvs[7] = {{"conv1.0", 1, 16, false},  {"conv1.1", 16, 16, false}, {"conv1.2", 16, 16, false},
+                            {"conv2.0", 16, 32, true},  {"conv2.1", 32, 32, false}, {"conv3.0", 32, 32, false},
+                            {"conv3.1", 32, 32, false}};
+constexpr float kBnEps = 1e-5f;   // nn.BatchNorm default
+
+}  // namespace
+
+std::vector<std::pair<std::string, size_t>> dc_music_required(int music_dim) {
+    std::vector<std::pair<std::string, size_t>> r;
+    const std::string me = "music_encoder.";
+    for (const ConvSpec& c : kConvs) {
+        const std::string p = me + c.name;
+        r.push_back({p + ".conv2d_layer.0.weight", (size_t)c.cout * c.cin * 9});
+        r.push_back({p + ".conv2d_layer.0.bias", (size_t)c.cout});
+        for (const char* s : {"weight", "bias", "running_mean", "running_var"}) r.push_back({p + ".conv2d_layer.1." + s, (size_t)c.cout});
+        if (c.res_conv) {
+            r.push_back({p + ".residual.0.weight", (size_t)c.cout * c.cin});
+            r.push_back({p + ".residual.0.bias", (size_t)c.cout});
+            for (const char* s : {"weight", "bias", "running_mean", "running_var"}) r.push_back({p + ".residual.1." + s, (size_t)c.cout});
+        }
+    }
+    r.push_back({me + "conv4.0.weight", (size_t)music_dim * 512});
+    r.push_back({me + "conv4.0.bias", (size_t)music_dim});
+    for (const char* s : {"weight", "bias", "running_mean", "running_var"}) r.push_back({me + "conv4.1." + s, (size_t)music_dim});
+    r.push_back({"proj.weight", (size_t)music_dim * music_dim});
+    r.push_back({"proj.bias", (size_t)music_dim});
+    return r;
+}
+
+dc_music* dc_music_build(const std::map<std::string, std::vector<float>>& params, int music_dim, std::string* err) {
+    if (music_dim != DC_C) {
+        *err = "music encoder kernels are built for 64 output channels";
+        return nullptr;
+    }
+    for (const auto& rq : dc_music_required(music_dim)) {
+        auto it = params.find(rq.first);
+        if (it == params.end()) {
+            *err = "missing parameter '" + rq.first + "'";
+            return nullptr;
+        }
+        if (it->second.size() != rq.second) {
+            *err = "parameter '" + rq.first + "' has the wrong size";
+            return nullptr;
+        }
+    }
+    auto P = [&](const std::string& n) -> const std::vector<float>& { return params.find(n)->second; };
+    std::vector<uint8_t> host;
+    auto add = [&](const void* p, size_t bytes) {
+        const size_t off = (host.size() + 255) & ~(size_t)255;
+        host.resize(off + bytes);
+        memcpy(host.data() + off, p, bytes);
+        return off;
+    };
+    // eval-mode BatchNorm folded into the convolution in front of it: s = gamma / sqrt(var + eps)
+    auto bn_fold = [&](const std::string& bn, const std::vector<float>& cb, std::vector<float>& scale, std::vector<float>& bias) {
+        const auto &g = P(bn + ".weight"), &be = P(bn + ".bias"), &mu = P(bn + ".running_mean"), &var = P(bn + ".running_var");
+        const size_t n = g.size();
+        scale.resize(n);
+        bias.resize(n);
+        for (size_t c = 0; c < n; ++c) {
+            scale[c] = g[c] / std::sqrt(var[c] + kBnEps);
+            bias[c] = (cb[c] - mu[c]) * scale[c] + be[c];
+        }
+    };
+    struct Off {
+        size_t w, bias, rbias;
+    } off[7];
+    const std::string me = "music_encoder.";
+    for (int i = 0; i < 7; ++i) {
+        const ConvSpec& c = kConvs[i];
+        const std::string p = me + c.name;
+        std::vector<float> sc, bi;
+        bn_fold(p + ".conv2d_layer.1", P(p + ".conv2d_layer.0.bias"), sc, bi);
+        const auto& w = P(p + ".conv2d_layer.0.weight");                 // [cout][cin][3][3]
+        const int K = c.cin >= 16 ? 9 * c.cin : 16, KS = K / 16;
+        std::vector<float> Wm((size_t)c.cout * K, 0.f);
+        for (int co = 0; co < c.cout; ++co)
+            for (int ci = 0; ci < c.cin; ++ci)
+                for (int tap = 0; tap < 9; ++tap)
+                    Wm[(size_t)co * K + tap * c.cin + ci] = w[((size_t)co * c.cin + ci) * 9 + tap] * sc[co];
+        std::vector<uint16_t> frags = pack_nat(Wm, c.cout, K, 1, KS);
+        off[i].rbias = (size_t)-1;
+        std::vector<float> rb_ft;
+        if (c.res_conv) {
+            std::vector<float> rs, rb;
+            bn_fold(p + ".residual.1", P(p + ".residual.0.bias"), rs, rb);
+            const auto& rw = P(p + ".residual.0.weight");                // [cout][cin][1][1]
+            std::vector<float> Rm((size_t)c.cout * c.cin);
+            for (int co = 0; co < c.cout; ++co)
+                for (int ci = 0; ci < c.cin; ++ci) Rm[(size_t)co * c.cin + ci] = rw[(size_t)co * c.cin + ci] * rs[co];
+            const std::vector<uint16_t> rf = pack_nat(Rm, c.cout, c.cin, 1, c.cin / 16);
+            frags.insert(frags.end(), rf.begin(), rf.end());
+            rb_ft = ftvec(rb, 1);
+        }
+        off[i].w = add(frags.data(), frags.size() * 2);
+        const std::vector<float> b_ft = ftvec(bi, 1);
+        off[i].bias = add(b_ft.data(), b_ft.size() * 4);
+        if (c.res_conv) off[i].rbias = add(rb_ft.data(), rb_ft.size() * 4);
+    }
+    // conv4 + BatchNorm1d; reference feature index c*16 + bin  ->  plane order bin*32 + c
+    std::vector<float> s4, b4;
+    bn_fold(me + "conv4.1", P(me + "conv4.0.bias"), s4, b4);
+    const auto& w4 = P(me + "conv4.0.weight");
+    std::vector<float> W4((size_t)64 * 512);
+    for (int o = 0; o < 64; ++o)
+        for (int c = 0; c < 32; ++c)
+            for (int bin = 0; bin < 16; ++bin) W4[(size_t)o * 512 + bin * 32 + c] = w4[(size_t)o * 512 + c * 16 + bin] * s4[o];
+    const std::vector<uint16_t> f4 = pack_nat(W4, 64, 512, 2, 32);
+    const size_t o_w4 = add(f4.data(), f4.size() * 2);
+    const std::vector<float> b4_ft = ftvec(b4, 2);
+    const size_t o_b4 = add(b4_ft.data(), b4_ft.size() * 4);
+    const std::vector<uint16_t> fp = pack_nat(P("proj.weight"), 64, 64, 2, 4);
+    const size_t o_wp = add(fp.data(), fp.size() * 2);
+    const std::vector<float> bp_ft = ftvec(P("proj.bias"), 2);
+    const size_t o_bp = add(bp_ft.data(), bp_ft.size() * 4);
+
+    dc_music* m = new dc_music();
+    if (hipMalloc((void**)&m->arena, host.size()) != hipSuccess ||
+        hipMemcpy(m->arena, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        *err = "device allocation/upload of the music encoder weights failed";
+        dc_music_destroy(m);
+        return nullptr;
+    }
+    m->ws_bytes = (long long)host.size();
+    for (int i = 0; i < 7; ++i) {
+        m->conv[i].w = reinterpret_cast<const bf16x8*>(m->arena + off[i].w);
+        m->conv[i].bias = reinterpret_cast<const float*>(m->arena + off[i].bias);
+        m->conv[i].rbias = off[i].rbias == (size_t)-1 ? nullptr : reinterpret_cast<const float*>(m->arena + off[i].rbias);
+    }
+    m->w4 = reinterpret_cast<const bf16x8*>(m->arena + o_w4);
+    m->b4 = reinterpret_cast<const float*>(m->arena + o_b4);
+    m->wp = reinterpret_cast<const bf16x8*>(m->arena + o_wp);
+    m->bp = reinterpret_cast<const float*>(m->arena + o_bp);
+    return m;
+}
+
+void dc_music_destroy(dc_music* m) {
+    if (!m) return;
+    for (void* p : {(void*)m->arena, (void*)m->a_hi, (void*)m->a_lo, (void*)m->b_hi, (void*)m->b_lo})
+        if (p) hipFree(p);
+    delete m;
+}
+
+int dc_music_frames(int Tm) { return (Tm - 1) / 3 + 1; }   // max_pool2d (5,5), stride 3, padding 2 along time
+long long dc_music_workspace_bytes(const dc_music* m) { return m ? m->ws_bytes : 0; }
+
+namespace {
+
+template <int CIN, int COUT, int RES>
+hipError_t launch_conv(hipStream_t st, const ConvDev& c, const float* mel, const bf16x8* ih, const bf16x8* il, bf16x8* oh,
+                       bf16x8* ol, int Bc, int H, int W) {
+    constexpr int KC = CIN >= 16 ? CIN / 16 : 1, NKS = CIN >= 16 ? 9 * KC : 1, NF = 2 * NKS + (RES == 2 ? 2 * KC : 0);
+    constexpr int TPW = 4;
+    const long long tiles = (long long)Bc * H * (W / 32);
+    const unsigned grid = (unsigned)((tiles + 4 * TPW - 1) / (4 * TPW));
+    k_me_conv<CIN, COUT, RES><<<dim3(grid), dim3(256), NF * 1024, st>>>(mel, ih, il, reinterpret_cast<__bf16*>(oh),
+                                                                      reinterpret_cast<__bf16*>(ol), c.w, c.bias, c.rbias, Bc, H, W,
+                                                                      TPW);
+    return hipGetLastError();
+}
+template <int KH, int KW, int SH, int SW, int PH, int PW>
+hipError_t launch_pool(hipStream_t st, const bf16x8* ih, const bf16x8* il, bf16x8* oh, bf16x8* ol, int Bc, int H, int W, int C,
+                       int Ho, int Wo) {
+    const long long total = (long long)Bc * Ho * Wo * (C / 8);
+    k_me_pool<KH, KW, SH, SW, PH, PW><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(ih, il, oh, ol, Bc, H, W, C / 8, Ho, Wo);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t dc_music_encode(dc_music* m, const float* d_mel, int B, int Tm, float* d_xf_proj, float* d_xf_out, hipStream_t st,
+                           std::string* err) {
+    const int T = dc_music_frames(Tm);
+    // chunk of clips whose largest activation (16 channels x Tm x 128 bins, two bf16 planes) stays under ~0.4 GB per buffer
+    const int chunk = std::max(1, std::min(B, 8 * 5400 / std::max(Tm, 1)));
+    if (chunk > m->cap || Tm > m->cap_tm) {
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+        const int ncap = std::max(chunk, m->cap), ntm = std::max(Tm, m->cap_tm);
+        const size_t plane = (size_t)ncap * ntm * 128 * 16 * 2;
+        for (bf16x8** p : {&m->a_hi, &m->a_lo, &m->b_hi, &m->b_lo}) {
+            if (*p) hipFree(*p);
+            *p = nullptr;
+            if ((e = hipMalloc((void**)p, plane)) != hipSuccess) {
+                *err = "activation plane allocation failed";
+                m->cap = m->cap_tm = 0;
+                return e;
+            }
+        }
+        m->ws_bytes += 4 * (long long)plane - 4LL * m->cap * m->cap_tm * 128 * 16 * 2;
+        m->cap = ncap;
+        m->cap_tm = ntm;
+    }
+    bf16x8 *ah = m->a_hi, *al = m->a_lo, *bh = m->b_hi, *bl = m->b_lo;
+#define ME_TRY(x)                         \
+    do {                                  \
+        hipError_t e_ = (x);              \
+        if (e_ != hipSuccess) return e_;  \
+    } while (0)
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int Bc = std::min(chunk, B - b0);
+        const float* mel = d_mel + (size_t)b0 * Tm * 128;
+        ME_TRY((launch_conv<1, 16, 0>(st, m->conv[0], mel, nullptr, nullptr, ah, al, Bc, Tm, 128)));
+        ME_TRY((launch_conv<16, 16, 1>(st, m->conv[1], nullptr, ah, al, bh, bl, Bc, Tm, 128)));
+        ME_TRY((launch_conv<16, 16, 1>(st, m->conv[2], nullptr, bh, bl, ah, al, Bc, Tm, 128)));
+        ME_TRY((launch_pool<5, 5, 1, 2, 2, 2>(st, ah, al, bh, bl, Bc, Tm, 128, 16, Tm, 64)));
+        ME_TRY((launch_conv<16, 32, 2>(st, m->conv[3], nullptr, bh, bl, ah, al, Bc, Tm, 64)));
+        ME_TRY((launch_conv<32, 32, 1>(st, m->conv[4], nullptr, ah, al, bh, bl, Bc, Tm, 64)));
+        ME_TRY((launch_pool<5, 5, 3, 2, 2, 2>(st, bh, bl, ah, al, Bc, Tm, 64, 32, T, 32)));
+        ME_TRY((launch_conv<32, 32, 1>(st, m->conv[5], nullptr, ah, al, bh, bl, Bc, T, 32)));
+        ME_TRY((launch_conv<32, 32, 1>(st, m->conv[6], nullptr, bh, bl, ah, al, Bc, T, 32)));
+        ME_TRY((launch_pool<3, 3, 1, 2, 1, 1>(st, ah, al, bh, bl, Bc, T, 32, 32, T, 16)));
+        const int M = Bc * T;
+        const unsigned grid = (unsigned)((M + 127) / 128);
+        float* xo = d_xf_out + (size_t)b0 * T * 64;
+        float* xp = d_xf_proj + (size_t)b0 * T * 64;
+        k_me_head<<<dim3(grid), dim3(256), 0, st>>>(bh, bl, m->w4, m->b4, xo, M);
+        ME_TRY(hipGetLastError());
+        k_me_proj<<<dim3(grid), dim3(256), 0, st>>>(xo, m->wp, m->bp, xp, M);
+        ME_TRY(hipGetLastError());
+    }
+#undef ME_TRY
+    return hipSuccess;
+}

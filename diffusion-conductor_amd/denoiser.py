@@ -3,16 +3,13 @@
 Mirrors Diffusion_Stage/models/transformer.py:360-497: same constructor keywords, the same
 ``state_dict`` keys (so ``load_state_dict`` takes the reference's ``state['encoder']``), and
 ``forward`` / ``encode_music`` / ``generate_src_mask`` with the reference's argument meaning.
-``forward`` runs entirely in libdc_ddim.so (hand-written gfx950 kernels); there is no
-PyTorch-op or CPU fallback for it.
-
-``encode_music`` (the one-time MusicEncoder conv stack, transformer.py:289-340,447-459) still
-runs on PyTorch-ROCm ops in this round (next to move to HIP).
+``forward`` and ``encode_music`` (the one-time MusicEncoder conv stack, transformer.py:289-340,
+447-459) run entirely in libdc_ddim.so (hand-written gfx950 kernels); there is no PyTorch-op or
+CPU fallback for either.
 """
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from .native import NativeSampler
@@ -101,12 +98,11 @@ class MotionTransformer(nn.Module):
         """transformer.py:447-459 in eval mode: mel [B,Tm,128] -> (x_proj, x), each [B,Tm/3,64]."""
         if self.training:
             raise NotImplementedError("sampling path only: call .eval() (training-time token dropout not built)")
-        from .music_encoder import music_encoder_forward
-        with torch.no_grad():
-            mel = text.to(device=device, dtype=torch.float32)
-            x = music_encoder_forward(self, mel)
-            x_proj = F.linear(x, self.proj.weight, self.proj.bias)
-        return x_proj, x
+        nat = self._ensure_native(device)
+        mel = text.to(device=device, dtype=torch.float32).contiguous()
+        if mel.dim() != 3:
+            raise ValueError("mel must be [B, Tm, 128]")
+        return nat.encode_music(mel)
 
     def set_conditioning(self, xf_proj, xf_out, length=None):
         nat = self._ensure_native(xf_proj.device)

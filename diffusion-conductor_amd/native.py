@@ -20,7 +20,7 @@ DC_PREC = {"bf16": 0, "mixed": 1, "bf16x3": 2, "fp16": 3}
 EXPORTS = [
     "dc_last_error", "dc_version", "dc_linear_beta_schedule", "dc_ddim_coefficients", "dc_pack_weight",
     "dc_sampler_create", "dc_sampler_destroy", "dc_sampler_set_param", "dc_sampler_finalize_params",
-    "dc_sampler_set_conditioning", "dc_sampler_denoise", "dc_sampler_ddim_loop", "dc_sampler_profile_loop",
+    "dc_sampler_set_conditioning", "dc_sampler_encode_music", "dc_sampler_denoise", "dc_sampler_ddim_loop", "dc_sampler_profile_loop",
     "dc_kernel_name", "dc_kernel_count", "dc_sampler_workspace_bytes", "dc_sampler_debug_denoise",
     "dc_sampler_debug_read",
 ]
@@ -37,8 +37,8 @@ class DcError(RuntimeError):
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into libdc_ddim.so (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("dc_kernels.hip", "dc_api.hip")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("dc_common.h", "dc_launch.h")] + \
+    srcs = [os.path.join(CSRC, f) for f in ("dc_kernels.hip", "dc_api.hip", "dc_music.hip")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("dc_common.h", "dc_launch.h", "dc_music.h")] + \
         [os.path.join(os.path.dirname(_HERE), "include", "dc_ddim.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
@@ -80,6 +80,8 @@ def lib():
     L.dc_sampler_set_param.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_int64]
     L.dc_sampler_finalize_params.argtypes = [C.c_void_p]
     L.dc_sampler_set_conditioning.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, ip, C.c_int32, C.c_int32, C.c_void_p]
+    L.dc_sampler_encode_music.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]
     L.dc_sampler_denoise.argtypes = [C.c_void_p, C.c_void_p, ip, C.c_void_p, C.c_void_p]
     L.dc_sampler_ddim_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, fp, ip, C.c_int32, C.c_void_p, C.c_void_p]
     L.dc_sampler_debug_denoise.argtypes = [C.c_void_p, C.c_void_p, ip, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
@@ -201,6 +203,18 @@ class NativeSampler:
             lp = _iptr(la)
         _check(lib().dc_sampler_set_conditioning(self._h, xf_proj.data_ptr(), xf_out.data_ptr(), lp, B, T, self._stream()))
         self.B, self.T = B, T
+
+    def encode_music(self, mel):
+        """mel fp32 [B, Tm, 128] on the device -> (xf_proj, xf_out), each [B, (Tm-1)//3+1, 64]."""
+        import torch
+        assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous() and mel.dim() == 3
+        B, Tm, nm = mel.shape
+        T = (Tm - 1) // 3 + 1
+        xf_proj = torch.empty((B, T, 64), dtype=torch.float32, device=mel.device)
+        xf_out = torch.empty_like(xf_proj)
+        _check(lib().dc_sampler_encode_music(self._h, mel.data_ptr(), B, Tm, nm, xf_proj.data_ptr(), xf_out.data_ptr(),
+                                             self._stream()))
+        return xf_proj, xf_out
 
     def denoise(self, x, timesteps):
         import torch

@@ -124,6 +124,14 @@ int dc_sampler_finalize_params(dc_sampler* s);
 int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const float* d_xf_out,
                                 const int32_t* h_length, int32_t B, int32_t T, void* stream);
 
+/* MotionTransformer.encode_music in eval mode (models/transformer.py:447-459) with the MusicEncoder conv stack
+ * (:289-340) as MFMA kernels: d_mel fp32 [B, Tm, n_mels=128] (the tensor generate_music_motion builds at
+ * trainers/ddpm_trainer.py:186-189) -> d_xf_out = music_encoder(mel) and d_xf_proj = proj(d_xf_out), both fp32
+ * [B, (Tm-1)/3+1, 64], caller-allocated.  Needs the `music_encoder.*` and `proj.*` state_dict entries
+ * (optional as a group in dc_sampler_set_param; DC_ERR_PARAM here when they were not supplied). */
+int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t B, int32_t Tm, int32_t n_mels,
+                            float* d_xf_proj, float* d_xf_out, void* stream);
+
 /* One MotionTransformer.forward (models/transformer.py:469-497) on the conditioning set
  * above: d_x fp32 [B, T, input_feats], h_timesteps int32 [B] -> d_out fp32 [B, T, input_feats]. */
 int dc_sampler_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timesteps,

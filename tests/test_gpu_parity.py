@@ -184,13 +184,32 @@ def test_harness_generate_music_motion_golden(models):
 
 
 def test_encode_music_golden(models):
-    """G4: MusicEncoder + proj (PyTorch-ROCm ops this round)."""
+    """G4: MusicEncoder + proj through dc_sampler_encode_music (bf16x3 MFMA conv stack) vs the reference's own
+    outputs.  Tolerance 1e-4 rel-L2 (fp32 reference; the split-bf16 products carry ~16 mantissa bits)."""
     g = golden("g4_encode_music.npz")
     m = models["fp16"]
     xp, x = m.encode_music(torch.from_numpy(batch_mel(1, 270)).cuda(), "cuda:0")
     assert rel_l2(xp, g["small_x_proj"]) <= 1e-4 and rel_l2(x, g["small_x"]) <= 1e-4
     xp, x = m.encode_music(torch.from_numpy(batch_mel(1, 5400)).cuda(), "cuda:0")
     assert rel_l2(xp.cpu()[:, ::25], g["full_x_proj_sub"]) <= 1e-4
+
+
+def test_encode_music_batched_vs_oracle(models):
+    """Clips are encoded in chunks of 8 at full length; a batch of 9 crosses the chunk edge.  30-s clips
+    (Tm = 2700 -> T = 900) and an odd frame count exercise the stride-3 pool's floor."""
+    from oracle import ddim_oracle as O
+    m = models["fp16"]
+    p = oracle_params()
+    for B, Tm in ((9, 5400), (3, 2700), (2, 271)):
+        mel = torch.from_numpy(batch_mel(B, Tm))
+        xp, x = m.encode_music(mel.cuda(), "cuda:0")
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            rxp, rx = O.encode_music(p, mel)
+        assert tuple(x.shape) == tuple(rx.shape)
+        e1, e2 = rel_l2(xp, rxp), rel_l2(x, rx)
+        print(f"encode_music B={B} Tm={Tm}: rel-L2 x_proj {e1:.2e} x {e2:.2e}")
+        assert e1 <= 1e-4 and e2 <= 1e-4
 
 
 def test_error_behaviour(models):
