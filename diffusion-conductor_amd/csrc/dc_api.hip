@@ -143,7 +143,7 @@ struct dc_sampler {
 
     // workspace (capacity-tracked)
     int B = 0, T = 0, M = 0, G = 0;
-    size_t cap_G = 0, cap_B = 0, cap_MP = 0, cap_steps = 0, cap_snap = 0;
+    size_t cap_G = 0, cap_B = 0, cap_MP = 0, cap_steps = 0, cap_snap = 0, cap_kv = 0;
     int* d_length = nullptr;
     float* d_pp = nullptr;
     void *d_s_hi = nullptr, *d_s_lo = nullptr;
@@ -151,6 +151,8 @@ struct dc_sampler {
     float* d_h = nullptr;
     float* d_recs = nullptr;
     void *d_a_sa = nullptr, *d_a_ca = nullptr;
+    void *d_kv_sa[2] = {nullptr, nullptr}, *d_kv_ca = nullptr;   // no_eff: key-tile arrays (dc_kernels.hip, full attention)
+    int KT = 0;                                                   // key tiles per clip array
     float* d_x = nullptr;
     float* d_snaps = nullptr;
     // conditioning temporaries
@@ -329,6 +331,10 @@ int build_model(dc_sampler* s) {
         }
     };
     const double LOG2E = 1.4426950408889634;
+    // softmax inputs: the linear-attention kernels use exp2 on log2(e)-scaled queries/keys; the full-attention
+    // (no_eff) kernels keep keys unscaled and fold the 1/sqrt(head_dim) = 1/4 into the queries (exact)
+    const bool full = c.no_eff != 0;
+    const double QS = full ? 0.25 : LOG2E, KS = full ? 1.0 : LOG2E;
     // FiLM: all 3L blocks stacked along the output axis -> one [3L*256][512] GEMM operand; inside a block the
     // 32-row tiles are interleaved (scale0, shift0, scale1, shift1, ...) so one wave holds matching pairs
     const int NT = 3 * L * DC_FILM_TILES_PER_BLOCK;
@@ -340,18 +346,18 @@ int build_model(dc_sampler* s) {
         std::vector<float> wf, cf;
         const float* sg = P_(p + ".sa_block.norm.weight");
         const float* sb = P_(p + ".sa_block.norm.bias");
-        fold_ln(P_(p + ".sa_block.query.weight"), P_(p + ".sa_block.query.bias"), sg, sb, D, D, wf, cf, LOG2E);
+        fold_ln(P_(p + ".sa_block.query.weight"), P_(p + ".sa_block.query.bias"), sg, sb, D, D, wf, cf, QS);
         {
             const std::vector<float> c = ftvec(cf.data(), D, 4);
             add_image(&y.img_sa_q, wf.data(), D, D, ssp, c.data(), c.size());
         }
-        fold_ln(P_(p + ".sa_block.key.weight"), P_(p + ".sa_block.key.bias"), sg, sb, D, D, wf, cf, LOG2E);
+        fold_ln(P_(p + ".sa_block.key.weight"), P_(p + ".sa_block.key.bias"), sg, sb, D, D, wf, cf, KS);
         add_image(&y.img_sa_k, wf.data(), D, D, ssp, cf.data(), cf.size());          // plain bias[128]
         fold_ln(P_(p + ".sa_block.value.weight"), P_(p + ".sa_block.value.bias"), sg, sb, D, D, wf, cf);
         add_image(&y.img_sa_v, wf.data(), D, D, ssp, cf.data(), cf.size());
         add_styl(&y.img_sa_o, p + ".sa_block.proj_out");
         fold_ln(P_(p + ".ca_block.query.weight"), P_(p + ".ca_block.query.bias"), P_(p + ".ca_block.norm.weight"),
-                P_(p + ".ca_block.norm.bias"), D, D, wf, cf, LOG2E);
+                P_(p + ".ca_block.norm.bias"), D, D, wf, cf, QS);
         {
             const std::vector<float> c = ftvec(cf.data(), D, 4);
             add_image(&y.img_ca_q, wf.data(), D, D, ssp, c.data(), c.size());
@@ -366,7 +372,7 @@ int build_model(dc_sampler* s) {
                 const float* w = P_(nm + ".weight");
                 const float* bb = P_(nm + ".bias");
                 std::vector<float> wf((size_t)D * DC_E), bf(D);
-                const double sc = kv ? 1.0 : LOG2E;      // keys feed exp2 in the partial records
+                const double sc = kv ? 1.0 : KS;         // keys feed exp2 in the partial records
                 for (int o = 0; o < D; ++o) {
                     double acc = bb[o];
                     for (int k = 0; k < DC_E; ++k) {
@@ -471,14 +477,28 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
         if ((rc = dev_alloc(s, s->d_s_lo, g * 32 * 64 * 16))) return rc;
         if ((rc = dev_alloc(s, s->d_E, g * s->NT * 64 * 32))) return rc;
         if ((rc = dev_alloc(s, s->d_h, g * 4 * 64 * 64))) return rc;
+        HIP_TRY(hipMemset(s->d_h, 0, g * 4 * 64 * 64));     // rows past M are read (never written) by the full-attention front half
         if ((rc = dev_alloc(s, s->d_recs, g * 2 * DC_REC_FLOATS * 4))) return rc;
         if ((rc = dev_alloc(s, s->d_y, g * 32 * 512 * 4))) return rc;
         if ((rc = dev_alloc(s, s->d_mean, g * 32 * 4))) return rc;
         if ((rc = dev_alloc(s, s->d_rstd, g * 32 * 4))) return rc;
         if ((rc = dev_alloc(s, s->d_nh_hi, g * 32 * 64 * 16))) return rc;
         if ((rc = dev_alloc(s, s->d_nh_lo, g * 32 * 64 * 16))) return rc;
-        if ((rc = dev_alloc(s, s->d_recs_ca, (size_t)L * g * 2 * DC_REC_FLOATS * 4))) return rc;
+        if (!s->cfg.no_eff && (rc = dev_alloc(s, s->d_recs_ca, (size_t)L * g * 2 * DC_REC_FLOATS * 4))) return rc;
         s->cap_G = g;
+    }
+    if (s->cfg.no_eff) {     // key-tile arrays: [B][KT] tiles of 16 KiB; two for self-attention (layer parity), L for cross-attention
+        const int KT = (T + 31) / 32 + 1;
+        const size_t need = (size_t)B * KT;
+        if (need > s->cap_kv) {
+            drop_graph(s);
+            int rc;
+            for (int i = 0; i < 2; ++i)
+                if ((rc = dev_alloc(s, s->d_kv_sa[i], need * 16384))) return rc;
+            if ((rc = dev_alloc(s, s->d_kv_ca, (size_t)L * need * 16384))) return rc;
+            s->cap_kv = need;
+        }
+        s->KT = KT;
     }
     if ((size_t)B > s->cap_B) {
         drop_graph(s);
@@ -559,8 +579,17 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
                                              s->d_t_clip, s->d_coef_cur, s->d_snap_cur, B));
     LAUNCH(K_SILU, dc_launch_silu_emb(st, ff, sf, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, G, T, B));
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->h_model.film_g, s->h_model.film_beta, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT));
-    LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G));
     const int nl_run = (s->dbg_layers >= 0 && s->dbg_layers < L) ? s->dbg_layers : L;
+    if (s->cfg.no_eff) {
+        LAUNCH(K_EMBED, dc_launch_embed_front_full(st, fs, s->d_model, x_src, s->d_h, s->d_kv_sa[0], M, T, B, s->KT));
+        for (int l = 0; l < nl_run; ++l)
+            LAUNCH(K_LAYER, dc_launch_layer_full(st, fs, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_kv_sa[l & 1], s->d_kv_sa[(l + 1) & 1],
+                                                 s->d_kv_ca, s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur,
+                                                 s->d_snap_cur, s->d_snaps, M, T, B, s->KT,
+                                                 (l == nl_run - 1) ? (s->dbg_stage ? s->dbg_stage : (nl_run < L ? 3 : 0)) : 0));
+        return DC_OK;
+    }
+    LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G));
     for (int l = 0; l < nl_run; ++l) {
         static const int ablate = getenv("DC_ABLATE") ? (int)strtol(getenv("DC_ABLATE"), nullptr, 0) : 0;   // timing experiments
         const int dbg = ((l == nl_run - 1) ? s->dbg_stage : 0) | ablate;
@@ -709,7 +738,8 @@ int dc_sampler_create(const dc_config* cfg, dc_sampler** out) {
                     "(transformer.py:385,404,482)", cfg->latent_dim, cfg->num_heads, cfg->ff_size);
     if (cfg->input_feats < 1 || cfg->input_feats > DC_PMAX) return fail(DC_ERR_UNSUPPORTED, "input_feats must be in [1,32]");
     if (cfg->num_layers < 1 || cfg->num_layers > DC_MAX_LAYERS) return fail(DC_ERR_UNSUPPORTED, "num_layers must be in [1,%d]", DC_MAX_LAYERS);
-    if (cfg->no_eff) return fail(DC_ERR_UNSUPPORTED, "no_eff (full T x T attention) is not built yet");
+    if (cfg->no_eff && cfg->precision != DC_PREC_FP16 && cfg->precision != DC_PREC_BF16)
+        return fail(DC_ERR_UNSUPPORTED, "no_eff (full T x T attention) is built for the fp16 and bf16 precision modes only");
     if (cfg->precision < DC_PREC_BF16 || cfg->precision > DC_PREC_FP16) return fail(DC_ERR_INVALID, "unknown precision %d", cfg->precision);
     if (cfg->max_timesteps < 1) return fail(DC_ERR_INVALID, "max_timesteps must be >= 1");
     int ndev = 0;
@@ -743,7 +773,8 @@ void dc_sampler_destroy(dc_sampler* s) {
     drop_graph(s);
     void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_y, s->d_mean, s->d_rstd, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
-                    s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t};
+                    s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t,
+                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps};
     for (void* p : ptrs)
         if (p) hipFree(p);
     dc_music_destroy(s->music);
@@ -828,8 +859,12 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
     HIP_TRY(dc_launch_row_stats(st, s->d_y, s->d_mean, s->d_rstd, Mpad));
     HIP_TRY(dc_launch_cond_pack(st, 1, s->d_y, s->d_mean, s->d_rstd, nullptr, s->d_nh_hi, s->d_nh_lo, G));
     // one-time cost: always split precision (plain bf16 here alone costs ~2e-3 on A_cross)
-    HIP_TRY(dc_launch_ca_partials(st, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_recs_ca, M, T, G, L));
-    HIP_TRY(dc_launch_attn_combine(st, s->small_fmt, s->d_recs_ca, s->d_a_ca, T, G, B, L, 32));
+    if (s->cfg.no_eff) {
+        HIP_TRY(dc_launch_ca_kv(st, s->small_fmt, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_kv_ca, M, T, G, B, s->KT, L));
+    } else {
+        HIP_TRY(dc_launch_ca_partials(st, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_recs_ca, M, T, G, L));
+        HIP_TRY(dc_launch_attn_combine(st, s->small_fmt, s->d_recs_ca, s->d_a_ca, T, G, B, L, 32));
+    }
     HIP_TRY(hipStreamSynchronize(st));   // `len` is host memory
     s->cond_set = true;
     return sync_out(s, user);

@@ -1407,6 +1407,417 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     }
 }
 
+// ====================================================================================
+// `no_eff` variant: full T x T attention (TemporalSelfAttention / TemporalCrossAttention,
+// transformer.py:198-287) instead of the linear form.  Non-split operand formats only.
+//
+// Work split: a workgroup = 8 query groups of ONE clip (grid = B x WPC); the flat 32-token groups that
+// straddle a clip edge are processed by both neighbours, each for its own lanes only (everything per token is
+// identical in both; only the attention differs, and stores are per lane).  Keys/values of a clip live in a
+// per-clip array of key tiles (tile kt = flat group g_lo(b) + kt, 16 fragments of 1 KiB):
+//   frag h      (h < 8): K of head h, A operand of S = K Q^T:  lane (key, kh), element j <-> d = 8(j>>2) + 4kh + (j&3)
+//   frag 8+2t+s        : V^T of feature tile t, keys 16s..16s+15 of the tile in accumulator-chaining order
+// i.e. exactly make_frag() of the FT-form K tile and of the TF-form V tile, written by the previous kernel's
+// front half.  A key tile (16 KiB) reaches LDS by LDS-DMA, double-buffered, and serves all 8 waves.
+// Per (key tile, head): one MFMA for the 32 x 32 scores (hd = 16 = one k-step), online softmax over keys
+// (registers + lane-half), two MFMAs for P V with the value rows of the other head of the pair zeroed, so both
+// heads of a pair accumulate into one FT tile.  The kernel is bound by v_exp_f32 (one per score), not by MFMA.
+// Reference quirks kept: the self-attention mask is added along the QUERY axis (-1e5 on every score of a padded
+// query row, transformer.py:224) - reproduced including its fp32 rounding; values are never masked; the 1/sqrt(16)
+// is folded into the query projection on the host (exact).
+// ====================================================================================
+struct ClipCtx {
+    int b, g_lo, nkt, g, c, hh, tok, n;
+    bool active, lane_ok;
+};
+DEV ClipCtx make_clip_ctx(int blk, int WPC, int wave, int lane, int T, int M) {
+    ClipCtx x;
+    x.b = blk / WPC;
+    const int j = blk % WPC;
+    x.g_lo = (x.b * T) / 32;
+    const int g_hi = ((x.b + 1) * T - 1) / 32;
+    x.nkt = g_hi - x.g_lo + 1;
+    x.g = x.g_lo + j * 8 + wave;
+    x.active = x.g <= g_hi;
+    if (!x.active) x.g = g_hi;
+    x.c = lane & 31;
+    x.hh = lane >> 5;
+    x.tok = 32 * x.g + x.c;
+    x.n = x.tok - x.b * T;
+    x.lane_ok = x.active && x.n >= 0 && x.n < T && x.tok < M;
+    return x;
+}
+DEV void store_h_lanes(const f32x16 (&h)[4], float* __restrict__ hbuf, int g, int lane, bool ok) {
+    if (!ok) return;
+    f32x16* p = reinterpret_cast<f32x16*>(hbuf) + (size_t)g * 256 + lane;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) p[t * 64] = h[t];
+}
+
+// K (FT form) and V (TF form) of n = LN(h) -> the 16 fragments of this group's key tile
+template <class T16>
+DEV void front_full(const XFrag<T16, false> (&nf)[4], const v8<T16>* __restrict__ wk, const v8<T16>* __restrict__ wv,
+                    v8<T16>* __restrict__ tile, int lane, int c, int hh) {
+    const float* bk = reinterpret_cast<const float*>(wk + 32 * 64);     // plain bias[128] behind the 32 fragments
+    const float* bv = reinterpret_cast<const float*>(wv + 32 * 64);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x16 K;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(bk + 32 * t + 8 * q + 4 * hh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) K[4 * q + i] = v[i];
+        }
+        mma_ot<4, 4, T16, false>(K, wk, t, nf, lane);
+        XFrag<T16, false> kf;
+        make_frag<T16, false>(K, kf);
+        tile[(2 * t) * 64 + lane] = kf.hi[0];
+        tile[(2 * t + 1) * 64 + lane] = kf.hi[1];
+        f32x16 V = splat(bv[32 * t + c]);
+        mmb_oc<4, 4, T16, false>(V, wv, t, nf, lane);
+        XFrag<T16, false> vf;
+        make_frag<T16, false>(V, vf);
+        tile[(8 + 2 * t) * 64 + lane] = vf.hi[0];
+        tile[(8 + 2 * t + 1) * 64 + lane] = vf.hi[1];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// y = softmax_keys(Q K^T) V per head for this wave's 32 queries against all keys of the clip.
+// wq: query projection image (LayerNorm affine and the 1/4 folded in), bias ftvec behind it (global memory).
+// kv: the clip's key-tile array; keys are valid for flat tokens in [key_lo, key_hi).
+template <class T16>
+DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const f32x16 (&h)[4],
+                     const v8<T16>* __restrict__ wq, const v8<T16>* __restrict__ kv, int nkt, int tok0, int key_lo,
+                     int key_hi, bool q_pad, bool any_pad, char* lds, bool active, int wave, int lane, int hh) {
+    constexpr float LOG2E = 1.4426950408889634f;
+    XFrag<T16, false> qf[4];
+    {
+        f32x16 q[4];
+        XFrag<T16, false> nf[4];
+        ln_frags<T16, false>(nf, h);
+        const float* bq = reinterpret_cast<const float*>(wq + 32 * 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q[t] = ld_ft(bq, t, hh);
+        gemm_wa<4, 4, T16, false>(q, wq, nf, lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) make_frag<T16, false>(q[t], qf[t]);
+    }
+    f32x16 Y[4];
+    float mx[8], ls[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Y[t] = splat(0.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        mx[i] = -1e30f;
+        ls[i] = 0.f;
+    }
+    const float qshift = q_pad ? -100000.f : 0.f;
+    auto issue = [&](int kt) {       // 16 fragments of key tile kt -> buffer kt & 1, two per wave
+        const v8<T16>* src = kv + (size_t)kt * 16 * 64;
+        char* dst = lds + (kt & 1) * 16384;
+        lds_dma16(src + (size_t)wave * 64 + lane, dst + wave * 1024);
+        lds_dma16(src + (size_t)(8 + wave) * 64 + lane, dst + (8 + wave) * 1024);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                 // nobody still reads the buffers (previous attention of this kernel)
+    issue(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) {
+            issue(kt + 1);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (active) {
+            const v8<T16>* fr = reinterpret_cast<const v8<T16>*>(lds + (kt & 1) * 16384);
+            const int k0 = tok0 + 32 * kt;                    // flat token of the tile's row 0
+            const bool edge = k0 < key_lo || k0 + 32 > key_hi;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const v8<T16> vf0 = fr[(8 + 2 * t) * 64 + lane], vf1 = fr[(8 + 2 * t + 1) * 64 + lane];
+#pragma unroll
+                for (int sh = 0; sh < 2; ++sh) {
+                    const int hd = 2 * t + sh;
+                    f32x16 S = mfma(fr[hd * 64 + lane], qf[t].hi[sh], splat(0.f));
+                    if (edge) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = k0 + tile_row(r, hh);
+                            if (key < key_lo || key >= key_hi) S[r] = -1e30f;
+                        }
+                    }
+                    if (any_pad) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) S[r] += qshift;
+                    }
+                    float mt = S[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, S[r]);
+                    mt = xhalf_max(mt);
+                    const float mn = fmaxf(mx[hd], mt);
+                    const float alpha = exp2f_fast((mx[hd] - mn) * LOG2E);
+                    mx[hd] = mn;
+                    const float ml = mn * LOG2E;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        S[r] = exp2f_fast(fmaf(S[r], LOG2E, -ml));
+                        sum += S[r];
+                    }
+                    ls[hd] = fmaf(ls[hd], alpha, sum);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) Y[t][8 * sh + r] *= alpha;
+                    XFrag<T16, false> pf;
+                    make_frag<T16, false>(S, pf);
+                    // value rows (features) of the other head of the pair contribute nothing
+                    const bool mine = ((lane & 31) >> 4) == sh;
+                    v8<T16> a0 = vf0, a1 = vf1;
+                    if (!mine) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a0[e] = a1[e] = (T16)0.f;
+                    }
+                    Y[t] = mfma(a0, pf.hi[0], Y[t]);
+                    Y[t] = mfma(a1, pf.hi[1], Y[t]);
+                    __builtin_amdgcn_sched_barrier(0);      // one head at a time: bounds the fragment-read lookahead
+                }
+            }
+        }
+        __syncthreads();             // the buffer just read is the next-but-one tile's target
+    }
+    RowStats st;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+            const float inv = fast_rcp(xhalf_sum(ls[2 * t + sh]));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) Y[t][8 * sh + r] *= inv;
+        }
+        st.add(Y[t]);
+        put_y<false>(y[t], Y[t]);
+    }
+    st.finish(y_rstd, y_shift);
+}
+
+template <class T16>
+__global__ __launch_bounds__(512, 2) void k_embed_front_full(const DcModel* __restrict__ dm, const float* __restrict__ x,
+                                                             float* __restrict__ hbuf, v8<T16>* __restrict__ kv_next,
+                                                             int M, int T, int KT, int WPC) {
+    using W = v8<T16>;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const ClipCtx cx = make_clip_ctx(blockIdx.x, WPC, wave, lane, T, M);
+    if (!cx.active) return;
+    const int P = dm->input_feats;
+    const bool live = cx.tok < M;
+    const int n = live ? cx.tok % T : 0;
+    f32x16 h[4];
+    {
+        XFrag<T16, true> xf[1];
+        f32x16 xv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = tile_row(r, cx.hh);
+            xv[r] = (live && f < P) ? x[(size_t)cx.tok * P + f] : 0.f;
+        }
+        make_frag<T16, true>(xv, xf[0]);
+        const W* img = reinterpret_cast<const W*>(dm->img_je);
+        const float* je_b = reinterpret_cast<const float*>(img + 16 * 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h[t] = ld_ft(je_b, t, cx.hh);
+        gemm_wa<4, 1, T16, true>(h, img, xf, lane);
+    }
+    const float* se = dm->seq_emb + (size_t)n * DC_D;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(se + 32 * t + 8 * q + 4 * cx.hh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[t][4 * q + i] += v[i];
+        }
+    store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok);
+    const DcLayer& L = dm->layer[0];
+    XFrag<T16, false> nf[4];
+    ln_frags<T16, false>(nf, h);
+    front_full<T16>(nf, reinterpret_cast<const W*>(L.img_sa_k), reinterpret_cast<const W*>(L.img_sa_v),
+                    kv_next + ((size_t)cx.b * KT + (cx.g - cx.g_lo)) * 16 * 64, lane, cx.c, cx.hh);
+}
+
+template <class T16>
+__global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf,
+                                                       const f16x16* __restrict__ E, int NT, const v8<T16>* __restrict__ kv_cur,
+                                                       v8<T16>* __restrict__ kv_next, const v8<T16>* __restrict__ kv_ca,
+                                                       const int* __restrict__ length, const float* __restrict__ xin,
+                                                       float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur,
+                                                       const int* __restrict__ snap_cur, float* __restrict__ snaps, int M, int T,
+                                                       int B, int KT, int WPC, int stop_after) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using W = v8<T16>;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const ClipCtx cx = make_clip_ctx(blockIdx.x, WPC, wave, lane, T, M);
+    if ((blockIdx.x % WPC) * 8 >= cx.nkt) return;          // no query group of the clip falls into this workgroup
+    const DcLayer& L = dm->layer[l];
+    const bool last = l + 1 >= dm->num_layers;
+    const int len = length[cx.b];
+    const bool any_pad = len < T;
+    const bool q_pad = cx.n >= len;
+    const int key_lo = cx.b * T, key_hi = min((cx.b + 1) * T, M);
+    const f16x8* Eg = reinterpret_cast<const f16x8*>(E) + ((size_t)cx.g * NT + (size_t)l * 24) * 128;
+    auto consts = [](const bf16x8* img) { return reinterpret_cast<const float*>(reinterpret_cast<const W*>(img) + 32 * 64); };
+    f32x16 h[4];
+    ytile<false> y[4];
+    float y_rstd, y_shift;
+    // ---- self-attention
+    load_h(h, hbuf, cx.g, lane);
+    full_attend<T16>(y, y_rstd, y_shift, h, reinterpret_cast<const W*>(L.img_sa_q), kv_cur + (size_t)cx.b * KT * 16 * 64, cx.nkt,
+                     cx.g_lo * 32, key_lo, key_hi, q_pad, any_pad, lds, cx.active, wave, lane, cx.hh);
+    load_h(h, hbuf, cx.g, lane);           // not kept live across the key loop
+    styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg, consts(L.img_sa_o), reinterpret_cast<const W*>(L.img_sa_o), lane, cx.hh, 0);
+    if (stop_after == 1) { store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok); return; }
+    // ---- cross-attention (no mask, transformer.py:244-264)
+    store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok);
+    full_attend<T16>(y, y_rstd, y_shift, h, reinterpret_cast<const W*>(L.img_ca_q), kv_ca + ((size_t)l * B + cx.b) * KT * 16 * 64,
+                     cx.nkt, cx.g_lo * 32, key_lo, key_hi, false, false, lds, cx.active, wave, lane, cx.hh);
+    load_h(h, hbuf, cx.g, lane);
+    styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg + 8 * 128, consts(L.img_ca_o), reinterpret_cast<const W*>(L.img_ca_o), lane,
+                                cx.hh, 0);
+    if (stop_after == 2) { store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok); return; }
+    // ---- FFN
+    {
+        const W* w1 = reinterpret_cast<const W*>(L.img_ffn_w1);
+        const W* w2 = reinterpret_cast<const W*>(L.img_ffn_w2);
+        const float* cb = reinterpret_cast<const float*>(w2 + 16 * 64);          // b1 ftvec[2] | b2 ftvec[4]
+        f32x16 u[2];
+        {
+            XFrag<T16, false> hf[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) make_frag<T16, false>(h[kt], hf[kt]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) u[t] = ld_ft(cb, t, cx.hh);
+            gemm_wa<2, 4, T16, false>(u, w1, hf, lane);
+        }
+        XFrag<T16, false> uf[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[kt][r] = gelu_erf(u[kt][r]);
+            make_frag<T16, false>(u[kt], uf[kt]);
+        }
+        RowStats st;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x16 yf = ld_ft(cb + 64, t, cx.hh);
+            mma_ot<4, 2, T16, false>(yf, w2, t, uf, lane);
+            st.add(yf);
+            put_y<false>(y[t], yf);
+        }
+        st.finish(y_rstd, y_shift);
+    }
+    styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg + 16 * 128, consts(L.img_ffn_o), reinterpret_cast<const W*>(L.img_ffn_o), lane,
+                                cx.hh, 0);
+    if (!cx.active) return;
+    if (!last || stop_after == 3) {
+        store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok);
+        if (last) return;
+        XFrag<T16, false> nf[4];
+        ln_frags<T16, false>(nf, h);
+        const DcLayer& Ln = dm->layer[l + 1];
+        front_full<T16>(nf, reinterpret_cast<const W*>(Ln.img_sa_k), reinterpret_cast<const W*>(Ln.img_sa_v),
+                        kv_next + ((size_t)cx.b * KT + (cx.g - cx.g_lo)) * 16 * 64, lane, cx.c, cx.hh);
+        return;
+    }
+    // ---- output projection (always split) + DDIM update (gaussian_diffusion.py:812-830 collapsed)
+    f32x16 x0[1];
+    {
+        const W* wo = reinterpret_cast<const W*>(dm->img_out);
+        XFrag<T16, true> hf[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) make_frag<T16, true>(h[kt], hf[kt]);
+        x0[0] = ld_ft(reinterpret_cast<const float*>(wo + 16 * 64), 0, cx.hh);
+        gemm_wa<1, 4, T16, true>(x0, wo, hf, lane);
+    }
+    if (!cx.lane_ok) return;
+    const int P = dm->input_feats;
+    if (out_mode == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = tile_row(r, cx.hh);
+            if (f < P) xout[(size_t)cx.tok * P + f] = x0[0][r];
+        }
+    } else {
+        const float sr = coef_cur[0], srm1 = coef_cur[1], cx0 = coef_cur[2], ceps = coef_cur[3];
+        const int snap = *snap_cur;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = tile_row(r, cx.hh);
+            if (f < P) {
+                const size_t o = (size_t)cx.tok * P + f;
+                const float xt = xin[o];
+                const float eps = (sr * xt - x0[0][r]) / srm1;
+                const float xn = x0[0][r] * cx0 + ceps * eps;
+                xout[o] = xn;
+                if (snap >= 0) snaps[(size_t)snap * M * P + o] = xn;
+            }
+        }
+    }
+}
+
+// Cross-attention keys/values of every layer as key tiles (one-time per batch): the linear-attention pre-pass's
+// projections (split-bf16 from the normalised conditioning operands) emitted as fragments instead of records.
+// grid (ceil(G/4), L); a group that straddles a clip edge is written into both clips' arrays.
+template <class T16>
+__global__ __launch_bounds__(256) void k_cond_ca_kv(const DcModel* __restrict__ dm, const bf16x8* __restrict__ nh_hi,
+                                                    const bf16x8* __restrict__ nh_lo, v8<T16>* __restrict__ kv_ca, int M, int T,
+                                                    int G, int B, int KT) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const int lane = threadIdx.x & 63;
+    const int l = blockIdx.y;
+    const DcLayer& L = dm->layer[l];
+    const GroupCtx cx = make_ctx(g, lane, M, T);
+    f32x16 K[4], V[4];
+#pragma unroll
+    for (int oc = 0; oc < 4; ++oc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) K[oc][r] = L.ca_bk[32 * oc + tile_row(r, cx.hh)];
+        V[oc] = splat(L.ca_bv[32 * oc + cx.c]);
+    }
+    constexpr int NF = 4 * DC_KS_E;
+    for (int ks = 0; ks < DC_KS_E; ++ks) {
+        const bf16x8 a = nh_hi[((size_t)g * DC_KS_E + ks) * 64 + lane];
+        const bf16x8 al = nh_lo[((size_t)g * DC_KS_E + ks) * 64 + lane];
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc) {
+            const int fi = oc * DC_KS_E + ks;
+            const bf16x8 wk = L.ca_wk[fi * 64 + lane];
+            const bf16x8 wv = L.ca_wv[fi * 64 + lane];
+            K[oc] = mfma(wk, a, K[oc]);                         // FT form: features on registers
+            V[oc] = mfma(a, wv, V[oc]);                         // TF form: tokens on registers
+            K[oc] = mfma(wk, al, K[oc]);
+            V[oc] = mfma(al, wv, V[oc]);
+            K[oc] = mfma(L.ca_wk[(NF + fi) * 64 + lane], a, K[oc]);
+            V[oc] = mfma(a, L.ca_wv[(NF + fi) * 64 + lane], V[oc]);
+        }
+    }
+    for (int b = cx.b0; b <= cx.b1; ++b) {
+        const int g_lo = (b * T) / 32;
+        v8<T16>* tile = kv_ca + (((size_t)l * B + b) * KT + (g - g_lo)) * 16 * 64;
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc) {
+            XFrag<T16, false> kf, vf;
+            make_frag<T16, false>(K[oc], kf);
+            make_frag<T16, false>(V[oc], vf);
+            tile[(2 * oc) * 64 + lane] = kf.hi[0];
+            tile[(2 * oc + 1) * 64 + lane] = kf.hi[1];
+            tile[(8 + 2 * oc) * 64 + lane] = vf.hi[0];
+            tile[(8 + 2 * oc + 1) * 64 + lane] = vf.hi[1];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // host-callable launchers (declared in dc_launch.h).  fmt: 0 = bf16, 1 = f16.
 // ------------------------------------------------------------------------------------
@@ -1574,4 +1985,46 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, const DcModel* d
                                                                          out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps)));
     }
     return e;
+}
+
+// ---- no_eff variant ------------------------------------------------------------------
+template <class T16>
+static hipError_t launch_full_t(hipStream_t st, int which, const DcModel* dm, int l, const float* x, float* hbuf, const void* E,
+                                int NT, const void* kv_cur, void* kv_next, const void* kv_ca, const int* length,
+                                const float* xin, float* xout, int out_mode, const float* coef_cur, const int* snap_cur,
+                                float* snaps, int M, int T, int B, int KT, int stop_after) {
+    const int WPC = (KT + 7) / 8;
+    if (which == 0)
+        k_embed_front_full<T16><<<dim3(B * WPC), dim3(512), 0, st>>>(dm, x, hbuf, (v8<T16>*)kv_next, M, T, KT, WPC);
+    else
+        k_layer_full<T16><<<dim3(B * WPC), dim3(512), 32768, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const v8<T16>*)kv_cur,
+                                                                   (v8<T16>*)kv_next, (const v8<T16>*)kv_ca, length, xin, xout,
+                                                                   out_mode, coef_cur, snap_cur, snaps, M, T, B, KT, WPC,
+                                                                   stop_after);
+    return hipGetLastError();
+}
+hipError_t dc_launch_embed_front_full(hipStream_t st, int fmt, const DcModel* dm, const float* x, float* hbuf, void* kv_next,
+                                      int M, int T, int B, int KT) {
+    return fmt == 1 ? launch_full_t<_Float16>(st, 0, dm, 0, x, hbuf, nullptr, 0, nullptr, kv_next, nullptr, nullptr, nullptr, nullptr,
+                                              0, nullptr, nullptr, nullptr, M, T, B, KT, 0)
+                    : launch_full_t<__bf16>(st, 0, dm, 0, x, hbuf, nullptr, 0, nullptr, kv_next, nullptr, nullptr, nullptr, nullptr, 0,
+                                            nullptr, nullptr, nullptr, M, T, B, KT, 0);
+}
+hipError_t dc_launch_layer_full(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
+                                const void* kv_cur, void* kv_next, const void* kv_ca, const int* length, const float* xin,
+                                float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps, int M,
+                                int T, int B, int KT, int stop_after) {
+    return fmt == 1 ? launch_full_t<_Float16>(st, 1, dm, l, nullptr, hbuf, E, NT, kv_cur, kv_next, kv_ca, length, xin, xout, out_mode,
+                                              coef_cur, snap_cur, snaps, M, T, B, KT, stop_after)
+                    : launch_full_t<__bf16>(st, 1, dm, l, nullptr, hbuf, E, NT, kv_cur, kv_next, kv_ca, length, xin, xout, out_mode,
+                                            coef_cur, snap_cur, snaps, M, T, B, KT, stop_after);
+}
+hipError_t dc_launch_ca_kv(hipStream_t st, int fmt, const DcModel* dm, const void* nh_hi, const void* nh_lo, void* kv_ca,
+                           int M, int T, int G, int B, int KT, int L) {
+    const dim3 grid((G + 3) / 4, L);
+    if (fmt == 1)
+        k_cond_ca_kv<_Float16><<<grid, dim3(256), 0, st>>>(dm, (const bf16x8*)nh_hi, (const bf16x8*)nh_lo, (f16x8*)kv_ca, M, T, G, B, KT);
+    else
+        k_cond_ca_kv<__bf16><<<grid, dim3(256), 0, st>>>(dm, (const bf16x8*)nh_hi, (const bf16x8*)nh_lo, (bf16x8*)kv_ca, M, T, G, B, KT);
+    return hipGetLastError();
 }

@@ -25,3 +25,13 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, const DcModel* d
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps);
+
+// ---- no_eff variant (full T x T attention); non-split formats only.  KT = key tiles per clip array.
+hipError_t dc_launch_ca_kv(hipStream_t st, int fmt, const DcModel* dm, const void* nh_hi, const void* nh_lo, void* kv_ca,
+                           int M, int T, int G, int B, int KT, int L);
+hipError_t dc_launch_embed_front_full(hipStream_t st, int fmt, const DcModel* dm, const float* x, float* hbuf, void* kv_next,
+                                      int M, int T, int B, int KT);
+hipError_t dc_launch_layer_full(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
+                                const void* kv_cur, void* kv_next, const void* kv_ca, const int* length, const float* xin,
+                                float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps, int M,
+                                int T, int B, int KT, int stop_after);

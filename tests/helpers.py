@@ -48,10 +48,10 @@ def xf_pair(B, T, first=0):
     return torch.nn.functional.linear(xf, p["proj.weight"], p["proj.bias"]), xf
 
 
-def make_model(precision="fp16", device="cuda"):
+def make_model(precision="fp16", device="cuda", no_eff=False):
     from diffusion_conductor_amd import MotionTransformer
     m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device=device,
-                          no_clip=True, precision=precision)
+                          no_clip=True, precision=precision, no_eff=no_eff)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state_dict_np().items()}, strict=True)
     return m.to(device).eval()
 

@@ -226,7 +226,68 @@ def test_error_behaviour(models):
         s.denoise(x, [0])
     s.close()
     with pytest.raises(native.DcError, match="no_eff"):
-        native.NativeSampler(DenoiserConfig(no_eff=True))
+        native.NativeSampler(DenoiserConfig(no_eff=True), "bf16x3")     # full attention: fp16 / bf16 modes only
     with pytest.raises(RuntimeError, match="no CPU path"):
         make_model("fp16", device="cpu")(torch.zeros(1, 64, 26), torch.zeros(1, dtype=torch.long),
                                           length=[64], xf_proj=torch.zeros(1, 64, 64), xf_out=torch.zeros(1, 64, 64))
+
+
+# ---- no_eff variant: full T x T attention (transformer.py:198-287) ----------------------------------------
+@pytest.fixture(scope="module")
+def model_no_eff():
+    return make_model("fp16", no_eff=True)
+
+
+def test_no_eff_forward_golden(model_no_eff):
+    """G3 `forward_no_eff`: one forward of the full-attention variant at B=2, T=64, ragged length (the padded
+    query rows carry the reference's -1e5 shift), per-clip timesteps - against the reference's own output."""
+    g = golden("g3_blocks.npz")
+    out = model_no_eff(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]), length=torch.from_numpy(g["length"]),
+                       xf_proj=torch.from_numpy(g["xf_proj"]).cuda(), xf_out=torch.from_numpy(g["xf_out"]).cuda())
+    torch.cuda.synchronize()
+    err = rel_l2(out, g["forward_no_eff"])
+    print(f"forward no_eff rel-L2 {err:.3e}")
+    assert torch.isfinite(out).all() and err <= 5e-3        # single forward at mixed timesteps; the gate is on DDIM x0
+
+
+def test_no_eff_ddim50_golden(model_no_eff):
+    """G6b: DDIM-50 of the full-attention variant, B=2, T=96, lengths [96, 70] (reference output)."""
+    xfp, xfo = xf_pair(2, 96, first=20)
+    noise = torch.from_numpy(batch_noise(2, 96, first=20))
+    out = _ddim(model_no_eff, 50, noise, xfp, xfo, [96, 70])
+    err = rel_l2(out, golden("g6b_no_eff.npz")["x0"])
+    print(f"ddim50 no_eff rel-L2 {err:.3e}")
+    assert err <= TOL_PARITY
+
+
+def test_no_eff_straddling_clips_vs_oracle(model_no_eff):
+    """T = 77: clip edges fall inside 32-token groups, so edge groups are computed by both neighbouring
+    workgroups (each for its own lanes) and edge key tiles are partly masked; 5 clips, ragged lengths."""
+    B, T = 5, 77
+    p = oracle_params()
+    xfp, xfo = xf_pair(B, T, first=30)
+    x = torch.from_numpy(batch_noise(B, T, first=30))
+    t = torch.tensor([0, 49, 13, 999, 500])
+    length = [77, 1, 40, 76, 33]
+    with torch.no_grad():
+        ref = O.denoiser_forward(p, x, t, length, xfp, xfo, no_eff=True)
+    out = model_no_eff(x.cuda(), t, length=torch.tensor(length), xf_proj=xfp.cuda(), xf_out=xfo.cuda())
+    torch.cuda.synchronize()
+    err = rel_l2(out, ref)
+    print(f"no_eff straddle rel-L2 {err:.3e}")
+    assert err <= 5e-3
+
+
+def test_no_eff_long_clip_vs_oracle(model_no_eff):
+    """A 60-s clip (T = 1800: 57 key tiles, 8 workgroups per clip) for 3 forwards' worth of DDIM at S=25."""
+    xfp, xfo = xf_pair(2, 1800, first=3)
+    noise = torch.from_numpy(batch_noise(2, 1800, first=3))
+    p = oracle_params()
+    t = torch.tensor([24, 3])
+    with torch.no_grad():
+        ref = O.denoiser_forward(p, noise, t, [1800, 1800], xfp, xfo, no_eff=True)
+    out = model_no_eff(noise.cuda(), t, length=torch.tensor([1800, 1800]), xf_proj=xfp.cuda(), xf_out=xfo.cuda())
+    torch.cuda.synchronize()
+    err = rel_l2(out, ref)
+    print(f"no_eff T=1800 forward rel-L2 {err:.3e}")
+    assert err <= 5e-3
