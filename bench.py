@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--ddim", type=int, default=50)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "mixed", "bf16", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eff", action="store_true", help="full T x T attention variant (reference --no_eff)")
     args = ap.parse_args()
 
     import numpy as np
@@ -111,7 +112,7 @@ def main():
     B, T, S = args.bs, args.frames, args.ddim
     sd = synthetic_state_dict()
     model = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device=dev,
-                              no_clip=True, precision=args.precision)
+                              no_clip=True, precision=args.precision, no_eff=args.no_eff)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     model = model.to(dev).eval()
     gd = GaussianDiffusion(betas=get_named_beta_schedule("linear", S), model_mean_type=ModelMeanType.START_X,
@@ -159,10 +160,13 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp16": "f16", "mixed": "bf16x3+f16", "bf16": "bf16", "bf16x3": "bf16x3"}[args.precision], "data": "synthetic",
-        "config": {"workload": f"configs[1]: DDIM-{S} sampling loop, bs={B} clips/GPU x {T} frames (60 s), linear attention, "
+        "config": {"workload": f"{'configs[1]: ' if (B, T, S) == (32, 1800, 50) and not args.no_eff else ''}DDIM-{S} sampling loop, bs={B} clips/GPU x {T} frames "
+                               f"({T // 30} s), {'full T x T attention (no_eff)' if args.no_eff else 'linear attention'}, "
                                f"precision={args.precision}, conditioning + x_T resident in HBM (loop-only)",
                    "clips_per_gpu": B, "frames_per_clip": T, "ddim_steps": S, "parallelism": f"clip-dp{world}"},
-        "mfma_roofline_frac_whole_loop": round(value / world * S * FLOP_PER_TOKEN_STEP / PEAK_BF16_FLOPS, 4),
+        # no_eff: 7.56 G + 13.27 G (T/1800) MAC per clip-step of 1800 tokens
+        "mfma_roofline_frac_whole_loop": round(value / world * S * (2 * (7.56e9 + 13.27e9 * T / 1800) / 1800 if args.no_eff
+                                                                      else FLOP_PER_TOKEN_STEP) / PEAK_BF16_FLOPS, 4),
     }
     if rank == 0:
         # end to end for the same batch (reported beside `value`, never as it): pinned host mel -> H2D -> encode_music

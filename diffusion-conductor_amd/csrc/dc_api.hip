@@ -577,22 +577,42 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     if (loop_mode)
         LAUNCH(K_BEGIN, dc_launch_begin_step(st, s->d_iter, s->d_t_of_iter, s->d_coef_of_t, s->d_snap_of_iter,
                                              s->d_t_clip, s->d_coef_cur, s->d_snap_cur, B));
-    LAUNCH(K_SILU, dc_launch_silu_emb(st, ff, sf, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, G, T, B));
-    LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->h_model.film_g, s->h_model.film_beta, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT));
+    // non-split formats: the FiLM GEMM produces its own operand from pp + temb (no k_silu_emb pass); the separate pass
+    // remains for the split formats, for the v1 kernel, and under the test hooks that read the operand image back
+    static const bool film_v1 = getenv("DC_FILM_V1") != nullptr, unfused = getenv("DC_UNFUSED_SILU") != nullptr;
+    const bool fuse_silu = !sf && !film_v1 && !unfused && s->dbg_layers < 0;
+    if (!fuse_silu)
+        LAUNCH(K_SILU, dc_launch_silu_emb(st, ff, sf, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, G, T, B));
+    // FiLM GEMM in `chunks` launches, each covering the feature tiles of L / chunks consecutive layers and issued right
+    // before the first of them: its output (88 MB per layer at bs=32 x 1800) is consumed while still cache-resident
+    static const int film_chunks_env = getenv("DC_FILM_CHUNKS") ? atoi(getenv("DC_FILM_CHUNKS")) : 1;
+    const int nround_all = s->NT / 16;                       // a layer owns 12 tile pairs = 1.5 rounds of 8
+    int chunks = (sf || film_chunks_env < 1 || L % film_chunks_env || ((L / film_chunks_env) & 1)) ? 1 : film_chunks_env;
+    const int lpc = L / chunks;                              // layers per chunk (even)
+    auto film_chunk = [&](int c) -> int {
+        LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->h_model.film_g, s->h_model.film_beta,
+                                           s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, c * lpc * 3 / 2, chunks == 1 ? nround_all : lpc * 3 / 2,
+                                           fuse_silu ? s->d_pp : nullptr, s->h_model.temb, s->d_t_clip, T, B));
+        return DC_OK;
+    };
+    { int rc = film_chunk(0); if (rc) return rc; }
     const int nl_run = (s->dbg_layers >= 0 && s->dbg_layers < L) ? s->dbg_layers : L;
     if (s->cfg.no_eff) {
         LAUNCH(K_EMBED, dc_launch_embed_front_full(st, fs, s->d_model, x_src, s->d_h, s->d_kv_sa[0], M, T, B, s->KT));
-        for (int l = 0; l < nl_run; ++l)
+        for (int l = 0; l < nl_run; ++l) {
+            if (l > 0 && l % lpc == 0) { int rc = film_chunk(l / lpc); if (rc) return rc; }
             LAUNCH(K_LAYER, dc_launch_layer_full(st, fs, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_kv_sa[l & 1], s->d_kv_sa[(l + 1) & 1],
                                                  s->d_kv_ca, s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur,
                                                  s->d_snap_cur, s->d_snaps, M, T, B, s->KT,
                                                  (l == nl_run - 1) ? (s->dbg_stage ? s->dbg_stage : (nl_run < L ? 3 : 0)) : 0));
+        }
         return DC_OK;
     }
     LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G));
     for (int l = 0; l < nl_run; ++l) {
         static const int ablate = getenv("DC_ABLATE") ? (int)strtol(getenv("DC_ABLATE"), nullptr, 0) : 0;   // timing experiments
         const int dbg = ((l == nl_run - 1) ? s->dbg_stage : 0) | ablate;
+        if (l > 0 && l % lpc == 0) { int rc = film_chunk(l / lpc); if (rc) return rc; }
         LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur,

@@ -798,7 +798,9 @@ DEV void lds_dma16(const void* gsrc /*per-lane*/, const char* lds_dst /*wave-uni
 template <class T16>
 __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict__ W, const float* __restrict__ bias_ft,
                                                        const float* __restrict__ g_ft, const float* __restrict__ beta_ft,
-                                                       const v8<T16>* __restrict__ S, f16x16* __restrict__ E, int G, int NT) {
+                                                       const v8<T16>* __restrict__ S, f16x16* __restrict__ E, int G, int NT, int round0,
+                                                       int nround, const float* __restrict__ pp, const float* __restrict__ temb,
+                                                       const int* __restrict__ t_clip, int T, int B) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using OP = v8<T16>;
     constexpr int PF = 4;       // measured: 8 (with the 256-register budget it needs) is 25 % slower
@@ -808,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
     // Persistent workgroups: the work is (token block of 4 groups) x (round of 8 feature-tile pairs, one pair per
     // wave); each workgroup owns a contiguous, equal share of those units so that all CUs finish together, and
     // reloads its slab only when it crosses into the next token block.
-    const int nround = NT / 16;                                   // pairs / 8 waves
+    // this launch covers rounds [round0, round0 + nround) of the NT / 16 rounds of 8 feature-tile pairs
     const int nblk = (G + 3) / 4;
     const long long nunit = (long long)nblk * nround;
     // (whole token blocks per workgroup, all sweeping the weight rounds in lockstep for L2 locality, was measured:
@@ -816,7 +818,7 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
     const int u0 = (int)(nunit * blockIdx.x / gridDim.x), u1 = (int)(nunit * (blockIdx.x + 1) / gridDim.x);
     int cur_blk = -1;
     OP a0[PF], a1[PF];
-    auto wbase = [&](int u) { return W + (size_t)(2 * ((u % nround) * 8 + wave)) * DC_KS_E * 64 + lane; };
+    auto wbase = [&](int u) { return W + (size_t)(2 * ((round0 + u % nround) * 8 + wave)) * DC_KS_E * 64 + lane; };
     if (u0 < u1) {
         const OP* w0 = wbase(u0);
 #pragma unroll
@@ -826,14 +828,31 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
         }
     }
     for (int u = u0; u < u1; ++u) {
-        const int tb = u / nround, p = (u % nround) * 8 + wave;
+        const int tb = u / nround, p = (round0 + u % nround) * 8 + wave;
         const int g0 = tb * 4;
         if (tb != cur_blk) {
             __syncthreads();                                      // everyone is done with the previous slab
             // slab: frag (g, ks) at [(g*32 + ks)]; groups past the end alias the last one (their stores are skipped)
-            for (int f = wave; f < 4 * DC_KS_E; f += 8) {
-                const int gg = min(g0 + (f >> 5), G - 1);
-                lds_dma16(S + ((size_t)gg * DC_KS_E + (f & 31)) * 64 + lane, lds + f * 1024);
+            if (pp) {
+                // fused operand production (was k_silu_emb): S = SiLU(temb[t_clip] + linear(xf_proj)) (transformer.py:73-74,482)
+                // straight from the fp32 fragment image into the slab - saves the 16-bit image's HBM round trip
+                v8<T16>* slab_w = reinterpret_cast<v8<T16>*>(lds);
+                for (int f = wave; f < 4 * DC_KS_E; f += 8) {      // (batching these loads 4 deep spilled and ran slower)
+                    const int gg = min(g0 + (f >> 5), G - 1), ks = f & 31;
+                    const size_t idx = ((size_t)gg * DC_KS_E + ks) * 64 + lane;
+                    const int b = min((gg * 32 + (lane & 31)) / T, B - 1);
+                    const f32x8 pv = reinterpret_cast<const f32x8*>(pp)[idx];
+                    const f32x8 tv = *reinterpret_cast<const f32x8*>(temb + (size_t)t_clip[b] * 512 + 16 * ks + 8 * (lane >> 5));
+                    v8<T16> hi;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hi[j] = (T16)silu(pv[j] + tv[j]);
+                    slab_w[f * 64 + lane] = hi;
+                }
+            } else {
+                for (int f = wave; f < 4 * DC_KS_E; f += 8) {
+                    const int gg = min(g0 + (f >> 5), G - 1);
+                    lds_dma16(S + ((size_t)gg * DC_KS_E + (f & 31)) * 64 + lane, lds + f * 1024);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1911,7 +1930,8 @@ static void launch_film_t(hipStream_t st, const void* W, const float* bias_ft, c
 }
 template <class T16>
 static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bias_ft, const float* g_ft, const float* beta_ft,
-                                 const void* s_hi, void* E, int G, int NT) {
+                                 const void* s_hi, void* E, int G, int NT, int round0, int nround, const float* pp, const float* temb,
+                                 const int* t_clip, int T, int B) {
     const size_t shm = 4 * DC_KS_E * 1024;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1922,15 +1942,17 @@ static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bia
     static const int ncu = [] { hipDeviceProp_t p; int d = 0; hipGetDevice(&d); hipGetDeviceProperties(&p, d); return p.multiProcessorCount; }();
     const int nblk = (G + 3) / 4;
     k_film_gemm2<T16><<<dim3(nblk < ncu ? nblk : ncu), dim3(512), shm, st>>>((const v8<T16>*)W, bias_ft, g_ft, beta_ft,
-                                                                (const v8<T16>*)s_hi, (f16x16*)E, G, NT);
+                                                                (const v8<T16>*)s_hi, (f16x16*)E, G, NT, round0, nround, pp, temb, t_clip, T, B);
     return hipGetLastError();
 }
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const float* g_ft,
-                               const float* beta_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT) {
+                               const float* beta_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
+                               int nround, const float* pp, const float* temb, const int* t_clip, int T, int B) {
     static const bool use_v1 = getenv("DC_FILM_V1") != nullptr;
     if (!split && !use_v1)
-        return fmt == 1 ? launch_film2_t<_Float16>(st, W, bias_ft, g_ft, beta_ft, s_hi, E, G, NT)
-                        : launch_film2_t<__bf16>(st, W, bias_ft, g_ft, beta_ft, s_hi, E, G, NT);
+        return fmt == 1 ? launch_film2_t<_Float16>(st, W, bias_ft, g_ft, beta_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B)
+                        : launch_film2_t<__bf16>(st, W, bias_ft, g_ft, beta_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B);
+    if (round0 != 0) return hipSuccess;        // the v1 / split kernels compute all rounds in their first launch
     DISPATCH(fmt, split, (launch_film_t<T16, SP>(st, W, bias_ft, g_ft, beta_ft, s_hi, s_lo, E, G, NT)));
     return LAUNCH_CHECK();
 }
