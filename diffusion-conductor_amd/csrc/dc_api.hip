@@ -608,13 +608,16 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         }
         return DC_OK;
     }
-    LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G));
+    // workgroup-level records (no combine launches) whenever a workgroup's 256 tokens cannot touch more than two clips
+    static const bool no_wgr = getenv("DC_NO_WGREC") != nullptr;
+    const bool wgr = !ss && T >= 256 && !no_wgr;
+    LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B));
     for (int l = 0; l < nl_run; ++l) {
         static const int ablate = getenv("DC_ABLATE") ? (int)strtol(getenv("DC_ABLATE"), nullptr, 0) : 0;   // timing experiments
         const int dbg = ((l == nl_run - 1) ? s->dbg_stage : 0) | ablate;
         if (l > 0 && l % lpc == 0) { int rc = film_chunk(l / lpc); if (rc) return rc; }
-        LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
-        LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
+        if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
+        LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur,
                                         s->d_snaps, M, T, G, B, dbg, (l == 3 && getenv("DC_STAMPS")) ? s->d_stamps : nullptr));
     }

@@ -388,6 +388,195 @@ DEV void front_stage(const XFrag<T16, SPLIT> (&nf)[4], const v8<T16>* wk, const 
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// Workgroup-level partial records (non-split formats, T >= 256 so that the 256 tokens of a workgroup touch at most
+// two clips, "slots" 0/1 = clips ub0, ub0+1).  Instead of one record per 32-token group the 8 waves reduce theirs
+// through LDS: column maxima first (so every wave exponentiates against the workgroup's maximum and no rescaling is
+// needed), then the exp(K-m)^T V blocks and column sums are summed over the waves in wave order (deterministic).
+// One record per workgroup and slot: 8x fewer record bytes to write and to combine, and the combine itself moves into
+// the consuming kernel's prologue (wg_combine_attn) - no separate combine launch.
+// LDS: mx [4 oc][2 slots][32 cols][8 waves] floats; pst [8 waves][4 oc][64 lanes] f32x8 (each wave's primary slot);
+//      xp [4 oc][64 lanes] f32x8 (second slot of the one wave that straddles the clip edge); ss [(8+1)][4 oc][32] floats.
+// ------------------------------------------------------------------------------------
+DEV RowRange valid_rows_clip(const GroupCtx& cx, int clip, int B, int M, int T, const int* __restrict__ length, bool active) {
+    RowRange rr;
+    rr.lo = 0;
+    rr.span = 0u;
+    if (!active || clip >= B) return rr;
+    const int len = length ? length[clip] : T;
+    const int first = max(clip * T, 32 * cx.g);
+    const int end = min(min(clip * T + min(len, T), M), 32 * cx.g + 32);
+    rr.lo = first - 32 * cx.g - 4 * cx.hh;
+    rr.span = end > first ? (unsigned)(end - first) : 0u;
+    return rr;
+}
+DEV void wg_put_maxes(const f32x16 (&K)[4], const GroupCtx& cx, const RowRange (&vr)[2], float* mx, int wave) {
+#pragma unroll
+    for (int oc = 0; oc < 4; ++oc)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = row_ok(vr[sl], r) ? fmaxf(m, K[oc][r]) : m;
+            m = xhalf_max(m);
+            if (cx.hh == 0) mx[((oc * 2 + sl) * 32 + cx.c) * 8 + wave] = m;
+        }
+}
+DEV float wg_colmax(const float* mx, int oc, int sl, int c) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(mx + ((oc * 2 + sl) * 32 + c) * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(mx + ((oc * 2 + sl) * 32 + c) * 8 + 4);
+    const float m = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+    return m == -INFINITY ? 0.f : m;
+}
+// one 32-feature tile against a GIVEN column maximum: column sums of exp2(K-m) and the kept head blocks of exp2(K-m)^T V
+template <class T16>
+DEV void partial_tile(const f32x16& K, const f32x16& V, const RowRange& rr, float m, const GroupCtx& cx, float& ssum, f32x8& keep) {
+    f32x16 Ee, Vm;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool ok = row_ok(rr, r);
+        const float e = ok ? exp2f_fast(K[r] - m) : 0.f;
+        Ee[r] = e;
+        s += e;
+        Vm[r] = ok ? V[r] : 0.f;
+    }
+    ssum = xhalf_sum(s);
+    XFrag<T16, false> ef, vf;
+    make_frag<T16, false>(Ee, ef);
+    make_frag<T16, false>(Vm, vf);
+    f32x16 P = splat(0.f);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) P = mfma(ef.hi[s2], vf.hi[s2], P);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) keep[i] = (cx.c >> 4) ? P[8 + i] : P[i];
+}
+// after the barrier that follows the last partial_tile: wave w sums tile oc = w & 3 of slot w >> 2 over the waves
+DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8* pst, const f32x8* xp, const float* ss,
+                         int wave, int lane, int ub0, int G, int M, int T) {
+    const int oc = wave & 3, sl = wave >> 2, c = lane & 31;
+    f32x8 acc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    float ssum = 0.f;
+    for (int v = 0; v < 8; ++v) {
+        const int gv = blockIdx.x * 8 + v;
+        if (gv >= G) break;
+        const int b0v = (32 * gv) / T, b1v = min(32 * gv + 31, M - 1) / T;
+        if (b0v - ub0 == sl) {
+            const f32x8 p = pst[(v * 4 + oc) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += p[i];
+            ssum += ss[(v * 4 + oc) * 32 + c];
+        }
+        if (b1v != b0v && sl == 1) {
+            const f32x8 p = xp[oc * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += p[i];
+            ssum += ss[(8 * 4 + oc) * 32 + c];
+        }
+    }
+    float* R = recs + ((size_t)blockIdx.x * 2 + sl) * DC_REC_FLOATS;
+    if (lane < 32) {
+        R[32 * oc + c] = wg_colmax(mx, oc, sl, c);
+        R[128 + 32 * oc + c] = ssum;
+    }
+    reinterpret_cast<f32x8*>(R + 256)[oc * 64 + lane] = acc;
+}
+// The workgroup's own combine (512 threads): attention operand fragments A[d][l] of clips ub0, ub0+1 from the unit
+// records of the previous kernel -> af [2 clips][8 frags][64 lanes] in LDS (the 8 hi fragments k_attn_combine makes).
+// scratch (LDS): w [2][NU][128] floats, z [2][128] floats.  Summation order is fixed.
+template <class T16>
+DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scratch, int ub0, int B, int M, int T, int tid) {
+    constexpr int NU = 17, PRE = 9;               // units per clip: T <= 4032; the first PRE are loaded before the weights exist
+    float* wsc = scratch;
+    float* zsc = scratch + 2 * NU * 128;
+    const int ci = tid >> 8, t = tid & 255, ln = t & 63, oc = t >> 6;
+    const int c = ln & 31, hh = ln >> 5;
+    const int b = ub0 + ci;
+    const bool live = b < B && (long long)b * T < M;
+    const int u_lo = live ? (b * T) / 256 : 0;
+    const int u_hi = live ? (min((b + 1) * T, M) - 1) / 256 : -1;
+    const int nu = u_hi - u_lo + 1;
+    // unit u (tokens 256u..256u+255) intersects the clip; the clip is the unit's slot 0 iff the unit starts inside it
+    auto rec_of = [&](int clip, int u) { return recs + ((size_t)u * 2 + ((u * 256 >= clip * T) ? 0 : 1)) * DC_REC_FLOATS; };
+    f32x8 pre[PRE];
+#pragma unroll
+    for (int k = 0; k < PRE; ++k)
+        if (k < nu) pre[k] = reinterpret_cast<const f32x8*>(rec_of(b, u_lo + k) + 256)[oc * 64 + ln];
+    if (tid < 256) {                              // phase A: per feature f of clip ca: m*, weights, normaliser
+        const int ca = tid >> 7, f = tid & 127, ba = ub0 + ca;
+        const bool la = ba < B && (long long)ba * T < M;
+        const int a_lo = la ? (ba * T) / 256 : 0, a_hi = la ? (min((ba + 1) * T, M) - 1) / 256 : -1;
+        const int na = a_hi - a_lo + 1;
+        float mr[NU], sr[NU];                     // every load is issued before the first use: one memory round trip
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            mr[k] = 0.f;
+            sr[k] = 0.f;
+            if (k < na) {
+                const float* R = rec_of(ba, a_lo + k);
+                mr[k] = R[f];
+                sr[k] = R[128 + f];
+            }
+        }
+        float mstar = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NU; ++k)
+            if (sr[k] > 0.f) mstar = fmaxf(mstar, mr[k]);
+        float z = 0.f;
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            const float ww = sr[k] > 0.f ? exp2f_fast(mr[k] - mstar) : 0.f;
+            if (k < na) wsc[(ca * NU + k) * 128 + f] = ww;
+            z += ww * sr[k];
+        }
+        zsc[ca * 128 + f] = z;
+    }
+    __syncthreads();
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const int rowb = 32 * oc + 16 * (c >> 4) + 4 * hh;       // kept value j <-> feature row rowb + (j&3) + 8*(j>>2)
+    auto wrow = [&](const float* base, float (&w8)[8]) {       // rows rowb..+3 and rowb+8..+11: two 16-byte LDS reads
+        const f32x4 a = *reinterpret_cast<const f32x4*>(base + rowb), c2 = *reinterpret_cast<const f32x4*>(base + rowb + 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w8[j] = a[j];
+            w8[4 + j] = c2[j];
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < PRE; ++k)
+        if (k < nu) {
+            float w8[8];
+            wrow(wsc + (ci * NU + k) * 128, w8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], pre[k][j], acc[j]);
+        }
+    for (int k = PRE; k < nu; ++k) {
+        const f32x8 pv = reinterpret_cast<const f32x8*>(rec_of(b, u_lo + k) + 256)[oc * 64 + ln];
+        float w8[8];
+        wrow(wsc + (ci * NU + k) * 128, w8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], pv[j], acc[j]);
+    }
+    v8<T16> out, zero;
+    {
+        float z8[8];
+        wrow(zsc + ci * 128, z8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            out[j] = (T16)(z8[j] > 0.f ? acc[j] * fast_rcp(z8[j]) : 0.f);
+            zero[j] = (T16)0.f;
+        }
+    }
+    const int s = c >> 4;
+    af[(ci * 8 + oc * 2 + s) * 64 + ln] = out;
+    af[(ci * 8 + oc * 2 + (s ^ 1)) * 64 + ln] = zero;
+}
+
 }  // namespace dc
 using namespace dc;
 
@@ -927,10 +1116,10 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
 // The K=26 input projection always runs split: rounding x_t itself to 8/11 mantissa bits is the
 // single largest error source otherwise, and the GEMM is tiny.
 // ------------------------------------------------------------------------------------
-template <class T16, bool SPLIT>
+template <class T16, bool SPLIT, bool WGR>
 __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
 void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /*[M][P]*/, float* __restrict__ hbuf,
-                   float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G) {
+                   float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G, int B) {
     constexpr int NW = SPLIT ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;
     using W = v8<T16>;
@@ -974,8 +1163,49 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
     ln_frags<T16, SPLIT>(nf, h);
     const W* wk = reinterpret_cast<const W*>(L.img_sa_k);
     const W* wv = reinterpret_cast<const W*>(L.img_sa_v);
-    front_stage<T16, SPLIT>(nf, wk, wv, reinterpret_cast<const float*>(wk + 32 * WM * 64),
-                            reinterpret_cast<const float*>(wv + 32 * WM * 64), cx, M, T, length, recs, active);
+    if constexpr (!WGR) {
+        front_stage<T16, SPLIT>(nf, wk, wv, reinterpret_cast<const float*>(wk + 32 * WM * 64),
+                                reinterpret_cast<const float*>(wv + 32 * WM * 64), cx, M, T, length, recs, active);
+    } else {     // workgroup-level record (see wg_* helpers); LDS: mx 8 KiB | pst 64 KiB | xp 8 KiB | ss 4.5 KiB
+        extern __shared__ __attribute__((aligned(16))) char lds[];
+        float* mx = reinterpret_cast<float*>(lds);
+        f32x8* pst = reinterpret_cast<f32x8*>(lds + 8192);
+        f32x8* xp = reinterpret_cast<f32x8*>(lds + 8192 + 65536);
+        float* ss = reinterpret_cast<float*>(lds + 8192 + 65536 + 8192);
+        const int ub0 = (blockIdx.x * NW * 32) / T;
+        const float* bk = reinterpret_cast<const float*>(wk + 32 * 64);
+        const float* bv = reinterpret_cast<const float*>(wv + 32 * 64);
+        const RowRange vr[2] = {valid_rows_clip(cx, ub0, B, M, T, length, active), valid_rows_clip(cx, ub0 + 1, B, M, T, length, active)};
+        f32x16 K[4];
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc) {
+            K[oc] = splat(bk[32 * oc + cx.c]);
+            mmb_oc<4, 4, T16, false>(K[oc], wk, oc, nf, lane);
+        }
+        wg_put_maxes(K, cx, vr, mx, wave);
+        __syncthreads();
+        const int s0 = cx.b0 - ub0;
+        RowRange vr_own = vr[0];
+        if (s0) vr_own = vr[1];
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc) {
+            f32x16 V = splat(bv[32 * oc + cx.c]);
+            mmb_oc<4, 4, T16, false>(V, wv, oc, nf, lane);
+            float ssum;
+            f32x8 keep;
+            partial_tile<T16>(K[oc], V, vr_own, wg_colmax(mx, oc, s0, cx.c), cx, ssum, keep);
+            pst[(wave * 4 + oc) * 64 + lane] = keep;
+            if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssum;
+            if (active && cx.straddle) {
+                partial_tile<T16>(K[oc], V, vr[1], wg_colmax(mx, oc, 1, cx.c), cx, ssum, keep);
+                xp[oc * 64 + lane] = keep;
+                if (cx.hh == 0) ss[(8 * 4 + oc) * 32 + cx.c] = ssum;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        wg_write_record(recs, mx, pst, xp, ss, wave, lane, ub0, G, M, T);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1177,7 +1407,7 @@ DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float 
 
 // DBG = true builds the test-hook variant (early exits after a stage, ablation switches, stage stamps); the
 // production instantiation has none of them - the extra exits alone cost 160 spilled registers.
-template <class T16, bool SPLIT, bool DBG, bool STAMP>
+template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR>
 __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
 void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
              const v8<T16>* __restrict__ a_sa /*[B][16][64]*/, const v8<T16>* __restrict__ a_ca /*[L][B][16][64]*/,
@@ -1215,7 +1445,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const float* c0 = reinterpret_cast<const float*>(buf0 + NFW * 1024);    // constants block of the image in buf0
     const float* c1 = reinterpret_cast<const float*>(buf1 + NFW * 1024);
     // attention frags come through LDS when the workgroup can span at most 2 clips, else straight from L2
-    const bool wg_lds = !SPLIT && T >= NW * 32;
+    const bool wg_lds = WGR || (!SPLIT && T >= NW * 32);       // WGR is only launched with T >= NW * 32
     const int ub0 = (blockIdx.x * NW * 32) / T;
     char* ring = lds + OFF_ER + wave * 8192;
     auto stage_attn = [&](const W* a) {          // frags of clips ub0, ub0+1 -> AF region
@@ -1226,16 +1456,19 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const W* af = reinterpret_cast<const W*>(lds + OFF_AF);
     const W* acl = a_ca + (size_t)l * B * 16 * 64;
 
+    DC_STAMP(0);
     stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
-    if (wg_lds) stage_attn(a_sa);
+    f32x16 h[4];
+    load_h(h, hbuf, g, lane);          // in flight across the combine below
+    if constexpr (WGR)      // self-attention matrices from the previous kernel's workgroup records (scratch: buf1)
+        wg_combine_attn<T16>(recs, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, M, T, threadIdx.x);
+    else if (wg_lds)
+        stage_attn(a_sa);
     constexpr bool use_ring = !SPLIT;             // FiLM tiles through the per-wave LDS ring (else: registers)
     if constexpr (use_ring) {
         ering_issue(Eg, 0, ring, lane);
         ering_issue(Eg, 1, ring + 4096, lane);
     }
-    f32x16 h[4];
-    DC_STAMP(0);
-    load_h(h, hbuf, g, lane);
     stage_sync(DBG ? dbg : 0);
     DC_STAMP(1);
 
@@ -1365,6 +1598,10 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             K[oc] = splat(c0[32 * oc + cx.c]);
             mmb_oc<4, 4, T16, SPLIT>(K[oc], w0, oc, nf, lane);
         }
+        if constexpr (WGR) {
+            const RowRange vr[2] = {valid_rows_clip(cx, ub0, B, M, T, length, active), valid_rows_clip(cx, ub0 + 1, B, M, T, length, active)};
+            wg_put_maxes(K, cx, vr, reinterpret_cast<float*>(lds + OFF_AF), wave);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (active)
             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -1373,7 +1610,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         DC_STAMP(12);
-        {
+        if constexpr (!WGR) {
             float* rec = recs + (size_t)cx.g * 2 * DC_REC_FLOATS;
             const RowRange valid0 = valid_rows(cx, 0, M, T, length);
             const RowRange valid1 = valid_rows(cx, cx.straddle ? 1 : 0, M, T, length);
@@ -1387,6 +1624,35 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
+            // workgroup record: the maxima went into the attention-frag region before the barrier above; the
+            // per-wave blocks go into the (idle) FiLM rings, the rest into buf0 (its key image is consumed)
+            const float* mx = reinterpret_cast<const float*>(lds + OFF_AF);
+            f32x8* pst = reinterpret_cast<f32x8*>(lds + OFF_ER);
+            f32x8* xp = reinterpret_cast<f32x8*>(buf0);
+            float* ss = reinterpret_cast<float*>(buf0 + 8192);
+            const RowRange vr[2] = {valid_rows_clip(cx, ub0, B, M, T, length, active), valid_rows_clip(cx, ub0 + 1, B, M, T, length, active)};
+            const int s0 = cx.b0 - ub0;
+            RowRange vr_own = vr[0];                 // (no dynamic indexing: that would put the array into scratch)
+            if (s0) vr_own = vr[1];
+#pragma unroll
+            for (int oc = 0; oc < 4; ++oc) {
+                f32x16 V = splat(c1[32 * oc + cx.c]);
+                mmb_oc<4, 4, T16, false>(V, w1, oc, nf, lane);
+                float ssum;
+                f32x8 keep;
+                partial_tile<T16>(K[oc], V, vr_own, wg_colmax(mx, oc, s0, cx.c), cx, ssum, keep);
+                pst[(wave * 4 + oc) * 64 + lane] = keep;
+                if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssum;
+                if (active && cx.straddle) {
+                    partial_tile<T16>(K[oc], V, vr[1], wg_colmax(mx, oc, 1, cx.c), cx, ssum, keep);
+                    xp[oc * 64 + lane] = keep;
+                    if (cx.hh == 0) ss[(8 * 4 + oc) * 32 + cx.c] = ssum;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            wg_write_record(recs, mx, pst, xp, ss, wave, lane, ub0, G, M, T);
         }
         DC_STAMP(13);
         return;
@@ -1957,21 +2223,35 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
     return LAUNCH_CHECK();
 }
 
-template <class T16, bool SP>
+template <class T16, bool SP, bool WGR>
 static hipError_t launch_embed_t(hipStream_t st, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
-                                 int M, int T, int G) {
+                                 int M, int T, int G, int B) {
     constexpr int NW = SP ? 4 : 8;
-    k_embed_front<T16, SP><<<dim3((G + NW - 1) / NW), dim3(NW * 64), 0, st>>>(dm, x, hbuf, recs, length, M, T, G);
+    const size_t shm = WGR ? 8192 + 65536 + 8192 + 9 * 4 * 32 * 4 : 0;
+    if (WGR) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_embed_front<T16, SP, WGR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+    }
+    k_embed_front<T16, SP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, B);
     return hipGetLastError();
 }
-hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, const DcModel* dm, const float* x, float* hbuf,
-                                 float* recs, const int* length, int M, int T, int G) {
+hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf,
+                                 float* recs, const int* length, int M, int T, int G, int B) {
     hipError_t e = hipSuccess;
-    DISPATCH(fmt, split, (e = launch_embed_t<T16, SP>(st, dm, x, hbuf, recs, length, M, T, G)));
+    if (wgr && !split) {
+        e = fmt == 1 ? launch_embed_t<_Float16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B)
+                     : launch_embed_t<__bf16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B);
+        return e;
+    }
+    DISPATCH(fmt, split, (e = launch_embed_t<T16, SP, false>(st, dm, x, hbuf, recs, length, M, T, G, B)));
     return e;
 }
 
-template <class T16, bool SP, bool DBG, bool STAMP>
+template <class T16, bool SP, bool DBG, bool STAMP, bool WGR>
 static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
@@ -1981,31 +2261,39 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
     const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192;
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
-        hipError_t e = hipFuncSetAttribute((const void*)k_layer<T16, SP, DBG, STAMP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipError_t e = hipFuncSetAttribute((const void*)k_layer<T16, SP, DBG, STAMP, WGR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    k_layer<T16, SP, DBG, STAMP><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
+    k_layer<T16, SP, DBG, STAMP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
                        (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
                        snaps, M, T, G, B, dbg, stamps);
     return hipGetLastError();
 }
 
-hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
+hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps) {
     hipError_t e = hipSuccess;
-    if (dbg != 0) {
-        DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, true, false>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout,
-                                                                        out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps)));
-    } else if (stamps != nullptr) {
-        DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, false, true>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout,
-                                                                        out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps)));
-    } else {
-        DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, false, false>(st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout,
-                                                                         out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps)));
+#define LAYER_ARGS st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps
+    if (wgr && !split) {        // workgroup-level records + in-kernel combine (non-split formats, T >= 256)
+        if (dbg != 0)
+            e = fmt == 1 ? launch_layer_t<_Float16, false, true, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, true, false, true>(LAYER_ARGS);
+        else if (stamps != nullptr)
+            e = fmt == 1 ? launch_layer_t<_Float16, false, false, true, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, false, true, true>(LAYER_ARGS);
+        else
+            e = fmt == 1 ? launch_layer_t<_Float16, false, false, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, false, false, true>(LAYER_ARGS);
+        return e;
     }
+    if (dbg != 0) {
+        DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, true, false, false>(LAYER_ARGS)));
+    } else if (stamps != nullptr) {
+        DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, false, true, false>(LAYER_ARGS)));
+    } else {
+        DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, false, false, false>(LAYER_ARGS)));
+    }
+#undef LAYER_ARGS
     return e;
 }
 

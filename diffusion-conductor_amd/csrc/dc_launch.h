@@ -21,9 +21,11 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
                                const float* beta_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
                                int nround, const float* pp, const float* temb, const int* t_clip, int T, int B);
 // pp != nullptr (non-split formats): the FiLM GEMM builds its operand SiLU(temb[t_clip] + pp) itself and s_hi is not read
-hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, const DcModel* dm, const float* x, float* hbuf, float* recs,
-                                 const int* length, int M, int T, int G);
-hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
+// wgr: workgroup-level partial records, combined by the consuming layer kernel itself (non-split formats and T >= 256 only;
+// no dc_launch_attn_combine between the layers then)
+hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf, float* recs,
+                                 const int* length, int M, int T, int G, int B);
+hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps);

@@ -146,8 +146,10 @@ def test_progressive_matches_fast_path(models):
 def test_bs32_full_size_properties(models):
     """BASELINE config 2 size (bs=32, T=1800, DDIM-50), checked through size-independent properties:
     (a) re-running is bit-identical (race check: all reductions are ordered);
-    (b) sharding: clips 0..15 and 16..31 sampled as two separate batches equal the joint batch bit for
-        bit (clips are independent and 16*1800 tokens is a whole number of 32-token groups);
+    (b) sharding: clips are independent; the partial softmax / K^T V records are summed per 256-token workgroup,
+        so a shard that starts on a workgroup edge (clips 0..15) equals the joint batch bit for bit, and one that
+        does not (clips 16..31: 16*1800 tokens = 112.5 workgroups) exponentiates the keys against different
+        workgroup maxima before the fp16 operand rounding - it agrees at the precision mode's noise level;
     (c) clip 0 of the batch matches the golden single-clip result within the parity bound."""
     B, T = 32, 1800
     xfp, xfo = xf_pair(B, T)
@@ -158,7 +160,10 @@ def test_bs32_full_size_properties(models):
     assert torch.isfinite(a).all() and torch.equal(a, b)
     lo = _ddim(m, 50, noise[:16], xfp[:16].contiguous(), xfo[:16].contiguous(), [T] * 16)
     hi = _ddim(m, 50, noise[16:], xfp[16:].contiguous(), xfo[16:].contiguous(), [T] * 16)
-    assert torch.equal(torch.cat([lo, hi]), a)
+    assert torch.equal(lo, a[:16])
+    e_hi = rel_l2(hi, a[16:])
+    print(f"shard 16..31 vs joint batch: rel-L2 {e_hi:.2e}")
+    assert e_hi <= TOL_PARITY
     err = rel_l2(a[:1], golden("g5_ddim50_b1.npz")["x0"])
     print(f"bs32 clip0 rel-L2 {err:.3e}")
     assert err <= TOL_PARITY
