@@ -160,6 +160,9 @@ struct dc_sampler {
     void *d_nh_hi = nullptr, *d_nh_lo = nullptr;
     // step state
     unsigned long long* d_stamps = nullptr;
+    unsigned* d_gbar = nullptr;   // grid-barrier arrival counter of the persistent layer kernel (zeroed before each launch)
+    int* d_gerr = nullptr;        // set by a workgroup whose grid-barrier spin ran out
+    int num_cu = 0;
     int *d_iter = nullptr, *d_t_clip = nullptr, *d_snap_cur = nullptr, *d_t_of_iter = nullptr, *d_snap_of_iter = nullptr;
     float *d_coef_cur = nullptr, *d_coef_of_t = nullptr;
     bool cond_set = false;
@@ -517,7 +520,10 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
     }
     if (!s->d_iter) {
         int rc;
-        if ((rc = dev_alloc(s, s->d_stamps, 8 * 16 * 8))) return rc;
+        if ((rc = dev_alloc(s, s->d_stamps, 8 * 32 * 8))) return rc;
+        if ((rc = dev_alloc(s, s->d_gbar, 16))) return rc;
+        if ((rc = dev_alloc(s, s->d_gerr, 16))) return rc;
+        HIP_TRY(hipMemset(s->d_gerr, 0, 16));
         if ((rc = dev_alloc(s, s->d_iter, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_snap_cur, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_coef_cur, 16))) return rc;
@@ -612,14 +618,30 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     static const bool no_wgr = getenv("DC_NO_WGREC") != nullptr;
     const bool wgr = !ss && T >= 256 && !no_wgr;
     LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B));
+    static const int ablate = getenv("DC_ABLATE") ? (int)strtol(getenv("DC_ABLATE"), nullptr, 0) : 0;   // timing experiments
+    static const bool want_stamps = getenv("DC_STAMPS") != nullptr;
+    const bool no_persist = false;
+    const int nwg = (G + 7) / 8;
+    const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
+    // persistent form: all layers in one launch (grid barriers between them) when every workgroup gets its own CU
+    // (measured at bs=32 x 1800: ~2 ms per DDIM-50 loop SLOWER than per-layer launches - the grid barrier costs more than
+    // the residual stream's HBM round trip and the launch edges it saves - so it is opt-in: DC_PERSIST=1)
+    const bool want_persist = getenv("DC_PERSIST") != nullptr;      // (read per call: the tests toggle it)
+    const bool persistent = want_persist && wgr && nwg <= s->num_cu && nl_run == L && s->dbg_stage == 0 && !ablate && !no_persist && L > 1;
+    if (persistent) {
+        HIP_TRY(hipMemsetAsync(s->d_gbar, 0, 4, st));
+        LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, 0, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
+                                        s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur, s->d_snaps,
+                                        M, T, G, B, 0, want_stamps ? s->d_stamps : nullptr, L, rec_stride, s->d_gbar, s->d_gerr));
+        return DC_OK;
+    }
     for (int l = 0; l < nl_run; ++l) {
-        static const int ablate = getenv("DC_ABLATE") ? (int)strtol(getenv("DC_ABLATE"), nullptr, 0) : 0;   // timing experiments
         const int dbg = ((l == nl_run - 1) ? s->dbg_stage : 0) | ablate;
-        if (l > 0 && l % lpc == 0) { int rc = film_chunk(l / lpc); if (rc) return rc; }
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur,
-                                        s->d_snaps, M, T, G, B, dbg, (l == 3 && getenv("DC_STAMPS")) ? s->d_stamps : nullptr));
+                                        s->d_snaps, M, T, G, B, dbg, (l == 3 && want_stamps) ? s->d_stamps : nullptr, l + 1, rec_stride,
+                                        s->d_gbar, s->d_gerr));
     }
     return DC_OK;
 }
@@ -669,7 +691,14 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     HIP_TRY(hipMemcpyAsync(s->d_coef_of_t, h_coef, (size_t)S * 16, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(s->d_iter, 0, 16, st));
     HIP_TRY(hipMemcpyAsync(s->d_x, d_noise, MP * 4, hipMemcpyDeviceToDevice, st));
+    int gerr = 0;
+    HIP_TRY(hipMemcpyAsync(&gerr, s->d_gerr, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));   // the host vectors above go out of scope
+    if (gerr) {
+        HIP_TRY(hipMemset(s->d_gerr, 0, 4));
+        return fail(DC_ERR_HIP, "an earlier persistent layer launch timed out in its grid barrier (workgroups not co-resident?); "
+                                "its results were invalid - set DC_NO_PERSIST=1 to use per-layer launches");
+    }
 
     const bool no_graph = getenv("DC_DISABLE_GRAPH") != nullptr;
     if (profile || no_graph) {
@@ -775,6 +804,7 @@ int dc_sampler_create(const dc_config* cfg, dc_sampler** out) {
         return fail(DC_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", cfg->device, prop.gcnArchName);
     dc_sampler* s = new dc_sampler();
     s->cfg = *cfg;
+    s->num_cu = prop.multiProcessorCount;
     s->split_small = cfg->precision == DC_PREC_MIXED || cfg->precision == DC_PREC_BF16X3;
     s->split_film = cfg->precision == DC_PREC_BF16X3;
     s->small_fmt = cfg->precision == DC_PREC_FP16 ? 1 : 0;
@@ -797,7 +827,7 @@ void dc_sampler_destroy(dc_sampler* s) {
     void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_y, s->d_mean, s->d_rstd, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
                     s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t,
-                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps};
+                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_gbar, s->d_gerr};
     for (void* p : ptrs)
         if (p) hipFree(p);
     dc_music_destroy(s->music);
@@ -989,7 +1019,7 @@ int dc_sampler_debug_read(dc_sampler* s, const char* what, void* h_out, int64_t 
     else if (w == "recs") { src = s->d_recs; have = g * 2 * DC_REC_FLOATS * 4; }
     else if (w == "a_sa") { src = s->d_a_sa; have = (size_t)s->B * 16 * 1024; }
     else if (w == "a_ca") { src = s->d_a_ca; have = (size_t)s->cfg.num_layers * s->B * 16 * 1024; }
-    else if (w == "stamps") { src = s->d_stamps; have = 8 * 16 * 8; }
+    else if (w == "stamps") { src = s->d_stamps; have = 8 * 32 * 8; }
     else if (w == "temb") { src = s->h_model.temb; have = (size_t)s->cfg.max_timesteps * 512 * 4; }
     else return fail(DC_ERR_INVALID, "unknown debug buffer '%s'", what);
     if (!src) return fail(DC_ERR_INVALID, "buffer '%s' not allocated yet", what);

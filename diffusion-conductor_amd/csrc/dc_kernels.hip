@@ -269,7 +269,7 @@ DEV GroupCtx make_ctx(int g, int lane, int M, int T) {
 // iff (unsigned)(crow(r) - lo) < span, crow(r) = (r&3) + 8*(r>>2).
 struct RowRange {
     int lo;
-    unsigned span;
+    unsigned span;      // wave-uniform; span == 32 means every row of the group is valid (the common case: no masking code)
 };
 DEV RowRange valid_rows(const GroupCtx& cx, int slot, int M, int T, const int* __restrict__ length) {
     const int bs = slot == 0 ? cx.b0 : cx.b1;
@@ -283,25 +283,51 @@ DEV RowRange valid_rows(const GroupCtx& cx, int slot, int M, int T, const int* _
 }
 DEV bool row_ok(const RowRange& rr, int r) { return (unsigned)(((r & 3) + 8 * (r >> 2)) - rr.lo) < rr.span; }
 
+// lanes of the upper 16 columns keep registers 8..15 of an accumulator tile, the others 0..7.  Written as a bit-select:
+// as `up ? P[8+i] : P[i]` the compiler forms a dynamic vector index and expands it into a 16-way compare/select chain
+// per element (~400 instructions per tile; it was most of the record stage's time).
+DEV f32x8 keep_head_block(const f32x16& P, int c) {
+    const unsigned mask = (c >> 4) ? 0xffffffffu : 0u;
+    f32x8 k;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] = __uint_as_float((__float_as_uint(P[i]) & ~mask) | (__float_as_uint(P[8 + i]) & mask));
+    return k;
+}
+
 // One 32-feature tile of a group's partial record: column max m, column sum of exp(K-m), and
 // exp2(K-m)^T V (32x32; only the two diagonal 16x16 head blocks are stored).
 template <class T16, bool SPLIT>
 DEV void emit_partial(const f32x16& K, const f32x16& V, int oc, const RowRange& rr, float* __restrict__ R,
                       const GroupCtx& cx) {
     float m = -INFINITY;
+    const bool full = __builtin_amdgcn_readfirstlane(rr.span) == 32u;     // no predicates for whole groups (3 instructions per element)
+    if (full) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m = row_ok(rr, r) ? fmaxf(m, K[r]) : m;
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, K[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = row_ok(rr, r) ? fmaxf(m, K[r]) : m;
+    }
     m = xhalf_max(m);
     if (m == -INFINITY) m = 0.f;
     f32x16 Ee, Vm;
     float ssum = 0.f;
+    if (full) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const bool ok = row_ok(rr, r);
-        const float e = ok ? exp2f_fast(K[r] - m) : 0.f;       // K carries log2(e): folded into Wk, bk
-        Ee[r] = e;
-        ssum += e;
-        Vm[r] = ok ? V[r] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            Ee[r] = exp2f_fast(K[r] - m);                           // K carries log2(e): folded into Wk, bk
+            ssum += Ee[r];
+        }
+        Vm = V;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = row_ok(rr, r);
+            const float e = ok ? exp2f_fast(K[r] - m) : 0.f;
+            Ee[r] = e;
+            ssum += e;
+            Vm[r] = ok ? V[r] : 0.f;
+        }
     }
     ssum = xhalf_sum(ssum);
     XFrag<T16, SPLIT> ef, vf;
@@ -321,10 +347,7 @@ DEV void emit_partial(const f32x16& K, const f32x16& V, int oc, const RowRange& 
         R[128 + 32 * oc + cx.c] = ssum;
     }
     // keep the diagonal head blocks only: rows 16*(c>>4) .. +15 of this lane's column = registers 8*(c>>4) .. +7
-    f32x8 keep;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) keep[i] = (cx.c >> 4) ? P[8 + i] : P[i];
-    reinterpret_cast<f32x8*>(R + 256)[oc * 64 + cx.lane] = keep;
+    reinterpret_cast<f32x8*>(R + 256)[oc * 64 + cx.lane] = keep_head_block(P, cx.c);
 }
 
 // FiLM tile image: [2 halves][64 lanes][8 fp16] - registers 0..7 then 8..15 of each lane, so that both a
@@ -351,15 +374,31 @@ DEV f16x16 load_etile(const f16x8* __restrict__ p /* tile base + lane; global or
     return v;
 }
 
+// Residual-stream image: [group][tile t][quarter q][64 lanes][4 floats] - register 4q+i of tile t of lane l.  Each 16-byte
+// access of a wave covers one contiguous KiB (the former [t][lane][16] order made every store instruction touch 32
+// cache lines a quarter each: the eight waves' stores queued for ~7 us behind one another).
 DEV void load_h(f32x16 (&h)[4], const float* __restrict__ hbuf, int g, int lane) {
-    const f32x16* p = reinterpret_cast<const f32x16*>(hbuf) + (size_t)g * 256 + lane;
+    const f32x4* p = reinterpret_cast<const f32x4*>(hbuf) + (size_t)g * 1024 + lane;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) h[t] = p[t * 64];
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = p[(t * 4 + q) * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[t][4 * q + i] = v[i];
+        }
 }
 DEV void store_h(const f32x16 (&h)[4], float* __restrict__ hbuf, int g, int lane) {
-    f32x16* p = reinterpret_cast<f32x16*>(hbuf) + (size_t)g * 256 + lane;
+    f32x4* p = reinterpret_cast<f32x4*>(hbuf) + (size_t)g * 1024 + lane;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) p[t * 64] = h[t];
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = h[t][4 * q + i];
+            p[(t * 4 + q) * 64] = v;
+        }
 }
 
 // "Front half" of LinearTemporalSelfAttention (transformer.py:104-117) for one token group, given the operand
@@ -417,8 +456,14 @@ DEV void wg_put_maxes(const f32x16 (&K)[4], const GroupCtx& cx, const RowRange (
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
             float m = -INFINITY;
+            const unsigned span = __builtin_amdgcn_readfirstlane(vr[sl].span);
+            if (span == 32u) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = row_ok(vr[sl], r) ? fmaxf(m, K[oc][r]) : m;
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, K[oc][r]);
+            } else if (span != 0u) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = row_ok(vr[sl], r) ? fmaxf(m, K[oc][r]) : m;
+            }
             m = xhalf_max(m);
             if (cx.hh == 0) mx[((oc * 2 + sl) * 32 + cx.c) * 8 + wave] = m;
         }
@@ -434,13 +479,22 @@ template <class T16>
 DEV void partial_tile(const f32x16& K, const f32x16& V, const RowRange& rr, float m, const GroupCtx& cx, float& ssum, f32x8& keep) {
     f32x16 Ee, Vm;
     float s = 0.f;
+    if (__builtin_amdgcn_readfirstlane(rr.span) == 32u) {       // all 32 rows valid: no predicates (they cost 3 instructions per element)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const bool ok = row_ok(rr, r);
-        const float e = ok ? exp2f_fast(K[r] - m) : 0.f;
-        Ee[r] = e;
-        s += e;
-        Vm[r] = ok ? V[r] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            Ee[r] = exp2f_fast(K[r] - m);
+            s += Ee[r];
+        }
+        Vm = V;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = row_ok(rr, r);
+            const float e = ok ? exp2f_fast(K[r] - m) : 0.f;
+            Ee[r] = e;
+            s += e;
+            Vm[r] = ok ? V[r] : 0.f;
+        }
     }
     ssum = xhalf_sum(s);
     XFrag<T16, false> ef, vf;
@@ -449,8 +503,7 @@ DEV void partial_tile(const f32x16& K, const f32x16& V, const RowRange& rr, floa
     f32x16 P = splat(0.f);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) P = mfma(ef.hi[s2], vf.hi[s2], P);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) keep[i] = (cx.c >> 4) ? P[8 + i] : P[i];
+    keep = keep_head_block(P, cx.c);
 }
 // after the barrier that follows the last partial_tile: wave w sums tile oc = w & 3 of slot w >> 2 over the waves
 DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8* pst, const f32x8* xp, const float* ss,
@@ -460,17 +513,20 @@ DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8*
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
     float ssum = 0.f;
+#pragma unroll
     for (int v = 0; v < 8; ++v) {
         const int gv = blockIdx.x * 8 + v;
-        if (gv >= G) break;
-        const int b0v = (32 * gv) / T, b1v = min(32 * gv + 31, M - 1) / T;
-        if (b0v - ub0 == sl) {
+        if (gv >= G) continue;
+        const int edge = (ub0 + 1) * T;                       // first token of slot 1's clip
+        const int s0v = 32 * gv >= edge ? 1 : 0;              // the wave's primary slot
+        const bool strad = !s0v && min(32 * gv + 31, M - 1) >= edge;
+        if (s0v == sl) {
             const f32x8 p = pst[(v * 4 + oc) * 64 + lane];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += p[i];
             ssum += ss[(v * 4 + oc) * 32 + c];
         }
-        if (b1v != b0v && sl == 1) {
+        if (strad && sl == 1) {
             const f32x8 p = xp[oc * 64 + lane];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += p[i];
@@ -495,7 +551,8 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
     const int ci = tid >> 8, t = tid & 255, ln = t & 63, oc = t >> 6;
     const int c = ln & 31, hh = ln >> 5;
     const int b = ub0 + ci;
-    const bool live = b < B && (long long)b * T < M;
+    const int ub1 = (min(((int)blockIdx.x + 1) * 256, M) - 1) / T;          // last clip this workgroup touches
+    const bool live = b <= ub1;
     const int u_lo = live ? (b * T) / 256 : 0;
     const int u_hi = live ? (min((b + 1) * T, M) - 1) / 256 : -1;
     const int nu = u_hi - u_lo + 1;
@@ -507,12 +564,12 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
         if (k < nu) pre[k] = reinterpret_cast<const f32x8*>(rec_of(b, u_lo + k) + 256)[oc * 64 + ln];
     if (tid < 256) {                              // phase A: per feature f of clip ca: m*, weights, normaliser
         const int ca = tid >> 7, f = tid & 127, ba = ub0 + ca;
-        const bool la = ba < B && (long long)ba * T < M;
+        const bool la = ba <= ub1;
         const int a_lo = la ? (ba * T) / 256 : 0, a_hi = la ? (min((ba + 1) * T, M) - 1) / 256 : -1;
         const int na = a_hi - a_lo + 1;
-        float mr[NU], sr[NU];                     // every load is issued before the first use: one memory round trip
+        float mr[PRE], sr[PRE];                   // the first PRE units: every load is issued before the first use
 #pragma unroll
-        for (int k = 0; k < NU; ++k) {
+        for (int k = 0; k < PRE; ++k) {
             mr[k] = 0.f;
             sr[k] = 0.f;
             if (k < na) {
@@ -523,14 +580,25 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
         }
         float mstar = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < NU; ++k)
+        for (int k = 0; k < PRE; ++k)
             if (sr[k] > 0.f) mstar = fmaxf(mstar, mr[k]);
+        for (int k = PRE; k < na; ++k) {          // clips longer than 9 workgroups (T > 2048)
+            const float* R = rec_of(ba, a_lo + k);
+            if (R[128 + f] > 0.f) mstar = fmaxf(mstar, R[f]);
+        }
         float z = 0.f;
 #pragma unroll
-        for (int k = 0; k < NU; ++k) {
+        for (int k = 0; k < PRE; ++k) {
             const float ww = sr[k] > 0.f ? exp2f_fast(mr[k] - mstar) : 0.f;
             if (k < na) wsc[(ca * NU + k) * 128 + f] = ww;
             z += ww * sr[k];
+        }
+        for (int k = PRE; k < na; ++k) {
+            const float* R = rec_of(ba, a_lo + k);
+            const float su = R[128 + f];
+            const float ww = su > 0.f ? exp2f_fast(R[f] - mstar) : 0.f;
+            wsc[(ca * NU + k) * 128 + f] = ww;
+            z += ww * su;
         }
         zsc[ca * 128 + f] = z;
     }
@@ -575,6 +643,30 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
     const int s = c >> 4;
     af[(ci * 8 + oc * 2 + s) * 64 + ln] = out;
     af[(ci * 8 + oc * 2 + (s ^ 1)) * 64 + ln] = zero;
+}
+
+
+// Grid-wide barrier between the layers of the persistent form of k_layer (all workgroups co-resident: the launcher
+// checks grid <= CU count at 1 workgroup per CU).  Release: the workgroup's record stores are written back
+// (__threadfence = agent-scope fence: L2 write-back + invalidate on gfx950's per-XCD L2s); acquire after the spin.
+// The spin is bounded: a workgroup that never sees the others arrive raises *err and goes on (wrong results, reported
+// by the host) instead of hanging the device.
+DEV void grid_barrier(unsigned* counter, unsigned target, int* err) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 21)) {
+                *err = 1;
+                break;
+            }
+        }
+        __threadfence();
+    }
+    __syncthreads();
 }
 
 }  // namespace dc
@@ -1414,7 +1506,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
              float* __restrict__ recs, const int* __restrict__ length, const float* __restrict__ xin,
              float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur, const int* __restrict__ snap_cur,
              float* __restrict__ snaps, int M, int T, int G, int B, int dbg,
-             unsigned long long* __restrict__ stamps) {
+             unsigned long long* __restrict__ stamps, int l_end, size_t rec_stride, unsigned* __restrict__ gbar,
+             int* __restrict__ gerr) {
+    // Layers l .. l_end-1 in one launch when l_end > l + 1 (persistent form, WGR only): the residual stream stays in
+    // registers, a grid barrier separates the layers, and the unit records alternate between two buffers
+    // (recs + parity * rec_stride) so that a fast workgroup's records for layer l+1 never overwrite what a slow one
+    // still combines for layer l.
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int NW = SPLIT ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;            // operand images per matrix (hi [+ lo])
@@ -1422,22 +1519,32 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     // diagnostic build aid: 100 MHz timestamps per stage for the waves of workgroup 3 (stamps == nullptr normally)
 #define DC_STAMP(k)                                                                                        \
     do {                                                                                                   \
-        if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0)                                 \
-            stamps[(threadIdx.x >> 6) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                      \
+        if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0 && (l == 3 || l_end == l_first + 1)) \
+            stamps[(threadIdx.x >> 6) * 32 + (k)] = __builtin_amdgcn_s_memrealtime();                      \
     } while (0)                 // frags of one 128x128 stage image (constants block follows)
     constexpr int WSZ = (NFW + 1) * 1024;
     constexpr int OFF_AF = 2 * WSZ;              // non-split: attention frags of the workgroup's <= 2 clips (16 KiB)
     constexpr int OFF_ER = OFF_AF + 16384;       // non-split: per-wave FiLM tile rings (8 KiB each)
+    constexpr int OFF_SS = OFF_ER + 8 * 8192;    // non-split: column sums of the workgroup record (4.5 KiB)
     using W = v8<T16>;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nl = dm->num_layers;
+    const int l_first = l;
+    f32x16 h[4];
+    {
+        const int g0 = min((int)(blockIdx.x * NW + (threadIdx.x >> 6)), G - 1);
+        load_h(h, hbuf, g0, threadIdx.x & 63);      // in flight across the first prologue
+    }
+#pragma nounroll
+  for (;; ++l) {                       // layer loop (one iteration unless persistent)
+    // Everything derived from the thread index is re-derived per layer from an opaque copy: hoisted out of the loop
+    // these values would stay live across the whole body next to the loop-carried residual stream (it spilled ~100 VGPRs).
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), lane = tid_ & 63;
     int g = blockIdx.x * NW + wave;
     const bool active = g < G;                   // idle waves still take part in the staging and barriers
     if (!active) g = G - 1;
     const GroupCtx cx = make_ctx(g, lane, M, T);
-    const DcLayer& L = dm->layer[l];
-    const int nl = dm->num_layers;
-    const bool last = l + 1 >= nl;
-    const f16x8* Eg = reinterpret_cast<const f16x8*>(E) + ((size_t)g * NT + (size_t)l * 24) * 128;   // 3 blocks x 8 tiles
     char* buf0 = lds;
     char* buf1 = lds + WSZ;
     const W* w0 = reinterpret_cast<const W*>(buf0);
@@ -1454,21 +1561,28 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         stage_frags<NW>(a + (size_t)c1i * 16 * 64, lds + OFF_AF + 8192, 8, wave, lane);
     };
     const W* af = reinterpret_cast<const W*>(lds + OFF_AF);
+    const DcLayer& L = dm->layer[l];
+    const bool last = l + 1 >= nl;
+    const bool more = WGR && l + 1 < l_end;      // the next layer runs in this launch
+    const f16x8* Eg = reinterpret_cast<const f16x8*>(E) + ((size_t)g * NT + (size_t)l * 24) * 128;   // 3 blocks x 8 tiles
     const W* acl = a_ca + (size_t)l * B * 16 * 64;
+    const float* recs_in = recs + (size_t)(l & 1) * rec_stride;
+    float* recs_out = recs + (size_t)((l + 1) & 1) * rec_stride;
 
     DC_STAMP(0);
     stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
-    f32x16 h[4];
-    load_h(h, hbuf, g, lane);          // in flight across the combine below
-    if constexpr (WGR)      // self-attention matrices from the previous kernel's workgroup records (scratch: buf1)
-        wg_combine_attn<T16>(recs, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, M, T, threadIdx.x);
+    if constexpr (WGR)      // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
+        wg_combine_attn<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, M, T, threadIdx.x);
     else if (wg_lds)
         stage_attn(a_sa);
+    DC_STAMP(14);
     constexpr bool use_ring = !SPLIT;             // FiLM tiles through the per-wave LDS ring (else: registers)
     if constexpr (use_ring) {
         ering_issue(Eg, 0, ring, lane);
         ering_issue(Eg, 1, ring + 4096, lane);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DC_STAMP(15);
     stage_sync(DBG ? dbg : 0);
     DC_STAMP(1);
 
@@ -1587,30 +1701,98 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         // youngest operations (the 16 dwordx4 stores of h) are outstanding means "the image has landed" while the
         // stores keep draining behind the K/V projections.
         __builtin_amdgcn_sched_barrier(0);
-        if (active) store_h(h, hbuf, g, lane);
+        const bool st_h = active && !more;               // the residual stream only leaves the registers at a launch edge
+        if (st_h) store_h(h, hbuf, g, lane);
         __builtin_amdgcn_sched_barrier(0);
         XFrag<T16, SPLIT> nf[4];
         ln_frags<T16, SPLIT>(nf, h);
+        DC_STAMP(19);
         if constexpr (DBG) if (dbg & 0x400) return;      // timing experiment: no front stage
-        f32x16 K[4];                  // keys from buf0 while the value image lands in buf1
-#pragma unroll
-        for (int oc = 0; oc < 4; ++oc) {
-            K[oc] = splat(c0[32 * oc + cx.c]);
-            mmb_oc<4, 4, T16, SPLIT>(K[oc], w0, oc, nf, lane);
-        }
         if constexpr (WGR) {
-            const RowRange vr[2] = {valid_rows_clip(cx, ub0, B, M, T, length, active), valid_rows_clip(cx, ub0 + 1, B, M, T, length, active)};
-            wg_put_maxes(K, cx, vr, reinterpret_cast<float*>(lds + OFF_AF), wave);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (active)
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-        DC_STAMP(12);
-        if constexpr (!WGR) {
+            // workgroup record, two passes over the key image (buf0) so that no key tile stays live next to the
+            // loop-carried residual stream: (1) column maxima per wave -> LDS; barrier (which also covers the value
+            // image landing in buf1); (2) per feature tile: keys again, values, exp2 against the workgroup maxima,
+            // exp(K-m)^T V -> LDS (per-wave blocks in the idle FiLM rings); barrier; summed in wave order and written.
+            float* mx = reinterpret_cast<float*>(lds + OFF_AF);
+            f32x8* pst = reinterpret_cast<f32x8*>(lds + OFF_ER);
+            f32x8* xp = reinterpret_cast<f32x8*>(lds + OFF_AF + 8192);
+            float* ss = reinterpret_cast<float*>(lds + OFF_SS);
+            const RowRange vr0 = valid_rows_clip(cx, ub0, B, M, T, length, active);
+            const RowRange vr1 = valid_rows_clip(cx, ub0 + 1, B, M, T, length, active);
+#pragma unroll
+            for (int oc = 0; oc < 4; ++oc) {
+                f32x16 K = splat(c0[32 * oc + cx.c]);
+                mmb_oc<4, 4, T16, false>(K, w0, oc, nf, lane);
+                float m0 = -INFINITY, m1 = -INFINITY;
+                if (__builtin_amdgcn_readfirstlane(vr0.span) == 32u) {       // whole group in slot 0: plain maximum
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m0 = fmaxf(m0, K[r]);
+                } else if (__builtin_amdgcn_readfirstlane(vr1.span) == 32u) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m1 = fmaxf(m1, K[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        m0 = row_ok(vr0, r) ? fmaxf(m0, K[r]) : m0;
+                        m1 = row_ok(vr1, r) ? fmaxf(m1, K[r]) : m1;
+                    }
+                }
+                m0 = xhalf_max(m0);
+                m1 = xhalf_max(m1);
+                if (cx.hh == 0) {
+                    mx[((oc * 2 + 0) * 32 + cx.c) * 8 + wave] = m0;
+                    mx[((oc * 2 + 1) * 32 + cx.c) * 8 + wave] = m1;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            DC_STAMP(20);
+            if (st_h)
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DC_STAMP(21);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            DC_STAMP(12);
+            const int s0 = cx.b0 - ub0;
+            const RowRange vr_own = s0 ? vr1 : vr0;
+#pragma unroll
+            for (int oc = 0; oc < 4; ++oc) {
+                f32x16 K = splat(c0[32 * oc + cx.c]);
+                mmb_oc<4, 4, T16, false>(K, w0, oc, nf, lane);
+                f32x16 V = splat(c1[32 * oc + cx.c]);
+                mmb_oc<4, 4, T16, false>(V, w1, oc, nf, lane);
+                float ssum;
+                f32x8 keep;
+                partial_tile<T16>(K, V, vr_own, wg_colmax(mx, oc, s0, cx.c), cx, ssum, keep);
+                pst[(wave * 4 + oc) * 64 + lane] = keep;
+                if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssum;
+                if (active && cx.straddle) {
+                    partial_tile<T16>(K, V, vr1, wg_colmax(mx, oc, 1, cx.c), cx, ssum, keep);
+                    xp[oc * 64 + lane] = keep;
+                    if (cx.hh == 0) ss[(8 * 4 + oc) * 32 + cx.c] = ssum;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            DC_STAMP(16);
+            __syncthreads();
+            DC_STAMP(17);
+            wg_write_record(recs_out, mx, pst, xp, ss, wave, lane, ub0, G, M, T);
+        } else {
+            f32x16 K[4];                  // keys from buf0 while the value image lands in buf1
+#pragma unroll
+            for (int oc = 0; oc < 4; ++oc) {
+                K[oc] = splat(c0[32 * oc + cx.c]);
+                mmb_oc<4, 4, T16, SPLIT>(K[oc], w0, oc, nf, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (st_h)
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            DC_STAMP(12);
             float* rec = recs + (size_t)cx.g * 2 * DC_REC_FLOATS;
             const RowRange valid0 = valid_rows(cx, 0, M, T, length);
             const RowRange valid1 = valid_rows(cx, cx.straddle ? 1 : 0, M, T, length);
@@ -1624,37 +1806,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        } else {
-            // workgroup record: the maxima went into the attention-frag region before the barrier above; the
-            // per-wave blocks go into the (idle) FiLM rings, the rest into buf0 (its key image is consumed)
-            const float* mx = reinterpret_cast<const float*>(lds + OFF_AF);
-            f32x8* pst = reinterpret_cast<f32x8*>(lds + OFF_ER);
-            f32x8* xp = reinterpret_cast<f32x8*>(buf0);
-            float* ss = reinterpret_cast<float*>(buf0 + 8192);
-            const RowRange vr[2] = {valid_rows_clip(cx, ub0, B, M, T, length, active), valid_rows_clip(cx, ub0 + 1, B, M, T, length, active)};
-            const int s0 = cx.b0 - ub0;
-            RowRange vr_own = vr[0];                 // (no dynamic indexing: that would put the array into scratch)
-            if (s0) vr_own = vr[1];
-#pragma unroll
-            for (int oc = 0; oc < 4; ++oc) {
-                f32x16 V = splat(c1[32 * oc + cx.c]);
-                mmb_oc<4, 4, T16, false>(V, w1, oc, nf, lane);
-                float ssum;
-                f32x8 keep;
-                partial_tile<T16>(K[oc], V, vr_own, wg_colmax(mx, oc, s0, cx.c), cx, ssum, keep);
-                pst[(wave * 4 + oc) * 64 + lane] = keep;
-                if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssum;
-                if (active && cx.straddle) {
-                    partial_tile<T16>(K[oc], V, vr[1], wg_colmax(mx, oc, 1, cx.c), cx, ssum, keep);
-                    xp[oc * 64 + lane] = keep;
-                    if (cx.hh == 0) ss[(8 * 4 + oc) * 32 + cx.c] = ssum;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();
-            wg_write_record(recs, mx, pst, xp, ss, wave, lane, ub0, G, M, T);
         }
         DC_STAMP(13);
+        if (more) {
+            grid_barrier(gbar, (unsigned)gridDim.x * (unsigned)(l - l_first + 1), gerr);
+            continue;
+        }
         return;
     }
     // ---- output projection [buf0, split] + DDIM update
@@ -1690,6 +1847,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             }
         }
     }
+    return;
+  }   // layer loop
 }
 
 // ====================================================================================
@@ -1733,10 +1892,7 @@ DEV ClipCtx make_clip_ctx(int blk, int WPC, int wave, int lane, int T, int M) {
     return x;
 }
 DEV void store_h_lanes(const f32x16 (&h)[4], float* __restrict__ hbuf, int g, int lane, bool ok) {
-    if (!ok) return;
-    f32x16* p = reinterpret_cast<f32x16*>(hbuf) + (size_t)g * 256 + lane;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) p[t * 64] = h[t];
+    if (ok) store_h(h, hbuf, g, lane);
 }
 
 // K (FT form) and V (TF form) of n = LN(h) -> the 16 fragments of this group's key tile
@@ -2255,10 +2411,11 @@ template <class T16, bool SP, bool DBG, bool STAMP, bool WGR>
 static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                                 int M, int T, int G, int B, int dbg, unsigned long long* stamps) {
+                                 int M, int T, int G, int B, int dbg, unsigned long long* stamps, int l_end, size_t rec_stride,
+                                 unsigned* gbar, int* gerr) {
     constexpr int NW = SP ? 4 : 8;
     // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
-    const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192;
+    const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
         hipError_t e = hipFuncSetAttribute((const void*)k_layer<T16, SP, DBG, STAMP, WGR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -2267,16 +2424,18 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
     }
     k_layer<T16, SP, DBG, STAMP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
                        (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
-                       snaps, M, T, G, B, dbg, stamps);
+                       snaps, M, T, G, B, dbg, stamps, l_end, rec_stride, gbar, gerr);
     return hipGetLastError();
 }
 
 hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                           int M, int T, int G, int B, int dbg, unsigned long long* stamps) {
+                           int M, int T, int G, int B, int dbg, unsigned long long* stamps, int l_end, size_t rec_stride,
+                           unsigned* gbar, int* gerr) {
     hipError_t e = hipSuccess;
-#define LAYER_ARGS st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps
+#define LAYER_ARGS st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps, \
+                   l_end, rec_stride, gbar, gerr
     if (wgr && !split) {        // workgroup-level records + in-kernel combine (non-split formats, T >= 256)
         if (dbg != 0)
             e = fmt == 1 ? launch_layer_t<_Float16, false, true, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, true, false, true>(LAYER_ARGS);

@@ -28,7 +28,11 @@ hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, 
 hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                           int M, int T, int G, int B, int dbg, unsigned long long* stamps);
+                           int M, int T, int G, int B, int dbg, unsigned long long* stamps, int l_end, size_t rec_stride,
+                           unsigned* gbar, int* gerr);
+// l_end > l + 1 (wgr only): layers l .. l_end-1 in ONE launch with grid barriers in between - the caller guarantees that all
+// ceil(G/8) workgroups are co-resident (<= CU count) and that *gbar == 0 at launch; rec_stride: floats between the two
+// alternating unit-record buffers (0 = single buffer, non-wgr)
 
 // ---- no_eff variant (full T x T attention); non-split formats only.  KT = key tiles per clip array.
 hipError_t dc_launch_ca_kv(hipStream_t st, int fmt, const DcModel* dm, const void* nh_hi, const void* nh_lo, void* kv_ca,

@@ -268,8 +268,9 @@ class NativeSampler:
     def read_h(self):
         """Residual stream [M_pad, 128] unpacked from the FT-tile image [G][4][64][16]."""
         G = (self.B * self.T + 31) // 32
-        raw = self.debug_read("h", np.float32, G * 4 * 64 * 16).reshape(G, 4, 64, 16)
-        return unpack_ft(raw)
+        # device order [G][tile][quarter][lane][4] -> [G][tile][lane][16 regs]
+        raw = self.debug_read("h", np.float32, G * 4 * 64 * 16).reshape(G, 4, 4, 64, 4)
+        return unpack_ft(raw.transpose(0, 1, 3, 2, 4).reshape(G, 4, 64, 16))
 
     def workspace_bytes(self):
         return int(lib().dc_sampler_workspace_bytes(self._h))

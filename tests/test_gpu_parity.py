@@ -126,6 +126,21 @@ def test_graph_equals_eager(models):
     assert torch.equal(a, b)
 
 
+def test_persistent_layer_kernel_equals_per_layer_launches(models):
+    """DC_PERSIST=1: all 8 layers in one launch with grid barriers between them (opt-in; needs one CU per
+    256-token workgroup).  Same arithmetic in the same order as the per-layer launches: bit-identical."""
+    xfp, xfo = xf_pair(3, 900, first=40)
+    noise = torch.from_numpy(batch_noise(3, 900, first=40))
+    a = _ddim(models["fp16"], 25, noise, xfp, xfo, [900, 512, 333])
+    os.environ["DC_PERSIST"] = "1"
+    os.environ["DC_DISABLE_GRAPH"] = "1"
+    try:
+        b = _ddim(models["fp16"], 25, noise, xfp, xfo, [900, 512, 333])
+    finally:
+        del os.environ["DC_PERSIST"], os.environ["DC_DISABLE_GRAPH"]
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_progressive_matches_fast_path(models):
     """ddim_sample_loop_progressive (per-step host loop over the native denoiser) ends where the
     graph-replayed loop ends, and yields num_timesteps samples."""

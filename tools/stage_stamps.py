@@ -13,10 +13,21 @@ gd = make_diffusion(50)
 for _ in range(2):
     nat.ddim_loop(noise, gd.native_coefficients())
 torch.cuda.synchronize()
-st = nat.debug_read("stamps", np.uint64, 8 * 16).reshape(8, 16).astype(np.int64)
+st = nat.debug_read("stamps", np.uint64, 8 * 32).reshape(8, 32).astype(np.int64)
 names = ["load h + image 0", "Q + attend (SA)", "barrier", "stylize (SA)", "barrier", "Q + attend (CA)", "barrier + stylize (CA)", "barrier", "FFN", "barrier + stylize (FFN)", "barrier", "LN + K proj + barrier", "store h + V proj + partial records"]
 t0 = st[:, 0].min()
 print("wave:      " + "".join(f"{w:8d}" for w in range(8)))
 for k in range(1, 14):
     print(f"{k:2d} {names[k-1][:16]:16s}" + "".join(f"{(st[w, k] - st[w, k-1]) / 100.0:8.2f}" for w in range(8)))
 print("total (us) " + "".join(f"{(st[w, 13] - st[w, 0]) / 100.0:8.2f}" for w in range(8)))
+print("prologue split (us): issue->combine done " + "".join(f"{(st[w, 14] - st[w, 0]) / 100.0:7.2f}" for w in range(8)))
+print("                      ->own loads landed  " + "".join(f"{(st[w, 15] - st[w, 14]) / 100.0:7.2f}" for w in range(8)))
+print("                      ->barrier           " + "".join(f"{(st[w, 1] - st[w, 15]) / 100.0:7.2f}" for w in range(8)))
+def seg(a, b): return "".join(f"{(st[w, b] - st[w, a]) / 100.0:7.2f}" for w in range(8))
+print("tail split (us): 11->LN done      " + seg(11, 19))
+print("                 ->K pass 1 done   " + seg(19, 20))
+print("                 ->image landed    " + seg(20, 21))
+print("                 ->barrier         " + seg(21, 12))
+print("                 ->pass 2 done     " + seg(12, 16))
+print("                 ->barrier         " + seg(16, 17))
+print("                 ->record written  " + seg(17, 13))
