@@ -160,6 +160,22 @@ DEV void mmb_oc(f32x16& acc, const v8<T16>* __restrict__ w, int oc, const XFrag<
         }
 }
 
+// two independent accumulator chains interleaved (non-split): tiles (wa, oca) and (wb, ocb) of the same operand x.
+// A single tile is a chain of 8 dependent MFMAs (~70 cycles each); two chains keep the matrix pipe busy.
+template <int OC, int KT, class T16>
+DEV void mmb_oc_pair(f32x16& acca, f32x16& accb, const v8<T16>* __restrict__ wa, int oca, const v8<T16>* __restrict__ wb, int ocb,
+                     const XFrag<T16, false> (&x)[KT], int lane) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const v8<T16> ba = wa[((kt * OC + oca) * 2 + s) * 64 + lane];
+            const v8<T16> bb = wb[((kt * OC + ocb) * 2 + s) * 64 + lane];
+            acca = mfma(x[kt].hi[s], ba, acca);
+            accb = mfma(x[kt].hi[s], bb, accb);
+        }
+}
+
 // per-feature vector stored as [tile][lane-half][16] so a lane reads its 16 values with one 64-B load
 DEV f32x16 ld_ft(const float* __restrict__ p, int tile, int hh) {
     return *reinterpret_cast<const f32x16*>(p + (tile * 2 + hh) * 16);
@@ -348,6 +364,20 @@ DEV void emit_partial(const f32x16& K, const f32x16& V, int oc, const RowRange& 
     }
     // keep the diagonal head blocks only: rows 16*(c>>4) .. +15 of this lane's column = registers 8*(c>>4) .. +7
     reinterpret_cast<f32x8*>(R + 256)[oc * 64 + cx.lane] = keep_head_block(P, cx.c);
+}
+
+// fp32 fragment image of the step-invariant emb term: [g][ks][2 halves][64 lanes][4 floats] - element j of lane l in half
+// j>>2, so each 16-byte access of a wave covers one contiguous KiB
+DEV f32x8 ld_pp(const float* __restrict__ pp, size_t frag /* g*32 + ks */, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(pp) + frag * 128 + lane;
+    const f32x4 a = p[0], b = p[64];
+    f32x8 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = a[i];
+        v[4 + i] = b[i];
+    }
+    return v;
 }
 
 // FiLM tile image: [2 halves][64 lanes][8 fp16] - registers 0..7 then 8..15 of each lane, so that both a
@@ -774,7 +804,15 @@ __global__ void k_cond_pack(const float* __restrict__ y, const float* __restrict
     const float* src = y + tok * 512 + 16 * ks + 8 * (lane >> 5);
     f32x8 v = *reinterpret_cast<const f32x8*>(src);
     if constexpr (MODE == 0) {
-        reinterpret_cast<f32x8*>(out_f32)[idx] = v;
+        f32x4* o = reinterpret_cast<f32x4*>(out_f32) + (idx >> 6) * 128 + lane;      // layout: ld_pp
+        f32x4 a, b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = v[i];
+            b[i] = v[4 + i];
+        }
+        o[0] = a;
+        o[64] = b;
     } else {
         const float mu = mean[tok], rs = rstd[tok];
         bf16x8 hi, lo;
@@ -967,7 +1005,7 @@ __global__ void k_silu_emb(const float* __restrict__ pp /*frag-major fp32*/, con
     const int tok = g * 32 + (lane & 31);
     const int b = min(tok / T, B - 1);
     const float* te = temb + (size_t)t_clip[b] * 512 + 16 * ks + 8 * (lane >> 5);
-    const f32x8 p = reinterpret_cast<const f32x8*>(pp)[idx];
+    const f32x8 p = ld_pp(pp, idx >> 6, lane);
     const f32x8 tv = *reinterpret_cast<const f32x8*>(te);
     v8<T16> hi, lo;
 #pragma unroll
@@ -1120,9 +1158,8 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
                 v8<T16>* slab_w = reinterpret_cast<v8<T16>*>(lds);
                 for (int f = wave; f < 4 * DC_KS_E; f += 8) {      // (batching these loads 4 deep spilled and ran slower)
                     const int gg = min(g0 + (f >> 5), G - 1), ks = f & 31;
-                    const size_t idx = ((size_t)gg * DC_KS_E + ks) * 64 + lane;
                     const int b = min((gg * 32 + (lane & 31)) / T, B - 1);
-                    const f32x8 pv = reinterpret_cast<const f32x8*>(pp)[idx];
+                    const f32x8 pv = ld_pp(pp, (size_t)gg * DC_KS_E + ks, lane);
                     const f32x8 tv = *reinterpret_cast<const f32x8*>(temb + (size_t)t_clip[b] * 512 + 16 * ks + 8 * (lane >> 5));
                     v8<T16> hi;
 #pragma unroll
@@ -1499,7 +1536,7 @@ DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float 
 
 // DBG = true builds the test-hook variant (early exits after a stage, ablation switches, stage stamps); the
 // production instantiation has none of them - the extra exits alone cost 160 spilled registers.
-template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR>
+template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR, bool PERS>
 __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
 void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
              const v8<T16>* __restrict__ a_sa /*[B][16][64]*/, const v8<T16>* __restrict__ a_ca /*[L][B][16][64]*/,
@@ -1563,7 +1600,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const W* af = reinterpret_cast<const W*>(lds + OFF_AF);
     const DcLayer& L = dm->layer[l];
     const bool last = l + 1 >= nl;
-    const bool more = WGR && l + 1 < l_end;      // the next layer runs in this launch
+    const bool more = PERS && l + 1 < l_end;     // the next layer runs in this launch (compile-time false otherwise: the
+                                                 // residual stream is then dead after its store and the loop has no back edge)
     const f16x8* Eg = reinterpret_cast<const f16x8*>(E) + ((size_t)g * NT + (size_t)l * 24) * 128;   // 3 blocks x 8 tiles
     const W* acl = a_ca + (size_t)l * B * 16 * 64;
     const float* recs_in = recs + (size_t)(l & 1) * rec_stride;
@@ -1720,28 +1758,33 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             const RowRange vr0 = valid_rows_clip(cx, ub0, B, M, T, length, active);
             const RowRange vr1 = valid_rows_clip(cx, ub0 + 1, B, M, T, length, active);
 #pragma unroll
-            for (int oc = 0; oc < 4; ++oc) {
-                f32x16 K = splat(c0[32 * oc + cx.c]);
-                mmb_oc<4, 4, T16, false>(K, w0, oc, nf, lane);
-                float m0 = -INFINITY, m1 = -INFINITY;
-                if (__builtin_amdgcn_readfirstlane(vr0.span) == 32u) {       // whole group in slot 0: plain maximum
+            for (int op = 0; op < 2; ++op) {                  // two key tiles at a time: two independent MFMA chains
+                f32x16 Kp[2] = {splat(c0[32 * (2 * op) + cx.c]), splat(c0[32 * (2 * op + 1) + cx.c])};
+                mmb_oc_pair<4, 4, T16>(Kp[0], Kp[1], w0, 2 * op, w0, 2 * op + 1, nf, lane);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m0 = fmaxf(m0, K[r]);
-                } else if (__builtin_amdgcn_readfirstlane(vr1.span) == 32u) {
+                for (int q = 0; q < 2; ++q) {
+                    const int oc = 2 * op + q;
+                    const f32x16& K = Kp[q];
+                    float m0 = -INFINITY, m1 = -INFINITY;
+                    if (__builtin_amdgcn_readfirstlane(vr0.span) == 32u) {       // whole group in slot 0: plain maximum
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m1 = fmaxf(m1, K[r]);
-                } else {
+                        for (int r = 0; r < 16; ++r) m0 = fmaxf(m0, K[r]);
+                    } else if (__builtin_amdgcn_readfirstlane(vr1.span) == 32u) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        m0 = row_ok(vr0, r) ? fmaxf(m0, K[r]) : m0;
-                        m1 = row_ok(vr1, r) ? fmaxf(m1, K[r]) : m1;
+                        for (int r = 0; r < 16; ++r) m1 = fmaxf(m1, K[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            m0 = row_ok(vr0, r) ? fmaxf(m0, K[r]) : m0;
+                            m1 = row_ok(vr1, r) ? fmaxf(m1, K[r]) : m1;
+                        }
                     }
-                }
-                m0 = xhalf_max(m0);
-                m1 = xhalf_max(m1);
-                if (cx.hh == 0) {
-                    mx[((oc * 2 + 0) * 32 + cx.c) * 8 + wave] = m0;
-                    mx[((oc * 2 + 1) * 32 + cx.c) * 8 + wave] = m1;
+                    m0 = xhalf_max(m0);
+                    m1 = xhalf_max(m1);
+                    if (cx.hh == 0) {
+                        mx[((oc * 2 + 0) * 32 + cx.c) * 8 + wave] = m0;
+                        mx[((oc * 2 + 1) * 32 + cx.c) * 8 + wave] = m1;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1759,9 +1802,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
 #pragma unroll
             for (int oc = 0; oc < 4; ++oc) {
                 f32x16 K = splat(c0[32 * oc + cx.c]);
-                mmb_oc<4, 4, T16, false>(K, w0, oc, nf, lane);
                 f32x16 V = splat(c1[32 * oc + cx.c]);
-                mmb_oc<4, 4, T16, false>(V, w1, oc, nf, lane);
+                mmb_oc_pair<4, 4, T16>(K, V, w0, oc, w1, oc, nf, lane);
                 float ssum;
                 f32x8 keep;
                 partial_tile<T16>(K, V, vr_own, wg_colmax(mx, oc, s0, cx.c), cx, ssum, keep);
@@ -2407,7 +2449,7 @@ hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, 
     return e;
 }
 
-template <class T16, bool SP, bool DBG, bool STAMP, bool WGR>
+template <class T16, bool SP, bool DBG, bool STAMP, bool WGR, bool PERS = false>
 static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
@@ -2418,11 +2460,11 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
     const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
-        hipError_t e = hipFuncSetAttribute((const void*)k_layer<T16, SP, DBG, STAMP, WGR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipError_t e = hipFuncSetAttribute((const void*)k_layer<T16, SP, DBG, STAMP, WGR, PERS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    k_layer<T16, SP, DBG, STAMP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
+    k_layer<T16, SP, DBG, STAMP, WGR, PERS><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
                        (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
                        snaps, M, T, G, B, dbg, stamps, l_end, rec_stride, gbar, gerr);
     return hipGetLastError();
@@ -2440,7 +2482,13 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
         if (dbg != 0)
             e = fmt == 1 ? launch_layer_t<_Float16, false, true, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, true, false, true>(LAYER_ARGS);
         else if (stamps != nullptr)
-            e = fmt == 1 ? launch_layer_t<_Float16, false, false, true, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, false, true, true>(LAYER_ARGS);
+            e = l_end > l + 1 ? (fmt == 1 ? launch_layer_t<_Float16, false, false, true, true, true>(LAYER_ARGS)
+                                          : launch_layer_t<__bf16, false, false, true, true, true>(LAYER_ARGS))
+                              : (fmt == 1 ? launch_layer_t<_Float16, false, false, true, true>(LAYER_ARGS)
+                                          : launch_layer_t<__bf16, false, false, true, true>(LAYER_ARGS));
+        else if (l_end > l + 1)       // persistent form: its own instantiation (loop-carried residual stream)
+            e = fmt == 1 ? launch_layer_t<_Float16, false, false, false, true, true>(LAYER_ARGS)
+                         : launch_layer_t<__bf16, false, false, false, true, true>(LAYER_ARGS);
         else
             e = fmt == 1 ? launch_layer_t<_Float16, false, false, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, false, false, true>(LAYER_ARGS);
         return e;

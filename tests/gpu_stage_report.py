@@ -92,7 +92,8 @@ def main():
             tref = torch.nn.functional.linear(torch.nn.functional.silu(torch.nn.functional.linear(
                 te, p["time_embed.0.weight"], p["time_embed.0.bias"])), p["time_embed.2.weight"], p["time_embed.2.bias"])
         print(f"  temb table          {rel_l2(temb, tref):.3e}")
-        pp = unpack_kmajor(nat.debug_read("pp", np.float32, G * 32 * 64 * 8), G)[:M]
+        ppraw = nat.debug_read("pp", np.float32, G * 32 * 64 * 8).reshape(G, 32, 2, 64, 4)       # [g][ks][half][lane][4]
+        pp = unpack_kmajor(np.ascontiguousarray(ppraw.transpose(0, 1, 3, 2, 4)).reshape(-1), G)[:M]
         ppref = (taps["emb"] - tref[t][:, None, :]).reshape(M, 512)
         print(f"  linear(xf_proj)     {rel_l2(pp, ppref):.3e}")
         A, off = unpack_afrag(nat.debug_read("a_ca", np.uint16, 8 * B * 16 * 64 * 8), 8, B, prec == "fp16")
