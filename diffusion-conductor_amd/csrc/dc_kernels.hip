@@ -588,26 +588,29 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
     const int nu = u_hi - u_lo + 1;
     // unit u (tokens 256u..256u+255) intersects the clip; the clip is the unit's slot 0 iff the unit starts inside it
     auto rec_of = [&](int clip, int u) { return recs + ((size_t)u * 2 + ((u * 256 >= clip * T) ? 0 : 1)) * DC_REC_FLOATS; };
+    // All loads of the combine are issued up front, branch-free (indices clamped to a valid unit, results predicated), so that
+    // one memory round trip covers them: phase A's scalars first (they are needed first), then the K^T V blocks.
+    const int ca = (tid >> 7) & 1, f = tid & 127, ba = ub0 + ca;
+    const bool la = ba <= ub1;
+    const int bav = la ? ba : ub0;                                   // a clip that certainly has units
+    const int a_lo = (bav * T) / 256, a_hi = (min((bav + 1) * T, M) - 1) / 256;
+    const int na = la ? a_hi - a_lo + 1 : 0;
+    float mr[PRE], sr[PRE];
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+        const float* R = rec_of(bav, min(a_lo + k, a_hi));
+        mr[k] = R[f];
+        sr[k] = R[128 + f];
+    }
+    const int bv = live ? b : ub0;
+    const int v_lo = (bv * T) / 256, v_hi = (min((bv + 1) * T, M) - 1) / 256;
     f32x8 pre[PRE];
 #pragma unroll
-    for (int k = 0; k < PRE; ++k)
-        if (k < nu) pre[k] = reinterpret_cast<const f32x8*>(rec_of(b, u_lo + k) + 256)[oc * 64 + ln];
+    for (int k = 0; k < PRE; ++k) pre[k] = reinterpret_cast<const f32x8*>(rec_of(bv, min(v_lo + k, v_hi)) + 256)[oc * 64 + ln];
     if (tid < 256) {                              // phase A: per feature f of clip ca: m*, weights, normaliser
-        const int ca = tid >> 7, f = tid & 127, ba = ub0 + ca;
-        const bool la = ba <= ub1;
-        const int a_lo = la ? (ba * T) / 256 : 0, a_hi = la ? (min((ba + 1) * T, M) - 1) / 256 : -1;
-        const int na = a_hi - a_lo + 1;
-        float mr[PRE], sr[PRE];                   // the first PRE units: every load is issued before the first use
 #pragma unroll
-        for (int k = 0; k < PRE; ++k) {
-            mr[k] = 0.f;
-            sr[k] = 0.f;
-            if (k < na) {
-                const float* R = rec_of(ba, a_lo + k);
-                mr[k] = R[f];
-                sr[k] = R[128 + f];
-            }
-        }
+        for (int k = 0; k < PRE; ++k)
+            if (k >= na) sr[k] = 0.f;
         float mstar = -INFINITY;
 #pragma unroll
         for (int k = 0; k < PRE; ++k)
