@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_FLOPS = 2.5e15            # dense bf16 MFMA, MI355X
 FLOP_PER_TOKEN_STEP = 2 * 4250112   # algorithmic, hoisted (SURVEY.md section 8d / BASELINE.md section 4)
 FILM_FLOP_PER_TOKEN = 2 * 512 * 6144
+LAYER_BYTES_PER_TOKEN = 512 + 512 + 24 * 64 + 72 + 36    # k_layer, per token and layer
+PEAK_HBM_BYTES = 8.0e12                                   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def cpu_baseline(steps_sample=6):
@@ -195,17 +197,37 @@ def main():
         prof, _ = nat.profile_loop(noise, coef)
         log("profile pass done: " + ", ".join(f"{k} {v[0]:.2f}ms/{v[1]}" for k, v in prof.items()))
         tot = sum(ms for ms, _ in prof.values())
-        ms, cnt = prof["k_film_gemm"]
-        per_launch = ms / cnt * 1e-3
-        achieved = FILM_FLOP_PER_TOKEN * B * T / per_launch / 1e12
-        traffic = None       # HBM bytes per launch of this kernel from the committed PMC passes of this same command
-        tf = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tf) and (B, T, S, args.precision) == (32, 1800, 50, "fp16"):
-            traffic = json.load(open(tf)).get("k_film_gemm", {}).get("traffic_bytes")
-        line["roofline"] = {"bound": "mfma", "kernel": "k_film_gemm", "achieved": round(achieved, 1), "peak": PEAK_BF16_FLOPS / 1e12,
-                            "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_FLOPS, 4), "traffic": traffic,
-                            "avg_launch_us": round(per_launch * 1e6, 1), "launches": cnt,
-                            "time_share_by_kernel": {k: round(v[0] / tot, 3) for k, v in prof.items()}}
+        tj = {}
+        tf = os.path.join(ROOT, "profiles", "r01_traffic.json")   # HBM bytes per launch from the committed PMC passes of this command
+        if os.path.exists(tf) and (B, T, S, args.precision, args.no_eff) == (32, 1800, 50, "fp16", False):
+            tj = json.load(open(tf))
+
+        def film_roofline():
+            ms, cnt = prof["k_film_gemm"]
+            per = ms / cnt * 1e-3
+            ach = FILM_FLOP_PER_TOKEN * B * T / per / 1e12
+            return {"bound": "mfma", "kernel": "k_film_gemm", "achieved": round(ach, 1), "peak": PEAK_BF16_FLOPS / 1e12,
+                    "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16_FLOPS, 4),
+                    "traffic": tj.get("k_film_gemm", {}).get("traffic_bytes"), "avg_launch_us": round(per * 1e6, 1), "launches": cnt}
+
+        def layer_roofline():
+            # k_layer (one decoder layer for all tokens) moves per token: residual stream 512 B in + 512 B out, FiLM tiles
+            # 24 x 64 B, workgroup records 72 B out + 36 B in and runs ~0.28 MFLOP: HBM is its nearer roof
+            ms, cnt = prof["k_layer"]
+            per = ms / cnt * 1e-3
+            ach = LAYER_BYTES_PER_TOKEN * B * T / per / 1e9
+            return {"bound": "hbm", "kernel": "k_layer", "achieved": round(ach, 1), "peak": PEAK_HBM_BYTES / 1e9, "unit": "GB/s",
+                    "frac": round(ach * 1e9 / PEAK_HBM_BYTES, 4), "traffic": tj.get("k_layer", {}).get("traffic_bytes"),
+                    "avg_launch_us": round(per * 1e6, 1), "launches": cnt}
+
+        # `roofline` = the kernel with the largest share of the loop; the other of the two big kernels rides along
+        if args.no_eff or prof["k_film_gemm"][0] >= prof["k_layer"][0]:
+            line["roofline"], other = film_roofline(), (None if args.no_eff else layer_roofline())
+        else:
+            line["roofline"], other = layer_roofline(), film_roofline()
+        line["roofline"]["time_share_by_kernel"] = {k: round(v[0] / tot, 3) for k, v in prof.items()}
+        if other:
+            line["roofline_second_kernel"] = other
         if not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores) ...")
             line["cpu_baseline"] = cpu_baseline()
