@@ -1135,8 +1135,10 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
     // this launch covers rounds [round0, round0 + nround) of the NT / 16 rounds of 8 feature-tile pairs
     const int nblk = (G + 3) / 4;
     const long long nunit = (long long)nblk * nround;
-    // (whole token blocks per workgroup, all sweeping the weight rounds in lockstep for L2 locality, was measured:
-    // 5 % faster per sweep, but 450 blocks on 256 CUs need 2 full sweeps instead of 1.76 - slower overall)
+    // (measured alternatives: whole token blocks per workgroup sweeping the weight rounds in lock-step for L2 locality -
+    // 5 % faster per sweep, but 450 blocks on 256 CUs need 2 full sweeps instead of 1.76; and a balanced lock-step
+    // form, 7-8 groups per workgroup as a 4-group + 3-group sweep - fabric re-fetches of the weights gone, yet 2 %
+    // slower overall.  The sweep is bound by its own issue stream, not by where the weights come from.)
     const int u0 = (int)(nunit * blockIdx.x / gridDim.x), u1 = (int)(nunit * (blockIdx.x + 1) / gridDim.x);
     int cur_blk = -1;
     OP a0[PF], a1[PF];
