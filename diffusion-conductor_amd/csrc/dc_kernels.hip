@@ -252,6 +252,15 @@ DEV float gelu_erf(float x) {
     return 0.5f * x * (1.f + copysignf(erfa, x));
 }
 
+// XCD-aware workgroup index: blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so logical workgroup
+// ids are handed out in contiguous runs per XCD - the ~8 workgroups of a clip then share one L2 for the clip's unit
+// records and attention fragments.  Bijective for any grid size; affects speed only (placement is not guaranteed).
+DEV int wg_index() {
+    const int n = gridDim.x, b = blockIdx.x;
+    const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+    return x * q + min(x, r) + i;
+}
+
 // token group geometry shared by the per-group kernels
 struct GroupCtx {
     int g, lane, c, hh;
@@ -537,7 +546,7 @@ DEV void partial_tile(const f32x16& K, const f32x16& V, const RowRange& rr, floa
 }
 // after the barrier that follows the last partial_tile: wave w sums tile oc = w & 3 of slot w >> 2 over the waves
 DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8* pst, const f32x8* xp, const float* ss,
-                         int wave, int lane, int ub0, int G, int M, int T) {
+                         int wave, int lane, int ub0, int G, int M, int T, int wg) {
     const int oc = wave & 3, sl = wave >> 2, c = lane & 31;
     f32x8 acc;
 #pragma unroll
@@ -545,7 +554,7 @@ DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8*
     float ssum = 0.f;
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
-        const int gv = blockIdx.x * 8 + v;
+        const int gv = wg * 8 + v;
         if (gv >= G) continue;
         const int edge = (ub0 + 1) * T;                       // first token of slot 1's clip
         const int s0v = 32 * gv >= edge ? 1 : 0;              // the wave's primary slot
@@ -563,7 +572,7 @@ DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8*
             ssum += ss[(8 * 4 + oc) * 32 + c];
         }
     }
-    float* R = recs + ((size_t)blockIdx.x * 2 + sl) * DC_REC_FLOATS;
+    float* R = recs + ((size_t)wg * 2 + sl) * DC_REC_FLOATS;
     if (lane < 32) {
         R[32 * oc + c] = wg_colmax(mx, oc, sl, c);
         R[128 + 32 * oc + c] = ssum;
@@ -574,14 +583,16 @@ DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8*
 // records of the previous kernel -> af [2 clips][8 frags][64 lanes] in LDS (the 8 hi fragments k_attn_combine makes).
 // scratch (LDS): w [2][NU][128] floats, z [2][128] floats.  Summation order is fixed.
 template <class T16>
-DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scratch, int ub0, int B, int M, int T, int tid) {
+DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scratch, int ub0, int B, int M, int T, int tid, int wg,
+                         unsigned long long* st = nullptr) {
+#define CSTAMP(k) do { if (st && (tid & 63) == 0) st[(tid >> 6) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     constexpr int NU = 17, PRE = 9;               // units per clip: T <= 4032; the first PRE are loaded before the weights exist
     float* wsc = scratch;
     float* zsc = scratch + 2 * NU * 128;
     const int ci = tid >> 8, t = tid & 255, ln = t & 63, oc = t >> 6;
     const int c = ln & 31, hh = ln >> 5;
     const int b = ub0 + ci;
-    const int ub1 = (min(((int)blockIdx.x + 1) * 256, M) - 1) / T;          // last clip this workgroup touches
+    const int ub1 = (min((wg + 1) * 256, M) - 1) / T;          // last clip this workgroup touches
     const bool live = b <= ub1;
     const int u_lo = live ? (b * T) / 256 : 0;
     const int u_hi = live ? (min((b + 1) * T, M) - 1) / 256 : -1;
@@ -605,8 +616,11 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
     const int bv = live ? b : ub0;
     const int v_lo = (bv * T) / 256, v_hi = (min((bv + 1) * T, M) - 1) / 256;
     f32x8 pre[PRE];
+    if (live) {                      // wave-uniform (ci is the wave's half of the workgroup): idle halves issue nothing
 #pragma unroll
-    for (int k = 0; k < PRE; ++k) pre[k] = reinterpret_cast<const f32x8*>(rec_of(bv, min(v_lo + k, v_hi)) + 256)[oc * 64 + ln];
+        for (int k = 0; k < PRE; ++k) pre[k] = reinterpret_cast<const f32x8*>(rec_of(bv, min(v_lo + k, v_hi)) + 256)[oc * 64 + ln];
+    }
+    CSTAMP(22);
     if (tid < 256) {                              // phase A: per feature f of clip ca: m*, weights, normaliser
 #pragma unroll
         for (int k = 0; k < PRE; ++k)
@@ -635,7 +649,9 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
         }
         zsc[ca * 128 + f] = z;
     }
+    CSTAMP(23);
     __syncthreads();
+    CSTAMP(24);
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -663,6 +679,7 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], pv[j], acc[j]);
     }
+    CSTAMP(25);
     v8<T16> out, zero;
     {
         float z8[8];
@@ -1258,7 +1275,8 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
     constexpr int WM = SPLIT ? 2 : 1;
     using W = v8<T16>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int g = blockIdx.x * NW + wave;
+    const int wg = WGR ? wg_index() : (int)blockIdx.x;
+    int g = wg * NW + wave;
     const bool active = g < G;
     if (!active) g = G - 1;
     const GroupCtx cx = make_ctx(g, lane, M, T);
@@ -1306,7 +1324,7 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
         f32x8* pst = reinterpret_cast<f32x8*>(lds + 8192);
         f32x8* xp = reinterpret_cast<f32x8*>(lds + 8192 + 65536);
         float* ss = reinterpret_cast<float*>(lds + 8192 + 65536 + 8192);
-        const int ub0 = (blockIdx.x * NW * 32) / T;
+        const int ub0 = (wg * NW * 32) / T;
         const float* bk = reinterpret_cast<const float*>(wk + 32 * 64);
         const float* bv = reinterpret_cast<const float*>(wv + 32 * 64);
         const RowRange vr[2] = {valid_rows_clip(cx, ub0, B, M, T, length, active), valid_rows_clip(cx, ub0 + 1, B, M, T, length, active)};
@@ -1338,7 +1356,7 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-        wg_write_record(recs, mx, pst, xp, ss, wave, lane, ub0, G, M, T);
+        wg_write_record(recs, mx, pst, xp, ss, wave, lane, ub0, G, M, T, wg);
     }
 }
 
@@ -1573,7 +1591,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const int l_first = l;
     f32x16 h[4];
     {
-        const int g0 = min((int)(blockIdx.x * NW + (threadIdx.x >> 6)), G - 1);
+        const int g0 = min((int)((WGR ? wg_index() : (int)blockIdx.x) * NW + (threadIdx.x >> 6)), G - 1);
         load_h(h, hbuf, g0, threadIdx.x & 63);      // in flight across the first prologue
     }
 #pragma nounroll
@@ -1583,7 +1601,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     int tid_ = threadIdx.x;
     asm volatile("" : "+v"(tid_));
     const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), lane = tid_ & 63;
-    int g = blockIdx.x * NW + wave;
+    const int wg = WGR ? wg_index() : (int)blockIdx.x;
+    int g = wg * NW + wave;
     const bool active = g < G;                   // idle waves still take part in the staging and barriers
     if (!active) g = G - 1;
     const GroupCtx cx = make_ctx(g, lane, M, T);
@@ -1595,7 +1614,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const float* c1 = reinterpret_cast<const float*>(buf1 + NFW * 1024);
     // attention frags come through LDS when the workgroup can span at most 2 clips, else straight from L2
     const bool wg_lds = WGR || (!SPLIT && T >= NW * 32);       // WGR is only launched with T >= NW * 32
-    const int ub0 = (blockIdx.x * NW * 32) / T;
+    const int ub0 = (wg * NW * 32) / T;
     char* ring = lds + OFF_ER + wave * 8192;
     auto stage_attn = [&](const W* a) {          // frags of clips ub0, ub0+1 -> AF region
         const int c1i = min(ub0 + 1, B - 1);
@@ -1615,7 +1634,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(0);
     stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
     if constexpr (WGR)      // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
-        wg_combine_attn<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, M, T, threadIdx.x);
+        wg_combine_attn<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, M, T, threadIdx.x, wg,
+                             (STAMP && stamps && blockIdx.x == 3 && (l == 3 || l_end == l_first + 1)) ? stamps : nullptr);
     else if (wg_lds)
         stage_attn(a_sa);
     DC_STAMP(14);
@@ -1824,7 +1844,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             DC_STAMP(16);
             __syncthreads();
             DC_STAMP(17);
-            wg_write_record(recs_out, mx, pst, xp, ss, wave, lane, ub0, G, M, T);
+            wg_write_record(recs_out, mx, pst, xp, ss, wave, lane, ub0, G, M, T, wg);
         } else {
             f32x16 K[4];                  // keys from buf0 while the value image lands in buf1
 #pragma unroll
