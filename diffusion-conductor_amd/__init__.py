@@ -10,7 +10,8 @@ Importing the package does not touch the GPU or load the shared library.
 from .param_spec import DenoiserConfig, param_shapes  # noqa: F401
 
 __version__ = "0.1.0"
-__all__ = ["MotionTransformer", "GaussianDiffusion", "DDPMTrainer", "DenoiserConfig", "param_shapes"]
+__all__ = ["MotionTransformer", "GaussianDiffusion", "DDPMTrainer", "DenoiserConfig", "param_shapes", "evaluate_dataset",
+           "smooth_motion"]
 
 
 def __getattr__(name):   # lazy: torch is only imported when the classes are used
@@ -23,4 +24,7 @@ def __getattr__(name):   # lazy: torch is only imported when the classes are use
     if name == "DDPMTrainer":
         from .harness import DDPMTrainer
         return DDPMTrainer
+    if name in ("evaluate_dataset", "smooth_motion", "mse_loss", "list_clips"):
+        from . import evaluate
+        return getattr(evaluate, name)
     raise AttributeError(name)

@@ -2,6 +2,7 @@
 // hipGraph capture/replay and the C ABI declared in include/dc_ddim.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -938,6 +939,80 @@ int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t B, int32_
     const hipError_t e = dc_music_encode(s->music, d_mel, B, Tm, d_xf_proj, d_xf_out, st, &err);
     if (e != hipSuccess) return fail(DC_ERR_HIP, "encode_music: %s %s", hipGetErrorString(e), err.c_str());
     return sync_out(s, user);
+}
+
+// Hat matrix H = A (A^T A)^-1 A^T of the degree-`order` polynomial fit over `window` equally spaced samples, fp64 normal
+// equations with positions centred and scaled to [-1, 1] (well conditioned for the window sizes in use).
+int dc_savgol_coefficients(int32_t window, int32_t order, float* h_coef) {
+    if (window < 3 || !(window & 1) || window > 99 || order < 0 || order >= window || order > 10 || !h_coef)
+        return fail(DC_ERR_INVALID, "savgol: need an odd window in [3,99] and 0 <= order < window (order <= 10)");
+    const int w = window, n = order + 1, hw = w / 2;
+    std::vector<double> A((size_t)w * n), G((size_t)n * n, 0.0), Ginv((size_t)n * n, 0.0);
+    for (int i = 0; i < w; ++i) {
+        const double u = (double)(i - hw) / hw;
+        double pw = 1.0;
+        for (int j = 0; j < n; ++j) {
+            A[(size_t)i * n + j] = pw;
+            pw *= u;
+        }
+    }
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {
+            double acc = 0.0;
+            for (int i = 0; i < w; ++i) acc += A[(size_t)i * n + a] * A[(size_t)i * n + b];
+            G[(size_t)a * n + b] = acc;
+        }
+    // Gauss-Jordan inverse with partial pivoting (n <= 11)
+    std::vector<double> M((size_t)n * 2 * n, 0.0);
+    for (int a = 0; a < n; ++a) {
+        for (int b = 0; b < n; ++b) M[(size_t)a * 2 * n + b] = G[(size_t)a * n + b];
+        M[(size_t)a * 2 * n + n + a] = 1.0;
+    }
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < n; ++r)
+            if (std::fabs(M[(size_t)r * 2 * n + c]) > std::fabs(M[(size_t)piv * 2 * n + c])) piv = r;
+        if (std::fabs(M[(size_t)piv * 2 * n + c]) < 1e-300) return fail(DC_ERR_INVALID, "savgol: singular normal equations");
+        if (piv != c)
+            for (int k = 0; k < 2 * n; ++k) std::swap(M[(size_t)piv * 2 * n + k], M[(size_t)c * 2 * n + k]);
+        const double d = M[(size_t)c * 2 * n + c];
+        for (int k = 0; k < 2 * n; ++k) M[(size_t)c * 2 * n + k] /= d;
+        for (int r = 0; r < n; ++r)
+            if (r != c) {
+                const double f = M[(size_t)r * 2 * n + c];
+                if (f != 0.0)
+                    for (int k = 0; k < 2 * n; ++k) M[(size_t)r * 2 * n + k] -= f * M[(size_t)c * 2 * n + k];
+            }
+    }
+    for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) Ginv[(size_t)a * n + b] = M[(size_t)a * 2 * n + n + b];
+    for (int i = 0; i < w; ++i)
+        for (int k = 0; k < w; ++k) {
+            double acc = 0.0;
+            for (int a = 0; a < n; ++a) {
+                double t = 0.0;
+                for (int b = 0; b < n; ++b) t += Ginv[(size_t)a * n + b] * A[(size_t)k * n + b];
+                acc += A[(size_t)i * n + a] * t;
+            }
+            h_coef[(size_t)i * w + k] = (float)acc;
+        }
+    return DC_OK;
+}
+
+int dc_savgol_filter(const float* d_in, float* d_out, int32_t B, int32_t T, int32_t P, int32_t window, int32_t order, void* stream) {
+    if (!d_in || !d_out || d_in == d_out || B < 1 || P < 1) return fail(DC_ERR_INVALID, "savgol: bad arguments (in-place is not supported)");
+    if (T < window) return fail(DC_ERR_INVALID, "savgol: T=%d shorter than the window %d", T, window);
+    std::vector<float> coef((size_t)window * window);
+    int rc = dc_savgol_coefficients(window, order, coef.data());
+    if (rc) return rc;
+    float* d_coef = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMallocAsync((void**)&d_coef, coef.size() * 4, st));
+    HIP_TRY(hipMemcpyAsync(d_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));          // `coef` is pageable host memory
+    HIP_TRY(dc_launch_savgol(st, d_in, d_out, d_coef, B, T, P, window));
+    HIP_TRY(hipFreeAsync(d_coef, st));
+    return DC_OK;
 }
 
 int dc_sampler_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timesteps, float* d_out, void* stream) {

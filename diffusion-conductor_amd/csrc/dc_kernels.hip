@@ -2570,3 +2570,40 @@ hipError_t dc_launch_ca_kv(hipStream_t st, int fmt, const DcModel* dm, const voi
         k_cond_ca_kv<__bf16><<<grid, dim3(256), 0, st>>>(dm, (const bf16x8*)nh_hi, (const bf16x8*)nh_lo, (bf16x8*)kv_ca, M, T, G, B, KT);
     return hipGetLastError();
 }
+
+// ---- post-processing: Savitzky-Golay smoothing of the sampled poses (tools/visualization.py:20-26, applied with
+// kernel=19, order=5 at :126; scipy.signal.savgol_filter, mode="interp") --------------------------------------------------
+// Along time, per clip and pose channel: interior frames are a fixed `win`-tap FIR; the first / last win/2 frames are
+// the least-squares polynomial of the first / last `win` frames evaluated at their own positions, i.e. rows of the
+// same hat matrix H = A pinv(A).  coef: H row-major [win][win] fp32 (row win/2 = the FIR).  One thread per output value;
+// consecutive threads walk the channel axis, so every tap is a coalesced row read.  HBM-bound: 2 x 4 bytes per value.
+__global__ __launch_bounds__(256) void k_savgol(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ coef,
+                                                int B, int T, int P, int win) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)B * T * P) return;
+    const int p = (int)(idx % P);
+    const int t = (int)((idx / P) % T);
+    const int b = (int)(idx / ((long long)P * T));
+    const int h = win >> 1;
+    int row, t0;                        // hat-matrix row to apply and first frame of the window it applies to
+    if (t < h) {
+        row = t;
+        t0 = 0;
+    } else if (t >= T - h) {
+        row = win - (T - t);
+        t0 = T - win;
+    } else {
+        row = h;
+        t0 = t - h;
+    }
+    const float* c = coef + row * win;
+    const float* src = x + ((size_t)b * T + t0) * P + p;
+    float acc = 0.f;
+    for (int k = 0; k < win; ++k) acc = fmaf(c[k], src[(size_t)k * P], acc);
+    y[idx] = acc;
+}
+hipError_t dc_launch_savgol(hipStream_t st, const float* x, float* y, const float* coef, int B, int T, int P, int win) {
+    const long long n = (long long)B * T * P;
+    k_savgol<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(x, y, coef, B, T, P, win);
+    return hipGetLastError();
+}

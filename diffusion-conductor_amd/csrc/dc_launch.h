@@ -43,3 +43,6 @@ hipError_t dc_launch_layer_full(hipStream_t st, int fmt, const DcModel* dm, int 
                                 const void* kv_cur, void* kv_next, const void* kv_ca, const int* length, const float* xin,
                                 float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps, int M,
                                 int T, int B, int KT, int stop_after);
+
+// Savitzky-Golay smoothing along time of [B][T][P] fp32 (coef: hat matrix [win][win]); y != x
+hipError_t dc_launch_savgol(hipStream_t st, const float* x, float* y, const float* coef, int B, int T, int P, int win);

@@ -22,7 +22,7 @@ EXPORTS = [
     "dc_sampler_create", "dc_sampler_destroy", "dc_sampler_set_param", "dc_sampler_finalize_params",
     "dc_sampler_set_conditioning", "dc_sampler_encode_music", "dc_sampler_denoise", "dc_sampler_ddim_loop", "dc_sampler_profile_loop",
     "dc_kernel_name", "dc_kernel_count", "dc_sampler_workspace_bytes", "dc_sampler_debug_denoise",
-    "dc_sampler_debug_read",
+    "dc_sampler_debug_read", "dc_savgol_coefficients", "dc_savgol_filter",
 ]
 
 
@@ -83,6 +83,8 @@ def lib():
     L.dc_sampler_encode_music.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                           C.c_void_p]
     L.dc_sampler_denoise.argtypes = [C.c_void_p, C.c_void_p, ip, C.c_void_p, C.c_void_p]
+    L.dc_savgol_coefficients.argtypes = [C.c_int32, C.c_int32, fp]
+    L.dc_savgol_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.dc_sampler_ddim_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, fp, ip, C.c_int32, C.c_void_p, C.c_void_p]
     L.dc_sampler_debug_denoise.argtypes = [C.c_void_p, C.c_void_p, ip, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.dc_sampler_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
@@ -121,6 +123,26 @@ def ddim_coefficients(alphas_cumprod: np.ndarray) -> np.ndarray:
     ac = np.ascontiguousarray(alphas_cumprod, np.float64)
     out = np.empty((ac.shape[0], 4), np.float32)
     _check(lib().dc_ddim_coefficients(ac.shape[0], ac.ctypes.data_as(C.POINTER(C.c_double)), _fptr(out)))
+    return out
+
+
+def savgol_coefficients(window: int, order: int) -> np.ndarray:
+    """dc_savgol_coefficients: the [window, window] hat matrix (host only)."""
+    out = np.empty((window, window), np.float32)
+    _check(lib().dc_savgol_coefficients(int(window), int(order), _fptr(out)))
+    return out
+
+
+def savgol_filter(poses, window: int = 19, order: int = 5):
+    """dc_savgol_filter on a CUDA(ROCm) fp32 tensor [B, T, P] (or [B, T, J, 2]); returns a new tensor."""
+    import torch
+    assert poses.is_cuda and poses.dtype == torch.float32
+    x = poses.contiguous()
+    B, T = x.shape[0], x.shape[1]
+    P = x.numel() // (B * T)
+    out = torch.empty_like(x)
+    _check(lib().dc_savgol_filter(x.data_ptr(), out.data_ptr(), B, T, P, int(window), int(order),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return out
 
 

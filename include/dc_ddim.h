@@ -170,6 +170,15 @@ int dc_sampler_debug_denoise(dc_sampler* s, const float* d_x, const int32_t* h_t
                              int32_t n_layers, int32_t stage, void* stream);
 int dc_sampler_debug_read(dc_sampler* s, const char* what, void* h_out, int64_t nbytes);
 
+/* Post-processing of the sampled poses as tools/visualization.py applies it (smooth_motion :20-26, called with kernel=19,
+ * order 5 at :126): scipy.signal.savgol_filter(mode="interp") along time for every pose channel.
+ * dc_savgol_coefficients: host only; h_coef receives the [window][window] hat matrix of the polynomial fit (row window/2 =
+ * the FIR taps, rows 0..window/2-1 and window/2+1.. the edge frames).  dc_savgol_filter: d_in, d_out fp32 [B, T, P] device
+ * pointers (distinct), T >= window. */
+int dc_savgol_coefficients(int32_t window, int32_t order, float* h_coef);
+int dc_savgol_filter(const float* d_in, float* d_out, int32_t B, int32_t T, int32_t P, int32_t window, int32_t order,
+                     void* stream);
+
 /* Introspection used by tests: bytes of device workspace currently held. */
 int64_t dc_sampler_workspace_bytes(const dc_sampler* s);
 

@@ -311,3 +311,50 @@ def test_no_eff_long_clip_vs_oracle(model_no_eff):
     err = rel_l2(out, ref)
     print(f"no_eff T=1800 forward rel-L2 {err:.3e}")
     assert err <= 5e-3
+
+
+# ---- post-processing and the batched evaluation driver ------------------------------------------
+def test_savgol_smoothing_matches_scipy():
+    """smooth_motion (tools/visualization.py:20-26, kernel 19, order 5) on the GPU vs scipy.signal.savgol_filter."""
+    from scipy.signal import savgol_filter
+    from diffusion_conductor_amd.evaluate import smooth_motion
+    x = torch.from_numpy(batch_noise(3, 1800)).view(3, 1800, 13, 2)
+    for kernel in (19, 11):
+        y = smooth_motion(x.cuda(), kernel=kernel)
+        ref = savgol_filter(x.numpy().astype(np.float64), kernel, 5, axis=1)
+        err = rel_l2(y, ref)
+        print(f"savgol kernel {kernel}: rel-L2 {err:.2e}")
+        assert tuple(y.shape) == (3, 1800, 13, 2) and err <= 1e-5
+    one = smooth_motion(x[0].cuda(), kernel=19)                     # the reference's [T, 13, 2] form
+    assert torch.equal(one, smooth_motion(x.cuda(), kernel=19)[0])
+
+
+def test_batched_evaluation_driver(models, tmp_path):
+    """evaluate_dataset on a 5-clip dataset in the reference's on-disk format: per-clip MSE against the oracle's
+    prediction for the same mel and noise, independent of the batch size (30-s clips, DDIM-25)."""
+    import types
+    from diffusion_conductor_amd import DDPMTrainer
+    from diffusion_conductor_amd import evaluate as ev
+    rng = np.random.default_rng(5)
+    mels = batch_mel(5, 810)                                          # 9 s of mel -> T = 270 frames
+    for i in range(5):
+        d = tmp_path / f"{i:03d}"
+        d.mkdir()
+        np.save(d / "mel.npy", mels[i])
+        np.save(d / "motion.npy", rng.standard_normal((270, 13, 2)).astype(np.float32))
+    opt = types.SimpleNamespace(device=torch.device("cuda:0"), diffusion_steps=25, is_train=False)
+    tr = DDPMTrainer(opt, models["fp16"])
+    tr.eval_mode()
+    a = ev.evaluate_dataset(tr, str(tmp_path), 26, batch_size=4, seed=11, verbose=False)
+    b = ev.evaluate_dataset(tr, str(tmp_path), 26, batch_size=5, seed=11, verbose=False)
+    assert list(a["per_clip"]) == [f"{i:03d}" for i in range(5)]
+    p = oracle_params()
+    noise = torch.stack([ev.clip_noise(11, i, 270, 26) for i in range(5)])
+    with torch.no_grad():
+        ref = O.generate_music_motion(p, torch.from_numpy(mels), 26, 25, noise)
+    for i in range(5):
+        gt = np.load(tmp_path / f"{i:03d}" / "motion.npy")
+        want = float(ev.mse_loss(gt, ref[i].numpy().reshape(270, 13, 2)))
+        assert abs(a["per_clip"][f"{i:03d}"] - want) <= 2e-3 * want
+        assert abs(b["per_clip"][f"{i:03d}"] - a["per_clip"][f"{i:03d}"]) <= 2e-3 * want
+    print(f"evaluation driver: final_mse {a['final_mse']:.5f}, {a['frames_per_s']:.0f} frames/s")

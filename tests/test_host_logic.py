@@ -168,3 +168,51 @@ def test_shard_bounds_partition():
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_savgol_coefficients_match_scipy():
+    """dc_savgol_coefficients (host) vs scipy.signal: row window/2 of the hat matrix is savgol_coeffs, and the edge rows
+    reproduce savgol_filter(mode="interp") on unit impulses (tools/visualization.py:20-26 uses kernel 19 / 11, order 5)."""
+    from scipy.signal import savgol_coeffs, savgol_filter
+    from diffusion_conductor_amd import native
+    for w, o in ((19, 5), (11, 5), (5, 2)):
+        H = native.savgol_coefficients(w, o).astype(np.float64)
+        assert np.allclose(H[w // 2], savgol_coeffs(w, o, use="dot"), atol=2e-6)
+        eye = np.eye(w)
+        ref = savgol_filter(eye, w, o, axis=0, mode="interp")       # column k = response to an impulse at k
+        assert np.allclose(H, ref, atol=2e-6), (w, o)
+    with pytest.raises(native.DcError):
+        native.savgol_coefficients(18, 5)
+
+
+def test_evaluate_dataset_host_logic(tmp_path):
+    """Directory walk, batching, noise independence of batch size and the reference's MSE bookkeeping
+    (eval_new.py:104-134) with a stand-in sampler (no GPU)."""
+    import torch
+    from diffusion_conductor_amd import evaluate as ev
+    rng = np.random.default_rng(0)
+    for i in (3, 1, 2, 10):
+        d = tmp_path / f"clip{i:02d}"
+        d.mkdir()
+        np.save(d / "mel.npy", rng.random((270, 128), dtype=np.float32))
+        np.save(d / "motion.npy", rng.standard_normal((90, 13, 2)).astype(np.float32))
+    (tmp_path / "stray").mkdir()                     # no npy files: skipped
+    assert ev.list_clips(str(tmp_path)) == ["clip01", "clip02", "clip03", "clip10"]
+
+    class FakeTrainer:
+        calls = []
+
+        def generate_music_motion(self, mel, dim_pose, noise=None, **kw):
+            self.calls.append(mel.shape[0])
+            return noise * 0.5 + mel[:, ::3, :dim_pose]      # any deterministic per-clip function of (mel, noise)
+
+    a = ev.evaluate_dataset(FakeTrainer(), str(tmp_path), 26, batch_size=3, seed=7, verbose=False)
+    b = ev.evaluate_dataset(FakeTrainer(), str(tmp_path), 26, batch_size=1, seed=7, verbose=False)
+    assert a["clips"] == 4 and FakeTrainer.calls[:2] == [3, 1]
+    assert a["per_clip"] == b["per_clip"] and abs(a["final_mse"] - b["final_mse"]) < 1e-6
+    # the reference's arithmetic for one clip
+    mel = np.load(tmp_path / "clip02" / "mel.npy")
+    pred = (ev.clip_noise(7, 1, 90, 26) * 0.5 + torch.from_numpy(mel)[::3, :26]).numpy().reshape(90, 13, 2)
+    assert a["per_clip"]["clip02"] == float(ev.mse_loss(np.load(tmp_path / "clip02" / "motion.npy"), pred))
+    # like the reference, the running total stays in the precision of the per-clip values (float32 numpy scalars)
+    assert abs(a["total_loss"] - sum(a["per_clip"][k] for k in sorted(a["per_clip"]))) < 1e-5
