@@ -228,7 +228,7 @@ def main():
         line["roofline"]["time_share_by_kernel"] = {k: round(v[0] / tot, 3) for k, v in prof.items()}
         if other:
             line["roofline_second_kernel"] = other
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # contract: rank 0 at N=1 only
             log("cpu baseline (oracle on host cores) ...")
             line["cpu_baseline"] = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
