@@ -1824,23 +1824,34 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             DC_STAMP(12);
             const int s0 = cx.b0 - ub0;
             const RowRange vr_own = s0 ? vr1 : vr0;
+            // software-pipelined over the four feature tiles: the projections of tile oc+1 (MFMA) are issued ahead of
+            // the exponentials / packing of tile oc (VALU)
+            f32x16 Kc = splat(c0[cx.c]), Vc = splat(c1[cx.c]);
+            mmb_oc_pair<4, 4, T16>(Kc, Vc, w0, 0, w1, 0, nf, lane);
 #pragma unroll
             for (int oc = 0; oc < 4; ++oc) {
-                f32x16 K = splat(c0[32 * oc + cx.c]);
-                f32x16 V = splat(c1[32 * oc + cx.c]);
-                mmb_oc_pair<4, 4, T16>(K, V, w0, oc, w1, oc, nf, lane);
+                f32x16 Kn, Vn;
+                if (oc < 3) {
+                    Kn = splat(c0[32 * (oc + 1) + cx.c]);
+                    Vn = splat(c1[32 * (oc + 1) + cx.c]);
+                    mmb_oc_pair<4, 4, T16>(Kn, Vn, w0, oc + 1, w1, oc + 1, nf, lane);
+                }
                 float ssum;
                 f32x8 keep;
-                partial_tile<T16>(K, V, vr_own, wg_colmax(mx, oc, s0, cx.c), cx, ssum, keep);
+                partial_tile<T16>(Kc, Vc, vr_own, wg_colmax(mx, oc, s0, cx.c), cx, ssum, keep);
                 pst[(wave * 4 + oc) * 64 + lane] = keep;
                 if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssum;
                 if (active && cx.straddle) {
-                    partial_tile<T16>(K, V, vr1, wg_colmax(mx, oc, 1, cx.c), cx, ssum, keep);
+                    partial_tile<T16>(Kc, Vc, vr1, wg_colmax(mx, oc, 1, cx.c), cx, ssum, keep);
                     xp[oc * 64 + lane] = keep;
                     if (cx.hh == 0) ss[(8 * 4 + oc) * 32 + cx.c] = ssum;
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (oc < 3) {
+                    Kc = Kn;
+                    Vc = Vn;
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
             DC_STAMP(16);
             __syncthreads();
             DC_STAMP(17);
