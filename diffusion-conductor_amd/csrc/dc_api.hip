@@ -596,10 +596,12 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const int nround_all = s->NT / 16;                       // a layer owns 12 tile pairs = 1.5 rounds of 8
     int chunks = (sf || film_chunks_env < 1 || L % film_chunks_env || ((L / film_chunks_env) & 1)) ? 1 : film_chunks_env;
     const int lpc = L / chunks;                              // layers per chunk (even)
+    static const bool want_stamps_film = getenv("DC_STAMPS") != nullptr;       // clock stamps land in stamp slots 28..31 of wave 7
     auto film_chunk = [&](int c) -> int {
         LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->h_model.film_g, s->h_model.film_beta,
                                            s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, c * lpc * 3 / 2, chunks == 1 ? nround_all : lpc * 3 / 2,
-                                           fuse_silu ? s->d_pp : nullptr, s->h_model.temb, s->d_t_clip, T, B));
+                                           fuse_silu ? s->d_pp : nullptr, s->h_model.temb, s->d_t_clip, T, B,
+                                           want_stamps_film ? s->d_stamps + 252 : nullptr));
         return DC_OK;
     };
     { int rc = film_chunk(0); if (rc) return rc; }

@@ -1139,10 +1139,17 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
                                                        const float* __restrict__ g_ft, const float* __restrict__ beta_ft,
                                                        const v8<T16>* __restrict__ S, f16x16* __restrict__ E, int G, int NT, int round0,
                                                        int nround, const float* __restrict__ pp, const float* __restrict__ temb,
-                                                       const int* __restrict__ t_clip, int T, int B) {
+                                                       const int* __restrict__ t_clip, int T, int B, int abl,
+                                                       unsigned long long* __restrict__ clk) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using OP = v8<T16>;
     constexpr int PF = 4;       // measured: 8 (with the 256-register budget it needs) is 25 % slower
+    // diagnostic (clk == nullptr normally): core-clock and 100-MHz stamps around one workgroup's whole sweep give the
+    // clock the chip actually holds under this kernel (MI355X_MICROARCH.md, DVFS give-back item 6)
+    if (clk && blockIdx.x == 5 && threadIdx.x == 0) {
+        clk[0] = __builtin_amdgcn_s_memtime();
+        clk[1] = __builtin_amdgcn_s_memrealtime();
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hh = lane >> 5;
     const OP* slab = reinterpret_cast<const OP*>(lds);
@@ -1159,7 +1166,8 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
     const int u0 = (int)(nunit * blockIdx.x / gridDim.x), u1 = (int)(nunit * (blockIdx.x + 1) / gridDim.x);
     int cur_blk = -1;
     OP a0[PF], a1[PF];
-    auto wbase = [&](int u) { return W + (size_t)(2 * ((round0 + u % nround) * 8 + wave)) * DC_KS_E * 64 + lane; };
+    // abl & 1 (timing experiment, garbage results): every round reads the same 8 tile pairs - weights always cache-resident
+    auto wbase = [&](int u) { return W + (size_t)(2 * ((abl & 1 ? 0 : (round0 + u % nround)) * 8 + wave)) * DC_KS_E * 64 + lane; };
     if (u0 < u1) {
         const OP* w0 = wbase(u0);
 #pragma unroll
@@ -1218,7 +1226,7 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
                 const int ksn = (ks0 + q + 1) & (DC_KS_E - 1);              // next k-step (wraps harmlessly at the end)
                 if ((q & 1) == 0) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) bB[g] = slab[(g * DC_KS_E + ksn) * 64 + lane];
+                    for (int g = 0; g < 4; ++g) bB[g] = slab[(g * DC_KS_E + ((abl & 2) ? 0 : ksn)) * 64 + lane];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         acc[0][g] = mfma(a0[q], bA[g], acc[0][g]);
@@ -1226,7 +1234,7 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
                     }
                 } else {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) bA[g] = slab[(g * DC_KS_E + ksn) * 64 + lane];
+                    for (int g = 0; g < 4; ++g) bA[g] = slab[(g * DC_KS_E + ((abl & 2) ? 0 : ksn)) * 64 + lane];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         acc[0][g] = mfma(a0[q], bB[g], acc[0][g]);
@@ -1255,9 +1263,14 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
                 og[r] = (_Float16)(fmaf(gg[r], sc1, -1.f));
                 oh[r] = (_Float16)(fmaf(be[r], sc1, acc[1][g][r] + bh[r]));
             }
+            if (abl & 4) continue;                                  // timing experiment: no output stores
             store_etile(E, (size_t)(g0 + g) * NT + blk * 8 + t, lane, og);
             store_etile(E, (size_t)(g0 + g) * NT + blk * 8 + 4 + t, lane, oh);
         }
+    }
+    if (clk && blockIdx.x == 5 && threadIdx.x == 0) {
+        clk[2] = __builtin_amdgcn_s_memtime();
+        clk[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -2431,7 +2444,7 @@ static void launch_film_t(hipStream_t st, const void* W, const float* bias_ft, c
 template <class T16>
 static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bias_ft, const float* g_ft, const float* beta_ft,
                                  const void* s_hi, void* E, int G, int NT, int round0, int nround, const float* pp, const float* temb,
-                                 const int* t_clip, int T, int B) {
+                                 const int* t_clip, int T, int B, unsigned long long* clk) {
     const size_t shm = 4 * DC_KS_E * 1024;
     static bool attr_set = false;
     if (!attr_set) {
@@ -2442,16 +2455,17 @@ static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bia
     static const int ncu = [] { hipDeviceProp_t p; int d = 0; hipGetDevice(&d); hipGetDeviceProperties(&p, d); return p.multiProcessorCount; }();
     const int nblk = (G + 3) / 4;
     k_film_gemm2<T16><<<dim3(nblk < ncu ? nblk : ncu), dim3(512), shm, st>>>((const v8<T16>*)W, bias_ft, g_ft, beta_ft,
-                                                                (const v8<T16>*)s_hi, (f16x16*)E, G, NT, round0, nround, pp, temb, t_clip, T, B);
+                                                                (const v8<T16>*)s_hi, (f16x16*)E, G, NT, round0, nround, pp, temb, t_clip, T, B,
+                                                                getenv("DC_FILM_ABL") ? atoi(getenv("DC_FILM_ABL")) : 0, clk);
     return hipGetLastError();
 }
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const float* g_ft,
                                const float* beta_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
-                               int nround, const float* pp, const float* temb, const int* t_clip, int T, int B) {
+                               int nround, const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk) {
     static const bool use_v1 = getenv("DC_FILM_V1") != nullptr;
     if (!split && !use_v1)
-        return fmt == 1 ? launch_film2_t<_Float16>(st, W, bias_ft, g_ft, beta_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B)
-                        : launch_film2_t<__bf16>(st, W, bias_ft, g_ft, beta_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B);
+        return fmt == 1 ? launch_film2_t<_Float16>(st, W, bias_ft, g_ft, beta_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk)
+                        : launch_film2_t<__bf16>(st, W, bias_ft, g_ft, beta_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk);
     if (round0 != 0) return hipSuccess;        // the v1 / split kernels compute all rounds in their first launch
     DISPATCH(fmt, split, (launch_film_t<T16, SP>(st, W, bias_ft, g_ft, beta_ft, s_hi, s_lo, E, G, NT)));
     return LAUNCH_CHECK();

@@ -36,3 +36,6 @@ print("                    ->phase A done    " + seg(22, 23))
 print("                    ->barrier         " + seg(23, 24))
 print("                    ->FMAs done       " + seg(24, 25))
 print("                    ->frags written   " + seg(25, 14))
+ck = nat.debug_read("stamps", np.uint64, 8 * 32).astype(np.int64)[252:256]
+if ck[3] > ck[1]:
+    print(f"k_film_gemm workgroup 5: {(ck[3] - ck[1]) / 100.0:.1f} us, core clock {(ck[2] - ck[0]) / (ck[3] - ck[1]) * 100.0:.0f} MHz")
