@@ -2036,6 +2036,14 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
 #pragma unroll
         for (int t = 0; t < 4; ++t) make_frag<T16, false>(q[t], qf[t]);
     }
+    // the 8 query fragments live in this wave's own 8 KiB of LDS during the key loop (32 VGPRs the loop cannot afford:
+    // kept in registers they were spilled to scratch and reloaded once per head and key tile)
+    v8<T16>* qs = reinterpret_cast<v8<T16>*>(lds + 32768 + wave * 8192);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        qs[(2 * t) * 64 + lane] = qf[t].hi[0];
+        qs[(2 * t + 1) * 64 + lane] = qf[t].hi[1];
+    }
     f32x16 Y[4];
     float mx[8], ls[8];
 #pragma unroll
@@ -2073,7 +2081,7 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
 #pragma unroll
                 for (int sh = 0; sh < 2; ++sh) {
                     const int hd = 2 * t + sh;
-                    f32x16 S = mfma(fr[hd * 64 + lane], qf[t].hi[sh], splat(0.f));
+                    f32x16 S = mfma(fr[hd * 64 + lane], qs[hd * 64 + lane], splat(0.f));
                     if (edge) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
@@ -2089,19 +2097,23 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
 #pragma unroll
                     for (int r = 1; r < 16; ++r) mt = fmaxf(mt, S[r]);
                     mt = xhalf_max(mt);
-                    const float mn = fmaxf(mx[hd], mt);
-                    const float alpha = exp2f_fast((mx[hd] - mn) * LOG2E);
-                    mx[hd] = mn;
-                    const float ml = mn * LOG2E;
+                    // the running maximum rarely moves after the first key tiles: rescale only when some lane's did (wave-uniform)
+                    if (__builtin_amdgcn_ballot_w64(mt > mx[hd]) != 0) {
+                        const float mn = fmaxf(mx[hd], mt);
+                        const float alpha = exp2f_fast((mx[hd] - mn) * LOG2E);
+                        mx[hd] = mn;
+                        ls[hd] *= alpha;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) Y[t][8 * sh + r] *= alpha;
+                    }
+                    const float ml = mx[hd] * LOG2E;
                     float sum = 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         S[r] = exp2f_fast(fmaf(S[r], LOG2E, -ml));
                         sum += S[r];
                     }
-                    ls[hd] = fmaf(ls[hd], alpha, sum);
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) Y[t][8 * sh + r] *= alpha;
+                    ls[hd] += sum;
                     XFrag<T16, false> pf;
                     make_frag<T16, false>(S, pf);
                     // value rows (features) of the other head of the pair contribute nothing
@@ -2561,10 +2573,16 @@ static hipError_t launch_full_t(hipStream_t st, int which, const DcModel* dm, in
                                 const float* xin, float* xout, int out_mode, const float* coef_cur, const int* snap_cur,
                                 float* snaps, int M, int T, int B, int KT, int stop_after) {
     const int WPC = (KT + 7) / 8;
+    static bool attr_set = false;
+    if (!attr_set) {   // key-tile double buffer (32 KiB) + per-wave query fragments (64 KiB) > 64 KiB of dynamic LDS
+        hipError_t e = hipFuncSetAttribute((const void*)k_layer_full<T16>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 + 8 * 8192);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     if (which == 0)
         k_embed_front_full<T16><<<dim3(B * WPC), dim3(512), 0, st>>>(dm, x, hbuf, (v8<T16>*)kv_next, M, T, KT, WPC);
     else
-        k_layer_full<T16><<<dim3(B * WPC), dim3(512), 32768, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const v8<T16>*)kv_cur,
+        k_layer_full<T16><<<dim3(B * WPC), dim3(512), 32768 + 8 * 8192, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const v8<T16>*)kv_cur,
                                                                    (v8<T16>*)kv_next, (const v8<T16>*)kv_ca, length, xin, xout,
                                                                    out_mode, coef_cur, snap_cur, snaps, M, T, B, KT, WPC,
                                                                    stop_after);
