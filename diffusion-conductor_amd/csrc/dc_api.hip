@@ -630,7 +630,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     // (measured at bs=32 x 1800: ~2 ms per DDIM-50 loop SLOWER than per-layer launches - the grid barrier costs more than
     // the residual stream's HBM round trip and the launch edges it saves - so it is opt-in: DC_PERSIST=1)
     const bool want_persist = getenv("DC_PERSIST") != nullptr;      // (read per call: the tests toggle it)
-    const bool persistent = want_persist && wgr && nwg <= s->num_cu && nl_run == L && s->dbg_stage == 0 && !ablate && !no_persist && L > 1;
+    const bool persistent = want_persist && chunks == 1 && wgr && nwg <= s->num_cu && nl_run == L && s->dbg_stage == 0 && !ablate && !no_persist && L > 1;
     if (persistent) {
         HIP_TRY(hipMemsetAsync(s->d_gbar, 0, 4, st));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, 0, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
@@ -639,6 +639,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         return DC_OK;
     }
     for (int l = 0; l < nl_run; ++l) {
+        if (l > 0 && l % lpc == 0) { int rc = film_chunk(l / lpc); if (rc) return rc; }
         const int dbg = ((l == nl_run - 1) ? s->dbg_stage : 0) | ablate;
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
