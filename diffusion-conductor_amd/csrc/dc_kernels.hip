@@ -1182,19 +1182,35 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
         if (tb != cur_blk) {
             __syncthreads();                                      // everyone is done with the previous slab
             // slab: frag (g, ks) at [(g*32 + ks)]; groups past the end alias the last one (their stores are skipped)
-            if (pp) {
+            if (abl & 8) {
+                // timing experiment: no slab fill at all
+            } else if (pp) {
                 // fused operand production (was k_silu_emb): S = SiLU(temb[t_clip] + linear(xf_proj)) (transformer.py:73-74,482)
                 // straight from the fp32 fragment image into the slab - saves the 16-bit image's HBM round trip
                 v8<T16>* slab_w = reinterpret_cast<v8<T16>*>(lds);
-                for (int f = wave; f < 4 * DC_KS_E; f += 8) {      // (batching these loads 4 deep spilled and ran slower)
-                    const int gg = min(g0 + (f >> 5), G - 1), ks = f & 31;
-                    const int b = min((gg * 32 + (lane & 31)) / T, B - 1);
-                    const f32x8 pv = ld_pp(pp, (size_t)gg * DC_KS_E + ks, lane);
-                    const f32x8 tv = *reinterpret_cast<const f32x8*>(temb + (size_t)t_clip[b] * 512 + 16 * ks + 8 * (lane >> 5));
-                    v8<T16> hi;
+                // a wave fills fragments f = wave + 8i, i < 16.  The loads of 8 fragments are issued before the first SiLU:
+                // one by one (load, SiLU, write) the fill exposed 16 HBM latencies per slab = 16 % of the kernel
+#pragma unroll 1
+                for (int half = 0; half < 2; ++half) {
+                    f32x8 pv[8], tv[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) hi[j] = (T16)silu(pv[j] + tv[j]);
-                    slab_w[f * 64 + lane] = hi;
+                    for (int i = 0; i < 8; ++i) {
+                        const int f = wave + 8 * (8 * half + i);
+                        const int gg = min(g0 + (f >> 5), G - 1), ks = f & 31;
+                        const int b = min((gg * 32 + (lane & 31)) / T, B - 1);
+                        pv[i] = ld_pp(pp, (size_t)gg * DC_KS_E + ks, lane);
+                        tv[i] = *reinterpret_cast<const f32x8*>(temb + (size_t)t_clip[b] * 512 + 16 * ks + 8 * (lane >> 5));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int f = wave + 8 * (8 * half + i);
+                        v8<T16> hi;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) hi[j] = (T16)silu(pv[i][j] + tv[i][j]);
+                        slab_w[f * 64 + lane] = hi;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
                 for (int f = wave; f < 4 * DC_KS_E; f += 8) {
