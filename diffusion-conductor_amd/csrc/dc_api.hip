@@ -597,9 +597,17 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     int chunks = (sf || film_chunks_env < 1 || L % film_chunks_env || ((L / film_chunks_env) & 1)) ? 1 : film_chunks_env;
     const int lpc = L / chunks;                              // layers per chunk (even)
     static const bool want_stamps_film = getenv("DC_STAMPS") != nullptr;       // clock stamps land in stamp slots 28..31 of wave 7
+    // DC_FILM_ALIAS=1 (with DC_FILM_CHUNKS > 1): every chunk writes the SAME buffer region (tiles of lpc layers per group), so the
+    // FiLM tiles are overwritten in place chunk after chunk and can live in the 256-MB Infinity Cache instead of streaming
+    // 708 MB per step through HBM
+    static const bool alias = getenv("DC_FILM_ALIAS") != nullptr;
+    const bool aliased = alias && chunks > 1;
+    const int NTe = aliased ? s->NT / chunks : s->NT;
+    auto e_for_layer = [&](int l) -> void* { return aliased ? (void*)((char*)s->d_E - (size_t)(l - l % lpc) * 24 * 2048) : s->d_E; };
     auto film_chunk = [&](int c) -> int {
         LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->h_model.film_g, s->h_model.film_beta,
-                                           s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, c * lpc * 3 / 2, chunks == 1 ? nround_all : lpc * 3 / 2,
+                                           s->d_s_hi, s->d_s_lo, aliased ? (void*)((char*)s->d_E - (size_t)c * lpc * 3 * 8 * 2048) : s->d_E, G, NTe,
+                                           c * lpc * 3 / 2, chunks == 1 ? nround_all : lpc * 3 / 2,
                                            fuse_silu ? s->d_pp : nullptr, s->h_model.temb, s->d_t_clip, T, B,
                                            want_stamps_film ? s->d_stamps + 252 : nullptr));
         return DC_OK;
@@ -642,7 +650,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         if (l > 0 && l % lpc == 0) { int rc = film_chunk(l / lpc); if (rc) return rc; }
         const int dbg = ((l == nl_run - 1) ? s->dbg_stage : 0) | ablate;
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
-        LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
+        LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, e_for_layer(l), NTe, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur,
                                         s->d_snaps, M, T, G, B, dbg, (l == 3 && want_stamps) ? s->d_stamps : nullptr, l + 1, rec_stride,
                                         s->d_gbar, s->d_gerr));
