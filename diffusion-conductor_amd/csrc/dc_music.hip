@@ -158,24 +158,26 @@ __global__ __launch_bounds__(256) void k_me_conv(const float* __restrict__ mel, 
 // max_pool2d on the plane pair; padding never wins (torch pads with -inf).  One thread per (pixel, 8 channels).
 // hi + lo is exact in fp32 (<= 17 significant bits), so the maximum re-splits into the very planes it came from.
 // ---------------------------------------------------------------------------------------------------------
+// Sliding window along time: a thread owns (clip, output column, 8 channels) and walks NY consecutive output rows,
+// keeping the last KH row maxima (each the maximum over the KW taps of one input row) in registers; an output row
+// costs SH new input rows instead of KH (5x5 stride 1: 5x fewer loads than one thread per output).
 template <int KH, int KW, int SH, int SW, int PH, int PW>
 __global__ __launch_bounds__(256) void k_me_pool(const bf16x8* __restrict__ in_hi, const bf16x8* __restrict__ in_lo,
                                                  bf16x8* __restrict__ out_hi, bf16x8* __restrict__ out_lo, int Bc, int H, int W,
-                                                 int C8, int Ho, int Wo) {
+                                                 int C8, int Ho, int Wo, int NY) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)Bc * Ho * Wo * C8;
+    const int strips = (Ho + NY - 1) / NY;
+    const long long total = (long long)Bc * strips * Wo * C8;
     if (idx >= total) return;
     const int c8 = (int)(idx % C8);
     const int xo = (int)((idx / C8) % Wo);
-    const int yo = (int)((idx / ((long long)C8 * Wo)) % Ho);
-    const int b = (int)(idx / ((long long)C8 * Wo * Ho));
-    float m[8];
+    const int sy = (int)((idx / ((long long)C8 * Wo)) % strips);
+    const int b = (int)(idx / ((long long)C8 * Wo * strips));
+    float ring[KH][8];                   // ring[k] = row maximum of input row (next_row - KH + k), oldest first
+    auto row_max = [&](int yy, float (&m)[8]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
-#pragma unroll
-    for (int ky = 0; ky < KH; ++ky) {
-        const int yy = yo * SH - PH + ky;
-        if (yy < 0 || yy >= H) continue;
+        for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+        if (yy < 0 || yy >= H) return;
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx) {
             const int xx = xo * SW - PW + kx;
@@ -185,11 +187,32 @@ __global__ __launch_bounds__(256) void k_me_pool(const bf16x8* __restrict__ in_h
 #pragma unroll
             for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)h[j] + (float)l[j]);
         }
+    };
+    const int yo0 = sy * NY, yo1 = min(yo0 + NY, Ho);
+#pragma unroll
+    for (int k = 0; k < KH; ++k) row_max(yo0 * SH - PH + k, ring[k]);
+    for (int yo = yo0; yo < yo1; ++yo) {
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            m[j] = ring[0][j];
+#pragma unroll
+            for (int k = 1; k < KH; ++k) m[j] = fmaxf(m[j], ring[k][j]);
+        }
+        bf16x8 oh, ol;
+        split8(m, oh, ol);
+        const size_t oidx = (((size_t)b * Ho + yo) * Wo + xo) * C8 + c8;
+        out_hi[oidx] = oh;
+        out_lo[oidx] = ol;
+        if (yo + 1 < yo1) {              // advance the window by SH input rows
+#pragma unroll
+            for (int k = 0; k + SH < KH; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ring[k][j] = ring[k + SH][j];
+#pragma unroll
+            for (int k = (KH > SH ? KH - SH : 0); k < KH; ++k) row_max((yo + 1) * SH - PH + k, ring[k]);
+        }
     }
-    bf16x8 oh, ol;
-    split8(m, oh, ol);
-    out_hi[idx] = oh;
-    out_lo[idx] = ol;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -493,8 +516,9 @@ hipError_t launch_conv(hipStream_t st, const ConvDev& c, const float* mel, const
 template <int KH, int KW, int SH, int SW, int PH, int PW>
 hipError_t launch_pool(hipStream_t st, const bf16x8* ih, const bf16x8* il, bf16x8* oh, bf16x8* ol, int Bc, int H, int W, int C,
                        int Ho, int Wo) {
-    const long long total = (long long)Bc * Ho * Wo * (C / 8);
-    k_me_pool<KH, KW, SH, SW, PH, PW><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(ih, il, oh, ol, Bc, H, W, C / 8, Ho, Wo);
+    constexpr int NY = 24;                 // output rows per thread: (NY + KH - 1) / NY of the minimum input traffic
+    const long long total = (long long)Bc * ((Ho + NY - 1) / NY) * Wo * (C / 8);
+    k_me_pool<KH, KW, SH, SW, PH, PW><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(ih, il, oh, ol, Bc, H, W, C / 8, Ho, Wo, NY);
     return hipGetLastError();
 }
 
