@@ -1498,14 +1498,46 @@ DEV void query_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const
     st.finish(y_rstd, y_shift);
 }
 
+// v_fma_mix_f32: d = a * b + c with a read as the low / high fp16 half of a packed register - no separate conversion.
+// (hipcc does not form it from `fmaf((float)half, ...)`: the FiLM tiles and the packed y tiles cost 3 cvt per element.)
+typedef __attribute__((ext_vector_type(8))) uint32_t u32x8;
+template <int HI>
+DEV float fma_mix_h(uint32_t h2, float b, float c) {
+    float d;
+    if constexpr (HI)
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(b), "v"(c));
+    else
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(b), "v"(c));
+    return d;
+}
+template <int HI>
+DEV float add_mix_h(uint32_t h2, float c) {        // (float)half + c
+    float d;
+    if constexpr (HI)
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(c));
+    else
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(c));
+    return d;
+}
+
 // one k-tile of the FiLM-modulated, SiLU'ed operand: z = SiLU(nhat*G' + H'), gp = G' - 1
 template <class T16, bool SPLIT, class YTile>
 DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shift, const f16x16& gp, const f16x16& hp) {
     f32x16 z;
+    if constexpr (std::is_same<YTile, f16x16>::value) {      // packed y (non-split formats): three mixed-precision FMAs per element
+        const u32x8 yw = __builtin_bit_cast(u32x8, y), gw = __builtin_bit_cast(u32x8, gp), hw = __builtin_bit_cast(u32x8, hp);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float n = fmaf((float)y[r], rstd, shift);
-        z[r] = silu(fmaf(n, (float)gp[r], n + (float)hp[r]));
+        for (int k = 0; k < 8; ++k) {
+            const float n0 = fma_mix_h<0>(yw[k], rstd, shift), n1 = fma_mix_h<1>(yw[k], rstd, shift);
+            z[2 * k] = silu(add_mix_h<0>(hw[k], fma_mix_h<0>(gw[k], n0, n0)));
+            z[2 * k + 1] = silu(add_mix_h<1>(hw[k], fma_mix_h<1>(gw[k], n1, n1)));
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float n = fmaf((float)y[r], rstd, shift);
+            z[r] = silu(fmaf(n, (float)gp[r], n + (float)hp[r]));
+        }
     }
     make_frag<T16, SPLIT>(z, zf);
 }
