@@ -1162,7 +1162,9 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
     // (measured alternatives: whole token blocks per workgroup sweeping the weight rounds in lock-step for L2 locality -
     // 5 % faster per sweep, but 450 blocks on 256 CUs need 2 full sweeps instead of 1.76; and a balanced lock-step
     // form, 7-8 groups per workgroup as a 4-group + 3-group sweep - fabric re-fetches of the weights gone, yet 2 %
-    // slower overall.  The sweep is bound by its own issue stream, not by where the weights come from.)
+    // slower overall; a single-wave-per-SIMD form - 4 waves, 2 pairs x 4 groups each, the 256 accumulator registers in
+    // AGPRs, half the LDS reads per MFMA - ran 33 % slower: two waves per SIMD hide each other's waits far better than
+    // a deeper prefetch ring does.)
     const int u0 = (int)(nunit * blockIdx.x / gridDim.x), u1 = (int)(nunit * (blockIdx.x + 1) / gridDim.x);
     int cur_blk = -1;
     OP a0[PF], a1[PF];
