@@ -1586,13 +1586,44 @@ DEV void ering_issue(const f16x8* __restrict__ Eg, int kt, char* slot, int lane)
     lds_dma16(hsrc, slot + 2048);
     lds_dma16(hsrc + 64, slot + 3072);
 }
-// same StylizationBlock with the FiLM tiles arriving through the ring: k-tiles 0,1 were issued a stage ago;
-// k-tiles 2,3 are issued as soon as 0,1 sit in registers and land behind the first half's VALU + MFMA work.
-// `prefetch_next` (the next stage's weight image) is issued only after that wait, so the wait covers just 8 KiB.
+// same StylizationBlock with the FiLM tiles of k-tiles 0,1 arriving through the ring (issued a stage ago) and those of
+// k-tiles 2,3 prefetched into registers at the start of the preceding stage (EPre; they landed with that stage's closing
+// vmcnt(0)): nothing in this stage waits on HBM.  `prefetch_next` (the next stage's weight image and the next block's
+// ring tiles) is issued as soon as both ring slots have been read.
+struct EPre {
+    f16x8 glo[2], ghi[2], hlo[2], hhi[2];       // the 16-byte halves exactly as loaded: nothing may touch them before they land
+};
+// The loads are inline asm on purpose: hipcc would guard the first use of a load it knows about with a vmcnt wait that
+// also covers the LDS-DMAs issued (invisibly to it) just before that use; these tiles are complete at the preceding
+// stage's closing `s_waitcnt vmcnt(0)`, so no wait is wanted at the use.
+DEV f16x8 ld16_nowait(const f16x8* p) {
+    f16x8 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+DEV void epre_load(EPre& e, const f16x8* __restrict__ Eg, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const f16x8* pg = Eg + (2 + i) * 128 + lane;
+        const f16x8* ph = Eg + (4 + 2 + i) * 128 + lane;
+        e.glo[i] = ld16_nowait(pg);
+        e.ghi[i] = ld16_nowait(pg + 64);
+        e.hlo[i] = ld16_nowait(ph);
+        e.hhi[i] = ld16_nowait(ph + 64);
+    }
+}
+DEV f16x16 join16(const f16x8& lo8, const f16x8& hi8) {
+    f16x16 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v[i] = lo8[i];
+        v[8 + i] = hi8[i];
+    }
+    return v;
+}
 template <class T16, bool SPLIT, class F>
-DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd, float shift,
-                              const f16x8* __restrict__ Eg, char* ring, const float* bo, const v8<T16>* w, int lane,
-                              int hh, F&& prefetch_next) {
+DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd, float shift, const EPre& ep,
+                              char* ring, const float* bo, const v8<T16>* w, int lane, int hh, F&& prefetch_next) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const f32x16 bb = ld_ft(bo, t, hh);
@@ -1600,19 +1631,21 @@ DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float 
         for (int r = 0; r < 16; ++r) h[t][r] += bb[r];
     }
     __builtin_amdgcn_sched_barrier(0);
-    // one k-tile at a time (one (G'-1, H') pair = 16 registers live): read slot kt&1, hand the slot back to the
-    // DMA engine for k-tile kt+2, modulate, accumulate.
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-        char* slot = ring + (kt & 1) * 4096;
-        if (kt == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // k-tiles 2,3 have landed
-        const f16x8* sp = reinterpret_cast<const f16x8*>(slot) + lane;
-        const f16x16 gp = load_etile(sp), hp = load_etile(sp + 128);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt < 2) ering_issue(Eg, kt + 2, slot, lane);
-        if (kt == 3) prefetch_next();                                       // both slots are free again
-        __builtin_amdgcn_sched_barrier(0);
+        f16x16 gp, hp;
+        if (kt < 2) {
+            const f16x8* sp = reinterpret_cast<const f16x8*>(ring + kt * 4096) + lane;
+            gp = load_etile(sp);
+            hp = load_etile(sp + 128);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt == 1) prefetch_next();                                   // both slots have been read
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            gp = join16(ep.glo[kt - 2], ep.ghi[kt - 2]);
+            hp = join16(ep.hlo[kt - 2], ep.hhi[kt - 2]);
+        }
         XFrag<T16, SPLIT> zf;
         styl_tile<T16, SPLIT, ytile<SPLIT>>(zf, y[kt], rstd, shift, gp, hp);
         mma_kt<4, 4, T16, SPLIT>(h, w, kt, zf, lane);
@@ -1714,6 +1747,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
 
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
     stage_frags<NW>(L.img_sa_o, buf1, NFW + 1, wave, lane);
+    EPre ep;
+    if constexpr (use_ring) epre_load(ep, Eg, lane);
     ytile<SPLIT> y[4];
     float y_rstd, y_shift;
     if (wg_lds)     // two instantiations so that each keeps its address space (a generic pointer means flat loads)
@@ -1731,7 +1766,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         if (wg_lds) stage_attn(acl);
         styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh, dbg);
     } else {
-        styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, ring, c1, w1, lane, cx.hh, [&]() {
+        styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, [&]() {
             stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
             if (wg_lds) stage_attn(acl);
             ering_issue(Eg + 8 * 128, 0, ring, lane);
@@ -1744,6 +1779,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(5);
     // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
     stage_frags<NW>(L.img_ca_o, buf1, NFW + 1, wave, lane);
+    if constexpr (use_ring) epre_load(ep, Eg + 8 * 128, lane);
     if (wg_lds)
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (size_t)(cx.b0 - ub0) * 8 * 64,
                                  af + (size_t)(cx.b1 - ub0) * 8 * 64, cx);
@@ -1758,7 +1794,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
         styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh, dbg);
     } else {
-        styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, ring, c1, w1, lane, cx.hh, [&]() {
+        styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, [&]() {
             stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
             stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
             ering_issue(Eg + 16 * 128, 0, ring, lane);
@@ -1771,6 +1807,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(8);
     // ---- stage 5: FFN [buf0]; prefetch FFN out-proj -> buf1
     stage_frags<NW>(L.img_ffn_o, buf1, NFW + 1, wave, lane);
+    if constexpr (use_ring) epre_load(ep, Eg + 16 * 128, lane);
     {
         f32x16 u[2];
         {
@@ -1812,7 +1849,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             next_w();
             styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, c1, w1, lane, cx.hh, dbg);
         } else {
-            styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, ring, c1, w1, lane, cx.hh, next_w);
+            styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, next_w);
         }
     }
     if constexpr (DBG) if ((dbg & 0xff) == 3) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
