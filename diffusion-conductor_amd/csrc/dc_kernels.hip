@@ -1872,43 +1872,68 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         DC_STAMP(19);
         if constexpr (DBG) if (dbg & 0x400) return;      // timing experiment: no front stage
         if constexpr (WGR) {
-            // workgroup record, two passes over the key image (buf0) so that no key tile stays live next to the
-            // loop-carried residual stream: (1) column maxima per wave -> LDS; barrier (which also covers the value
-            // image landing in buf1); (2) per feature tile: keys again, values, exp2 against the workgroup maxima,
-            // exp(K-m)^T V -> LDS (per-wave blocks in the idle FiLM rings); barrier; summed in wave order and written.
+            // Workgroup record in one pass over each image.  While the value image is still landing in buf1: keys of all
+            // four feature tiles (pairs of MFMA chains), exponentiated against THIS WAVE's column maxima and kept as
+            // operand fragments (32 registers); the maxima go to LDS.  One barrier (maxima visible, values landed).  Then
+            // values, exp(K-m_w)^T V, and the rescale exp2(m_w - M) to the workgroup maximum applied to the fp32 blocks,
+            // staged per wave in the idle FiLM rings; barrier; summed in wave order and written by wg_write_record.
             float* mx = reinterpret_cast<float*>(lds + OFF_AF);
             f32x8* pst = reinterpret_cast<f32x8*>(lds + OFF_ER);
             f32x8* xp = reinterpret_cast<f32x8*>(lds + OFF_AF + 8192);
             float* ss = reinterpret_cast<float*>(lds + OFF_SS);
+            float* scw = reinterpret_cast<float*>(buf0) + wave * 2 * 4 * 32;   // this wave's rescale factors [2 slots][4 oc][32 cols];
+                                                                              // buf0's key image is consumed before the barrier below
             const RowRange vr0 = valid_rows_clip(cx, ub0, B, M, T, length, active);
             const RowRange vr1 = valid_rows_clip(cx, ub0 + 1, B, M, T, length, active);
+            const int s0 = cx.b0 - ub0;
+            const RowRange vr_own = s0 ? vr1 : vr0;
+            const bool strad = active && cx.straddle;
+            XFrag<T16, false> efA[4], efB[4];
+            float ssA[4], ssB[4], mA[4], mB[4];
+            auto keys_of = [&](const f32x16& K, const RowRange& rr, XFrag<T16, false>& ef, float& ssum, float& mcol) {
+                float m = -INFINITY;
+                const bool full = __builtin_amdgcn_readfirstlane(rr.span) == 32u;
+                if (full) {
 #pragma unroll
-            for (int op = 0; op < 2; ++op) {                  // two key tiles at a time: two independent MFMA chains
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, K[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m = row_ok(rr, r) ? fmaxf(m, K[r]) : m;
+                }
+                m = xhalf_max(m);
+                mcol = m;                                               // -inf: no valid row of this slot in the wave
+                const float mz = m == -INFINITY ? 0.f : m;
+                f32x16 Ee;
+                float sacc = 0.f;
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        Ee[r] = exp2f_fast(K[r] - mz);
+                        sacc += Ee[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        Ee[r] = row_ok(rr, r) ? exp2f_fast(K[r] - mz) : 0.f;
+                        sacc += Ee[r];
+                    }
+                }
+                ssum = xhalf_sum(sacc);
+                make_frag<T16, false>(Ee, ef);
+            };
+#pragma unroll
+            for (int op = 0; op < 2; ++op) {
                 f32x16 Kp[2] = {splat(c0[32 * (2 * op) + cx.c]), splat(c0[32 * (2 * op + 1) + cx.c])};
                 mmb_oc_pair<4, 4, T16>(Kp[0], Kp[1], w0, 2 * op, w0, 2 * op + 1, nf, lane);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int oc = 2 * op + q;
-                    const f32x16& K = Kp[q];
-                    float m0 = -INFINITY, m1 = -INFINITY;
-                    if (__builtin_amdgcn_readfirstlane(vr0.span) == 32u) {       // whole group in slot 0: plain maximum
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) m0 = fmaxf(m0, K[r]);
-                    } else if (__builtin_amdgcn_readfirstlane(vr1.span) == 32u) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) m1 = fmaxf(m1, K[r]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            m0 = row_ok(vr0, r) ? fmaxf(m0, K[r]) : m0;
-                            m1 = row_ok(vr1, r) ? fmaxf(m1, K[r]) : m1;
-                        }
-                    }
-                    m0 = xhalf_max(m0);
-                    m1 = xhalf_max(m1);
+                    keys_of(Kp[q], vr_own, efA[oc], ssA[oc], mA[oc]);
+                    mB[oc] = -INFINITY;
+                    if (strad) keys_of(Kp[q], vr1, efB[oc], ssB[oc], mB[oc]);
                     if (cx.hh == 0) {
-                        mx[((oc * 2 + 0) * 32 + cx.c) * 8 + wave] = m0;
-                        mx[((oc * 2 + 1) * 32 + cx.c) * 8 + wave] = m1;
+                        mx[((oc * 2 + s0) * 32 + cx.c) * 8 + wave] = mA[oc];
+                        mx[((oc * 2 + (s0 ^ 1)) * 32 + cx.c) * 8 + wave] = s0 ? -INFINITY : mB[oc];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1922,33 +1947,55 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
             DC_STAMP(12);
-            const int s0 = cx.b0 - ub0;
-            const RowRange vr_own = s0 ? vr1 : vr0;
-            // software-pipelined over the four feature tiles: the projections of tile oc+1 (MFMA) are issued ahead of
-            // the exponentials / packing of tile oc (VALU)
-            f32x16 Kc = splat(c0[cx.c]), Vc = splat(c1[cx.c]);
-            mmb_oc_pair<4, 4, T16>(Kc, Vc, w0, 0, w1, 0, nf, lane);
+            // rescale factors of this wave's columns, through its own LDS strip (each lane needs 8 of them as row factors)
 #pragma unroll
             for (int oc = 0; oc < 4; ++oc) {
-                f32x16 Kn, Vn;
-                if (oc < 3) {
-                    Kn = splat(c0[32 * (oc + 1) + cx.c]);
-                    Vn = splat(c1[32 * (oc + 1) + cx.c]);
-                    mmb_oc_pair<4, 4, T16>(Kn, Vn, w0, oc + 1, w1, oc + 1, nf, lane);
+                const float fa = mA[oc] == -INFINITY ? 0.f : exp2f_fast(mA[oc] - wg_colmax(mx, oc, s0, cx.c));
+                ssA[oc] *= fa;
+                if (cx.hh == 0) scw[(0 * 4 + oc) * 32 + cx.c] = fa;
+                if (strad) {
+                    const float fb = mB[oc] == -INFINITY ? 0.f : exp2f_fast(mB[oc] - wg_colmax(mx, oc, 1, cx.c));
+                    ssB[oc] *= fb;
+                    if (cx.hh == 0) scw[(1 * 4 + oc) * 32 + cx.c] = fb;
                 }
-                float ssum;
-                f32x8 keep;
-                partial_tile<T16>(Kc, Vc, vr_own, wg_colmax(mx, oc, s0, cx.c), cx, ssum, keep);
-                pst[(wave * 4 + oc) * 64 + lane] = keep;
-                if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssum;
-                if (active && cx.straddle) {
-                    partial_tile<T16>(Kc, Vc, vr1, wg_colmax(mx, oc, 1, cx.c), cx, ssum, keep);
-                    xp[oc * 64 + lane] = keep;
-                    if (cx.hh == 0) ss[(8 * 4 + oc) * 32 + cx.c] = ssum;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int rowq = 16 * (cx.c >> 4) + 4 * cx.hh;            // kept value j <-> column (row of P) rowq + (j&3) + 8(j>>2)
+            auto block_of = [&](const XFrag<T16, false>& ef, const f32x16& V, const RowRange& rr, const float* sc) {
+                f32x16 Vm;
+                if (__builtin_amdgcn_readfirstlane(rr.span) == 32u) {
+                    Vm = V;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Vm[r] = row_ok(rr, r) ? V[r] : 0.f;
                 }
-                if (oc < 3) {
-                    Kc = Kn;
-                    Vc = Vn;
+                XFrag<T16, false> vf;
+                make_frag<T16, false>(Vm, vf);
+                f32x16 P = splat(0.f);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) P = mfma(ef.hi[s2], vf.hi[s2], P);
+                f32x8 keep = keep_head_block(P, cx.c);
+                const f32x4 f0 = *reinterpret_cast<const f32x4*>(sc + rowq), f1 = *reinterpret_cast<const f32x4*>(sc + rowq + 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    keep[i] *= f0[i];
+                    keep[4 + i] *= f1[i];
+                }
+                return keep;
+            };
+#pragma unroll
+            for (int op = 0; op < 2; ++op) {
+                f32x16 Vp[2] = {splat(c1[32 * (2 * op) + cx.c]), splat(c1[32 * (2 * op + 1) + cx.c])};
+                mmb_oc_pair<4, 4, T16>(Vp[0], Vp[1], w1, 2 * op, w1, 2 * op + 1, nf, lane);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int oc = 2 * op + q;
+                    pst[(wave * 4 + oc) * 64 + lane] = block_of(efA[oc], Vp[q], vr_own, scw + (0 * 4 + oc) * 32);
+                    if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssA[oc];
+                    if (strad) {
+                        xp[oc * 64 + lane] = block_of(efB[oc], Vp[q], vr1, scw + (1 * 4 + oc) * 32);
+                        if (cx.hh == 0) ss[(8 * 4 + oc) * 32 + cx.c] = ssB[oc];
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
