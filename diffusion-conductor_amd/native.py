@@ -59,10 +59,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise DcError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("DC_DDIM_LIB", LIB_PATH)      # A/B builds of the same ABI side by side (tools/ab.sh); default in-tree
+    if not os.path.exists(path):
+        raise DcError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(there is no CPU fallback for the sampler)")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     L.dc_last_error.restype = C.c_char_p
     L.dc_version.restype = C.c_char_p
     L.dc_kernel_name.restype = C.c_char_p
