@@ -399,8 +399,10 @@ DEV void store_etile(f16x16* __restrict__ E, size_t tile, int lane, const f16x16
         lo8[i] = v[i];
         hi8[i] = v[8 + i];
     }
-    p[0] = lo8;
-    p[64] = hi8;
+    // written once and read by a later kernel: non-temporal stores keep the 708 MB per step from evicting the FiLM
+    // weights (and later the layer kernels' own lines) from L2 - measured -1.8 % on the whole loop (tools/ab.sh)
+    __builtin_nontemporal_store(lo8, p);
+    __builtin_nontemporal_store(hi8, p + 64);
 }
 DEV f16x16 load_etile(const f16x8* __restrict__ p /* tile base + lane; global or LDS */) {
     const f16x8 lo8 = p[0], hi8 = p[64];
