@@ -1580,13 +1580,24 @@ DEV void styl_accumulate(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd,
 }
 
 // Per-wave FiLM tile ring in LDS: two 4-KiB slots, each holding one k-tile's (G'-1, H') tile pair.
+// FiLM tiles are read exactly once: non-temporal, so that 88 MB per layer do not flush the weights, attention fragments and
+// records the workgroups of an XCD share through L2 (same-box A/B: -4 % k_layer, -3.5 % loop)
+DEV void lds_dma16_nt(const void* gsrc, const char* lds_dst) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
 DEV void ering_issue(const f16x8* __restrict__ Eg, int kt, char* slot, int lane) {
     const f16x8* gsrc = Eg + kt * 128 + lane;
     const f16x8* hsrc = Eg + (4 + kt) * 128 + lane;
-    lds_dma16(gsrc, slot);
-    lds_dma16(gsrc + 64, slot + 1024);
-    lds_dma16(hsrc, slot + 2048);
-    lds_dma16(hsrc + 64, slot + 3072);
+    lds_dma16_nt(gsrc, slot);
+    lds_dma16_nt(gsrc + 64, slot + 1024);
+    lds_dma16_nt(hsrc, slot + 2048);
+    lds_dma16_nt(hsrc + 64, slot + 3072);
 }
 // same StylizationBlock with the FiLM tiles of k-tiles 0,1 arriving through the ring (issued a stage ago) and those of
 // k-tiles 2,3 prefetched into registers at the start of the preceding stage (EPre; they landed with that stage's closing
@@ -1600,7 +1611,7 @@ struct EPre {
 // stage's closing `s_waitcnt vmcnt(0)`, so no wait is wanted at the use.
 DEV f16x8 ld16_nowait(const f16x8* p) {
     f16x8 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
 DEV void epre_load(EPre& e, const f16x8* __restrict__ Eg, int lane) {
