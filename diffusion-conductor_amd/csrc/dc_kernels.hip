@@ -176,6 +176,22 @@ DEV void mmb_oc_pair(f32x16& acca, f32x16& accb, const v8<T16>* __restrict__ wa,
         }
 }
 
+// all four output tiles of one 128 x 128 image at once: four independent chains (non-split)
+template <int OC, int KT, class T16>
+DEV void mmb_oc_quad(f32x16& a, f32x16& b, f32x16& c, f32x16& d, const v8<T16>* __restrict__ w, const XFrag<T16, false> (&x)[KT], int lane) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const v8<T16> fa = w[((kt * OC + 0) * 2 + s) * 64 + lane], fb = w[((kt * OC + 1) * 2 + s) * 64 + lane];
+            const v8<T16> fc = w[((kt * OC + 2) * 2 + s) * 64 + lane], fd = w[((kt * OC + 3) * 2 + s) * 64 + lane];
+            a = mfma(x[kt].hi[s], fa, a);
+            b = mfma(x[kt].hi[s], fb, b);
+            c = mfma(x[kt].hi[s], fc, c);
+            d = mfma(x[kt].hi[s], fd, d);
+        }
+}
+
 // per-feature vector stored as [tile][lane-half][16] so a lane reads its 16 values with one 64-B load
 DEV f32x16 ld_ft(const float* __restrict__ p, int tile, int hh) {
     return *reinterpret_cast<const f32x16*>(p + (tile * 2 + hh) * 16);
@@ -1934,13 +1950,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 ssum = xhalf_sum(sacc);
                 make_frag<T16, false>(Ee, ef);
             };
+            {
+                f32x16 Kp[4] = {splat(c0[cx.c]), splat(c0[32 + cx.c]), splat(c0[64 + cx.c]), splat(c0[96 + cx.c])};
+                mmb_oc_quad<4, 4, T16>(Kp[0], Kp[1], Kp[2], Kp[3], w0, nf, lane);
 #pragma unroll
-            for (int op = 0; op < 2; ++op) {
-                f32x16 Kp[2] = {splat(c0[32 * (2 * op) + cx.c]), splat(c0[32 * (2 * op + 1) + cx.c])};
-                mmb_oc_pair<4, 4, T16>(Kp[0], Kp[1], w0, 2 * op, w0, 2 * op + 1, nf, lane);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int oc = 2 * op + q;
+                for (int q = 0; q < 4; ++q) {
+                    const int oc = q;
                     keys_of(Kp[q], vr_own, efA[oc], ssA[oc], mA[oc]);
                     mB[oc] = -INFINITY;
                     if (strad) keys_of(Kp[q], vr1, efB[oc], ssB[oc], mB[oc]);
@@ -1996,13 +2011,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 }
                 return keep;
             };
+            {
+                f32x16 Vp[4] = {splat(c1[cx.c]), splat(c1[32 + cx.c]), splat(c1[64 + cx.c]), splat(c1[96 + cx.c])};
+                mmb_oc_quad<4, 4, T16>(Vp[0], Vp[1], Vp[2], Vp[3], w1, nf, lane);
 #pragma unroll
-            for (int op = 0; op < 2; ++op) {
-                f32x16 Vp[2] = {splat(c1[32 * (2 * op) + cx.c]), splat(c1[32 * (2 * op + 1) + cx.c])};
-                mmb_oc_pair<4, 4, T16>(Vp[0], Vp[1], w1, 2 * op, w1, 2 * op + 1, nf, lane);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int oc = 2 * op + q;
+                for (int q = 0; q < 4; ++q) {
+                    const int oc = q;
                     pst[(wave * 4 + oc) * 64 + lane] = block_of(efA[oc], Vp[q], vr_own, scw + (0 * 4 + oc) * 32);
                     if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssA[oc];
                     if (strad) {
