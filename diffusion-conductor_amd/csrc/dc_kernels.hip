@@ -1630,15 +1630,26 @@ DEV f16x8 ld16_nowait(const f16x8* p) {
     asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
+// SAFE: ordinary loads (the compiler tracks them and waits before any use, including a spill) - for the kernel variants
+// that spill registers (test hooks, persistent form): a register that an untracked load is still writing must never be
+// copied, so the no-wait form is only for the spill-free production instantiation.
+template <bool SAFE>
 DEV void epre_load(EPre& e, const f16x8* __restrict__ Eg, int lane) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const f16x8* pg = Eg + (2 + i) * 128 + lane;
         const f16x8* ph = Eg + (4 + 2 + i) * 128 + lane;
-        e.glo[i] = ld16_nowait(pg);
-        e.ghi[i] = ld16_nowait(pg + 64);
-        e.hlo[i] = ld16_nowait(ph);
-        e.hhi[i] = ld16_nowait(ph + 64);
+        if constexpr (SAFE) {
+            e.glo[i] = pg[0];
+            e.ghi[i] = pg[64];
+            e.hlo[i] = ph[0];
+            e.hhi[i] = ph[64];
+        } else {
+            e.glo[i] = ld16_nowait(pg);
+            e.ghi[i] = ld16_nowait(pg + 64);
+            e.hlo[i] = ld16_nowait(ph);
+            e.hhi[i] = ld16_nowait(ph + 64);
+        }
     }
 }
 DEV f16x16 join16(const f16x8& lo8, const f16x8& hi8) {
@@ -1777,7 +1788,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
     stage_frags<NW>(L.img_sa_o, buf1, NFW + 1, wave, lane);
     EPre ep;
-    if constexpr (use_ring) epre_load(ep, Eg, lane);
+    if constexpr (use_ring) epre_load<DBG || PERS>(ep, Eg, lane);
     ytile<SPLIT> y[4];
     float y_rstd, y_shift;
     if (wg_lds)     // two instantiations so that each keeps its address space (a generic pointer means flat loads)
@@ -1808,7 +1819,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(5);
     // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
     stage_frags<NW>(L.img_ca_o, buf1, NFW + 1, wave, lane);
-    if constexpr (use_ring) epre_load(ep, Eg + 8 * 128, lane);
+    if constexpr (use_ring) epre_load<DBG || PERS>(ep, Eg + 8 * 128, lane);
     if (wg_lds)
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (size_t)(cx.b0 - ub0) * 8 * 64,
                                  af + (size_t)(cx.b1 - ub0) * 8 * 64, cx);
@@ -1836,7 +1847,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(8);
     // ---- stage 5: FFN [buf0]; prefetch FFN out-proj -> buf1
     stage_frags<NW>(L.img_ffn_o, buf1, NFW + 1, wave, lane);
-    if constexpr (use_ring) epre_load(ep, Eg + 16 * 128, lane);
+    if constexpr (use_ring) epre_load<DBG || PERS>(ep, Eg + 16 * 128, lane);
     {
         f32x16 u[2];
         {

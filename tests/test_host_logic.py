@@ -216,3 +216,31 @@ def test_evaluate_dataset_host_logic(tmp_path):
     assert a["per_clip"]["clip02"] == float(ev.mse_loss(np.load(tmp_path / "clip02" / "motion.npy"), pred))
     # like the reference, the running total stays in the precision of the per-clip values (float32 numpy scalars)
     assert abs(a["total_loss"] - sum(a["per_clip"][k] for k in sorted(a["per_clip"]))) < 1e-5
+
+
+def test_production_layer_kernel_has_no_register_spills():
+    """The production k_layer instantiations prefetch FiLM tiles with untracked (inline-asm) loads; that is only sound
+    while the register allocator never has to copy those registers, i.e. while the kernel does not spill.  The variants
+    that do spill (test hooks, persistent form) are compiled with tracked loads instead (epre_load<SAFE>)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "diffusion-conductor_amd", "csrc", "dc_kernels.hip")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only", "-Wno-unused-value",
+                          src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    spills = {}
+    name = None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"VGPRs Spill: (\d+)", line)
+        if m and name:
+            spills[name] = int(m.group(1))
+    prod = [k for k in spills if re.match(r"_Z7k_layerIDF16[_b]Lb0ELb0ELb[01]ELb1ELb0E", k)]     # non-split, no hooks, WGR, not persistent
+    assert len(prod) == 4, prod
+    assert all(spills[k] == 0 for k in prod), {k: spills[k] for k in prod}
