@@ -2324,7 +2324,7 @@ __global__ __launch_bounds__(512, 2) void k_embed_front_full(const DcModel* __re
                                                              int M, int T, int KT, int WPC) {
     using W = v8<T16>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const ClipCtx cx = make_clip_ctx(blockIdx.x, WPC, wave, lane, T, M);
+    const ClipCtx cx = make_clip_ctx(wg_index(), WPC, wave, lane, T, M);
     if (!cx.active) return;
     const int P = dm->input_feats;
     const bool live = cx.tok < M;
@@ -2373,8 +2373,8 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using W = v8<T16>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const ClipCtx cx = make_clip_ctx(blockIdx.x, WPC, wave, lane, T, M);
-    if ((blockIdx.x % WPC) * 8 >= cx.nkt) return;          // no query group of the clip falls into this workgroup
+    const ClipCtx cx = make_clip_ctx(wg_index(), WPC, wave, lane, T, M);
+    if ((wg_index() % WPC) * 8 >= cx.nkt) return;          // no query group of the clip falls into this workgroup
     const DcLayer& L = dm->layer[l];
     const bool last = l + 1 >= dm->num_layers;
     const int len = length[cx.b];
