@@ -417,6 +417,19 @@ int build_model(dc_sampler* s) {
     add_ft(&m.film_b, film_b.data(), NT * 32, NT);
     add_ft(&m.film_g, film_g.data(), 3 * L * 128, 3 * L * 4);
     add_ft(&m.film_beta, film_beta.data(), 3 * L * 128, 3 * L * 4);
+    {   // epilogue constants with the emb_layers biases folded in (per block j: features f of the scale / shift halves)
+        std::vector<float> cg((size_t)3 * L * 128), ch((size_t)3 * L * 128);
+        for (int blk = 0; blk < 3 * L; ++blk)
+            for (int t = 0; t < 4; ++t)
+                for (int f = 0; f < 32; ++f) {
+                    const size_t k = (size_t)blk * 128 + 32 * t + f;
+                    const double bs = film_b[((size_t)blk * 8 + 2 * t) * 32 + f], bh = film_b[((size_t)blk * 8 + 2 * t + 1) * 32 + f];
+                    cg[k] = (float)((double)film_g[k] * (1.0 + bs) - 1.0);
+                    ch[k] = (float)((double)film_beta[k] * (1.0 + bs) + bh);
+                }
+        add_ft(&m.film_cg, cg.data(), 3 * L * 128, 3 * L * 4);
+        add_ft(&m.film_ch, ch.data(), 3 * L * 128, 3 * L * 4);
+    }
     {   // the two pose projections always run split: [hi][lo][bias]
         const std::vector<float> jb = ftvec(P_("joint_embed.bias"), D, 4);
         add_image(&m.img_je, P_("joint_embed.weight"), D, P, true, jb.data(), jb.size());
@@ -606,6 +619,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     auto e_for_layer = [&](int l) -> void* { return aliased ? (void*)((char*)s->d_E - (size_t)(l - l % lpc) * 24 * 2048) : s->d_E; };
     auto film_chunk = [&](int c) -> int {
         LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->h_model.film_g, s->h_model.film_beta,
+                                           s->h_model.film_cg, s->h_model.film_ch,
                                            s->d_s_hi, s->d_s_lo, aliased ? (void*)((char*)s->d_E - (size_t)c * lpc * 3 * 8 * 2048) : s->d_E, G, NTe,
                                            c * lpc * 3 / 2, chunks == 1 ? nround_all : lpc * 3 / 2,
                                            fuse_silu ? s->d_pp : nullptr, s->h_model.temb, s->d_t_clip, T, B,

@@ -64,6 +64,8 @@ struct DcModel {
     const float* film_b;     // ftvec [3*L*8 tiles]
     const float* film_g;     // ftvec [3*L*4 tiles]: StylizationBlock.norm weight per block
     const float* film_beta;  // ftvec [3*L*4 tiles]: StylizationBlock.norm bias per block
+    const float* film_cg;    // ftvec [3*L*4 tiles]: g*(1 + b_scale) - 1   (FiLM epilogue constants with the biases folded in:
+    const float* film_ch;    // ftvec [3*L*4 tiles]: beta*(1 + b_scale) + b_shift   G'-1 = g*acc_s + cg, H' = beta*acc_s + acc_h + ch)
     const float* lin_wt;     // `linear` weight transposed [64][512]
     const float* lin_b;      // [512]
     const float* temb;       // [max_timesteps][512]

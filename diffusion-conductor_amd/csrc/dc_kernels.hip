@@ -1153,7 +1153,8 @@ DEV void lds_dma16(const void* gsrc /*per-lane*/, const char* lds_dst /*wave-uni
 // Per k-step and wave: 2 weight loads + 4 LDS reads feed 8 MFMAs (accumulators 2 x 4 tiles = 128 VGPRs).
 // ------------------------------------------------------------------------------------
 template <class T16>
-__global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict__ W, const float* __restrict__ bias_ft,
+__global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict__ W, const float* __restrict__ cg_ft,
+                                                       const float* __restrict__ ch_ft,
                                                        const float* __restrict__ g_ft, const float* __restrict__ beta_ft,
                                                        const v8<T16>* __restrict__ S, f16x16* __restrict__ E, int G, int NT, int round0,
                                                        int nround, const float* __restrict__ pp, const float* __restrict__ temb,
@@ -1287,7 +1288,8 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
         }
         // epilogue: fold the block's LayerNorm affine, fp16, store
         const int blk = p >> 2, t = p & 3;
-        const f32x16 bs = ld_ft(bias_ft, 2 * p, hh), bh = ld_ft(bias_ft, 2 * p + 1, hh);
+        // G'-1 = g*(1 + s + b_s) - 1 = g*s + cg,  H' = beta*(1 + s + b_s) + h + b_h = beta*s + h + ch   (cg, ch from the host)
+        const f32x16 cg = ld_ft(cg_ft, blk * 4 + t, hh), ch = ld_ft(ch_ft, blk * 4 + t, hh);
         const f32x16 gg = ld_ft(g_ft, blk * 4 + t, hh), be = ld_ft(beta_ft, blk * 4 + t, hh);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1295,9 +1297,8 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
             f16x16 og, oh;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float sc1 = 1.f + acc[0][g][r] + bs[r];
-                og[r] = (_Float16)(fmaf(gg[r], sc1, -1.f));
-                oh[r] = (_Float16)(fmaf(be[r], sc1, acc[1][g][r] + bh[r]));
+                og[r] = (_Float16)(fmaf(gg[r], acc[0][g][r], cg[r]));
+                oh[r] = (_Float16)(fmaf(be[r], acc[0][g][r], acc[1][g][r] + ch[r]));
             }
             if (abl & 4) continue;                                  // timing experiment: no output stores
             store_etile(E, (size_t)(g0 + g) * NT + blk * 8 + t, lane, og);
@@ -2626,7 +2627,7 @@ static void launch_film_t(hipStream_t st, const void* W, const float* bias_ft, c
                                                                          (f16x16*)E, G, NT);
 }
 template <class T16>
-static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bias_ft, const float* g_ft, const float* beta_ft,
+static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* cg_ft, const float* ch_ft, const float* g_ft, const float* beta_ft,
                                  const void* s_hi, void* E, int G, int NT, int round0, int nround, const float* pp, const float* temb,
                                  const int* t_clip, int T, int B, unsigned long long* clk) {
     const size_t shm = 4 * DC_KS_E * 1024;
@@ -2638,18 +2639,18 @@ static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bia
     }
     static const int ncu = [] { hipDeviceProp_t p; int d = 0; hipGetDevice(&d); hipGetDeviceProperties(&p, d); return p.multiProcessorCount; }();
     const int nblk = (G + 3) / 4;
-    k_film_gemm2<T16><<<dim3(nblk < ncu ? nblk : ncu), dim3(512), shm, st>>>((const v8<T16>*)W, bias_ft, g_ft, beta_ft,
+    k_film_gemm2<T16><<<dim3(nblk < ncu ? nblk : ncu), dim3(512), shm, st>>>((const v8<T16>*)W, cg_ft, ch_ft, g_ft, beta_ft,
                                                                 (const v8<T16>*)s_hi, (f16x16*)E, G, NT, round0, nround, pp, temb, t_clip, T, B,
                                                                 getenv("DC_FILM_ABL") ? atoi(getenv("DC_FILM_ABL")) : 0, clk);
     return hipGetLastError();
 }
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const float* g_ft,
-                               const float* beta_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
+                               const float* beta_ft, const float* cg_ft, const float* ch_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
                                int nround, const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk) {
     static const bool use_v1 = getenv("DC_FILM_V1") != nullptr;
     if (!split && !use_v1)
-        return fmt == 1 ? launch_film2_t<_Float16>(st, W, bias_ft, g_ft, beta_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk)
-                        : launch_film2_t<__bf16>(st, W, bias_ft, g_ft, beta_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk);
+        return fmt == 1 ? launch_film2_t<_Float16>(st, W, cg_ft, ch_ft, g_ft, beta_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk)
+                        : launch_film2_t<__bf16>(st, W, cg_ft, ch_ft, g_ft, beta_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk);
     if (round0 != 0) return hipSuccess;        // the v1 / split kernels compute all rounds in their first launch
     DISPATCH(fmt, split, (launch_film_t<T16, SP>(st, W, bias_ft, g_ft, beta_ft, s_hi, s_lo, E, G, NT)));
     return LAUNCH_CHECK();
