@@ -343,7 +343,7 @@ int build_model(dc_sampler* s) {
     // 32-row tiles are interleaved (scale0, shift0, scale1, shift1, ...) so one wave holds matching pairs
     const int NT = 3 * L * DC_FILM_TILES_PER_BLOCK;
     s->NT = NT;
-    std::vector<float> film_w((size_t)NT * 32 * DC_E), film_b((size_t)NT * 32), film_g((size_t)3 * L * 128), film_beta((size_t)3 * L * 128);
+    std::vector<float> film_w((size_t)NT * 32 * DC_E), film_b((size_t)NT * 32);
     for (int i = 0; i < L; ++i) {
         const std::string p = "temporal_decoder_blocks." + std::to_string(i);
         DcLayer& y = m.layer[i];
@@ -403,33 +403,29 @@ int build_model(dc_sampler* s) {
             const size_t row0 = (size_t)(3 * i + j) * 256;
             const float* w = P_(p + blk[j] + ".emb_layers.1.weight");   // rows 0..127 scale, 128..255 shift
             const float* bb = P_(p + blk[j] + ".emb_layers.1.bias");
+            const float* ng = P_(p + blk[j] + ".norm.weight");
+            const float* nb = P_(p + blk[j] + ".norm.bias");
+            // y = LN(h) (1 + scale) + shift with LN = g n + beta (transformer.py:74-78) becomes  y = n G' + H',
+            //   G' = g (1 + scale), H' = beta (1 + scale) + shift, both affine in S = SiLU(emb): fold g / beta into the rows
+            // (tile 2t = G' - 1 of features 32t.., tile 2t+1 = H' of the same features, so one wave holds matching pairs)
             for (int t = 0; t < 4; ++t)
-                for (int half = 0; half < 2; ++half) {       // interleave: tile 2t = scale tile t, 2t+1 = shift tile t
-                    const size_t dst = row0 + (size_t)(2 * t + half) * 32, src = (size_t)half * 128 + 32 * t;
-                    memcpy(&film_w[dst * DC_E], &w[src * DC_E], (size_t)32 * DC_E * 4);
-                    memcpy(&film_b[dst], &bb[src], 32 * 4);
+                for (int f = 0; f < 32; ++f) {
+                    const int o = 32 * t + f;
+                    const float* ws = w + (size_t)o * DC_E;
+                    const float* wh = w + (size_t)(128 + o) * DC_E;
+                    float* dg = &film_w[(row0 + (size_t)(2 * t) * 32 + f) * DC_E];
+                    float* dh = &film_w[(row0 + (size_t)(2 * t + 1) * 32 + f) * DC_E];
+                    for (int k = 0; k < DC_E; ++k) {
+                        dg[k] = (float)((double)ng[o] * ws[k]);
+                        dh[k] = (float)((double)nb[o] * ws[k] + wh[k]);
+                    }
+                    film_b[row0 + (size_t)(2 * t) * 32 + f] = (float)((double)ng[o] * (1.0 + bb[o]) - 1.0);
+                    film_b[row0 + (size_t)(2 * t + 1) * 32 + f] = (float)((double)nb[o] * (1.0 + bb[o]) + bb[128 + o]);
                 }
-            memcpy(&film_g[(size_t)(3 * i + j) * 128], P_(p + blk[j] + ".norm.weight"), 128 * 4);
-            memcpy(&film_beta[(size_t)(3 * i + j) * 128], P_(p + blk[j] + ".norm.bias"), 128 * 4);
         }
     }
     add_packed(&m.film_w, film_w.data(), NT * 32, DC_E, false, s->film_fmt == 1);
     add_ft(&m.film_b, film_b.data(), NT * 32, NT);
-    add_ft(&m.film_g, film_g.data(), 3 * L * 128, 3 * L * 4);
-    add_ft(&m.film_beta, film_beta.data(), 3 * L * 128, 3 * L * 4);
-    {   // epilogue constants with the emb_layers biases folded in (per block j: features f of the scale / shift halves)
-        std::vector<float> cg((size_t)3 * L * 128), ch((size_t)3 * L * 128);
-        for (int blk = 0; blk < 3 * L; ++blk)
-            for (int t = 0; t < 4; ++t)
-                for (int f = 0; f < 32; ++f) {
-                    const size_t k = (size_t)blk * 128 + 32 * t + f;
-                    const double bs = film_b[((size_t)blk * 8 + 2 * t) * 32 + f], bh = film_b[((size_t)blk * 8 + 2 * t + 1) * 32 + f];
-                    cg[k] = (float)((double)film_g[k] * (1.0 + bs) - 1.0);
-                    ch[k] = (float)((double)film_beta[k] * (1.0 + bs) + bh);
-                }
-        add_ft(&m.film_cg, cg.data(), 3 * L * 128, 3 * L * 4);
-        add_ft(&m.film_ch, ch.data(), 3 * L * 128, 3 * L * 4);
-    }
     {   // the two pose projections always run split: [hi][lo][bias]
         const std::vector<float> jb = ftvec(P_("joint_embed.bias"), D, 4);
         add_image(&m.img_je, P_("joint_embed.weight"), D, P, true, jb.data(), jb.size());
@@ -618,8 +614,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const int NTe = aliased ? s->NT / chunks : s->NT;
     auto e_for_layer = [&](int l) -> void* { return aliased ? (void*)((char*)s->d_E - (size_t)(l - l % lpc) * 24 * 2048) : s->d_E; };
     auto film_chunk = [&](int c) -> int {
-        LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->h_model.film_g, s->h_model.film_beta,
-                                           s->h_model.film_cg, s->h_model.film_ch,
+        LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b,
                                            s->d_s_hi, s->d_s_lo, aliased ? (void*)((char*)s->d_E - (size_t)c * lpc * 3 * 8 * 2048) : s->d_E, G, NTe,
                                            c * lpc * 3 / 2, chunks == 1 ? nround_all : lpc * 3 / 2,
                                            fuse_silu ? s->d_pp : nullptr, s->h_model.temb, s->d_t_clip, T, B,

@@ -60,12 +60,11 @@ struct DcModel {
     const bf16x8* img_je;    // joint_embed: chained pack OT=4 KT=1 (8 frags/half, always used split) + bias ftvec[4]
     const float* seq_emb;    // row-major [num_frames][128]
     const bf16x8* img_out;   // out: chained pack OT=1 KT=4 (8 frags/half, always used split) + bias ftvec[1]
-    const bf16x8* film_w;    // natural-k pack [3*L*8 tiles][32 ks], hi then lo; bf16 or f16 bits (film format)
-    const float* film_b;     // ftvec [3*L*8 tiles]
-    const float* film_g;     // ftvec [3*L*4 tiles]: StylizationBlock.norm weight per block
-    const float* film_beta;  // ftvec [3*L*4 tiles]: StylizationBlock.norm bias per block
-    const float* film_cg;    // ftvec [3*L*4 tiles]: g*(1 + b_scale) - 1   (FiLM epilogue constants with the biases folded in:
-    const float* film_ch;    // ftvec [3*L*4 tiles]: beta*(1 + b_scale) + b_shift   G'-1 = g*acc_s + cg, H' = beta*acc_s + acc_h + ch)
+    // FiLM operands with the StylizationBlock LayerNorm affine (g, beta) and the emb_layers bias folded in on the host, so the
+    // GEMM produces the E tiles directly:  G'-1 = (g (.) W_scale) S + [g (1 + b_scale) - 1],
+    //                                       H'   = (beta (.) W_scale + W_shift) S + [beta (1 + b_scale) + b_shift]
+    const bf16x8* film_w;    // natural-k pack [3*L*8 tiles][32 ks] (tiles interleaved G'0, H'0, G'1, H'1, ...), hi then lo; bf16 or f16 bits
+    const float* film_b;     // ftvec [3*L*8 tiles]: the bracketed constants (accumulator initial values), same tile order
     const float* lin_wt;     // `linear` weight transposed [64][512]
     const float* lin_b;      // [512]
     const float* temb;       // [max_timesteps][512]

@@ -17,8 +17,7 @@ hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, vo
                                   int gran);
 hipError_t dc_launch_silu_emb(hipStream_t st, int fmt, bool split, const float* pp, const float* temb, const int* t_clip,
                               void* s_hi, void* s_lo, int G, int T, int B);
-hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const float* g_ft,
-                               const float* beta_ft, const float* cg_ft, const float* ch_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
+hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
                                int nround, const float* pp, const float* temb, const int* t_clip, int T, int B,
                                unsigned long long* clk /* diagnostic clock stamps or nullptr */);
 // pp != nullptr (non-split formats): the FiLM GEMM builds its operand SiLU(temb[t_clip] + pp) itself and s_hi is not read
