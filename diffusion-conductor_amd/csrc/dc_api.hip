@@ -316,7 +316,11 @@ int build_model(dc_sampler* s) {
     const bool ssp = s->split_small;
     auto add_styl = [&](const bf16x8** dst, const std::string& p) {
         const std::vector<float> bo = ftvec(P_(p + ".out_layers.2.bias"), D, 4);
-        add_image(dst, P_(p + ".out_layers.2.weight"), D, D, ssp, bo.data(), bo.size());
+        // the kernels hand over log2(e) * SiLU(.) (silu_l2_pair in dc_kernels.hip): ln 2 goes into the weights
+        const float* w = P_(p + ".out_layers.2.weight");
+        std::vector<float> ws((size_t)D * D);
+        for (size_t i = 0; i < ws.size(); ++i) ws[i] = (float)((double)w[i] * 0.6931471805599453);
+        add_image(dst, ws.data(), D, D, ssp, bo.data(), bo.size());
     };
     // W' = W diag(g), c' = c + W b  (LayerNorm affine folded into the projection that consumes it)
     // `scale` additionally multiplies the whole projection: log2(e) for the query / key projections, whose
@@ -406,7 +410,8 @@ int build_model(dc_sampler* s) {
             const float* ng = P_(p + blk[j] + ".norm.weight");
             const float* nb = P_(p + blk[j] + ".norm.bias");
             // y = LN(h) (1 + scale) + shift with LN = g n + beta (transformer.py:74-78) becomes  y = n G' + H',
-            //   G' = g (1 + scale), H' = beta (1 + scale) + shift, both affine in S = SiLU(emb): fold g / beta into the rows
+            //   G' = g (1 + scale), H' = beta (1 + scale) + shift, both affine in S = SiLU(emb): fold g / beta into the rows.
+            // The H' tiles additionally carry log2(e): the kernels evaluate SiLU on log2(e)-scaled arguments (silu_l2_pair)
             // (tile 2t = G' - 1 of features 32t.., tile 2t+1 = H' of the same features, so one wave holds matching pairs)
             for (int t = 0; t < 4; ++t)
                 for (int f = 0; f < 32; ++f) {
@@ -417,10 +422,10 @@ int build_model(dc_sampler* s) {
                     float* dh = &film_w[(row0 + (size_t)(2 * t + 1) * 32 + f) * DC_E];
                     for (int k = 0; k < DC_E; ++k) {
                         dg[k] = (float)((double)ng[o] * ws[k]);
-                        dh[k] = (float)((double)nb[o] * ws[k] + wh[k]);
+                        dh[k] = (float)(((double)nb[o] * ws[k] + wh[k]) * LOG2E);
                     }
                     film_b[row0 + (size_t)(2 * t) * 32 + f] = (float)((double)ng[o] * (1.0 + bb[o]) - 1.0);
-                    film_b[row0 + (size_t)(2 * t + 1) * 32 + f] = (float)((double)nb[o] * (1.0 + bb[o]) + bb[128 + o]);
+                    film_b[row0 + (size_t)(2 * t + 1) * 32 + f] = (float)(((double)nb[o] * (1.0 + bb[o]) + bb[128 + o]) * LOG2E);
                 }
         }
     }

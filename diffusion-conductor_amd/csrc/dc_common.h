@@ -62,7 +62,7 @@ struct DcModel {
     const bf16x8* img_out;   // out: chained pack OT=1 KT=4 (8 frags/half, always used split) + bias ftvec[1]
     // FiLM operands with the StylizationBlock LayerNorm affine (g, beta) and the emb_layers bias folded in on the host, so the
     // GEMM produces the E tiles directly:  G'-1 = (g (.) W_scale) S + [g (1 + b_scale) - 1],
-    //                                       H'   = (beta (.) W_scale + W_shift) S + [beta (1 + b_scale) + b_shift]
+    //                               log2(e) H'   = log2(e) { (beta (.) W_scale + W_shift) S + [beta (1 + b_scale) + b_shift] }
     const bf16x8* film_w;    // natural-k pack [3*L*8 tiles][32 ks] (tiles interleaved G'0, H'0, G'1, H'1, ...), hi then lo; bf16 or f16 bits
     const float* film_b;     // ftvec [3*L*8 tiles]: the bracketed constants (accumulator initial values), same tile order
     const float* lin_wt;     // `linear` weight transposed [64][512]

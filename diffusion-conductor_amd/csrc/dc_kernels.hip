@@ -197,20 +197,22 @@ DEV f32x16 ld_ft(const float* __restrict__ p, int tile, int hh) {
     return *reinterpret_cast<const f32x16*>(p + (tile * 2 + hh) * 16);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // operand of the packed-fp32 VALU ops (v_pk_add/mul/fma_f32)
 // nn.LayerNorm(128) over the feature axis of an FT activation (transformer.py:79,104,147)
 template <int NT>
 DEV void ln_stats(const f32x16 (&x)[NT], float& mean, float& rstd) {
     // one pass: sum and sum of squares (fp32, 128 terms: the cancellation in E[x^2]-mean^2 stays ~1e-7*mean^2/var)
-    float s = 0.f, q = 0.f;
+    f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s += x[t][r];
-            q = fmaf(x[t][r], x[t][r], q);
+        for (int r = 0; r < 8; ++r) {
+            const f32x2 v = {x[t][2 * r], x[t][2 * r + 1]};
+            s2 += v;
+            q2 = __builtin_elementwise_fma(v, v, q2);
         }
-    s = xhalf_sum(s);
-    q = xhalf_sum(q);
+    const float s = xhalf_sum(s2.x + s2.y);
+    const float q = xhalf_sum(q2.x + q2.y);
     mean = s * (1.f / (32 * NT));
     const float var = fmaxf(fmaf(-mean, mean, q * (1.f / (32 * NT))), 0.f);
     rstd = rsqrtf(var + 1e-5f);
@@ -225,7 +227,12 @@ DEV void ln_frags(XFrag<T16, SPLIT> (&nf)[4], const f32x16 (&x)[4]) {
     for (int kt = 0; kt < 4; ++kt) {
         f32x16 n;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) n[r] = fmaf(x[kt][r], rstd, shift);
+        for (int r = 0; r < 8; ++r) {
+            const f32x2 v = {x[kt][2 * r], x[kt][2 * r + 1]};
+            const f32x2 w = __builtin_elementwise_fma(v, (f32x2){rstd, rstd}, (f32x2){shift, shift});
+            n[2 * r] = w.x;
+            n[2 * r + 1] = w.y;
+        }
         make_frag<T16, SPLIT>(n, nf[kt]);
     }
 }
@@ -255,6 +262,16 @@ DEV void softmax_heads_ft(f32x16 (&q)[4]) {
 }
 
 DEV float silu(float z) { return z * fast_rcp(1.f + exp2f_fast(-1.4426950408889634f * z)); }
+// SiLU on log2(e)-scaled arguments, two elements at a time: u = log2(e) x  ->  u / (1 + 2^-u) = log2(e) SiLU(x).
+// The StylizationBlocks run in this scaling (the host folds log2(e) into the H' tiles and ln 2 into W_o; the caller scales
+// rstd / shift), which removes the per-element multiply in front of v_exp_f32; the add and the product are packed-fp32 ops.
+DEV f32x2 silu_l2_pair(float u0, float u1) {
+    const f32x2 u = {u0, u1};
+    f32x2 e = {exp2f_fast(-u0), exp2f_fast(-u1)};
+    e = e + 1.f;
+    const f32x2 r = {fast_rcp(e.x), fast_rcp(e.y)};
+    return u * r;
+}
 // nn.GELU() (exact-erf form).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 noise of the
 // surrounding GEMMs): erf(a) = 1 - (a1 t + ... + a5 t^5) exp(-a^2), t = 1/(1 + p a), a >= 0.
 DEV float gelu_erf(float x) {
@@ -1448,19 +1465,21 @@ template <> struct YT<true> { using tile = f32x16; };
 template <bool SPLIT> using ytile = typename YT<SPLIT>::tile;
 
 struct RowStats {
-    float s = 0.f, q = 0.f;
+    f32x2 s = {0.f, 0.f}, q = {0.f, 0.f};          // packed-fp32 partial sums (even / odd registers)
     DEV void add(const f32x16& x) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s += x[r];
-            q = fmaf(x[r], x[r], q);
+        for (int r = 0; r < 8; ++r) {
+            const f32x2 v = {x[2 * r], x[2 * r + 1]};
+            s += v;
+            q = __builtin_elementwise_fma(v, v, q);
         }
     }
-    DEV void finish(float& rstd, float& shift) {      // LayerNorm(128): n = x*rstd + shift
-        const float ss = xhalf_sum(s), qq = xhalf_sum(q);
+    // LayerNorm(128) of a StylizationBlock input, in the log2(e) scaling of styl_tile: log2(e) nhat = x*rstd + shift
+    DEV void finish(float& rstd, float& shift) {
+        const float ss = xhalf_sum(s.x + s.y), qq = xhalf_sum(q.x + q.y);
         const float mean = ss * (1.f / 128.f);
         const float var = fmaxf(fmaf(-mean, mean, qq * (1.f / 128.f)), 0.f);
-        rstd = rsqrtf(var + 1e-5f);
+        rstd = rsqrtf(var + 1e-5f) * 1.4426950408889634f;
         shift = -mean * rstd;
     }
 };
@@ -1532,7 +1551,8 @@ DEV float add_mix_h(uint32_t h2, float c) {        // (float)half + c
     return d;
 }
 
-// one k-tile of the FiLM-modulated, SiLU'ed operand: z = SiLU(nhat*G' + H'), gp = G' - 1
+// one k-tile of the FiLM-modulated, SiLU'ed operand: z = SiLU(nhat*G' + H'), gp = G' - 1; everything in the log2(e)
+// scaling of silu_l2_pair: rstd / shift arrive multiplied by log2(e), hp = log2(e) H', z = log2(e) SiLU(.)
 template <class T16, bool SPLIT, class YTile>
 DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shift, const f16x16& gp, const f16x16& hp) {
     f32x16 z;
@@ -1541,14 +1561,17 @@ DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shif
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float n0 = fma_mix_h<0>(yw[k], rstd, shift), n1 = fma_mix_h<1>(yw[k], rstd, shift);
-            z[2 * k] = silu(add_mix_h<0>(hw[k], fma_mix_h<0>(gw[k], n0, n0)));
-            z[2 * k + 1] = silu(add_mix_h<1>(hw[k], fma_mix_h<1>(gw[k], n1, n1)));
+            const f32x2 zz = silu_l2_pair(add_mix_h<0>(hw[k], fma_mix_h<0>(gw[k], n0, n0)), add_mix_h<1>(hw[k], fma_mix_h<1>(gw[k], n1, n1)));
+            z[2 * k] = zz.x;
+            z[2 * k + 1] = zz.y;
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float n = fmaf((float)y[r], rstd, shift);
-            z[r] = silu(fmaf(n, (float)gp[r], n + (float)hp[r]));
+        for (int k = 0; k < 8; ++k) {
+            const float n0 = fmaf((float)y[2 * k], rstd, shift), n1 = fmaf((float)y[2 * k + 1], rstd, shift);
+            const f32x2 zz = silu_l2_pair(fmaf(n0, (float)gp[2 * k], n0 + (float)hp[2 * k]), fmaf(n1, (float)gp[2 * k + 1], n1 + (float)hp[2 * k + 1]));
+            z[2 * k] = zz.x;
+            z[2 * k + 1] = zz.y;
         }
     }
     make_frag<T16, SPLIT>(z, zf);
