@@ -265,6 +265,14 @@ DEV float silu(float z) { return z * fast_rcp(1.f + exp2f_fast(-1.44269504088896
 // SiLU on log2(e)-scaled arguments, two elements at a time: u = log2(e) x  ->  u / (1 + 2^-u) = log2(e) SiLU(x).
 // The StylizationBlocks run in this scaling (the host folds log2(e) into the H' tiles and ln 2 into W_o; the caller scales
 // rstd / shift), which removes the per-element multiply in front of v_exp_f32; the add and the product are packed-fp32 ops.
+DEV f32x2 silu_pair(float x0, float x1) {          // plain SiLU of two elements, packed-fp32 products and sums
+    const f32x2 x = {x0, x1};
+    const f32x2 u = x * 1.4426950408889634f;
+    f32x2 e = {exp2f_fast(-u.x), exp2f_fast(-u.y)};
+    e = e + 1.f;
+    const f32x2 r = {fast_rcp(e.x), fast_rcp(e.y)};
+    return x * r;
+}
 DEV f32x2 silu_l2_pair(float u0, float u1) {
     const f32x2 u = {u0, u1};
     f32x2 e = {exp2f_fast(-u0), exp2f_fast(-u1)};
@@ -1210,39 +1218,53 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
         const int tb = u / nround, p = (round0 + u % nround) * 8 + wave;
         const int g0 = tb * 4;
         if (tb != cur_blk) {
-            __syncthreads();                                      // everyone is done with the previous slab
             // slab: frag (g, ks) at [(g*32 + ks)]; groups past the end alias the last one (their stores are skipped)
             if (abl & 8) {
-                // timing experiment: no slab fill at all
+                __syncthreads();                                  // timing experiment: no slab fill at all
             } else if (pp) {
                 // fused operand production (was k_silu_emb): S = SiLU(temb[t_clip] + linear(xf_proj)) (transformer.py:73-74,482)
                 // straight from the fp32 fragment image into the slab - saves the 16-bit image's HBM round trip
                 v8<T16>* slab_w = reinterpret_cast<v8<T16>*>(lds);
-                // a wave fills fragments f = wave + 8i, i < 16.  The loads of 8 fragments are issued before the first SiLU:
-                // one by one (load, SiLU, write) the fill exposed 16 HBM latencies per slab = 16 % of the kernel
-#pragma unroll 1
+                // a wave fills fragments f = wave + 8i, i < 16 (group i >> 2, k-step (wave + 8i) & 31).  The loads of 8 fragments
+                // are issued before the first SiLU: one by one (load, SiLU, write) the fill exposed 16 HBM latencies per slab
+                // = 16 % of the kernel.  The timestep rows of the four groups are looked up first, so that the only dependent
+                // load chain is t_clip -> temb once per slab, and the first half's loads are in flight while the workgroup
+                // waits for its slowest wave to leave the previous slab.
+                const float* trow[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int gg = min(g0 + g, G - 1);
+                    const int b = min((gg * 32 + (lane & 31)) / T, B - 1);
+                    trow[g] = temb + (size_t)t_clip[b] * 512 + 8 * (lane >> 5);
+                }
+#pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     f32x8 pv[8], tv[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int f = wave + 8 * (8 * half + i);
-                        const int gg = min(g0 + (f >> 5), G - 1), ks = f & 31;
-                        const int b = min((gg * 32 + (lane & 31)) / T, B - 1);
+                        const int gg = min(g0 + 2 * half + (i >> 2), G - 1), ks = f & 31;
                         pv[i] = ld_pp(pp, (size_t)gg * DC_KS_E + ks, lane);
-                        tv[i] = *reinterpret_cast<const f32x8*>(temb + (size_t)t_clip[b] * 512 + 16 * ks + 8 * (lane >> 5));
+                        tv[i] = *reinterpret_cast<const f32x8*>(trow[2 * half + (i >> 2)] + 16 * ks);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (half == 0) __syncthreads();               // everyone is done with the previous slab
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int f = wave + 8 * (8 * half + i);
                         v8<T16> hi;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) hi[j] = (T16)silu(pv[i][j] + tv[i][j]);
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x2 z = silu_pair(pv[i][2 * j] + tv[i][2 * j], pv[i][2 * j + 1] + tv[i][2 * j + 1]);
+                            hi[2 * j] = (T16)z.x;
+                            hi[2 * j + 1] = (T16)z.y;
+                        }
                         slab_w[f * 64 + lane] = hi;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
+                __syncthreads();                                  // everyone is done with the previous slab
                 for (int f = wave; f < 4 * DC_KS_E; f += 8) {
                     const int gg = min(g0 + (f >> 5), G - 1);
                     lds_dma16(S + ((size_t)gg * DC_KS_E + (f & 31)) * 64 + lane, lds + f * 1024);
@@ -1275,6 +1297,8 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
                 if ((q & 1) == 0) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) bB[g] = slab[(g * DC_KS_E + ((abl & 2) ? 0 : ksn)) * 64 + lane];
+                    // (hipcc sinks these reads behind the 7th MFMA and reuses the registers; fencing them up here, one whole
+                    //  k-step ahead in distinct registers, measured 4 % slower)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         acc[0][g] = mfma(a0[q], bA[g], acc[0][g]);
