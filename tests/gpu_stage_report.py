@@ -117,7 +117,8 @@ def main():
                     sc, sh = torch.chunk(e, 2, dim=-1)
                     npre = f"temporal_decoder_blocks.{i}.{blk}.proj_out.norm"
                     g_, b_ = p[npre + ".weight"], p[npre + ".bias"]
-                    eref.append(torch.cat([g_ * (1 + sc) - 1, b_ * (1 + sc) + sh], dim=-1))   # the folded (G'-1) | H' image
+                    # the folded (G'-1) | log2(e) H' image (the StylizationBlocks evaluate SiLU on log2(e)-scaled arguments)
+                    eref.append(torch.cat([g_ * (1 + sc) - 1, (b_ * (1 + sc) + sh) * 1.4426950408889634], dim=-1))
             eref = torch.cat(eref, dim=-1).reshape(M, -1)
         print(f"  FiLM G'|H'          {rel_l2(E, eref):.3e}")
         for i in range(8):
