@@ -535,7 +535,7 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
     }
     if (!s->d_iter) {
         int rc;
-        if ((rc = dev_alloc(s, s->d_stamps, 8 * 32 * 8))) return rc;
+        if ((rc = dev_alloc(s, s->d_stamps, (8 * 32 + 8 + 1024) * 8))) return rc;
         if ((rc = dev_alloc(s, s->d_gbar, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_gerr, 16))) return rc;
         HIP_TRY(hipMemset(s->d_gerr, 0, 16));
@@ -642,7 +642,8 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     // workgroup-level records (no combine launches) whenever a workgroup's 256 tokens cannot touch more than two clips
     static const bool no_wgr = getenv("DC_NO_WGREC") != nullptr;
     const bool wgr = !ss && T >= 256 && !no_wgr;
-    LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B));
+    LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
+                                          want_stamps_film ? s->d_stamps + 256 : nullptr));
     static const int ablate = getenv("DC_ABLATE") ? (int)strtol(getenv("DC_ABLATE"), nullptr, 0) : 0;   // timing experiments
     static const bool want_stamps = getenv("DC_STAMPS") != nullptr;
     const bool no_persist = false;
@@ -666,7 +667,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, e_for_layer(l), NTe, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur,
-                                        s->d_snaps, M, T, G, B, dbg, (l == 3 && want_stamps) ? s->d_stamps : nullptr, l + 1, rec_stride,
+                                        s->d_snaps, M, T, G, B, dbg, ((l == 3 || l == 4) && want_stamps) ? s->d_stamps : nullptr, l + 1, rec_stride,
                                         s->d_gbar, s->d_gerr));
     }
     return DC_OK;
@@ -1119,7 +1120,7 @@ int dc_sampler_debug_read(dc_sampler* s, const char* what, void* h_out, int64_t 
     else if (w == "recs") { src = s->d_recs; have = g * 2 * DC_REC_FLOATS * 4; }
     else if (w == "a_sa") { src = s->d_a_sa; have = (size_t)s->B * 16 * 1024; }
     else if (w == "a_ca") { src = s->d_a_ca; have = (size_t)s->cfg.num_layers * s->B * 16 * 1024; }
-    else if (w == "stamps") { src = s->d_stamps; have = 8 * 32 * 8; }
+    else if (w == "stamps") { src = s->d_stamps; have = (8 * 32 + 8 + 1024) * 8; }
     else if (w == "temb") { src = s->h_model.temb; have = (size_t)s->cfg.max_timesteps * 512 * 4; }
     else return fail(DC_ERR_INVALID, "unknown debug buffer '%s'", what);
     if (!src) return fail(DC_ERR_INVALID, "buffer '%s' not allocated yet", what);

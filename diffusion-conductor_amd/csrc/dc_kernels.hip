@@ -1352,9 +1352,15 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
 template <class T16, bool SPLIT, bool WGR>
 __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
 void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /*[M][P]*/, float* __restrict__ hbuf,
-                   float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G, int B) {
+                   float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G, int B,
+                   unsigned long long* __restrict__ clk /* diagnostic: 100-MHz stamps of one wave, or nullptr */) {
     constexpr int NW = SPLIT ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;
+    const bool stamping = clk && blockIdx.x == 100 && threadIdx.x == 0;
+    auto stamp = [&](int i) {
+        if (stamping) clk[i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
     using W = v8<T16>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wg = WGR ? wg_index() : (int)blockIdx.x;
@@ -1365,15 +1371,61 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
     const int P = dm->input_feats;
     const bool live = cx.tok < M;
     const int n = live ? cx.tok % T : 0;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int OFF_IMG_K = 8192, OFF_IMG_V = 8192 + 65536 + 8192 + 9 * 4 * 32 * 4;
+    if constexpr (WGR) {
+        // layer 0's key / value images (32 fragments + 1 KiB of bias each) go to LDS by LDS-DMA while the embedding is
+        // computed; the key image lies in the pst region, which is first written after the barrier that ends its use
+        const W* gk = reinterpret_cast<const W*>(dm->layer[0].img_sa_k);
+        const W* gv = reinterpret_cast<const W*>(dm->layer[0].img_sa_v);
+        for (int f = wave; f < 33; f += NW) {
+            lds_dma16(gk + f * 64 + lane, lds + OFF_IMG_K + f * 1024);
+            lds_dma16(gv + f * 64 + lane, lds + OFF_IMG_V + f * 1024);
+        }
+    }
+    // sequence_embedding rows: issued first, consumed after the embedding GEMM
+    const float* se = dm->seq_emb + (size_t)n * DC_D;
+    f32x4 sev[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sev[4 * t + q] = *reinterpret_cast<const f32x4*>(se + 32 * t + 8 * q + 4 * cx.hh);
     // x as chained-order operand: element j of k-step s <-> pose feature 16s + 8(j>>2) + 4hh + (j&3)
     f32x16 h[4];
     {
         XFrag<T16, true> xf[1];
         f32x16 xv;
+        bool staged = false;
+        if constexpr (WGR) {
+            // A group's 32 x P floats are contiguous: fetch them with 16-byte loads (<= 4 per lane) and turn them through a
+            // wave-private LDS patch.  (Per-element loads touch 32+ cache lines per instruction; the 8 waves' 128 such
+            // instructions queue in the CU's address unit for ~4 us.)  The last, partial group keeps the element loads.
+            constexpr int OFF_XS = 8192 + 34 * 1024;               // inside pst, behind the key image; 3.5 KiB per wave
+            staged = active && 32 * g + 32 <= M;                   // wave-uniform
+            if (staged) {
+                float* xs = reinterpret_cast<float*>(lds + OFF_XS + wave * 3584);
+                const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)g * 32 * P);
+                f32x4 ch[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = tile_row(r, cx.hh);
-            xv[r] = (live && f < P) ? x[(size_t)cx.tok * P + f] : 0.f;
+                for (int i = 0; i < 4; ++i)
+                    if (i * 64 + lane < 8 * P) ch[i] = src[i * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i * 64 + lane < 8 * P) reinterpret_cast<f32x4*>(xs)[i * 64 + lane] = ch[i];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = tile_row(r, cx.hh);
+                    xv[r] = f < P ? xs[cx.c * P + f] : 0.f;
+                }
+            }
+        }
+        if (!staged) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = tile_row(r, cx.hh);
+                xv[r] = (live && f < P) ? x[(size_t)cx.tok * P + f] : 0.f;
+            }
         }
         make_frag<T16, true>(xv, xf[0]);
         const W* img = reinterpret_cast<const W*>(dm->img_je);
@@ -1382,49 +1434,53 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
         for (int t = 0; t < 4; ++t) h[t] = ld_ft(je_b, t, cx.hh);
         gemm_wa<4, 1, T16, true>(h, img, xf, lane);
     }
-    const float* se = dm->seq_emb + (size_t)n * DC_D;
+    stamp(1);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(se + 32 * t + 8 * q + 4 * cx.hh);
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) h[t][4 * q + i] += v[i];
-        }
+            for (int i = 0; i < 4; ++i) h[t][4 * q + i] += sev[4 * t + q][i];
     if (active) store_h(h, hbuf, g, lane);
     const DcLayer& L = dm->layer[0];
     XFrag<T16, SPLIT> nf[4];
     ln_frags<T16, SPLIT>(nf, h);
+    stamp(2);
     const W* wk = reinterpret_cast<const W*>(L.img_sa_k);
     const W* wv = reinterpret_cast<const W*>(L.img_sa_v);
     if constexpr (!WGR) {
         front_stage<T16, SPLIT>(nf, wk, wv, reinterpret_cast<const float*>(wk + 32 * WM * 64),
                                 reinterpret_cast<const float*>(wv + 32 * WM * 64), cx, M, T, length, recs, active);
-    } else {     // workgroup-level record (see wg_* helpers); LDS: mx 8 KiB | pst 64 KiB | xp 8 KiB | ss 4.5 KiB
-        extern __shared__ __attribute__((aligned(16))) char lds[];
+    } else {     // workgroup-level record (see wg_* helpers); LDS: mx 8 KiB | pst 64 KiB | xp 8 KiB | ss 4.5 KiB | value image 33 KiB
         float* mx = reinterpret_cast<float*>(lds);
         f32x8* pst = reinterpret_cast<f32x8*>(lds + 8192);
         f32x8* xp = reinterpret_cast<f32x8*>(lds + 8192 + 65536);
         float* ss = reinterpret_cast<float*>(lds + 8192 + 65536 + 8192);
         const int ub0 = (wg * NW * 32) / T;
-        const float* bk = reinterpret_cast<const float*>(wk + 32 * 64);
-        const float* bv = reinterpret_cast<const float*>(wv + 32 * 64);
+        const W* lk = reinterpret_cast<const W*>(lds + OFF_IMG_K);
+        const W* lv = reinterpret_cast<const W*>(lds + OFF_IMG_V);
+        const float* bk = reinterpret_cast<const float*>(lk + 32 * 64);
+        const float* bv = reinterpret_cast<const float*>(lv + 32 * 64);
         const RowRange vr[2] = {valid_rows_clip(cx, ub0, B, M, T, length, active), valid_rows_clip(cx, ub0 + 1, B, M, T, length, active)};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's image pieces have landed
+        __syncthreads();
+        stamp(3);
         f32x16 K[4];
 #pragma unroll
         for (int oc = 0; oc < 4; ++oc) {
             K[oc] = splat(bk[32 * oc + cx.c]);
-            mmb_oc<4, 4, T16, false>(K[oc], wk, oc, nf, lane);
+            mmb_oc<4, 4, T16, false>(K[oc], lk, oc, nf, lane);
         }
         wg_put_maxes(K, cx, vr, mx, wave);
         __syncthreads();
+        stamp(4);
         const int s0 = cx.b0 - ub0;
         RowRange vr_own = vr[0];
         if (s0) vr_own = vr[1];
 #pragma unroll
         for (int oc = 0; oc < 4; ++oc) {
             f32x16 V = splat(bv[32 * oc + cx.c]);
-            mmb_oc<4, 4, T16, false>(V, wv, oc, nf, lane);
+            mmb_oc<4, 4, T16, false>(V, lv, oc, nf, lane);
             float ssum;
             f32x8 keep;
             partial_tile<T16>(K[oc], V, vr_own, wg_colmax(mx, oc, s0, cx.c), cx, ssum, keep);
@@ -1437,8 +1493,11 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        stamp(5);
         __syncthreads();
+        stamp(6);
         wg_write_record(recs, mx, pst, xp, ss, wave, lane, ub0, G, M, T, wg);
+        stamp(7);
     }
 }
 
@@ -1754,9 +1813,15 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     // diagnostic build aid: 100 MHz timestamps per stage for the waves of workgroup 3 (stamps == nullptr normally)
 #define DC_STAMP(k)                                                                                        \
     do {                                                                                                   \
-        if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0 && (l == 3 || l_end == l_first + 1)) \
+        if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0 && l == 3)                       \
             stamps[(threadIdx.x >> 6) * 32 + (k)] = __builtin_amdgcn_s_memrealtime();                      \
-    } while (0)                 // frags of one 128x128 stage image (constants block follows)
+    } while (0)
+    // ... and begin / end stamps of every workgroup of layers 3 and 4 (two consecutive launches): [layer][workgroup][2] from slot 264
+#define DC_WGSTAMP(e)                                                                                      \
+    do {                                                                                                   \
+        if (STAMP && stamps && threadIdx.x == 0 && (l == 3 || l == 4) && blockIdx.x < 256)                 \
+            stamps[264 + ((l - 3) * 256 + blockIdx.x) * 2 + (e)] = __builtin_amdgcn_s_memrealtime();       \
+    } while (0)
     constexpr int WSZ = (NFW + 1) * 1024;
     constexpr int OFF_AF = 2 * WSZ;              // non-split: attention frags of the workgroup's <= 2 clips (16 KiB)
     constexpr int OFF_ER = OFF_AF + 16384;       // non-split: per-wave FiLM tile rings (8 KiB each)
@@ -1807,10 +1872,11 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     float* recs_out = recs + (size_t)((l + 1) & 1) * rec_stride;
 
     DC_STAMP(0);
+    DC_WGSTAMP(0);
     stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
     if constexpr (WGR)      // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
-        wg_combine_attn<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, M, T, threadIdx.x, wg,
-                             (STAMP && stamps && blockIdx.x == 3 && (l == 3 || l_end == l_first + 1)) ? stamps : nullptr);
+        wg_combine_attn<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, M, T, tid_, wg,
+                             (STAMP && stamps && blockIdx.x == 3 && l == 3) ? stamps : nullptr);
     else if (wg_lds)
         stage_attn(a_sa);
     DC_STAMP(14);
@@ -2110,6 +2176,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             }
         }
         DC_STAMP(13);
+        DC_WGSTAMP(1);
         if (more) {
             grid_barrier(gbar, (unsigned)gridDim.x * (unsigned)(l - l_first + 1), gerr);
             continue;
@@ -2695,9 +2762,9 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
 
 template <class T16, bool SP, bool WGR>
 static hipError_t launch_embed_t(hipStream_t st, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
-                                 int M, int T, int G, int B) {
+                                 int M, int T, int G, int B, unsigned long long* clk) {
     constexpr int NW = SP ? 4 : 8;
-    const size_t shm = WGR ? 8192 + 65536 + 8192 + 9 * 4 * 32 * 4 : 0;
+    const size_t shm = WGR ? 8192 + 65536 + 8192 + 9 * 4 * 32 * 4 + 33 * 1024 : 0;
     if (WGR) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -2706,18 +2773,18 @@ static hipError_t launch_embed_t(hipStream_t st, const DcModel* dm, const float*
             attr_set = true;
         }
     }
-    k_embed_front<T16, SP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, B);
+    k_embed_front<T16, SP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, B, clk);
     return hipGetLastError();
 }
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf,
-                                 float* recs, const int* length, int M, int T, int G, int B) {
+                                 float* recs, const int* length, int M, int T, int G, int B, unsigned long long* clk) {
     hipError_t e = hipSuccess;
     if (wgr && !split) {
-        e = fmt == 1 ? launch_embed_t<_Float16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B)
-                     : launch_embed_t<__bf16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B);
+        e = fmt == 1 ? launch_embed_t<_Float16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk)
+                     : launch_embed_t<__bf16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk);
         return e;
     }
-    DISPATCH(fmt, split, (e = launch_embed_t<T16, SP, false>(st, dm, x, hbuf, recs, length, M, T, G, B)));
+    DISPATCH(fmt, split, (e = launch_embed_t<T16, SP, false>(st, dm, x, hbuf, recs, length, M, T, G, B, clk)));
     return e;
 }
 

@@ -24,7 +24,8 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
 // wgr: workgroup-level partial records, combined by the consuming layer kernel itself (non-split formats and T >= 256 only;
 // no dc_launch_attn_combine between the layers then)
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf, float* recs,
-                                 const int* length, int M, int T, int G, int B);
+                                 const int* length, int M, int T, int G, int B,
+                                 unsigned long long* clk /* diagnostic stamps (8 slots) or nullptr */);
 hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,

@@ -39,3 +39,18 @@ print("                    ->frags written   " + seg(25, 14))
 ck = nat.debug_read("stamps", np.uint64, 8 * 32).astype(np.int64)[252:256]
 if ck[3] > ck[1]:
     print(f"k_film_gemm workgroup 5: {(ck[3] - ck[1]) / 100.0:.1f} us, core clock {(ck[2] - ck[0]) / (ck[3] - ck[1]) * 100.0:.0f} MHz")
+ef = nat.debug_read("stamps", np.uint64, 8 * 32 + 8).astype(np.int64)[256:264]
+if ef[7] > ef[0]:
+    names = ["x loads + joint_embed", "seq_emb, store h, LN", "images landed + barrier", "K proj + maxima + barrier", "V proj + partial tiles",
+             "barrier", "record written"]
+    print("k_embed_front workgroup 100, wave 0 (us): " + "   ".join(f"{n} {(ef[i + 1] - ef[i]) / 100.0:.2f}" for i, n in enumerate(names))
+          + f"   total {(ef[7] - ef[0]) / 100.0:.2f}")
+wg = nat.debug_read("stamps", np.uint64, 8 * 32 + 8 + 1024).astype(np.int64)[264:].reshape(2, 256, 2)[:, :225]
+if wg[0, :, 1].max() > 0:
+    t0 = wg[0, :, 0].min()
+    q = lambda a: " ".join(f"{v / 100.0:7.2f}" for v in np.percentile(a, [0, 10, 50, 90, 100]))
+    print("per-workgroup stamps, us relative to the first workgroup of layer 3 (min p10 p50 p90 max):")
+    for i, name in enumerate(("layer 3", "layer 4")):
+        print(f"  {name} begin {q(wg[i, :, 0] - t0)}   end {q(wg[i, :, 1] - t0)}   lifetime {q(wg[i, :, 1] - wg[i, :, 0])}")
+    print(f"  last end of layer 3 -> first begin of layer 4: {(wg[1, :, 0].min() - wg[0, :, 1].max()) / 100.0:.2f} us;"
+          f"  first begin to first begin: {(wg[1, :, 0].min() - wg[0, :, 0].min()) / 100.0:.2f} us")
