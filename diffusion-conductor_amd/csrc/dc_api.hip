@@ -161,6 +161,8 @@ struct dc_sampler {
     void *d_nh_hi = nullptr, *d_nh_lo = nullptr;
     // step state
     unsigned long long* d_stamps = nullptr;
+    float* d_film_rate = nullptr;  // FiLM GEMM: per-workgroup speeds measured by the previous launches, two buffers of 1024 (ping-pong)
+    int film_rate_parity = 0;
     unsigned* d_gbar = nullptr;   // grid-barrier arrival counter of the persistent layer kernel (zeroed before each launch)
     int* d_gerr = nullptr;        // set by a workgroup whose grid-barrier spin ran out
     int num_cu = 0;
@@ -535,8 +537,10 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
     }
     if (!s->d_iter) {
         int rc;
-        if ((rc = dev_alloc(s, s->d_stamps, (8 * 32 + 8 + 1024) * 8))) return rc;
+        if ((rc = dev_alloc(s, s->d_stamps, (8 * 32 + 8 + 1024 + 1024 + 256 + 8) * 8))) return rc;
         if ((rc = dev_alloc(s, s->d_gbar, 16))) return rc;
+        if ((rc = dev_alloc(s, s->d_film_rate, 2 * 1024 * sizeof(float)))) return rc;
+        HIP_TRY(hipMemset(s->d_film_rate, 0, 2 * 1024 * sizeof(float)));      // 0 = not measured yet: equal shares
         if ((rc = dev_alloc(s, s->d_gerr, 16))) return rc;
         HIP_TRY(hipMemset(s->d_gerr, 0, 16));
         if ((rc = dev_alloc(s, s->d_iter, 16))) return rc;
@@ -618,12 +622,18 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const bool aliased = alias && chunks > 1;
     const int NTe = aliased ? s->NT / chunks : s->NT;
     auto e_for_layer = [&](int l) -> void* { return aliased ? (void*)((char*)s->d_E - (size_t)(l - l % lpc) * 24 * 2048) : s->d_E; };
+    // adaptive work shares of the persistent FiLM GEMM (dc_kernels.hip, k_film_gemm2); DC_FILM_STATIC=1 keeps equal shares
+    static const bool film_static = getenv("DC_FILM_STATIC") != nullptr;
+    const bool adapt = !film_static && s->num_cu <= 1024;
     auto film_chunk = [&](int c) -> int {
         LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b,
                                            s->d_s_hi, s->d_s_lo, aliased ? (void*)((char*)s->d_E - (size_t)c * lpc * 3 * 8 * 2048) : s->d_E, G, NTe,
                                            c * lpc * 3 / 2, chunks == 1 ? nround_all : lpc * 3 / 2,
                                            fuse_silu ? s->d_pp : nullptr, s->h_model.temb, s->d_t_clip, T, B,
-                                           want_stamps_film ? s->d_stamps + 252 : nullptr));
+                                           want_stamps_film ? s->d_stamps + 252 : nullptr,
+                                           adapt ? s->d_film_rate + 1024 * s->film_rate_parity : nullptr,
+                                           adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr));
+        s->film_rate_parity ^= 1;
         return DC_OK;
     };
     { int rc = film_chunk(0); if (rc) return rc; }
@@ -854,7 +864,7 @@ void dc_sampler_destroy(dc_sampler* s) {
     void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_y, s->d_mean, s->d_rstd, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
                     s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t,
-                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_gbar, s->d_gerr};
+                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_gbar, s->d_gerr, s->d_film_rate};
     for (void* p : ptrs)
         if (p) hipFree(p);
     dc_music_destroy(s->music);
@@ -1120,7 +1130,7 @@ int dc_sampler_debug_read(dc_sampler* s, const char* what, void* h_out, int64_t 
     else if (w == "recs") { src = s->d_recs; have = g * 2 * DC_REC_FLOATS * 4; }
     else if (w == "a_sa") { src = s->d_a_sa; have = (size_t)s->B * 16 * 1024; }
     else if (w == "a_ca") { src = s->d_a_ca; have = (size_t)s->cfg.num_layers * s->B * 16 * 1024; }
-    else if (w == "stamps") { src = s->d_stamps; have = (8 * 32 + 8 + 1024) * 8; }
+    else if (w == "stamps") { src = s->d_stamps; have = (8 * 32 + 8 + 1024 + 1024 + 256 + 8) * 8; }
     else if (w == "temb") { src = s->h_model.temb; have = (size_t)s->cfg.max_timesteps * 512 * 4; }
     else return fail(DC_ERR_INVALID, "unknown debug buffer '%s'", what);
     if (!src) return fail(DC_ERR_INVALID, "buffer '%s' not allocated yet", what);

@@ -1176,15 +1176,22 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
                                                        const v8<T16>* __restrict__ S, f16x16* __restrict__ E, int G, int NT, int round0,
                                                        int nround, const float* __restrict__ pp, const float* __restrict__ temb,
                                                        const int* __restrict__ t_clip, int T, int B, int abl,
-                                                       unsigned long long* __restrict__ clk) {
+                                                       unsigned long long* __restrict__ clk, const float* __restrict__ rate_in,
+                                                       float* __restrict__ rate_out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using OP = v8<T16>;
     constexpr int PF = 4;       // measured: 8 (with the 256-register budget it needs) is 25 % slower
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     // diagnostic (clk == nullptr normally): core-clock and 100-MHz stamps around one workgroup's whole sweep give the
     // clock the chip actually holds under this kernel (MI355X_MICROARCH.md, DVFS give-back item 6)
     if (clk && blockIdx.x == 5 && threadIdx.x == 0) {
         clk[0] = __builtin_amdgcn_s_memtime();
         clk[1] = __builtin_amdgcn_s_memrealtime();
+    }
+    // ... and for every workgroup (slots 1036.. relative to clk = stamps + 252): clock and finish time per XCD
+    if (clk && threadIdx.x == 0 && blockIdx.x < 256) {
+        clk[1036 + blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+        clk[1036 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hh = lane >> 5;
@@ -1201,8 +1208,59 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
     // slower overall; a single-wave-per-SIMD form - 4 waves, 2 pairs x 4 groups each, the 256 accumulator registers in
     // AGPRs, half the LDS reads per MFMA - ran 33 % slower: two waves per SIMD hide each other's waits far better than
     // a deeper prefetch ring does.)
-    const int u0 = (int)(nunit * blockIdx.x / gridDim.x), u1 = (int)(nunit * (blockIdx.x + 1) / gridDim.x);
+    // Shares: equal on the first launch, then proportional to the speed (units per 100-MHz tick, smoothed) that the
+    // workgroups of each XCD measured in the previous launches.  The XCDs of one MI355X hold clocks 10-12 % apart under
+    // this kernel, and with equal shares the slowest XCD's workgroups finish up to 30 us after the fastest's.  Only the
+    // per-XCD mean is used: a single workgroup's speed depends on how many slab fills its range happens to contain, and
+    // feeding that back makes the boundaries oscillate.  The partition does not change any result (a unit's tiles do not
+    // depend on who computes them).  Every wave derives the same integer boundaries.
+    int u0, u1;
+    {
+        const int nw = gridDim.x, b = blockIdx.x;
+        float xs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // lane i covers workgroups i, i + 64, ...: all on XCD i & 7
+        int nzero = 0;
+        for (int i = lane; i < nw; i += 64) {
+            const float r = rate_in ? rate_in[i] : 0.f;
+            xs[0] += r;
+            nzero += !(r > 0.f);
+        }
+        // sum over the lanes of the same XCD (lane & 7 fixed): xor-shuffles with 8, 16, 32
+        float xsum = xs[0];
+#pragma unroll
+        for (int m = 32; m >= 8; m >>= 1) xsum += __shfl_xor(xsum, m);
+        int cnt = 0;
+        for (int i = lane; i < nw; i += 64) ++cnt;
+#pragma unroll
+        for (int m = 32; m >= 8; m >>= 1) cnt += __shfl_xor(cnt, m);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) nzero += __shfl_xor(nzero, m);
+        float tot = xsum;                                           // sum over all workgroups
+#pragma unroll
+        for (int m = 4; m >= 1; m >>= 1) tot += __shfl_xor(tot, m);
+        const bool adaptive = rate_in && nzero == 0 && nw >= 64;
+        // this lane's XCD weight (relative speed, clamped), as an integer
+        int wx = 4096;
+        if (adaptive) wx = (int)(fminf(fmaxf((xsum / (float)cnt) * ((float)nw / tot), 0.8f), 1.2f) * 4096.f + 0.5f);
+        int before = 0, mine = 0, total = 0;
+        for (int i = lane; i < nw; i += 64) {                       // workgroup i is on XCD i & 7 == lane & 7
+            total += wx;
+            before += i < b ? wx : 0;
+            mine += i == b ? wx : 0;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            total += __shfl_xor(total, m);
+            before += __shfl_xor(before, m);
+            mine += __shfl_xor(mine, m);
+        }
+        u0 = __builtin_amdgcn_readfirstlane((int)(nunit * before / total));
+        u1 = __builtin_amdgcn_readfirstlane((int)(nunit * (before + mine) / total));
+    }
     int cur_blk = -1;
+    // diagnostic: where a slab fill's time goes (summed over this workgroup's fills, wave 0): wait for the slowest wave of the
+    // previous slab | SiLU + slab writes + second half | last loads + closing barrier
+    const bool ftime = clk && blockIdx.x == 5 && threadIdx.x == 0;
+    unsigned long long fill_t[3] = {0, 0, 0}, fill_n = 0;
     OP a0[PF], a1[PF];
     // abl & 1 (timing experiment, garbage results): every round reads the same 8 tile pairs - weights always cache-resident
     auto wbase = [&](int u) { return W + (size_t)(2 * ((abl & 1 ? 0 : (round0 + u % nround)) * 8 + wave)) * DC_KS_E * 64 + lane; };
@@ -1218,6 +1276,8 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
         const int tb = u / nround, p = (round0 + u % nround) * 8 + wave;
         const int g0 = tb * 4;
         if (tb != cur_blk) {
+            const unsigned long long tf0 = ftime ? __builtin_amdgcn_s_memrealtime() : 0;
+            unsigned long long tf1 = tf0;
             // slab: frag (g, ks) at [(g*32 + ks)]; groups past the end alias the last one (their stores are skipped)
             if (abl & 8) {
                 __syncthreads();                                  // timing experiment: no slab fill at all
@@ -1248,7 +1308,10 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
                         tv[i] = *reinterpret_cast<const f32x8*>(trow[2 * half + (i >> 2)] + 16 * ks);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (half == 0) __syncthreads();               // everyone is done with the previous slab
+                    if (half == 0) {
+                        __syncthreads();               // everyone is done with the previous slab
+                        if (ftime) tf1 = __builtin_amdgcn_s_memrealtime();
+                    }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int f = wave + 8 * (8 * half + i);
@@ -1270,8 +1333,16 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
                     lds_dma16(S + ((size_t)gg * DC_KS_E + (f & 31)) * 64 + lane, lds + f * 1024);
                 }
             }
+            const unsigned long long tf2 = ftime ? __builtin_amdgcn_s_memrealtime() : 0;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (ftime) {
+                const unsigned long long tf3 = __builtin_amdgcn_s_memrealtime();
+                fill_t[0] += tf1 - tf0;
+                fill_t[1] += tf2 - tf1;
+                fill_t[2] += tf3 - tf2;
+                ++fill_n;
+            }
             cur_blk = tb;
         }
         const OP* w0 = wbase(u);                                  // scale tile of the pair; the shift tile follows
@@ -1340,6 +1411,21 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
     if (clk && blockIdx.x == 5 && threadIdx.x == 0) {
         clk[2] = __builtin_amdgcn_s_memtime();
         clk[3] = __builtin_amdgcn_s_memrealtime();
+        clk[1036 + 1024 + 256 + 0] = fill_t[0];
+        clk[1036 + 1024 + 256 + 1] = fill_t[1];
+        clk[1036 + 1024 + 256 + 2] = fill_t[2];
+        clk[1036 + 1024 + 256 + 3] = fill_n;
+    }
+    if (clk && threadIdx.x == 0 && blockIdx.x < 256) {
+        clk[1036 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+        clk[1036 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        clk[1036 + 1024 + blockIdx.x] = (unsigned long long)(u1 - u0);
+    }
+    if (rate_out && threadIdx.x == 0) {
+        const float ticks = (float)(long long)(__builtin_amdgcn_s_memrealtime() - t_begin);
+        const float old = rate_in ? rate_in[blockIdx.x] : 0.f;
+        const float now = (u1 > u0 && ticks > 0.f) ? (float)(u1 - u0) / ticks : 0.f;
+        rate_out[blockIdx.x] = now > 0.f ? (old > 0.f ? 0.5f * old + 0.5f * now : now) : old;
     }
 }
 
@@ -2734,7 +2820,7 @@ static void launch_film_t(hipStream_t st, const void* W, const float* bias_ft,
 template <class T16>
 static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bias_ft,
                                  const void* s_hi, void* E, int G, int NT, int round0, int nround, const float* pp, const float* temb,
-                                 const int* t_clip, int T, int B, unsigned long long* clk) {
+                                 const int* t_clip, int T, int B, unsigned long long* clk, const float* rate_in, float* rate_out) {
     const size_t shm = 4 * DC_KS_E * 1024;
     static bool attr_set = false;
     if (!attr_set) {
@@ -2746,15 +2832,16 @@ static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bia
     const int nblk = (G + 3) / 4;
     k_film_gemm2<T16><<<dim3(nblk < ncu ? nblk : ncu), dim3(512), shm, st>>>((const v8<T16>*)W, bias_ft,
                                                                 (const v8<T16>*)s_hi, (f16x16*)E, G, NT, round0, nround, pp, temb, t_clip, T, B,
-                                                                getenv("DC_FILM_ABL") ? atoi(getenv("DC_FILM_ABL")) : 0, clk);
+                                                                getenv("DC_FILM_ABL") ? atoi(getenv("DC_FILM_ABL")) : 0, clk, rate_in, rate_out);
     return hipGetLastError();
 }
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
-                               int nround, const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk) {
+                               int nround, const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk,
+                               const float* rate_in, float* rate_out) {
     static const bool use_v1 = getenv("DC_FILM_V1") != nullptr;
     if (!split && !use_v1)
-        return fmt == 1 ? launch_film2_t<_Float16>(st, W, bias_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk)
-                        : launch_film2_t<__bf16>(st, W, bias_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk);
+        return fmt == 1 ? launch_film2_t<_Float16>(st, W, bias_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out)
+                        : launch_film2_t<__bf16>(st, W, bias_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out);
     if (round0 != 0) return hipSuccess;        // the v1 / split kernels compute all rounds in their first launch
     DISPATCH(fmt, split, (launch_film_t<T16, SP>(st, W, bias_ft, s_hi, s_lo, E, G, NT)));
     return LAUNCH_CHECK();

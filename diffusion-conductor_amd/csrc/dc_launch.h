@@ -19,7 +19,8 @@ hipError_t dc_launch_silu_emb(hipStream_t st, int fmt, bool split, const float* 
                               void* s_hi, void* s_lo, int G, int T, int B);
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
                                int nround, const float* pp, const float* temb, const int* t_clip, int T, int B,
-                               unsigned long long* clk /* diagnostic clock stamps or nullptr */);
+                               unsigned long long* clk /* diagnostic clock stamps or nullptr */,
+                               const float* rate_in, float* rate_out /* per-workgroup speeds of the previous / this launch (num_cu floats) or nullptr */);
 // pp != nullptr (non-split formats): the FiLM GEMM builds its operand SiLU(temb[t_clip] + pp) itself and s_hi is not read
 // wgr: workgroup-level partial records, combined by the consuming layer kernel itself (non-split formats and T >= 256 only;
 // no dc_launch_attn_combine between the layers then)

@@ -54,3 +54,40 @@ if wg[0, :, 1].max() > 0:
         print(f"  {name} begin {q(wg[i, :, 0] - t0)}   end {q(wg[i, :, 1] - t0)}   lifetime {q(wg[i, :, 1] - wg[i, :, 0])}")
     print(f"  last end of layer 3 -> first begin of layer 4: {(wg[1, :, 0].min() - wg[0, :, 1].max()) / 100.0:.2f} us;"
           f"  first begin to first begin: {(wg[1, :, 0].min() - wg[0, :, 0].min()) / 100.0:.2f} us")
+if wg[0, :, 1].max() > 0:
+    # which workgroups are the slow ones?  logical index (wg_index: contiguous runs per XCD) and whether the 256-token unit spans two clips
+    nwg = 225
+    q_, r_ = nwg >> 3, nwg & 7
+    logical = np.array([(b & 7) * q_ + min(b & 7, r_) + (b >> 3) for b in range(nwg)])
+    strad = np.array([(w * 256) // T != min(w * 256 + 255, B * T - 1) // T for w in logical])
+    life = (wg[0, :, 1] - wg[0, :, 0]) / 100.0
+    print(f"  layer 3 lifetime: straddling units ({strad.sum()}) mean {life[strad].mean():.2f} max {life[strad].max():.2f};"
+          f"  others mean {life[~strad].mean():.2f} max {life[~strad].max():.2f}")
+    for x in range(8):
+        sel = (np.arange(nwg) & 7) == x
+        print(f"  XCD {x}: {sel.sum()} workgroups, lifetime mean {life[sel].mean():.2f} max {life[sel].max():.2f}, end max {(wg[0, sel, 1].max() - t0) / 100.0:.2f}")
+raw = nat.debug_read("stamps", np.uint64, 8 * 32 + 8 + 1024 + 1024 + 256 + 8).astype(np.int64)
+fk = raw[1288:2312].reshape(256, 4)
+units = raw[2312:2568]
+if fk[:, 3].max() > 0:
+    t0f = fk[:, 1].min()
+    print("k_film_gemm per XCD (workgroup b runs on XCD b & 7): core clock MHz (mean), sweep us (mean / max), finish us after the first start (max)")
+    for x in range(8):
+        sel = (np.arange(256) & 7) == x
+        mhz = (fk[sel, 2] - fk[sel, 0]) / (fk[sel, 3] - fk[sel, 1]) * 100.0
+        us = (fk[sel, 3] - fk[sel, 1]) / 100.0
+        print(f"  XCD {x}: {mhz.mean():6.0f} MHz   {us.mean():6.1f} / {us.max():6.1f}   {(fk[sel, 3].max() - t0f) / 100.0:6.1f}")
+    us_all = (fk[:, 3] - fk[:, 1]) / 100.0
+    print("  all workgroups: sweep us min/p10/p50/p90/max " + " ".join(f"{v:.1f}" for v in np.percentile(us_all, [0, 10, 50, 90, 100]))
+          + f";  units per workgroup min/mean/max {units.min()} / {units.mean():.2f} / {units.max()}")
+    order = np.argsort(us_all)
+    print("  slowest 8 workgroups (id, units, us, us per unit): " + "  ".join(f"{i}:{units[i]}:{us_all[i]:.0f}:{us_all[i] / max(units[i], 1):.2f}" for i in order[-8:]))
+    print("  fastest 8 workgroups (id, units, us, us per unit): " + "  ".join(f"{i}:{units[i]}:{us_all[i]:.0f}:{us_all[i] / max(units[i], 1):.2f}" for i in order[:8]))
+    nfill = np.array([len(set(range(int(units[:i].sum()) // 12, (int(units[:i + 1].sum()) - 1) // 12 + 1))) for i in range(256)])
+    for f in sorted(set(nfill)):
+        sel = nfill == f
+        print(f"  workgroups with {f} slab fills: {sel.sum()}, us per unit mean {np.mean(us_all[sel] / np.maximum(units[sel], 1)):.2f}")
+    ft = raw[2568:2572]
+    if ft[3] > 0:
+        print(f"  workgroup 5: {ft[3]} slab fills, per fill (us): wait for the previous slab's slowest wave {ft[0] / ft[3] / 100.0:.2f},"
+              f" SiLU + writes + second half {ft[1] / ft[3] / 100.0:.2f}, last loads + barrier {ft[2] / ft[3] / 100.0:.2f}")
