@@ -623,7 +623,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const int NTe = aliased ? s->NT / chunks : s->NT;
     auto e_for_layer = [&](int l) -> void* { return aliased ? (void*)((char*)s->d_E - (size_t)(l - l % lpc) * 24 * 2048) : s->d_E; };
     // adaptive work shares of the persistent FiLM GEMM (dc_kernels.hip, k_film_gemm2); DC_FILM_STATIC=1 keeps equal shares
-    static const bool film_static = getenv("DC_FILM_STATIC") != nullptr;
+    const bool film_static = getenv("DC_FILM_STATIC") != nullptr;           // (read per call: the tests toggle it)
     const bool adapt = !film_static && s->num_cu <= 1024;
     auto film_chunk = [&](int c) -> int {
         LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b,

@@ -141,6 +141,24 @@ def test_persistent_layer_kernel_equals_per_layer_launches(models):
     assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
+def test_film_adaptive_shares_do_not_change_results(models):
+    """The persistent FiLM GEMM sizes its workgroups' shares by the per-XCD speeds measured in earlier launches (>= 64
+    workgroups); which workgroup computes a tile must not matter: bit-identical to equal shares (DC_FILM_STATIC=1) and
+    across repeated loops whose shares differ."""
+    B, T = 5, 1800
+    xfp, xfo = xf_pair(B, T, first=40)
+    noise = torch.from_numpy(batch_noise(B, T, first=40))
+    a = _ddim(models["fp16"], 25, noise, xfp, xfo, [T] * B)
+    a2 = _ddim(models["fp16"], 25, noise, xfp, xfo, [T] * B)
+    os.environ["DC_FILM_STATIC"] = "1"
+    os.environ["DC_DISABLE_GRAPH"] = "1"          # eager launches: the switch is read when a launch is enqueued
+    try:
+        b = _ddim(models["fp16"], 25, noise, xfp, xfo, [T] * B)
+    finally:
+        del os.environ["DC_FILM_STATIC"], os.environ["DC_DISABLE_GRAPH"]
+    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, a2)
+
+
 def test_progressive_matches_fast_path(models):
     """ddim_sample_loop_progressive (per-step host loop over the native denoiser) ends where the
     graph-replayed loop ends, and yields num_timesteps samples."""
