@@ -163,11 +163,12 @@ struct dc_sampler {
     unsigned long long* d_stamps = nullptr;
     float* d_film_rate = nullptr;  // FiLM GEMM: per-workgroup speeds measured by the previous launches, two buffers of 1024 (ping-pong)
     int film_rate_parity = 0;
+    bool graph_folded = false;     // the captured steps look their timestep up through *d_iter (no k_begin_step launches)
     unsigned* d_gbar = nullptr;   // grid-barrier arrival counter of the persistent layer kernel (zeroed before each launch)
     int* d_gerr = nullptr;        // set by a workgroup whose grid-barrier spin ran out
     int num_cu = 0;
     int *d_iter = nullptr, *d_t_clip = nullptr, *d_snap_cur = nullptr, *d_t_of_iter = nullptr, *d_snap_of_iter = nullptr;
-    float *d_coef_cur = nullptr, *d_coef_of_t = nullptr;
+    float *d_coef_cur = nullptr, *d_coef_of_t = nullptr, *d_coef_of_iter = nullptr;   // DDIM scalars by timestep / by iteration
     bool cond_set = false;
     int64_t ws_bytes = 0;
 
@@ -567,6 +568,7 @@ int ensure_steps(dc_sampler* s, int S) {
         if ((rc = dev_alloc(s, s->d_t_of_iter, (size_t)S * 4))) return rc;
         if ((rc = dev_alloc(s, s->d_snap_of_iter, (size_t)S * 4))) return rc;
         if ((rc = dev_alloc(s, s->d_coef_of_t, (size_t)S * 16))) return rc;
+        if ((rc = dev_alloc(s, s->d_coef_of_iter, (size_t)S * 16))) return rc;
         s->cap_steps = (size_t)S;
     }
     return DC_OK;
@@ -595,17 +597,28 @@ struct Timed {   // RAII-less helper: wraps a launch with events when profiling
     } while (0)
 
 // One denoiser evaluation (+ DDIM update when loop_mode) enqueued on st.
-int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_src, float* x_dst) {
+// graph_step >= 0: step number inside a graph being captured.  On the default path (fused SiLU fill, per-layer launches) the
+// step's kernels then look the timestep / DDIM scalars up themselves - this step's slot of the per-iteration tables, offset by
+// the iteration at which the replay began (*d_iter, advanced once per replay) - and the per-step bookkeeping launch
+// (k_begin_step, 5 us + a launch gap) is dropped.
+int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_src, float* x_dst, int graph_step = -1) {
     const int B = s->B, T = s->T, M = s->M, G = s->G, L = s->cfg.num_layers;
     const bool ss = s->split_small, sf = s->split_film;
     const int fs = s->small_fmt, ff = s->film_fmt;
-    if (loop_mode)
-        LAUNCH(K_BEGIN, dc_launch_begin_step(st, s->d_iter, s->d_t_of_iter, s->d_coef_of_t, s->d_snap_of_iter,
-                                             s->d_t_clip, s->d_coef_cur, s->d_snap_cur, B));
     // non-split formats: the FiLM GEMM produces its own operand from pp + temb (no k_silu_emb pass); the separate pass
     // remains for the split formats, for the v1 kernel, and under the test hooks that read the operand image back
     static const bool film_v1 = getenv("DC_FILM_V1") != nullptr, unfused = getenv("DC_UNFUSED_SILU") != nullptr;
     const bool fuse_silu = !sf && !film_v1 && !unfused && s->dbg_layers < 0;
+    const bool folded = loop_mode && graph_step >= 0 && fuse_silu && !s->cfg.no_eff && !getenv("DC_PERSIST") &&
+                        !getenv("DC_BEGIN_STEP") && s->dbg_stage == 0;
+    const int* iter_base = folded ? s->d_iter : nullptr;
+    const int* t_src = folded ? s->d_t_of_iter + graph_step : s->d_t_clip;
+    const float* coef_src = folded ? s->d_coef_of_iter + 4 * (size_t)graph_step : s->d_coef_cur;
+    const int* snap_src = folded ? s->d_snap_of_iter + graph_step : s->d_snap_cur;
+    if (graph_step >= 0) s->graph_folded = folded;
+    if (loop_mode && !folded)
+        LAUNCH(K_BEGIN, dc_launch_begin_step(st, s->d_iter, s->d_t_of_iter, s->d_coef_of_t, s->d_snap_of_iter,
+                                             s->d_t_clip, s->d_coef_cur, s->d_snap_cur, B));
     if (!fuse_silu)
         LAUNCH(K_SILU, dc_launch_silu_emb(st, ff, sf, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, G, T, B));
     // FiLM GEMM in `chunks` launches, each covering the feature tiles of L / chunks consecutive layers and issued right
@@ -629,10 +642,10 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b,
                                            s->d_s_hi, s->d_s_lo, aliased ? (void*)((char*)s->d_E - (size_t)c * lpc * 3 * 8 * 2048) : s->d_E, G, NTe,
                                            c * lpc * 3 / 2, chunks == 1 ? nround_all : lpc * 3 / 2,
-                                           fuse_silu ? s->d_pp : nullptr, s->h_model.temb, s->d_t_clip, T, B,
+                                           fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
                                            want_stamps_film ? s->d_stamps + 252 : nullptr,
                                            adapt ? s->d_film_rate + 1024 * s->film_rate_parity : nullptr,
-                                           adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr));
+                                           adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr, iter_base));
         s->film_rate_parity ^= 1;
         return DC_OK;
     };
@@ -668,7 +681,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         HIP_TRY(hipMemsetAsync(s->d_gbar, 0, 4, st));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, 0, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur, s->d_snaps,
-                                        M, T, G, B, 0, want_stamps ? s->d_stamps : nullptr, L, rec_stride, s->d_gbar, s->d_gerr));
+                                        M, T, G, B, 0, want_stamps ? s->d_stamps : nullptr, L, rec_stride, s->d_gbar, s->d_gerr, nullptr));
         return DC_OK;
     }
     for (int l = 0; l < nl_run; ++l) {
@@ -676,9 +689,9 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         const int dbg = ((l == nl_run - 1) ? s->dbg_stage : 0) | ablate;
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, e_for_layer(l), NTe, s->d_a_sa, s->d_a_ca, s->d_recs,
-                                        s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur,
+                                        s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src,
                                         s->d_snaps, M, T, G, B, dbg, ((l == 3 || l == 4) && want_stamps) ? s->d_stamps : nullptr, l + 1, rec_stride,
-                                        s->d_gbar, s->d_gerr));
+                                        s->d_gbar, s->d_gerr, iter_base));
     }
     return DC_OK;
 }
@@ -726,6 +739,9 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     HIP_TRY(hipMemcpyAsync(s->d_t_of_iter, t_of_iter.data(), S * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s->d_snap_of_iter, snap_of_iter.data(), S * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s->d_coef_of_t, h_coef, (size_t)S * 16, hipMemcpyHostToDevice, st));
+    std::vector<float> coef_of_iter((size_t)S * 4);
+    for (int i = 0; i < S; ++i) memcpy(&coef_of_iter[4 * (size_t)i], h_coef + 4 * (size_t)t_of_iter[i], 16);
+    HIP_TRY(hipMemcpyAsync(s->d_coef_of_iter, coef_of_iter.data(), (size_t)S * 16, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(s->d_iter, 0, 16, st));
     HIP_TRY(hipMemcpyAsync(s->d_x, d_noise, MP * 4, hipMemcpyDeviceToDevice, st));
     int gerr = 0;
@@ -753,11 +769,20 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             for (int i = 0; i < K; ++i)
-                if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x))) {
+                if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, i))) {
                     hipStreamEndCapture(st, &g);
                     if (g) hipGraphDestroy(g);
                     return rc;
                 }
+            // steps that indexed the iteration tables themselves did not advance the counter (see enqueue_step)
+            if (s->graph_folded) {
+                hipError_t ea = dc_launch_advance_iter(st, s->d_iter, K);
+                if (ea != hipSuccess) {
+                    hipStreamEndCapture(st, &g);
+                    if (g) hipGraphDestroy(g);
+                    return fail(DC_ERR_HIP, "k_advance_iter: %s", hipGetErrorString(ea));
+                }
+            }
             HIP_TRY(hipStreamEndCapture(st, &g));
             hipError_t e = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0);
             hipGraphDestroy(g);
@@ -863,7 +888,7 @@ void dc_sampler_destroy(dc_sampler* s) {
     drop_graph(s);
     void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_y, s->d_mean, s->d_rstd, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
-                    s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t,
+                    s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t, s->d_coef_of_iter,
                     s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_gbar, s->d_gerr, s->d_film_rate};
     for (void* p : ptrs)
         if (p) hipFree(p);

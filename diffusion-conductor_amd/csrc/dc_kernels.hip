@@ -782,6 +782,9 @@ __global__ void k_begin_step(int* __restrict__ iter, const int* __restrict__ t_o
     }
 }
 
+// end of a captured graph of k steps whose kernels indexed the iteration tables themselves (iter_base): next replay starts k later
+__global__ void k_advance_iter(int* __restrict__ iter, int k) { *iter += k; }
+
 // ------------------------------------------------------------------------------------
 // timestep_embedding + time_embed MLP table (transformer.py:8-25, 410-414): one block per t
 // ------------------------------------------------------------------------------------
@@ -1177,7 +1180,7 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
                                                        int nround, const float* __restrict__ pp, const float* __restrict__ temb,
                                                        const int* __restrict__ t_clip, int T, int B, int abl,
                                                        unsigned long long* __restrict__ clk, const float* __restrict__ rate_in,
-                                                       float* __restrict__ rate_out) {
+                                                       float* __restrict__ rate_out, const int* __restrict__ iter_base) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using OP = v8<T16>;
     constexpr int PF = 4;       // measured: 8 (with the 256-register budget it needs) is 25 % slower
@@ -1295,7 +1298,9 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
                 for (int g = 0; g < 4; ++g) {
                     const int gg = min(g0 + g, G - 1);
                     const int b = min((gg * 32 + (lane & 31)) / T, B - 1);
-                    trow[g] = temb + (size_t)t_clip[b] * 512 + 8 * (lane >> 5);
+                    // graph-captured loop: one timestep for all clips, t_clip = this step's slot of the iteration table and
+                    // *iter_base = the iteration at which the graph replay began (no per-step bookkeeping launch)
+                    trow[g] = temb + (size_t)t_clip[iter_base ? *iter_base : b] * 512 + 8 * (lane >> 5);
                 }
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
@@ -1887,7 +1892,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
              float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur, const int* __restrict__ snap_cur,
              float* __restrict__ snaps, int M, int T, int G, int B, int dbg,
              unsigned long long* __restrict__ stamps, int l_end, size_t rec_stride, unsigned* __restrict__ gbar,
-             int* __restrict__ gerr) {
+             int* __restrict__ gerr, const int* __restrict__ iter_base) {
     // Layers l .. l_end-1 in one launch when l_end > l + 1 (persistent form, WGR only): the residual stream stays in
     // registers, a grid barrier separates the layers, and the unit records alternate between two buffers
     // (recs + parity * rec_stride) so that a fast workgroup's records for layer l+1 never overwrite what a slow one
@@ -2287,8 +2292,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             if (f < P) xout[(size_t)cx.tok * P + f] = x0[0][r];
         }
     } else {
+        // graph-captured loop: coef_cur / snap_cur point at this step's slot of the per-iteration tables and *iter_base is
+        // the iteration at which the graph replay began; otherwise they are the scalars k_begin_step prepared
+        const int ib = iter_base ? *iter_base : 0;
+        coef_cur += 4 * ib;
         const float sr = coef_cur[0], srm1 = coef_cur[1], cx0 = coef_cur[2], ceps = coef_cur[3];
-        const int snap = *snap_cur;
+        const int snap = snap_cur[ib];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = tile_row(r, cx.hh);
@@ -2743,6 +2752,10 @@ __global__ __launch_bounds__(256) void k_cond_ca_kv(const DcModel* __restrict__ 
         }                                                \
     } while (0)
 
+hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k) {
+    k_advance_iter<<<1, 1, 0, st>>>(iter, k);
+    return hipGetLastError();
+}
 hipError_t dc_launch_begin_step(hipStream_t st, int* iter, const int* t_of_iter, const float* coef_of_t,
                                 const int* snap_of_iter, int* t_clip, float* coef_cur, int* snap_cur, int B) {
     hipLaunchKernelGGL(k_begin_step, dim3(1), dim3(64), 0, st, iter, t_of_iter, coef_of_t, snap_of_iter, t_clip,
@@ -2820,7 +2833,8 @@ static void launch_film_t(hipStream_t st, const void* W, const float* bias_ft,
 template <class T16>
 static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bias_ft,
                                  const void* s_hi, void* E, int G, int NT, int round0, int nround, const float* pp, const float* temb,
-                                 const int* t_clip, int T, int B, unsigned long long* clk, const float* rate_in, float* rate_out) {
+                                 const int* t_clip, int T, int B, unsigned long long* clk, const float* rate_in, float* rate_out,
+                                 const int* iter_base) {
     const size_t shm = 4 * DC_KS_E * 1024;
     static bool attr_set = false;
     if (!attr_set) {
@@ -2832,16 +2846,16 @@ static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bia
     const int nblk = (G + 3) / 4;
     k_film_gemm2<T16><<<dim3(nblk < ncu ? nblk : ncu), dim3(512), shm, st>>>((const v8<T16>*)W, bias_ft,
                                                                 (const v8<T16>*)s_hi, (f16x16*)E, G, NT, round0, nround, pp, temb, t_clip, T, B,
-                                                                getenv("DC_FILM_ABL") ? atoi(getenv("DC_FILM_ABL")) : 0, clk, rate_in, rate_out);
+                                                                getenv("DC_FILM_ABL") ? atoi(getenv("DC_FILM_ABL")) : 0, clk, rate_in, rate_out, iter_base);
     return hipGetLastError();
 }
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
                                int nround, const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk,
-                               const float* rate_in, float* rate_out) {
+                               const float* rate_in, float* rate_out, const int* iter_base) {
     static const bool use_v1 = getenv("DC_FILM_V1") != nullptr;
     if (!split && !use_v1)
-        return fmt == 1 ? launch_film2_t<_Float16>(st, W, bias_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out)
-                        : launch_film2_t<__bf16>(st, W, bias_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out);
+        return fmt == 1 ? launch_film2_t<_Float16>(st, W, bias_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base)
+                        : launch_film2_t<__bf16>(st, W, bias_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base);
     if (round0 != 0) return hipSuccess;        // the v1 / split kernels compute all rounds in their first launch
     DISPATCH(fmt, split, (launch_film_t<T16, SP>(st, W, bias_ft, s_hi, s_lo, E, G, NT)));
     return LAUNCH_CHECK();
@@ -2880,7 +2894,7 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                                  int M, int T, int G, int B, int dbg, unsigned long long* stamps, int l_end, size_t rec_stride,
-                                 unsigned* gbar, int* gerr) {
+                                 unsigned* gbar, int* gerr, const int* iter_base) {
     constexpr int NW = SP ? 4 : 8;
     // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
     const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
@@ -2892,7 +2906,7 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
     }
     k_layer<T16, SP, DBG, STAMP, WGR, PERS><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
                        (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
-                       snaps, M, T, G, B, dbg, stamps, l_end, rec_stride, gbar, gerr);
+                       snaps, M, T, G, B, dbg, stamps, l_end, rec_stride, gbar, gerr, iter_base);
     return hipGetLastError();
 }
 
@@ -2900,10 +2914,10 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps, int l_end, size_t rec_stride,
-                           unsigned* gbar, int* gerr) {
+                           unsigned* gbar, int* gerr, const int* iter_base) {
     hipError_t e = hipSuccess;
 #define LAYER_ARGS st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps, \
-                   l_end, rec_stride, gbar, gerr
+                   l_end, rec_stride, gbar, gerr, iter_base
     if (wgr && !split) {        // workgroup-level records + in-kernel combine (non-split formats, T >= 256)
         if (dbg != 0)
             e = fmt == 1 ? launch_layer_t<_Float16, false, true, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, true, false, true>(LAYER_ARGS);

@@ -20,7 +20,8 @@ hipError_t dc_launch_silu_emb(hipStream_t st, int fmt, bool split, const float* 
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
                                int nround, const float* pp, const float* temb, const int* t_clip, int T, int B,
                                unsigned long long* clk /* diagnostic clock stamps or nullptr */,
-                               const float* rate_in, float* rate_out /* per-workgroup speeds of the previous / this launch (num_cu floats) or nullptr */);
+                               const float* rate_in, float* rate_out /* per-workgroup speeds of the previous / this launch (num_cu floats) or nullptr */,
+                               const int* iter_base /* captured loop: t_clip = &t_of_iter[step], indexed by *iter_base; else nullptr */);
 // pp != nullptr (non-split formats): the FiLM GEMM builds its operand SiLU(temb[t_clip] + pp) itself and s_hi is not read
 // wgr: workgroup-level partial records, combined by the consuming layer kernel itself (non-split formats and T >= 256 only;
 // no dc_launch_attn_combine between the layers then)
@@ -31,7 +32,10 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps, int l_end, size_t rec_stride,
-                           unsigned* gbar, int* gerr);
+                           unsigned* gbar, int* gerr,
+                           const int* iter_base /* captured loop: coef_cur / snap_cur = this step's slots of the per-iteration tables,
+                                                   indexed by *iter_base; else nullptr (scalars prepared by k_begin_step) */);
+hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);
 // l_end > l + 1 (wgr only): layers l .. l_end-1 in ONE launch with grid barriers in between - the caller guarantees that all
 // ceil(G/8) workgroups are co-resident (<= CU count) and that *gbar == 0 at launch; rec_stride: floats between the two
 // alternating unit-record buffers (0 = single buffer, non-wgr)
