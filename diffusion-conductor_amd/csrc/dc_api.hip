@@ -434,6 +434,25 @@ int build_model(dc_sampler* s) {
     }
     add_packed(&m.film_w, film_w.data(), NT * 32, DC_E, false, s->film_fmt == 1);
     add_ft(&m.film_b, film_b.data(), NT * 32, NT);
+    {   // 16x16x32 operand order (dc_common.h)
+        static const int pi[16] = {0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15};
+        const bool f16 = s->film_fmt == 1;
+        std::vector<uint16_t> w16((size_t)NT * 32 * DC_E);
+        std::vector<float> b16((size_t)NT * 32);
+        for (int ot = 0; ot < NT; ++ot)
+            for (int ks = 0; ks < DC_E / 32; ++ks)
+                for (int fb = 0; fb < 2; ++fb)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const float v = film_w[(size_t)(32 * ot + 16 * fb + pi[l & 15]) * DC_E + 32 * ks + 8 * (l >> 4) + j];
+                            w16[((((size_t)ot * (DC_E / 32) + ks) * 2 + fb) * 64 + l) * 8 + j] = f16 ? f2h(v) : f2bf(v);
+                        }
+        for (int ot = 0; ot < NT; ++ot)
+            for (int fb = 0; fb < 2; ++fb)
+                for (int r = 0; r < 16; ++r) b16[((size_t)ot * 2 + fb) * 16 + r] = film_b[(size_t)32 * ot + 16 * fb + pi[r]];
+        O.fix.push_back({(const void**)&m.film_w16, A.add(w16.data(), w16.size() * 2)});
+        add_raw(&m.film_b16, b16.data(), b16.size());
+    }
     {   // the two pose projections always run split: [hi][lo][bias]
         const std::vector<float> jb = ftvec(P_("joint_embed.bias"), D, 4);
         add_image(&m.img_je, P_("joint_embed.weight"), D, P, true, jb.data(), jb.size());
@@ -645,7 +664,8 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
                                            fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
                                            want_stamps_film ? s->d_stamps + 252 : nullptr,
                                            adapt ? s->d_film_rate + 1024 * s->film_rate_parity : nullptr,
-                                           adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr, iter_base));
+                                           adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr, iter_base,
+                                           s->h_model.film_w16, s->h_model.film_b16));
         s->film_rate_parity ^= 1;
         return DC_OK;
     };

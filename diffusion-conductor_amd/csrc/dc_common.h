@@ -65,6 +65,10 @@ struct DcModel {
     //                               log2(e) H'   = log2(e) { (beta (.) W_scale + W_shift) S + [beta (1 + b_scale) + b_shift] }
     const bf16x8* film_w;    // natural-k pack [3*L*8 tiles][32 ks] (tiles interleaved G'0, H'0, G'1, H'1, ...), hi then lo; bf16 or f16 bits
     const float* film_b;     // ftvec [3*L*8 tiles]: the bracketed constants (accumulator initial values), same tile order
+    // the same operands for the 16x16x32-MFMA form of the GEMM (k_film_gemm3): [tile][ks32][fb][64][8], lane l =
+    // row 16 fb + pi(l & 15), k = 32 ks32 + 8 (l >> 4) + j with pi = (0..3, 8..11, 4..7, 12..15); constants [tile][fb][l >> 4][4]
+    const bf16x8* film_w16;
+    const float* film_b16;
     const float* lin_wt;     // `linear` weight transposed [64][512]
     const float* lin_b;      // [512]
     const float* temb;       // [max_timesteps][512]

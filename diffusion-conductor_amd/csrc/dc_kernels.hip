@@ -37,6 +37,8 @@ template <class T> using v4 = typename V4<T>::type;
 
 DEV f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 DEV f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+DEV f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // value of the partner lane (lane ^ 32) combined with this lane's: one v_permlane32_swap, no LDS
 DEV float xhalf_sum(float v) {
@@ -198,6 +200,7 @@ DEV f32x16 ld_ft(const float* __restrict__ p, int tile, int hh) {
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));   // operand of the packed-fp32 VALU ops (v_pk_add/mul/fma_f32)
+typedef __attribute__((ext_vector_type(8))) uint32_t u32x8;
 // nn.LayerNorm(128) over the feature axis of an FT activation (transformer.py:79,104,147)
 template <int NT>
 DEV void ln_stats(const f32x16 (&x)[NT], float& mean, float& rstd) {
@@ -1153,6 +1156,49 @@ __global__ __launch_bounds__(256) void k_film_gemm(const v8<T16>* __restrict__ W
 }
 
 
+// Work shares of the persistent FiLM GEMMs: every wave derives the same integer boundaries (see k_film_gemm2).
+DEV void film_shares(int& u0, int& u1, long long nunit, const float* __restrict__ rate_in, int lane) {
+    const int nw = gridDim.x, b = blockIdx.x;
+    float xs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // lane i covers workgroups i, i + 64, ...: all on XCD i & 7
+    int nzero = 0;
+    for (int i = lane; i < nw; i += 64) {
+        const float r = rate_in ? rate_in[i] : 0.f;
+        xs[0] += r;
+        nzero += !(r > 0.f);
+    }
+    // sum over the lanes of the same XCD (lane & 7 fixed): xor-shuffles with 8, 16, 32
+    float xsum = xs[0];
+#pragma unroll
+    for (int m = 32; m >= 8; m >>= 1) xsum += __shfl_xor(xsum, m);
+    int cnt = 0;
+    for (int i = lane; i < nw; i += 64) ++cnt;
+#pragma unroll
+    for (int m = 32; m >= 8; m >>= 1) cnt += __shfl_xor(cnt, m);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) nzero += __shfl_xor(nzero, m);
+    float tot = xsum;                                           // sum over all workgroups
+#pragma unroll
+    for (int m = 4; m >= 1; m >>= 1) tot += __shfl_xor(tot, m);
+    const bool adaptive = rate_in && nzero == 0 && nw >= 64;
+    // this lane's XCD weight (relative speed, clamped), as an integer
+    int wx = 4096;
+    if (adaptive) wx = (int)(fminf(fmaxf((xsum / (float)cnt) * ((float)nw / tot), 0.8f), 1.2f) * 4096.f + 0.5f);
+    int before = 0, mine = 0, total = 0;
+    for (int i = lane; i < nw; i += 64) {                       // workgroup i is on XCD i & 7 == lane & 7
+        total += wx;
+        before += i < b ? wx : 0;
+        mine += i == b ? wx : 0;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        total += __shfl_xor(total, m);
+        before += __shfl_xor(before, m);
+        mine += __shfl_xor(mine, m);
+    }
+    u0 = __builtin_amdgcn_readfirstlane((int)(nunit * before / total));
+    u1 = __builtin_amdgcn_readfirstlane((int)(nunit * (before + mine) / total));
+}
+
 // LDS-DMA of one 1-KiB fragment: lane i's 16 bytes at gsrc land at lds_dst + 16*i.  Issued through inline asm
 // on purpose: for the builtin form hipcc inserts `s_waitcnt vmcnt(0)` before the next LDS read of ANY address
 // (it assumes the DMA may alias), which would turn every "one stage ahead" prefetch into a synchronous copy.
@@ -1218,47 +1264,7 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
     // feeding that back makes the boundaries oscillate.  The partition does not change any result (a unit's tiles do not
     // depend on who computes them).  Every wave derives the same integer boundaries.
     int u0, u1;
-    {
-        const int nw = gridDim.x, b = blockIdx.x;
-        float xs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // lane i covers workgroups i, i + 64, ...: all on XCD i & 7
-        int nzero = 0;
-        for (int i = lane; i < nw; i += 64) {
-            const float r = rate_in ? rate_in[i] : 0.f;
-            xs[0] += r;
-            nzero += !(r > 0.f);
-        }
-        // sum over the lanes of the same XCD (lane & 7 fixed): xor-shuffles with 8, 16, 32
-        float xsum = xs[0];
-#pragma unroll
-        for (int m = 32; m >= 8; m >>= 1) xsum += __shfl_xor(xsum, m);
-        int cnt = 0;
-        for (int i = lane; i < nw; i += 64) ++cnt;
-#pragma unroll
-        for (int m = 32; m >= 8; m >>= 1) cnt += __shfl_xor(cnt, m);
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) nzero += __shfl_xor(nzero, m);
-        float tot = xsum;                                           // sum over all workgroups
-#pragma unroll
-        for (int m = 4; m >= 1; m >>= 1) tot += __shfl_xor(tot, m);
-        const bool adaptive = rate_in && nzero == 0 && nw >= 64;
-        // this lane's XCD weight (relative speed, clamped), as an integer
-        int wx = 4096;
-        if (adaptive) wx = (int)(fminf(fmaxf((xsum / (float)cnt) * ((float)nw / tot), 0.8f), 1.2f) * 4096.f + 0.5f);
-        int before = 0, mine = 0, total = 0;
-        for (int i = lane; i < nw; i += 64) {                       // workgroup i is on XCD i & 7 == lane & 7
-            total += wx;
-            before += i < b ? wx : 0;
-            mine += i == b ? wx : 0;
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            total += __shfl_xor(total, m);
-            before += __shfl_xor(before, m);
-            mine += __shfl_xor(mine, m);
-        }
-        u0 = __builtin_amdgcn_readfirstlane((int)(nunit * before / total));
-        u1 = __builtin_amdgcn_readfirstlane((int)(nunit * (before + mine) / total));
-    }
+    film_shares(u0, u1, nunit, rate_in, lane);
     int cur_blk = -1;
     // diagnostic: where a slab fill's time goes (summed over this workgroup's fills, wave 0): wait for the slowest wave of the
     // previous slab | SiLU + slab writes + second half | last loads + closing barrier
@@ -1420,6 +1426,187 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict
         clk[1036 + 1024 + 256 + 1] = fill_t[1];
         clk[1036 + 1024 + 256 + 2] = fill_t[2];
         clk[1036 + 1024 + 256 + 3] = fill_n;
+    }
+    if (clk && threadIdx.x == 0 && blockIdx.x < 256) {
+        clk[1036 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
+        clk[1036 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        clk[1036 + 1024 + blockIdx.x] = (unsigned long long)(u1 - u0);
+    }
+    if (rate_out && threadIdx.x == 0) {
+        const float ticks = (float)(long long)(__builtin_amdgcn_s_memrealtime() - t_begin);
+        const float old = rate_in ? rate_in[blockIdx.x] : 0.f;
+        const float now = (u1 > u0 && ticks > 0.f) ? (float)(u1 - u0) / ticks : 0.f;
+        rate_out[blockIdx.x] = now > 0.f ? (old > 0.f ? 0.5f * old + 0.5f * now : now) : old;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// FiLM GEMM v3: the same S-stationary persistent schedule as v2 on v_mfma_f32_16x16x32 instead of 32x32x16.
+// Why: this kernel is power-limited (it holds 1.6-1.8 GHz), and on this part a loop of 16x16x32 MFMAs sustains a
+// higher clock than the same FLOPs issued as 32x32x16 (MI355X_MICROARCH.md, DVFS item 7).  Same bytes, same cycles:
+// per 32-deep k-step a wave feeds 32 MFMAs (4 weight fragments x 8 slab fragments) from 4 weight loads + 8 LDS reads.
+//   weight image  [tile][ks32][fb][64][8]: lane l = A[16 fb + pi(l & 15)][32 ks32 + 8 (l >> 4) + j]   (pi: see below)
+//   slab          [(g, tb16, ks32)][64][8]: lane l = S[token 32 g + 16 tb16 + (l & 15)][32 ks32 + 8 (l >> 4) + j]
+//   accumulators  32 blocks of 16 x 16: [tile 2][fb 2][g 4][tb16 2] x f32x4, lane l = rows 4 (l >> 4) + i, token l & 15
+// The E tiles keep their layout (32 x 32 accumulator order, dc_common.h): a v_permlane16_swap between the two token
+// halves of a block row puts tokens 0..31 on lanes 0..31 / 32..63, and the host orders the weight rows of each
+// 16-row block as pi = (0..3, 8..11, 4..7, 12..15), which is where the 32 x 32 layout expects them.
+// ------------------------------------------------------------------------------------
+template <class T16>
+__global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict__ W, const float* __restrict__ bias16,
+                                                       f16x16* __restrict__ E, int G, int NT, int round0, int nround,
+                                                       const float* __restrict__ pp, const float* __restrict__ temb,
+                                                       const int* __restrict__ t_clip, int T, int B,
+                                                       unsigned long long* __restrict__ clk, const float* __restrict__ rate_in,
+                                                       float* __restrict__ rate_out, const int* __restrict__ iter_base) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using OP = v8<T16>;
+    constexpr int PF = 2;                  // weight ring depth in 32-deep k-steps (= v2's 4 x 16)
+    constexpr int KS = DC_E / 32;          // 16 k-steps
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    if (clk && blockIdx.x == 5 && threadIdx.x == 0) {
+        clk[0] = __builtin_amdgcn_s_memtime();
+        clk[1] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (clk && threadIdx.x == 0 && blockIdx.x < 256) {
+        clk[1036 + blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+        clk[1036 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const OP* slab = reinterpret_cast<const OP*>(lds);
+    const int nblk = (G + 3) / 4;
+    const long long nunit = (long long)nblk * nround;
+    int u0, u1;
+    film_shares(u0, u1, nunit, rate_in, lane);
+    int cur_blk = -1;
+    OP a[PF][4];                           // ring slot q: (tile 0 fb 0, tile 0 fb 1, tile 1 fb 0, tile 1 fb 1)
+    auto wbase = [&](int u) { return W + (size_t)(2 * ((round0 + u % nround) * 8 + wave)) * 2 * KS * 64 + lane; };
+    auto wfrag = [&](const OP* w, int ks, int i) { return w[((size_t)(i >> 1) * 2 * KS + ks * 2 + (i & 1)) * 64]; };
+    if (u0 < u1) {
+        const OP* w0 = wbase(u0);
+#pragma unroll
+        for (int q = 0; q < PF; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[q][i] = wfrag(w0, q, i);
+    }
+    for (int u = u0; u < u1; ++u) {
+        const int tb = u / nround, p = (round0 + u % nround) * 8 + wave;
+        const int g0 = tb * 4;
+        if (tb != cur_blk) {
+            // slab fill (see k_film_gemm2): S = SiLU(temb[t] + linear(xf_proj)) from the fp32 fragment image, which is in
+            // the 32x32x16 operand order [g][ks16][2][64][4]: this lane's 8 values of (token, 32 ks32 + 8 (l >> 4) ..) are
+            // the two 16-byte pieces of lane' = 32 ((l >> 4) & 1) + 16 tb16 + (l & 15) in fragment ks16 = 2 ks32 + (l >> 5)
+            v8<T16>* slab_w = reinterpret_cast<v8<T16>*>(lds);
+            const float* trow[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int gg = min(g0 + (i >> 1), G - 1);
+                const int b = min((gg * 32 + 16 * (i & 1) + (lane & 15)) / T, B - 1);
+                trow[i] = temb + (size_t)t_clip[iter_base ? *iter_base : b] * 512 + 8 * (lane >> 4);
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f32x8 pv[8], tv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int f = wave + 8 * (8 * half + i);                 // fragment (g, tb16, ks32) = (f >> 5, (f >> 4) & 1, f & 15)
+                    const int gi = 2 * half + (i >> 2), t16 = (f >> 4) & 1, ks = f & 15;
+                    const int gg = min(g0 + gi, G - 1);
+                    pv[i] = ld_pp(pp, (size_t)gg * DC_KS_E + 2 * ks + (lane >> 5), 32 * ((lane >> 4) & 1) + 16 * t16 + (lane & 15));
+                    tv[i] = *reinterpret_cast<const f32x8*>(trow[2 * gi + t16] + 32 * ks);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (half == 0) __syncthreads();                              // everyone is done with the previous slab
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int f = wave + 8 * (8 * half + i);
+                    v8<T16> hi;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x2 z = silu_pair(pv[i][2 * j] + tv[i][2 * j], pv[i][2 * j + 1] + tv[i][2 * j + 1]);
+                        hi[2 * j] = (T16)z.x;
+                        hi[2 * j + 1] = (T16)z.y;
+                    }
+                    slab_w[f * 64 + lane] = hi;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur_blk = tb;
+        }
+        const OP* w0 = wbase(u);
+        const OP* wn = wbase(u + 1 < u1 ? u + 1 : u);
+        f32x4 acc[2][2][4][2];
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(bias16 + (((size_t)(2 * p + ti) * 2 + fb) * 4 + (lane >> 4)) * 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[ti][fb][g][0] = acc[ti][fb][g][1] = c;
+            }
+        // slab fragment (g, t16, ks) at ((g * 2 + t16) * KS + ks); the four fragments of a group pair are read one phase ahead
+        auto sfrag = [&](int gp, int i, int ks) { return slab[((size_t)((2 * gp + (i >> 1)) * 2 + (i & 1)) * KS + ks) * 64 + lane]; };
+        OP bA[4], bB[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bA[i] = sfrag(0, i, 0);
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < KS; ks0 += PF) {
+            const bool tail = ks0 + PF >= KS;
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int ks = ks0 + q, ksn = (ks + 1) & (KS - 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bB[i] = sfrag(1, i, ks);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)                                   // groups 0, 1
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        acc[k >> 1][k & 1][i >> 1][i & 1] = mfma16(a[q][k], bA[i], acc[k >> 1][k & 1][i >> 1][i & 1]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bA[i] = sfrag(0, i, ksn);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)                                   // groups 2, 3
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        acc[k >> 1][k & 1][2 + (i >> 1)][i & 1] = mfma16(a[q][k], bB[i], acc[k >> 1][k & 1][2 + (i >> 1)][i & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const OP* src = tail ? wn : w0;
+                    const int ksl = tail ? ks + PF - KS : ks + PF;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[q][i] = wfrag(src, ksl, i);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // epilogue: fp16, token halves swapped into place, store in the 32 x 32 tile order
+        const int blk = p >> 2, t = p & 3;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g0 + g >= G) continue;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                u32x8 o;
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const f32x4 x = acc[ti][fb][g][0], y = acc[ti][fb][g][1];
+                        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+                        const h2v xp = {(_Float16)x[2 * h2], (_Float16)x[2 * h2 + 1]}, yp = {(_Float16)y[2 * h2], (_Float16)y[2 * h2 + 1]};
+                        const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, xp), __builtin_bit_cast(uint32_t, yp), false, false);
+                        o[4 * fb + h2] = r[0];            // registers 8 fb + 2 h2, +1     (block rows 0..3 | 8..11 of this lane half)
+                        o[4 * fb + 2 + h2] = r[1];        // registers 8 fb + 4 + 2 h2, +1 (block rows 4..7 | 12..15)
+                    }
+                store_etile(E, (size_t)(g0 + g) * NT + blk * 8 + 4 * ti + t, lane, __builtin_bit_cast(f16x16, o));
+            }
+        }
+    }
+    if (clk && blockIdx.x == 5 && threadIdx.x == 0) {
+        clk[2] = __builtin_amdgcn_s_memtime();
+        clk[3] = __builtin_amdgcn_s_memrealtime();
     }
     if (clk && threadIdx.x == 0 && blockIdx.x < 256) {
         clk[1036 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
@@ -1705,7 +1892,6 @@ DEV void query_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const
 
 // v_fma_mix_f32: d = a * b + c with a read as the low / high fp16 half of a packed register - no separate conversion.
 // (hipcc does not form it from `fmaf((float)half, ...)`: the FiLM tiles and the packed y tiles cost 3 cvt per element.)
-typedef __attribute__((ext_vector_type(8))) uint32_t u32x8;
 template <int HI>
 DEV float fma_mix_h(uint32_t h2, float b, float c) {
     float d;
@@ -2849,10 +3035,36 @@ static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bia
                                                                 getenv("DC_FILM_ABL") ? atoi(getenv("DC_FILM_ABL")) : 0, clk, rate_in, rate_out, iter_base);
     return hipGetLastError();
 }
+template <class T16>
+static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* bias16, void* E, int G, int NT, int round0, int nround,
+                                 const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk,
+                                 const float* rate_in, float* rate_out, const int* iter_base) {
+    const size_t shm = 4 * DC_KS_E * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_film_gemm3<T16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    const int nblk = (G + 3) / 4;
+    k_film_gemm3<T16><<<dim3(nblk < ncu ? nblk : ncu), dim3(512), shm, st>>>((const v8<T16>*)W16, bias16, (f16x16*)E, G, NT, round0, nround,
+                                                                           pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base);
+    return hipGetLastError();
+}
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
                                int nround, const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk,
-                               const float* rate_in, float* rate_out, const int* iter_base) {
+                               const float* rate_in, float* rate_out, const int* iter_base, const void* W16, const float* bias16) {
     static const bool use_v1 = getenv("DC_FILM_V1") != nullptr;
+    const bool mfma32 = getenv("DC_FILM_MFMA32") != nullptr;          // (read per call: A/B within one process)
+    if (!split && !use_v1 && pp && W16 && !mfma32)
+        return fmt == 1 ? launch_film3_t<_Float16>(st, W16, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base)
+                        : launch_film3_t<__bf16>(st, W16, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base);
     if (!split && !use_v1)
         return fmt == 1 ? launch_film2_t<_Float16>(st, W, bias_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base)
                         : launch_film2_t<__bf16>(st, W, bias_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base);
