@@ -1461,7 +1461,10 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
                                                        float* __restrict__ rate_out, const int* __restrict__ iter_base) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using OP = v8<T16>;
-    constexpr int PF = 2;                  // weight ring depth in 32-deep k-steps (= v2's 4 x 16)
+#ifndef DC_FILM3_PF
+#define DC_FILM3_PF 2
+#endif
+    constexpr int PF = DC_FILM3_PF;        // weight ring depth in 32-deep k-steps (2 = v2's 4 x 16)
     constexpr int KS = DC_E / 32;          // 16 k-steps
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     if (clk && blockIdx.x == 5 && threadIdx.x == 0) {
