@@ -2152,6 +2152,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     float* recs_out = recs + (size_t)((l + 1) & 1) * rec_stride;
 
     DC_STAMP(0);
+    if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0 && l == 3) stamps[(threadIdx.x >> 6) * 32 + 26] = __builtin_amdgcn_s_memtime();
     DC_WGSTAMP(0);
     stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
     if constexpr (WGR)      // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
@@ -2456,6 +2457,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             }
         }
         DC_STAMP(13);
+        if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0 && l == 3) stamps[(threadIdx.x >> 6) * 32 + 27] = __builtin_amdgcn_s_memtime();
         DC_WGSTAMP(1);
         if (more) {
             grid_barrier(gbar, (unsigned)gridDim.x * (unsigned)(l - l_first + 1), gerr);

@@ -20,6 +20,7 @@ print("wave:      " + "".join(f"{w:8d}" for w in range(8)))
 for k in range(1, 14):
     print(f"{k:2d} {names[k-1][:16]:16s}" + "".join(f"{(st[w, k] - st[w, k-1]) / 100.0:8.2f}" for w in range(8)))
 print("total (us) " + "".join(f"{(st[w, 13] - st[w, 0]) / 100.0:8.2f}" for w in range(8)))
+print("core clock (MHz) " + "".join(f"{(st[w, 27] - st[w, 26]) / max(st[w, 13] - st[w, 0], 1) * 100.0:8.0f}" for w in range(8)))
 print("prologue split (us): issue->combine done " + "".join(f"{(st[w, 14] - st[w, 0]) / 100.0:7.2f}" for w in range(8)))
 print("                      ->own loads landed  " + "".join(f"{(st[w, 15] - st[w, 14]) / 100.0:7.2f}" for w in range(8)))
 print("                      ->barrier           " + "".join(f"{(st[w, 1] - st[w, 15]) / 100.0:7.2f}" for w in range(8)))
