@@ -159,6 +159,26 @@ def test_film_adaptive_shares_do_not_change_results(models):
     assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, a2)
 
 
+def test_film_gemm_mfma_shapes_agree(models):
+    """The FiLM GEMM runs on v_mfma_f32_16x16x32 (k_film_gemm3); DC_FILM_MFMA32=1 selects the 32x32x16 form (k_film_gemm2).
+    Same operands, different accumulation grouping: the two agree to fp32-accumulation noise on the fp16 E tiles, and both
+    meet the parity bound against the golden."""
+    g = golden("g6_variants.npz")
+    xfp, xfo = xf_pair(2, 900, first=10)
+    noise = torch.from_numpy(batch_noise(2, 900, first=10))
+    a = _ddim(models["fp16"], 50, noise, xfp, xfo, [900, 700])
+    os.environ["DC_FILM_MFMA32"] = "1"
+    os.environ["DC_DISABLE_GRAPH"] = "1"          # eager launches: the switch is read when a launch is enqueued
+    try:
+        b = _ddim(models["fp16"], 50, noise, xfp, xfo, [900, 700])
+    finally:
+        del os.environ["DC_FILM_MFMA32"], os.environ["DC_DISABLE_GRAPH"]
+    d = rel_l2(a, b.cpu().numpy())
+    eb = rel_l2(b, g["t900_x0"])
+    print(f"film gemm 16x16x32 vs 32x32x16: rel-L2 {d:.2e}; 32x32x16 vs golden {eb:.3e}")
+    assert d <= 2e-4 and eb <= TOL_PARITY
+
+
 def test_progressive_matches_fast_path(models):
     """ddim_sample_loop_progressive (per-step host loop over the native denoiser) ends where the
     graph-replayed loop ends, and yields num_timesteps samples."""
