@@ -1562,17 +1562,19 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
                 const int ks = ks0 + q, ksn = (ks + 1) & (KS - 1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bB[i] = sfrag(1, i, ks);
+                // (weight fragment outermost: four consecutive MFMAs share their A operand - measured 0.8 % faster than the
+                //  slab fragment outermost)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)                                   // groups 0, 1
+                for (int k = 0; k < 4; ++k)                                   // groups 0, 1
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
+                    for (int i = 0; i < 4; ++i)
                         acc[k >> 1][k & 1][i >> 1][i & 1] = mfma16(a[q][k], bA[i], acc[k >> 1][k & 1][i >> 1][i & 1]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bA[i] = sfrag(0, i, ksn);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)                                   // groups 2, 3
+                for (int k = 0; k < 4; ++k)                                   // groups 2, 3
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
+                    for (int i = 0; i < 4; ++i)
                         acc[k >> 1][k & 1][2 + (i >> 1)][i & 1] = mfma16(a[q][k], bB[i], acc[k >> 1][k & 1][2 + (i >> 1)][i & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 {
