@@ -1549,11 +1549,14 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[ti][fb][g][0] = acc[ti][fb][g][1] = c;
             }
-        // slab fragment (g, t16, ks) at ((g * 2 + t16) * KS + ks); the four fragments of a group pair are read one phase ahead
+        // slab fragment (g, t16, ks) at ((g * 2 + t16) * KS + ks)
         auto sfrag = [&](int gp, int i, int ks) { return slab[((size_t)((2 * gp + (i >> 1)) * 2 + (i & 1)) * KS + ks) * 64 + lane]; };
-        OP bA[4], bB[4];
+        // all eight slab fragments of a k-step are double-buffered (64 registers) and the weight fragment is outermost in the
+        // MFMA nest: eight consecutive MFMAs share their A operand.  (Measured: slab fragment outermost +0.8 %; the fragments of
+        // one group pair at a time, half a k-step ahead in 32 registers, +1.6 %.)
+        OP bb[2][8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bA[i] = sfrag(0, i, 0);
+        for (int i = 0; i < 8; ++i) bb[0][i] = sfrag(i >> 2, i & 3, 0);
 #pragma unroll 1
         for (int ks0 = 0; ks0 < KS; ks0 += PF) {
             const bool tail = ks0 + PF >= KS;
@@ -1561,21 +1564,12 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
             for (int q = 0; q < PF; ++q) {
                 const int ks = ks0 + q, ksn = (ks + 1) & (KS - 1);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bB[i] = sfrag(1, i, ks);
-                // (weight fragment outermost: four consecutive MFMAs share their A operand - measured 0.8 % faster than the
-                //  slab fragment outermost)
+                for (int i = 0; i < 8; ++i) bb[(q + 1) & 1][i] = sfrag(i >> 2, i & 3, ksn);
 #pragma unroll
-                for (int k = 0; k < 4; ++k)                                   // groups 0, 1
+                for (int k = 0; k < 4; ++k)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[k >> 1][k & 1][i >> 1][i & 1] = mfma16(a[q][k], bA[i], acc[k >> 1][k & 1][i >> 1][i & 1]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bA[i] = sfrag(0, i, ksn);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)                                   // groups 2, 3
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[k >> 1][k & 1][2 + (i >> 1)][i & 1] = mfma16(a[q][k], bB[i], acc[k >> 1][k & 1][2 + (i >> 1)][i & 1]);
+                    for (int i = 0; i < 8; ++i)
+                        acc[k >> 1][k & 1][i >> 1][i & 1] = mfma16(a[q][k], bb[q & 1][i], acc[k >> 1][k & 1][i >> 1][i & 1]);
                 __builtin_amdgcn_sched_barrier(0);
                 {
                     const OP* src = tail ? wn : w0;
