@@ -126,6 +126,23 @@ def test_graph_equals_eager(models):
     assert torch.equal(a, b)
 
 
+def test_captured_loop_table_lookup_equals_begin_step_launches(models):
+    """Inside a captured graph the step kernels index the per-iteration tables themselves (no k_begin_step launch; the
+    iteration counter advances once per replay).  DDIM-100 = two replays of a 50-step graph, snapshots in both:
+    bit-identical to eager launches with the per-step bookkeeping kernel."""
+    B, T, S = 2, 512, 100
+    xfp, xfo = xf_pair(B, T)
+    noise = torch.from_numpy(batch_noise(B, T))
+    a = _ddim(models["fp16"], S, noise, xfp, xfo, [T, T - 100], idxs=(0, 60, 99))
+    os.environ["DC_BEGIN_STEP"] = "1"
+    os.environ["DC_DISABLE_GRAPH"] = "1"
+    try:
+        b = _ddim(models["fp16"], S, noise, xfp, xfo, [T, T - 100], idxs=(0, 60, 99))
+    finally:
+        del os.environ["DC_BEGIN_STEP"], os.environ["DC_DISABLE_GRAPH"]
+    assert sorted(a.keys()) == [0, 60, 99, 100] and all(torch.equal(a[k], b[k]) for k in a)
+
+
 def test_persistent_layer_kernel_equals_per_layer_launches(models):
     """DC_PERSIST=1: all 8 layers in one launch with grid barriers between them (opt-in; needs one CU per
     256-token workgroup).  Same arithmetic in the same order as the per-layer launches: bit-identical."""
