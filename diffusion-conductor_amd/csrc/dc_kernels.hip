@@ -1481,21 +1481,29 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
     const long long nunit = (long long)nblk * nround;
     int u0, u1;
     film_shares(u0, u1, nunit, rate_in, lane);
-    int cur_blk = -1;
     OP a[PF][4];                           // ring slot q: (tile 0 fb 0, tile 0 fb 1, tile 1 fb 0, tile 1 fb 1)
-    auto wbase = [&](int u) { return W + (size_t)(2 * ((round0 + u % nround) * 8 + wave)) * 2 * KS * 64 + lane; };
+    auto wpair = [&](int p) { return W + (size_t)(2 * p) * 2 * KS * 64 + lane; };        // tile pair p = round * 8 + slot
     auto wfrag = [&](const OP* w, int ks, int i) { return w[((size_t)(i >> 1) * 2 * KS + ks * 2 + (i & 1)) * 64]; };
     if (u0 < u1) {
-        const OP* w0 = wbase(u0);
+        const OP* w0 = wpair((round0 + u0 % nround) * 8 + wave);
 #pragma unroll
         for (int q = 0; q < PF; ++q)
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[q][i] = wfrag(w0, q, i);
     }
-    for (int u = u0; u < u1; ++u) {
-        const int tb = u / nround, p = (round0 + u % nround) * 8 + wave;
+    // The eight waves share the tile pairs of a token block through a counter in LDS instead of owning one pair per round:
+    // under the SIMD's oldest-first arbitration one wave of each pair runs ~10 % ahead, and with fixed ownership it then
+    // waited ~20 us at every slab boundary while its partner finished alone.  A wave starts with pair `wave` of the segment
+    // (so its first weight fragments can be prefetched across the boundary) and claims the following ones when it starts a
+    // pair; which wave computes a pair does not change the result.
+    int* pair_cnt = reinterpret_cast<int*>(lds + 4 * DC_KS_E * 1024);
+    for (int useg = u0; useg < u1;) {
+        const int tb = useg / nround, ra = useg % nround;
+        const int nr = min(nround - ra, u1 - useg);               // rounds of this token block inside the workgroup's range
+        const int npairs = nr * 8;
+        const bool next_seg = useg + nr < u1;                     // (its first round is round 0 of the next block)
         const int g0 = tb * 4;
-        if (tb != cur_blk) {
+        {
             // slab fill (see k_film_gemm2): S = SiLU(temb[t] + linear(xf_proj)) from the fp32 fragment image, which is in
             // the 32x32x16 operand order [g][ks16][2][64][4]: this lane's 8 values of (token, 32 ks32 + 8 (l >> 4) ..) are
             // the two 16-byte pieces of lane' = 32 ((l >> 4) & 1) + 16 tb16 + (l & 15) in fragment ks16 = 2 ks32 + (l >> 5)
@@ -1534,12 +1542,18 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (threadIdx.x == 0) *pair_cnt = 8;                  // pairs 0..7 of the segment are taken (pair w by wave w)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            cur_blk = tb;
         }
-        const OP* w0 = wbase(u);
-        const OP* wn = wbase(u + 1 < u1 ? u + 1 : u);
+      for (int my = wave; my < npairs;) {
+        int nxt = 0;
+        if (lane == 0) nxt = __hip_atomic_fetch_add(pair_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        nxt = __builtin_amdgcn_readfirstlane(nxt);
+        const int p = (round0 + ra + (my >> 3)) * 8 + (my & 7);
+        const int ps = nxt < npairs ? (round0 + ra + (nxt >> 3)) * 8 + (nxt & 7) : (next_seg ? round0 * 8 + wave : p);
+        const OP* w0 = wpair(p);
+        const OP* wn = wpair(ps);                                 // successor: its first k-steps are prefetched in this pair's tail
         f32x4 acc[2][2][4][2];
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
@@ -1602,6 +1616,9 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
                 store_etile(E, (size_t)(g0 + g) * NT + blk * 8 + 4 * ti + t, lane, __builtin_bit_cast(f16x16, o));
             }
         }
+        my = nxt;
+      }
+        useg += nr;
     }
     if (clk && blockIdx.x == 5 && threadIdx.x == 0) {
         clk[2] = __builtin_amdgcn_s_memtime();
@@ -3040,7 +3057,7 @@ template <class T16>
 static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* bias16, void* E, int G, int NT, int round0, int nround,
                                  const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk,
                                  const float* rate_in, float* rate_out, const int* iter_base) {
-    const size_t shm = 4 * DC_KS_E * 1024;
+    const size_t shm = 4 * DC_KS_E * 1024 + 64;        // slab + the pair counter
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_film_gemm3<T16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
