@@ -9,20 +9,29 @@ cross-attention matrices) and x_T are resident in HBM when the timed region star
 number SURVEY.md section 8d defines as the roofline number).  value = frames completed by all ranks
 per second = n_gpus * 32 * 1800 * K / max-over-ranks(time).
 
-Multi-GPU: one process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE); clips are
+Multi-GPU: one process per GPU.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the
+environment is the PARENT: it never touches the GPU, starts N child processes of this file (one per
+rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), forwards rank 0's
+JSON line and exits with the children's worst return code.  Launched by `python -m
+torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks run directly.  Clips are
 sharded (weak scaling: 32 per GPU); the only collective is one RCCL all-gather of the final poses
 per step, inside the timed region.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (k_film_gemm) algorithmic FLOPs per launch / its mean duration,
-                measured with HIP events on the library's own stream in a separate eager pass;
-                peak = 2.5 PFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
-  cpu_baseline  the oracle (a port of the reference's eager path, PyTorch CPU ops) timed on this
-                box's host cores on a bounded sample of config 1 (bs=1, T=1800, a few DDIM steps)
+  roofline        the kernel with the largest share of the loop (k_layer, HBM roof; or k_film_gemm, MFMA
+                  roof): algorithmic bytes / FLOPs per launch over its mean duration, measured with HIP
+                  events on the library's own stream in a separate eager pass; `traffic` = HBM bytes per
+                  launch from the committed PMC passes of this very command, `traffic_source` names the file
+  cpu_baseline    the oracle (a port of the reference's eager path, PyTorch CPU ops) timed on this box's
+                  host cores on config 1 (bs=1, T=1800): 1 warm-up + 3 full DDIM-50 loops, median;
+                  loop-only (`value`) and end to end (`end_to_end`: encode_music + loop)
+  bf16_mode       the same loop in the bf16-MFMA mode that meets the parity bound ("mixed")
+  bs1             the reference's actual call pattern: one clip per call (ms per DDIM-50 loop)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,16 +41,18 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_FLOPS = 2.5e15            # dense bf16 MFMA, MI355X
 FLOP_PER_TOKEN_STEP = 2 * 4250112   # algorithmic, hoisted (SURVEY.md section 8d / BASELINE.md section 4)
 FILM_FLOP_PER_TOKEN = 2 * 512 * 6144
-LAYER_BYTES_PER_TOKEN = 512 + 512 + 24 * 64 + 72 + 36    # k_layer, per token and layer
-PEAK_HBM_BYTES = 8.0e12                                   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PEAK_HBM_BYTES = 8.0e12             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
 
-def cpu_baseline(steps_sample=6):
-    """Oracle on the host cores: bs=1, T=1800, `steps_sample` denoiser steps of the 50-step schedule
-    (every step costs the same), extrapolated to frames/s of a full DDIM-50 run.  PyTorch CPU ops do not
-    scale to hundreds of threads at this size, so a short sweep picks the fastest thread count."""
+def cpu_baseline(runs=3):
+    """the oracle on the host cores, config 1 (one 60 s clip, DDIM-50, fp32):
+    1 warm-up + `runs` full loops, median; loop-only and end to end (encode_music + loop).  PyTorch CPU ops do
+    not scale to hundreds of threads at this size, so a short sweep over denoiser forwards picks the thread
+    count first.  Returns (record, x0 of the last loop-only run) - the x0 doubles as the parity checker."""
+    import numpy as np
     import torch
-    from diffusion_conductor_amd.synthetic import batch_music_features, batch_noise, synthetic_state_dict
+    from diffusion_conductor_amd.synthetic import batch_mel, batch_music_features, batch_noise, synthetic_state_dict
     from oracle import ddim_oracle as O
     try:
         avail = len(os.sched_getaffinity(0))      # cores this process may actually run on
@@ -51,8 +62,9 @@ def cpu_baseline(steps_sample=6):
     xf = torch.from_numpy(batch_music_features(1, 1800))
     xfp = torch.nn.functional.linear(xf, p["proj.weight"], p["proj.bias"])
     x = torch.from_numpy(batch_noise(1, 1800))
+    mel = torch.from_numpy(batch_mel(1, 5400))
 
-    def run(n):
+    def fwd(n):
         t0 = time.perf_counter()
         with torch.no_grad():
             for i in range(n):
@@ -62,15 +74,28 @@ def cpu_baseline(steps_sample=6):
     best_n, best = 1, float("inf")
     for n in sorted({min(avail, c) for c in (8, 16, 32, 64)}):
         torch.set_num_threads(n)
-        run(1)
-        dt = run(2)
+        fwd(1)
+        dt = fwd(2)
         if dt < best:
             best_n, best = n, dt
     torch.set_num_threads(best_n)
-    dt = run(steps_sample)
-    return {"value": round(1800 / (50 * dt), 1), "unit": "frames/s", "cores": best_n, "kind": "port",
-            "sample": f"bs=1 T=1800 fp32: {steps_sample} denoiser steps timed ({dt*1e3:.0f} ms/step) x50 = one DDIM-50 loop; "
-                      f"fastest of 8/16/32/64 threads on {avail} available cores"}
+    loop, e2e, x0 = [], [], None
+    with torch.no_grad():
+        for r in range(runs + 1):                 # run 0 = warm-up
+            t0 = time.perf_counter()
+            x0 = O.ddim_sample_loop(p, x, xfp, xf, [1800], 50)
+            t1 = time.perf_counter()
+            O.generate_music_motion(p, mel, 26, 50, x)
+            t2 = time.perf_counter()
+            if r:
+                loop.append(t1 - t0)
+                e2e.append(t2 - t1)
+    tl, te = float(np.median(loop)), float(np.median(e2e))
+    rec = {"value": round(1800 / tl, 1), "unit": "frames/s", "cores": best_n, "kind": "port",
+           "sample": f"config 1 (bs=1, T=1800, DDIM-50, fp32): 1 warm-up + {runs} full loops, median {tl:.2f} s loop-only, "
+                     f"{te:.2f} s end to end; fastest of 8/16/32/64 threads on {avail} available cores",
+           "end_to_end": {"value": round(1800 / te, 1), "unit": "frames/s", "s": round(te, 3)}, "loop_s": round(tl, 3)}
+    return rec, x0
 
 
 def log(msg):
@@ -78,7 +103,7 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -88,35 +113,101 @@ def main():
     ap.add_argument("--ddim", type=int, default=50)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "mixed", "bf16", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bf16_mode / bs1 / end_to_end side measurements")
     ap.add_argument("--no-eff", action="store_true", help="full T x T attention variant (reference --no_eff)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Parent of an N-rank run: spawns the ranks BEFORE anything here touches the GPU (this process never does),
+    streams rank 0's stdout through and returns the worst child return code."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    worst = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            rc = p.poll()
+            if rc is None:
+                continue
+            procs.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                deadline = deadline or time.time() + 30     # a failed rank leaves the others in a collective: bounded wait
+        if deadline and time.time() > deadline:
+            for p in procs:
+                p.kill()
+        time.sleep(0.05)
+    return worst
+
+
+def build_model(precision, no_eff, dev):
     import numpy as np
+    import torch
+    from diffusion_conductor_amd import MotionTransformer
+    from diffusion_conductor_amd.synthetic import synthetic_state_dict
+    model = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device=dev,
+                              no_clip=True, precision=precision, no_eff=no_eff)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_state_dict().items()}, strict=True)
+    return model.to(dev).eval()
+
+
+def time_loops(nat, noise, coef, n, warm=1):
+    import torch
+    for _ in range(warm):
+        nat.ddim_loop(noise, coef)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out, _ = nat.ddim_loop(noise, coef)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, out
+
+
+def rel_l2(a, b):
+    import torch
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float(torch.linalg.norm(a - b) / torch.linalg.norm(b))
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path for the sampler)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from diffusion_conductor_amd import MotionTransformer
     from diffusion_conductor_amd.sampler import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,
                                                  get_named_beta_schedule)
     from diffusion_conductor_amd.sharding import gather_poses
-    from diffusion_conductor_amd.synthetic import batch_music_features, batch_noise, synthetic_state_dict
+    from diffusion_conductor_amd.synthetic import batch_music_features, batch_noise
 
     B, T, S = args.bs, args.frames, args.ddim
-    sd = synthetic_state_dict()
-    model = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device=dev,
-                              no_clip=True, precision=args.precision, no_eff=args.no_eff)
-    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
-    model = model.to(dev).eval()
+    model = build_model(args.precision, args.no_eff, dev)
     gd = GaussianDiffusion(betas=get_named_beta_schedule("linear", S), model_mean_type=ModelMeanType.START_X,
                            model_var_type=ModelVarType.FIXED_SMALL, loss_type=LossType.MSE)
     # this rank's shard of the global batch (clip ids rank*B .. rank*B+B-1), synthetic, resident in HBM
@@ -157,12 +248,13 @@ def main():
 
     frames = world * B * T * args.steps
     value = frames / dt
+    headline = (B, T, S) == (32, 1800, 50) and not args.no_eff
     line = {
         "metric": "motion frames/sec (DDIM-50, 60s clip, bs=32 per GPU)", "value": round(value, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp16": "f16", "mixed": "bf16x3+f16", "bf16": "bf16", "bf16x3": "bf16x3"}[args.precision], "data": "synthetic",
-        "config": {"workload": f"{'configs[1]: ' if (B, T, S) == (32, 1800, 50) and not args.no_eff else ''}DDIM-{S} sampling loop, bs={B} clips/GPU x {T} frames "
+        "config": {"workload": f"{'configs[1]: ' if headline else ''}DDIM-{S} sampling loop, bs={B} clips/GPU x {T} frames "
                                f"({T // 30} s), {'full T x T attention (no_eff)' if args.no_eff else 'linear attention'}, "
                                f"precision={args.precision}, conditioning + x_T resident in HBM (loop-only)",
                    "clips_per_gpu": B, "frames_per_clip": T, "ddim_steps": S, "parallelism": f"clip-dp{world}"},
@@ -171,67 +263,80 @@ def main():
                                                                       else FLOP_PER_TOKEN_STEP) / PEAK_BF16_FLOPS, 4),
     }
     if rank == 0:
-        # end to end for the same batch (reported beside `value`, never as it): pinned host mel -> H2D -> encode_music
-        # (HIP conv stack) -> set_conditioning (step-invariant pre-pass) -> DDIM loop -> poses back on the host
-        from diffusion_conductor_amd.synthetic import batch_mel
-        mel_h = torch.from_numpy(batch_mel(B, 3 * T)).pin_memory()
-        e2e = {}
-        for rep in range(2):                      # first repetition warms the encoder's activation planes
-            torch.cuda.synchronize()
-            t = [time.perf_counter()]
-            mel = mel_h.to(dev, non_blocking=True)
-            torch.cuda.synchronize(); t.append(time.perf_counter())
-            exp, ex = model.encode_music(mel, dev)
-            torch.cuda.synchronize(); t.append(time.perf_counter())
-            nat2 = model.set_conditioning(exp, ex, [T] * B)
-            torch.cuda.synchronize(); t.append(time.perf_counter())
-            o2, _ = nat2.ddim_loop(noise, coef)
-            o2h = o2.cpu(); t.append(time.perf_counter())
-            e2e = {"ms": round(1e3 * (t[-1] - t[0]), 2), "frames_per_s": round(B * T / (t[-1] - t[0]), 1),
-                   "h2d_mel_ms": round(1e3 * (t[1] - t[0]), 2), "encode_music_ms": round(1e3 * (t[2] - t[1]), 2),
-                   "set_conditioning_ms": round(1e3 * (t[3] - t[2]), 2), "loop_and_d2h_ms": round(1e3 * (t[4] - t[3]), 2)}
-        line["end_to_end"] = e2e
-        log(f"end to end: {e2e}")
-        nat = model.set_conditioning(xfp, xf, [T] * B)      # back to the benchmark's conditioning for the profile pass
+        from diffusion_conductor_amd import native
+        extras = not args.no_extras
+        if extras:
+            # end to end for the same batch (reported beside `value`, never as it): pinned host mel -> H2D -> encode_music
+            # (HIP conv stack) -> set_conditioning (step-invariant pre-pass) -> DDIM loop -> poses back on the host
+            from diffusion_conductor_amd.synthetic import batch_mel
+            mel_h = torch.from_numpy(batch_mel(B, 3 * T)).pin_memory()
+            e2e = {}
+            for rep in range(2):                      # first repetition warms the encoder's activation planes
+                torch.cuda.synchronize()
+                t = [time.perf_counter()]
+                mel = mel_h.to(dev, non_blocking=True)
+                torch.cuda.synchronize(); t.append(time.perf_counter())
+                exp, ex = model.encode_music(mel, dev)
+                torch.cuda.synchronize(); t.append(time.perf_counter())
+                nat2 = model.set_conditioning(exp, ex, [T] * B)
+                torch.cuda.synchronize(); t.append(time.perf_counter())
+                o2, _ = nat2.ddim_loop(noise, coef)
+                o2h = o2.cpu(); t.append(time.perf_counter())
+                e2e = {"ms": round(1e3 * (t[-1] - t[0]), 2), "frames_per_s": round(B * T / (t[-1] - t[0]), 1),
+                       "h2d_mel_ms": round(1e3 * (t[1] - t[0]), 2), "encode_music_ms": round(1e3 * (t[2] - t[1]), 2),
+                       "set_conditioning_ms": round(1e3 * (t[3] - t[2]), 2), "loop_and_d2h_ms": round(1e3 * (t[4] - t[3]), 2)}
+            line["end_to_end"] = e2e
+            log(f"end to end: {e2e}")
+            nat = model.set_conditioning(xfp, xf, [T] * B)      # back to the benchmark's conditioning for the profile pass
         # roofline of the dominant kernel: separate eager pass with per-launch HIP events
         prof, _ = nat.profile_loop(noise, coef)
-        log("profile pass done: " + ", ".join(f"{k} {v[0]:.2f}ms/{v[1]}" for k, v in prof.items()))
+        log("profile pass done: " + ", ".join(f"{k} {v[0]:.2f}ms/{v[1]}" for k, v in prof.items() if v[1]))
         tot = sum(ms for ms, _ in prof.values())
         tj = {}
-        tf = os.path.join(ROOT, "profiles", "r01_traffic.json")   # HBM bytes per launch from the committed PMC passes of this command
-        if os.path.exists(tf) and (B, T, S, args.precision, args.no_eff) == (32, 1800, 50, "fp16", False):
-            tj = json.load(open(tf))
+        if os.path.exists(os.path.join(ROOT, TRAFFIC_FILE)) and headline and args.precision == "fp16":
+            tj = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+        alg = native.algorithmic_work(B * T)       # per-launch algorithmic bytes / FLOPs of the build's kernels
 
-        def film_roofline():
-            ms, cnt = prof["k_film_gemm"]
+        def roof(name):
+            ms, cnt = prof[name]
             per = ms / cnt * 1e-3
-            ach = FILM_FLOP_PER_TOKEN * B * T / per / 1e12
-            return {"bound": "mfma", "kernel": "k_film_gemm", "achieved": round(ach, 1), "peak": PEAK_BF16_FLOPS / 1e12,
-                    "unit": "TFLOP/s", "frac": round(ach * 1e12 / PEAK_BF16_FLOPS, 4),
-                    "traffic": tj.get("k_film_gemm", {}).get("traffic_bytes"), "avg_launch_us": round(per * 1e6, 1), "launches": cnt}
-
-        def layer_roofline():
-            # k_layer (one decoder layer for all tokens) moves per token: residual stream 512 B in + 512 B out, FiLM tiles
-            # 24 x 64 B, workgroup records 72 B out + 36 B in and runs ~0.28 MFLOP: HBM is its nearer roof
-            ms, cnt = prof["k_layer"]
-            per = ms / cnt * 1e-3
-            ach = LAYER_BYTES_PER_TOKEN * B * T / per / 1e9
-            return {"bound": "hbm", "kernel": "k_layer", "achieved": round(ach, 1), "peak": PEAK_HBM_BYTES / 1e9, "unit": "GB/s",
-                    "frac": round(ach * 1e9 / PEAK_HBM_BYTES, 4), "traffic": tj.get("k_layer", {}).get("traffic_bytes"),
+            w = alg[name]
+            if w["bound"] == "mfma":
+                ach, peak, unit = w["flops"] / per / 1e12, PEAK_BF16_FLOPS / 1e12, "TFLOP/s"
+            else:
+                ach, peak, unit = w["bytes"] / per / 1e9, PEAK_HBM_BYTES / 1e9, "GB/s"
+            return {"bound": w["bound"], "kernel": name, "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                    "frac": round(ach / peak, 4), "traffic": tj.get(name, {}).get("traffic_bytes"),
+                    "traffic_source": TRAFFIC_FILE if name in tj else None,
                     "avg_launch_us": round(per * 1e6, 1), "launches": cnt}
 
-        # `roofline` = the kernel with the largest share of the loop; the other of the two big kernels rides along
-        if args.no_eff or prof["k_film_gemm"][0] >= prof["k_layer"][0]:
-            line["roofline"], other = film_roofline(), (None if args.no_eff else layer_roofline())
-        else:
-            line["roofline"], other = layer_roofline(), film_roofline()
-        line["roofline"]["time_share_by_kernel"] = {k: round(v[0] / tot, 3) for k, v in prof.items()}
-        if other:
-            line["roofline_second_kernel"] = other
+        big = sorted((k for k in prof if prof[k][1] and k in alg), key=lambda k: -prof[k][0])
+        if not args.no_eff and big:
+            line["roofline"] = roof(big[0])
+            line["roofline"]["time_share_by_kernel"] = {k: round(v[0] / tot, 3) for k, v in prof.items() if v[1]}
+            if len(big) > 1:
+                line["roofline_second_kernel"] = roof(big[1])
+        cpu_x0 = None
         if not args.no_cpu_baseline and world == 1:      # contract: rank 0 at N=1 only
-            log("cpu baseline (oracle on host cores) ...")
-            line["cpu_baseline"] = cpu_baseline()
+            log("cpu baseline (oracle on host cores: 1 warm-up + 3 DDIM-50 loops at bs=1) ...")
+            line["cpu_baseline"], cpu_x0 = cpu_baseline()
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
+        if extras and headline and world == 1:
+            # the reference's own call pattern: one clip per call
+            nat1 = model.set_conditioning(xfp[:1].contiguous(), xf[:1].contiguous(), [T])
+            t1, o1 = time_loops(nat1, noise[:1].contiguous(), coef, 5)
+            line["bs1"] = {"ms_per_loop": round(1e3 * t1, 3), "frames_per_s": round(T / t1, 1)}
+            if cpu_x0 is not None:
+                line["bs1"]["rel_l2_vs_oracle"] = float(f"{rel_l2(o1, cpu_x0):.3e}")
+            log(f"bs=1: {line['bs1']}")
+            if args.precision != "mixed":
+                del nat1, nat
+                m2 = build_model("mixed", False, dev)
+                n2 = m2.set_conditioning(xfp, xf, [T] * B)
+                t2, o2 = time_loops(n2, noise, coef, 3)
+                line["bf16_mode"] = {"precision": "mixed", "ms_per_step": round(1e3 * t2, 3), "frames_per_s": round(B * T / t2, 1),
+                                     "rel_l2": float(f"{rel_l2(o2[:1], cpu_x0):.3e}") if cpu_x0 is not None else None}
+                log(f"bf16 mode: {line['bf16_mode']}")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

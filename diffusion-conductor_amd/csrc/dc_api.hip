@@ -171,6 +171,12 @@ struct dc_sampler {
     float *d_coef_cur = nullptr, *d_coef_of_t = nullptr, *d_coef_of_iter = nullptr;   // DDIM scalars by timestep / by iteration
     bool cond_set = false;
     int64_t ws_bytes = 0;
+    std::map<void*, size_t> alloc_bytes;   // live workspace allocations (ws_bytes = their sum)
+    // host copies of the per-iteration tables currently on the device (tables_S == 0: none)
+    int tables_S = 0;
+    std::vector<int> tab_t, tab_snap;
+    std::vector<float> tab_coef, tab_coef_iter;
+    bool pers_used = false;                // a persistent layer launch ran since d_gerr was last read
 
     // graph cache: one per (B,T,steps_per_graph)
     hipGraphExec_t graph = nullptr;
@@ -180,19 +186,29 @@ struct dc_sampler {
 
     Prof prof;
     int dbg_layers = -1, dbg_stage = 0;   // test hooks (dc_sampler_debug_denoise)
+    int dbg_first = -1;                   // test hook (dc_sampler_debug_layer): start at this layer from the residual stream in d_h
 };
 
 namespace {
 
+// (Re)allocates one workspace buffer.  The caller's capacity field is only raised after every buffer of its group was
+// allocated (ensure_workspace resets it to 0 first), so a failed hipMalloc leaves "no capacity", never a stale one.
 template <class P>
 int dev_alloc(dc_sampler* s, P*& p, size_t bytes) {
     if (p) {
-        HIP_TRY(hipFree(p));
+        auto it = s->alloc_bytes.find((void*)p);
+        if (it != s->alloc_bytes.end()) {
+            s->ws_bytes -= (int64_t)it->second;
+            s->alloc_bytes.erase(it);
+        }
+        void* old = (void*)p;
         p = nullptr;
+        HIP_TRY(hipFree(old));
     }
     void* q = nullptr;
     HIP_TRY(hipMalloc(&q, bytes));
     p = (P*)q;
+    s->alloc_bytes[q] = bytes;
     s->ws_bytes += (int64_t)bytes;
     return DC_OK;
 }
@@ -511,6 +527,7 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
     if ((size_t)G > s->cap_G) {
         drop_graph(s);
         const size_t g = (size_t)G;
+        s->cap_G = 0;
         int rc;
         if ((rc = dev_alloc(s, s->d_pp, g * 32 * 64 * 8 * 4))) return rc;
         if ((rc = dev_alloc(s, s->d_s_hi, g * 32 * 64 * 16))) return rc;
@@ -532,6 +549,7 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
         const size_t need = (size_t)B * KT;
         if (need > s->cap_kv) {
             drop_graph(s);
+            s->cap_kv = 0;
             int rc;
             for (int i = 0; i < 2; ++i)
                 if ((rc = dev_alloc(s, s->d_kv_sa[i], need * 16384))) return rc;
@@ -542,6 +560,7 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
     }
     if ((size_t)B > s->cap_B) {
         drop_graph(s);
+        s->cap_B = 0;
         int rc;
         if ((rc = dev_alloc(s, s->d_length, (size_t)B * 4))) return rc;
         if ((rc = dev_alloc(s, s->d_t_clip, (size_t)B * 4))) return rc;
@@ -551,6 +570,7 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
     }
     if ((size_t)M * P > s->cap_MP) {
         drop_graph(s);
+        s->cap_MP = 0;
         int rc;
         if ((rc = dev_alloc(s, s->d_x, (size_t)M * P * 4))) return rc;
         s->cap_MP = (size_t)M * P;
@@ -583,6 +603,8 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
 int ensure_steps(dc_sampler* s, int S) {
     if ((size_t)S > s->cap_steps) {
         drop_graph(s);
+        s->cap_steps = 0;
+        s->tables_S = 0;
         int rc;
         if ((rc = dev_alloc(s, s->d_t_of_iter, (size_t)S * 4))) return rc;
         if ((rc = dev_alloc(s, s->d_snap_of_iter, (size_t)S * 4))) return rc;
@@ -684,9 +706,12 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     }
     // workgroup-level records (no combine launches) whenever a workgroup's 256 tokens cannot touch more than two clips
     static const bool no_wgr = getenv("DC_NO_WGREC") != nullptr;
-    const bool wgr = !ss && T >= 256 && !no_wgr;
-    LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
-                                          want_stamps_film ? s->d_stamps + 256 : nullptr));
+    const bool wgr = !ss && T >= 256 && !no_wgr && s->dbg_first < 0;
+    if (s->dbg_first >= 0)
+        LAUNCH(K_EMBED, dc_launch_front_from_h(st, fs, ss, s->d_model, s->d_h, s->d_recs, s->d_length, M, T, G, B, s->dbg_first));
+    else
+        LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
+                                              want_stamps_film ? s->d_stamps + 256 : nullptr));
     static const int ablate = getenv("DC_ABLATE") ? (int)strtol(getenv("DC_ABLATE"), nullptr, 0) : 0;   // timing experiments
     static const bool want_stamps = getenv("DC_STAMPS") != nullptr;
     const bool no_persist = false;
@@ -698,13 +723,14 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const bool want_persist = getenv("DC_PERSIST") != nullptr;      // (read per call: the tests toggle it)
     const bool persistent = want_persist && chunks == 1 && wgr && nwg <= s->num_cu && nl_run == L && s->dbg_stage == 0 && !ablate && !no_persist && L > 1;
     if (persistent) {
+        s->pers_used = true;
         HIP_TRY(hipMemsetAsync(s->d_gbar, 0, 4, st));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, 0, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur, s->d_snaps,
                                         M, T, G, B, 0, want_stamps ? s->d_stamps : nullptr, L, rec_stride, s->d_gbar, s->d_gerr, nullptr));
         return DC_OK;
     }
-    for (int l = 0; l < nl_run; ++l) {
+    for (int l = s->dbg_first >= 0 ? s->dbg_first : 0; l < nl_run; ++l) {
         if (l > 0 && l % lpc == 0) { int rc = film_chunk(l / lpc); if (rc) return rc; }
         const int dbg = ((l == nl_run - 1) ? s->dbg_stage : 0) | ablate;
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
@@ -745,32 +771,50 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     const size_t MP = (size_t)s->M * s->cfg.input_feats;
     if ((size_t)n_snap > s->cap_snap) {
         drop_graph(s);
+        s->cap_snap = 0;
         if ((rc = dev_alloc(s, s->d_snaps, (size_t)n_snap * MP * 4))) return rc;
         s->cap_snap = (size_t)n_snap;
     }
-    std::vector<int> t_of_iter(S), snap_of_iter(S, -1);
-    for (int i = 0; i < S; ++i) t_of_iter[i] = S - 1 - i;            // indices = range(num_timesteps)[::-1] (gaussian_diffusion.py:943)
+    // Per-iteration tables on the device: uploaded only when (S, coefficients, snapshot iterations) differ from the
+    // previous call - a sampling service calls the loop with the same schedule every time, and the four small H2D
+    // copies + the stream synchronisation they need cost as much as several kernels at bs=1.
+    std::vector<int> snap_of_iter(S, -1);
     for (int k = 0; k < n_snap; ++k) {
         if (h_snap_iters[k] < 0 || h_snap_iters[k] >= S) return fail(DC_ERR_INVALID, "snapshot iteration %d outside [0,%d)", h_snap_iters[k], S);
         snap_of_iter[h_snap_iters[k]] = k;
     }
+    const bool same_tables = s->tables_S == S && s->tab_snap == snap_of_iter &&
+                             memcmp(s->tab_coef.data(), h_coef, (size_t)S * 16) == 0;
     if ((rc = sync_in(s, user))) return rc;
     hipStream_t st = s->stream;
-    HIP_TRY(hipMemcpyAsync(s->d_t_of_iter, t_of_iter.data(), S * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_snap_of_iter, snap_of_iter.data(), S * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_coef_of_t, h_coef, (size_t)S * 16, hipMemcpyHostToDevice, st));
-    std::vector<float> coef_of_iter((size_t)S * 4);
-    for (int i = 0; i < S; ++i) memcpy(&coef_of_iter[4 * (size_t)i], h_coef + 4 * (size_t)t_of_iter[i], 16);
-    HIP_TRY(hipMemcpyAsync(s->d_coef_of_iter, coef_of_iter.data(), (size_t)S * 16, hipMemcpyHostToDevice, st));
+    if (!same_tables) {
+        HIP_TRY(hipStreamSynchronize(st));          // an earlier call's copies out of the member vectors are done
+        s->tables_S = 0;
+        s->tab_t.resize(S);
+        for (int i = 0; i < S; ++i) s->tab_t[i] = S - 1 - i;            // indices = range(num_timesteps)[::-1] (gaussian_diffusion.py:943)
+        s->tab_snap = snap_of_iter;
+        s->tab_coef.assign(h_coef, h_coef + (size_t)S * 4);
+        s->tab_coef_iter.resize((size_t)S * 4);
+        for (int i = 0; i < S; ++i) memcpy(&s->tab_coef_iter[4 * (size_t)i], h_coef + 4 * (size_t)s->tab_t[i], 16);
+        HIP_TRY(hipMemcpyAsync(s->d_t_of_iter, s->tab_t.data(), S * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->d_snap_of_iter, s->tab_snap.data(), S * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->d_coef_of_t, s->tab_coef.data(), (size_t)S * 16, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->d_coef_of_iter, s->tab_coef_iter.data(), (size_t)S * 16, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));          // pageable sources: the copies have left the host vectors
+        s->tables_S = S;
+    }
     HIP_TRY(hipMemsetAsync(s->d_iter, 0, 16, st));
     HIP_TRY(hipMemcpyAsync(s->d_x, d_noise, MP * 4, hipMemcpyDeviceToDevice, st));
-    int gerr = 0;
-    HIP_TRY(hipMemcpyAsync(&gerr, s->d_gerr, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));   // the host vectors above go out of scope
-    if (gerr) {
-        HIP_TRY(hipMemset(s->d_gerr, 0, 4));
-        return fail(DC_ERR_HIP, "an earlier persistent layer launch timed out in its grid barrier (workgroups not co-resident?); "
-                                "its results were invalid - set DC_NO_PERSIST=1 to use per-layer launches");
+    if (s->pers_used) {       // only the opt-in persistent layer form can raise the grid-barrier flag
+        int gerr = 0;
+        HIP_TRY(hipMemcpyAsync(&gerr, s->d_gerr, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        s->pers_used = false;
+        if (gerr) {
+            HIP_TRY(hipMemset(s->d_gerr, 0, 4));
+            return fail(DC_ERR_HIP, "an earlier persistent layer launch timed out in its grid barrier (workgroups not co-resident?); "
+                                    "its results were invalid - unset DC_PERSIST to use per-layer launches (the default)");
+        }
     }
 
     const bool no_graph = getenv("DC_DISABLE_GRAPH") != nullptr;
@@ -1154,6 +1198,38 @@ int dc_sampler_debug_denoise(dc_sampler* s, const float* d_x, const int32_t* h_t
     s->dbg_layers = n_layers;
     s->dbg_stage = stage;
     const int rc = dc_sampler_denoise(s, d_x, h_timesteps, d_out, stream);
+    s->dbg_layers = -1;
+    s->dbg_stage = 0;
+    return rc;
+}
+
+int dc_sampler_debug_layer(dc_sampler* s, const float* h_h, const int32_t* h_timesteps, int32_t layer, int32_t first_stage,
+                           int32_t stage, void* stream) {
+    if (!s || !s->finalized || !s->cond_set) return fail(DC_ERR_INVALID, "sampler not ready (finalize + set_conditioning first)");
+    if (!h_h || !h_timesteps) return fail(DC_ERR_INVALID, "null pointer argument");
+    if (layer < 0 || layer >= s->cfg.num_layers || first_stage < 1 || stage > 3 || first_stage > stage)
+        return fail(DC_ERR_INVALID, "layer / stage out of range (need 1 <= first_stage <= last_stage <= 3)");
+    if (s->cfg.no_eff) return fail(DC_ERR_UNSUPPORTED, "dc_sampler_debug_layer covers the linear-attention layers");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    // row-major [M][128] -> residual-stream image [G][tile][quarter][64 lanes][4] (dc_kernels.hip load_h)
+    const size_t G = (size_t)s->G;
+    std::vector<float> img(G * 4 * 4 * 64 * 4, 0.f);
+    for (size_t g = 0; g < G; ++g)
+        for (int t = 0; t < 4; ++t)
+            for (int q = 0; q < 4; ++q)
+                for (int l = 0; l < 64; ++l)
+                    for (int i = 0; i < 4; ++i) {
+                        const size_t tok = g * 32 + (l & 31);
+                        const int f = 32 * t + tile_row(4 * q + i, l >> 5);
+                        if (tok < (size_t)s->M) img[(((g * 4 + t) * 4 + q) * 64 + l) * 4 + i] = h_h[tok * DC_D + f];
+                    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(s->d_h, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+    s->dbg_first = layer;
+    s->dbg_layers = layer + 1;
+    s->dbg_stage = stage | ((first_stage - 1) << 16);
+    const int rc = dc_sampler_denoise(s, s->d_x, h_timesteps, s->d_x, stream);     // x is not read on this path; out_mode is never reached
+    s->dbg_first = -1;
     s->dbg_layers = -1;
     s->dbg_stage = 0;
     return rc;

@@ -1643,11 +1643,14 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
 // The K=26 input projection always runs split: rounding x_t itself to 8/11 mantissa bits is the
 // single largest error source otherwise, and the GEMM is tiny.
 // ------------------------------------------------------------------------------------
-template <class T16, bool SPLIT, bool WGR>
+// FROMH (test hook, per-group records only): the residual stream is taken from hbuf as it stands instead of being embedded
+// from x, and the front half is that of layer l0 - lets a test start a single decoder layer from a given h.
+template <class T16, bool SPLIT, bool WGR, bool FROMH = false>
 __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
 void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /*[M][P]*/, float* __restrict__ hbuf,
                    float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G, int B,
-                   unsigned long long* __restrict__ clk /* diagnostic: 100-MHz stamps of one wave, or nullptr */) {
+                   unsigned long long* __restrict__ clk /* diagnostic: 100-MHz stamps of one wave, or nullptr */, int l0 = 0) {
+    static_assert(!(FROMH && WGR), "the h-injection hook exists for the per-group-record form only");
     constexpr int NW = SPLIT ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;
     const bool stamping = clk && blockIdx.x == 100 && threadIdx.x == 0;
@@ -1686,7 +1689,9 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
         for (int q = 0; q < 4; ++q) sev[4 * t + q] = *reinterpret_cast<const f32x4*>(se + 32 * t + 8 * q + 4 * cx.hh);
     // x as chained-order operand: element j of k-step s <-> pose feature 16s + 8(j>>2) + 4hh + (j&3)
     f32x16 h[4];
-    {
+    if constexpr (FROMH) {
+        load_h(h, hbuf, g, lane);
+    } else {
         XFrag<T16, true> xf[1];
         f32x16 xv;
         bool staged = false;
@@ -1729,14 +1734,16 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
         gemm_wa<4, 1, T16, true>(h, img, xf, lane);
     }
     stamp(1);
+    if constexpr (!FROMH) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) h[t][4 * q + i] += sev[4 * t + q][i];
-    if (active) store_h(h, hbuf, g, lane);
-    const DcLayer& L = dm->layer[0];
+                for (int i = 0; i < 4; ++i) h[t][4 * q + i] += sev[4 * t + q][i];
+        if (active) store_h(h, hbuf, g, lane);
+    }
+    const DcLayer& L = dm->layer[FROMH ? l0 : 0];
     XFrag<T16, SPLIT> nf[4];
     ln_frags<T16, SPLIT>(nf, h);
     stamp(2);
@@ -2190,7 +2197,11 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if constexpr (use_ring) epre_load<DBG || PERS>(ep, Eg, lane);
     ytile<SPLIT> y[4];
     float y_rstd, y_shift;
-    if (wg_lds)     // two instantiations so that each keeps its address space (a generic pointer means flat loads)
+    // test hook (DBG builds): (dbg >> 16) & 3 = number of leading blocks of the layer to skip (1: no self-attention,
+    // 2: neither attention) - the staging, rings and barriers of a skipped block still run
+    const int skip_blocks = DBG ? (dbg >> 16) & 3 : 0;
+    if (DBG && skip_blocks >= 1) {
+    } else if (wg_lds)     // two instantiations so that each keeps its address space (a generic pointer means flat loads)
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (size_t)(cx.b0 - ub0) * 8 * 64,
                                  af + (size_t)(cx.b1 - ub0) * 8 * 64, cx);
     else
@@ -2203,14 +2214,18 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
         if (wg_lds) stage_attn(acl);
-        styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh, dbg);
+        if (!(DBG && skip_blocks >= 1)) styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh, dbg);
     } else {
-        styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, [&]() {
+        auto next2 = [&]() {
             stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
             if (wg_lds) stage_attn(acl);
             ering_issue(Eg + 8 * 128, 0, ring, lane);
             ering_issue(Eg + 8 * 128, 1, ring + 4096, lane);
-        });
+        };
+        if (DBG && skip_blocks >= 1)
+            next2();
+        else
+            styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, next2);
     }
     if constexpr (DBG) if ((dbg & 0xff) == 1) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after self-attention
     DC_STAMP(4);
@@ -2219,7 +2234,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
     stage_frags<NW>(L.img_ca_o, buf1, NFW + 1, wave, lane);
     if constexpr (use_ring) epre_load<DBG || PERS>(ep, Eg + 8 * 128, lane);
-    if (wg_lds)
+    if (DBG && skip_blocks >= 2) {
+    } else if (wg_lds)
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (size_t)(cx.b0 - ub0) * 8 * 64,
                                  af + (size_t)(cx.b1 - ub0) * 8 * 64, cx);
     else
@@ -2231,14 +2247,18 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
         stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
-        styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh, dbg);
+        if (!(DBG && skip_blocks >= 2)) styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh, dbg);
     } else {
-        styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, [&]() {
+        auto next4 = [&]() {
             stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
             stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
             ering_issue(Eg + 16 * 128, 0, ring, lane);
             ering_issue(Eg + 16 * 128, 1, ring + 4096, lane);
-        });
+        };
+        if (DBG && skip_blocks >= 2)
+            next4();
+        else
+            styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, next4);
     }
     if constexpr (DBG) if ((dbg & 0xff) == 2) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after cross-attention
     DC_STAMP(7);
@@ -2956,6 +2976,26 @@ __global__ __launch_bounds__(256) void k_cond_ca_kv(const DcModel* __restrict__ 
         }                                                \
     } while (0)
 
+// Kernels that use more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, and the attribute is
+// per DEVICE: `done` is a per-kernel bit mask of the devices that already have it (a process may hold samplers on several GPUs).
+static hipError_t lds_optin(const void* fn, int bytes, unsigned long long& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 64 && ((done >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev < 64) done |= 1ull << dev;
+    return e;
+}
+static int cu_count() {     // of the current device
+    static int n[64] = {0};
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!n[dev]) hipDeviceGetAttribute(&n[dev], hipDeviceAttributeMultiprocessorCount, dev);
+    return n[dev];
+}
+
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k) {
     k_advance_iter<<<1, 1, 0, st>>>(iter, k);
     return hipGetLastError();
@@ -3040,13 +3080,9 @@ static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bia
                                  const int* t_clip, int T, int B, unsigned long long* clk, const float* rate_in, float* rate_out,
                                  const int* iter_base) {
     const size_t shm = 4 * DC_KS_E * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_film_gemm2<T16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    static const int ncu = [] { hipDeviceProp_t p; int d = 0; hipGetDevice(&d); hipGetDeviceProperties(&p, d); return p.multiProcessorCount; }();
+    static unsigned long long optin_done = 0;
+    if (hipError_t e = lds_optin((const void*)k_film_gemm2<T16>, (int)shm, optin_done)) return e;
+    const int ncu = cu_count();
     const int nblk = (G + 3) / 4;
     k_film_gemm2<T16><<<dim3(nblk < ncu ? nblk : ncu), dim3(512), shm, st>>>((const v8<T16>*)W, bias_ft,
                                                                 (const v8<T16>*)s_hi, (f16x16*)E, G, NT, round0, nround, pp, temb, t_clip, T, B,
@@ -3058,18 +3094,9 @@ static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* b
                                  const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk,
                                  const float* rate_in, float* rate_out, const int* iter_base) {
     const size_t shm = 4 * DC_KS_E * 1024 + 64;        // slab + the pair counter
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_film_gemm3<T16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    }
+    static unsigned long long optin_done = 0;
+    if (hipError_t e = lds_optin((const void*)k_film_gemm3<T16>, (int)shm, optin_done)) return e;
+    const int ncu = cu_count();
     const int nblk = (G + 3) / 4;
     k_film_gemm3<T16><<<dim3(nblk < ncu ? nblk : ncu), dim3(512), shm, st>>>((const v8<T16>*)W16, bias16, (f16x16*)E, G, NT, round0, nround,
                                                                            pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base);
@@ -3091,18 +3118,28 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
     return LAUNCH_CHECK();
 }
 
+template <class T16, bool SP>
+static hipError_t launch_front_from_h_t(hipStream_t st, const DcModel* dm, float* hbuf, float* recs, const int* length,
+                                        int M, int T, int G, int B, int l0) {
+    constexpr int NW = SP ? 4 : 8;
+    k_embed_front<T16, SP, false, true><<<dim3((G + NW - 1) / NW), dim3(NW * 64), 0, st>>>(dm, nullptr, hbuf, recs, length, M, T, G, B, nullptr, l0);
+    return hipGetLastError();
+}
+hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcModel* dm, float* hbuf, float* recs, const int* length,
+                                  int M, int T, int G, int B, int l0) {
+    hipError_t e = hipSuccess;
+    DISPATCH(fmt, split, (e = launch_front_from_h_t<T16, SP>(st, dm, hbuf, recs, length, M, T, G, B, l0)));
+    return e;
+}
+
 template <class T16, bool SP, bool WGR>
 static hipError_t launch_embed_t(hipStream_t st, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
                                  int M, int T, int G, int B, unsigned long long* clk) {
     constexpr int NW = SP ? 4 : 8;
     const size_t shm = WGR ? 8192 + 65536 + 8192 + 9 * 4 * 32 * 4 + 33 * 1024 : 0;
     if (WGR) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_embed_front<T16, SP, WGR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
+        static unsigned long long optin_done = 0;
+        if (hipError_t e = lds_optin((const void*)k_embed_front<T16, SP, WGR>, (int)shm, optin_done)) return e;
     }
     k_embed_front<T16, SP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, B, clk);
     return hipGetLastError();
@@ -3128,12 +3165,8 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
     constexpr int NW = SP ? 4 : 8;
     // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
     const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
-    static bool attr_set = false;
-    if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
-        hipError_t e = hipFuncSetAttribute((const void*)k_layer<T16, SP, DBG, STAMP, WGR, PERS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long optin_done = 0;   // > 64 KiB of dynamic LDS needs the opt-in
+    if (hipError_t e = lds_optin((const void*)k_layer<T16, SP, DBG, STAMP, WGR, PERS>, (int)shm, optin_done)) return e;
     k_layer<T16, SP, DBG, STAMP, WGR, PERS><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
                        (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
                        snaps, M, T, G, B, dbg, stamps, l_end, rec_stride, gbar, gerr, iter_base);
@@ -3181,12 +3214,8 @@ static hipError_t launch_full_t(hipStream_t st, int which, const DcModel* dm, in
                                 const float* xin, float* xout, int out_mode, const float* coef_cur, const int* snap_cur,
                                 float* snaps, int M, int T, int B, int KT, int stop_after) {
     const int WPC = (KT + 7) / 8;
-    static bool attr_set = false;
-    if (!attr_set) {   // key-tile double buffer (32 KiB) + per-wave query fragments (64 KiB) > 64 KiB of dynamic LDS
-        hipError_t e = hipFuncSetAttribute((const void*)k_layer_full<T16>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 + 8 * 8192);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long optin_done = 0;   // key-tile double buffer (32 KiB) + per-wave query fragments (64 KiB) > 64 KiB of dynamic LDS
+    if (hipError_t e = lds_optin((const void*)k_layer_full<T16>, 32768 + 8 * 8192, optin_done)) return e;
     if (which == 0)
         k_embed_front_full<T16><<<dim3(B * WPC), dim3(512), 0, st>>>(dm, x, hbuf, (v8<T16>*)kv_next, M, T, KT, WPC);
     else

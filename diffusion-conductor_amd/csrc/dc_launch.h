@@ -29,6 +29,9 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf, float* recs,
                                  const int* length, int M, int T, int G, int B,
                                  unsigned long long* clk /* diagnostic stamps (8 slots) or nullptr */);
+// test hook: front half of layer l0 from the residual stream as it stands in hbuf (per-group records)
+hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcModel* dm, float* hbuf, float* recs, const int* length,
+                                  int M, int T, int G, int B, int l0);
 hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,

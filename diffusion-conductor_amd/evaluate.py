@@ -61,9 +61,16 @@ class _Prefetcher:
         pin = torch.cuda.is_available()
         self.buf = [torch.empty((batch_size,) + mel_shape, dtype=torch.float32, pin_memory=pin) for _ in range(2)]
         self.result = None
+        self.error = None
         self.thread = None
 
     def _load(self, k, slot):
+        try:
+            self._load_batch(k, slot)
+        except BaseException as e:      # handed to the consumer: a dead loader thread must not leave the previous batch behind
+            self.error = e
+
+    def _load_batch(self, k, slot):
         ids = self.ids[k * self.bs:(k + 1) * self.bs]
         mel = self.buf[slot][:len(ids)]
         gts = []
@@ -76,11 +83,15 @@ class _Prefetcher:
         self.result = (ids, mel, gts)
 
     def start(self, k):
+        self.result = None
+        self.error = None
         self.thread = threading.Thread(target=self._load, args=(k, k & 1), daemon=True)
         self.thread.start()
 
     def take(self):
         self.thread.join()
+        if self.error is not None:
+            raise self.error
         return self.result
 
 

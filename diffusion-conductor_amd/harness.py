@@ -55,14 +55,26 @@ class DDPMTrainer(object):
         if mel.dim() == 2:
             mel = mel.unsqueeze(0)
         mel = mel.to(self.device, dtype=torch.float32)
-        B, T = mel.shape[0], mel.shape[1] // 3
-        if noise is None and seed is not None:
-            g = torch.Generator().manual_seed(int(seed))
+        B, T = mel.shape[0], (mel.shape[1] - 1) // 3 + 1       # frames encode_music produces (MusicEncoder pools time by 3)
+        _, world = dist_info()
+        grouped = torch.distributed.is_available() and torch.distributed.is_initialized()     # a world-size-1 group still gathers
+        if noise is None and (seed is not None or world > 1):
+            # x_T for the WHOLE batch from one generator, sliced per shard: with every rank drawing from its own default
+            # generator, identically seeded ranks would hand all shards the same noise rows.  Without a seed, rank 0's draw
+            # is broadcast.
+            g = torch.Generator()
+            if seed is not None:
+                g.manual_seed(int(seed))
+            else:
+                s0 = torch.tensor([g.seed() & 0x7fffffffffffffff], dtype=torch.int64, device=self.device if world > 1 else "cpu")
+                if world > 1:
+                    import torch.distributed as dist
+                    dist.broadcast(s0, src=0)
+                g.manual_seed(int(s0.item()))
             noise = torch.randn(B, T, dim_pose, generator=g)
         if noise is not None:
             noise = torch.as_tensor(noise).to(self.device, dtype=torch.float32)
-        _, world = dist_info()
         with torch.no_grad():
-            if world == 1 or len(idxs):
+            if not grouped or len(idxs):
                 return self._sample_local(mel, noise, dim_pose, idxs)
-            return sharded_sample(lambda m, n: self._sample_local(m, n, dim_pose, []), mel, noise)
+            return sharded_sample(lambda m, n: self._sample_local(m, n, dim_pose, []), mel, noise, out_shape=(T, dim_pose))

@@ -22,7 +22,7 @@ EXPORTS = [
     "dc_sampler_create", "dc_sampler_destroy", "dc_sampler_set_param", "dc_sampler_finalize_params",
     "dc_sampler_set_conditioning", "dc_sampler_encode_music", "dc_sampler_denoise", "dc_sampler_ddim_loop", "dc_sampler_profile_loop",
     "dc_kernel_name", "dc_kernel_count", "dc_sampler_workspace_bytes", "dc_sampler_debug_denoise",
-    "dc_sampler_debug_read", "dc_savgol_coefficients", "dc_savgol_filter",
+    "dc_sampler_debug_read", "dc_sampler_debug_layer", "dc_savgol_coefficients", "dc_savgol_filter",
 ]
 
 
@@ -89,6 +89,7 @@ def lib():
     L.dc_sampler_ddim_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, fp, ip, C.c_int32, C.c_void_p, C.c_void_p]
     L.dc_sampler_debug_denoise.argtypes = [C.c_void_p, C.c_void_p, ip, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.dc_sampler_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+    L.dc_sampler_debug_layer.argtypes = [C.c_void_p, fp, ip, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.dc_sampler_profile_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, fp, fp, ip, C.c_int32, C.c_void_p]
     _lib = L
     return L
@@ -145,6 +146,15 @@ def savgol_filter(poses, window: int = 19, order: int = 5):
     _check(lib().dc_savgol_filter(x.data_ptr(), out.data_ptr(), B, T, P, int(window), int(order),
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return out
+
+
+def algorithmic_work(n_tokens: int) -> dict:
+    """Algorithmic work per launch of the loop's two big kernels at `n_tokens` = B*T, the
+    numerators of bench.py's roofline objects.  k_layer (one decoder layer for all tokens) moves per token the
+    residual stream 512 B in + 512 B out, its 24 FiLM tiles x 64 B and the workgroup records 72 B out + 36 B in:
+    HBM is its nearer roof.  k_film_gemm is the [6144 x 512] x [512 x tokens] FiLM GEMM: MFMA roof."""
+    return {"k_layer": {"bound": "hbm", "bytes": (512 + 512 + 24 * 64 + 72 + 36) * n_tokens},
+            "k_film_gemm": {"bound": "mfma", "flops": 2 * 512 * 6144 * n_tokens}}
 
 
 def pack_weight(w: np.ndarray, chained: bool):
@@ -282,6 +292,15 @@ class NativeSampler:
         _check(lib().dc_sampler_debug_denoise(self._h, x.data_ptr(), _iptr(ta), out.data_ptr(), n_layers, stage,
                                               self._stream()))
         return out
+
+    def debug_layer(self, h, timesteps, layer, first_stage, last_stage):
+        """Blocks first_stage..last_stage (1 = SA, 2 = CA, 3 = FFN) of decoder layer `layer` alone on the residual stream
+        h [B,T,128] (host array); returns h' [B,T,128]."""
+        ha = np.ascontiguousarray(np.asarray(h, np.float32).reshape(self.B * self.T, 128))
+        ta = np.ascontiguousarray(np.asarray(timesteps), np.int32)
+        _check(lib().dc_sampler_debug_layer(self._h, _fptr(ha), _iptr(ta), int(layer), int(first_stage), int(last_stage),
+                                            self._stream()))
+        return self.read_h()[:self.B * self.T].reshape(self.B, self.T, 128)
 
     def debug_read(self, what, dtype, count):
         a = np.empty(count, dtype)

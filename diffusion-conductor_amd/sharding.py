@@ -28,7 +28,7 @@ def gather_poses(local: torch.Tensor, n_clips: int, group=None) -> torch.Tensor:
     """All-gather per-rank results [b_local, T, P] into [n_clips, T, P] on every rank.
     Ragged shards are padded to the largest shard for the collective."""
     rank, world = dist_info(group)
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     sizes = [shard_bounds(n_clips, r, world) for r in range(world)]
     bmax = max(hi - lo for lo, hi in sizes)
@@ -40,11 +40,20 @@ def gather_poses(local: torch.Tensor, n_clips: int, group=None) -> torch.Tensor:
     return torch.cat([out[r * bmax: r * bmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)
 
 
-def sharded_sample(sample_fn, mel, noise=None, group=None):
+def sharded_sample(sample_fn, mel, noise=None, group=None, out_shape=None):
     """Run `sample_fn(mel_shard, noise_shard) -> [b_local,T,P]` on this rank's clips and gather.
-    mel: [B, Tm, 128]; noise: [B, T, P] or None."""
+    mel: [B, Tm, 128]; noise: [B, T, P] or None.  A rank whose shard is empty (fewer clips than ranks, e.g. the
+    last batch of a dataset) samples nothing and contributes zero rows of `out_shape` = (T, P) to the gather -
+    it must still enter the collective, or the other ranks would wait for it forever."""
     rank, world = dist_info(group)
     B = mel.shape[0]
     lo, hi = shard_bounds(B, rank, world)
-    local = sample_fn(mel[lo:hi], None if noise is None else noise[lo:hi])
+    if hi > lo:
+        local = sample_fn(mel[lo:hi], None if noise is None else noise[lo:hi])
+    else:
+        if out_shape is None:
+            if noise is None:
+                raise ValueError("sharded_sample: an empty shard needs out_shape=(T, P) or noise to size its contribution")
+            out_shape = tuple(noise.shape[1:])
+        local = torch.zeros((0,) + tuple(out_shape), dtype=torch.float32, device=mel.device)
     return gather_poses(local, B, group)

@@ -169,6 +169,13 @@ int32_t dc_kernel_count(void);
 int dc_sampler_debug_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timesteps, float* d_out,
                              int32_t n_layers, int32_t stage, void* stream);
 int dc_sampler_debug_read(dc_sampler* s, const char* what, void* h_out, int64_t nbytes);
+/* Test hook: decoder layer `layer` alone on a GIVEN residual stream - h_h is host fp32 [B*T][128] row-major, the `h` a
+ * LinearTemporalDiffusionTransformerDecoderLayer.forward receives (models/transformer.py:192-196); emb comes from
+ * h_timesteps and the conditioning set before.  Blocks first_stage .. last_stage of the layer run (1 = sa_block,
+ * 2 = ca_block, 3 = ffn; 1..3 = the whole layer); the result is left in the internal buffer "h" (dc_sampler_debug_read).
+ * Lets the block-level known answers of tests/golden/g3_blocks.npz gate the kernels directly. */
+int dc_sampler_debug_layer(dc_sampler* s, const float* h_h, const int32_t* h_timesteps, int32_t layer, int32_t first_stage,
+                           int32_t last_stage, void* stream);
 
 /* Post-processing of the sampled poses as tools/visualization.py applies it (smooth_motion :20-26, called with kernel=19,
  * order 5 at :126): scipy.signal.savgol_filter(mode="interp") along time for every pose channel.

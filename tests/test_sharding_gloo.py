@@ -68,3 +68,33 @@ def test_two_rank_even_shards(tmp_path):
 
 def test_two_rank_ragged_shards(tmp_path):
     _run(3, tmp_path)
+
+
+def _worker_small(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from diffusion_conductor_amd.sharding import shard_bounds, sharded_sample
+    B, T = 1, 8
+    calls = []
+
+    def fn(mel_shard, noise_shard):
+        calls.append(mel_shard.shape[0])
+        return noise_shard * 2.0
+
+    noise = torch.arange(B * T * 26, dtype=torch.float32).reshape(B, T, 26)
+    full = sharded_sample(fn, torch.zeros(B, 3, 1), noise)
+    lo, hi = shard_bounds(B, rank, world)
+    assert calls == ([1] if hi > lo else [])                 # the rank with the empty shard never calls the sampler ...
+    assert torch.equal(full, noise * 2.0)                     # ... but takes part in the gather and gets the result
+    if rank == 0:
+        np.save(out_path, full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fewer_clips_than_ranks(tmp_path):
+    """B=1 on 2 ranks (the last batch of a dataset): rank 1's shard is empty - it must still enter the all-gather."""
+    out = str(tmp_path / "small.npy")
+    mp.spawn(_worker_small, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert np.load(out).shape == (1, 8, 26)

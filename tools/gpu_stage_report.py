@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU bring-up report (not a pytest): compares every internal stage of the HIP denoiser with
 the oracle's taps and prints one rel-L2 line per stage, per precision mode.
-Usage on the GPU box:  python tests/gpu_stage_report.py [B T]"""
+Usage on the GPU box:  python tools/gpu_stage_report.py [B T]"""
 import os
 import sys
 
@@ -141,5 +141,5 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.path.insert(0, __file__.rsplit("/", 1)[0])
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
     main()
