@@ -8,6 +8,7 @@ import sys
 import numpy as np
 import torch
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from helpers import O, oracle_params, make_model, rel_l2, xf_pair, batch_noise  # noqa: E402
 from diffusion_conductor_amd import native
 
@@ -141,5 +142,4 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
     main()
