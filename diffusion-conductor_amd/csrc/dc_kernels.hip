@@ -16,757 +16,8 @@
 //
 // Operand formats: T16 = __bf16 or _Float16 (same MFMA rate on gfx950), optionally SPLIT
 // (x = hi + lo, three MFMAs per product: hi*hi + lo*hi + hi*lo) for ~fp32 accuracy.
-#include <hip/hip_runtime.h>
-#include <cstdlib>
-#include <type_traits>
-#include "dc_common.h"
+#include "dc_dev.h"
 
-#define DEV __device__ __forceinline__
-
-namespace dc {
-
-template <class T> struct V8;
-template <> struct V8<__bf16> { using type = bf16x8; };
-template <> struct V8<_Float16> { using type = f16x8; };
-template <class T> using v8 = typename V8<T>::type;
-typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
-template <class T> struct V4;
-template <> struct V4<__bf16> { using type = bf16x4; };
-template <> struct V4<_Float16> { using type = f16x4; };
-template <class T> using v4 = typename V4<T>::type;
-
-DEV f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-DEV f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-DEV f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-
-// value of the partner lane (lane ^ 32) combined with this lane's: one v_permlane32_swap, no LDS
-DEV float xhalf_sum(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-DEV float xhalf_max(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-DEV float exp2f_fast(float x) { return __builtin_amdgcn_exp2f(x); }     // v_exp_f32
-
-// row (feature in FT, token in TF) held by register r of lane-half hh
-DEV int tile_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
-
-DEV f32x16 splat(float v) {
-    f32x16 x;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = v;
-    return x;
-}
-
-// One 32-row tile as MFMA operand fragments for its two 16-deep k-steps (hi [+ lo]).
-template <class T16, bool SPLIT>
-struct XFrag {
-    v8<T16> hi[2];
-    v8<T16> lo[SPLIT ? 2 : 1];
-};
-
-template <class T16, bool SPLIT>
-DEV void make_frag(const f32x16& x, XFrag<T16, SPLIT>& f) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = x[8 * s + j];
-            const T16 h = (T16)v;
-            f.hi[s][j] = h;
-            if constexpr (SPLIT) f.lo[s][j] = (T16)(v - (float)h);
-        }
-}
-
-template <class T16, bool SPLIT>
-DEV void mask_frag(XFrag<T16, SPLIT>& f, bool keep) {
-    if (!keep) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                f.hi[s][j] = (T16)0.f;
-                if constexpr (SPLIT) f.lo[s][j] = (T16)0.f;
-            }
-    }
-}
-
-// Weight image order (chained pack): [hi | lo][kt][ot][s][64 lanes][8]  (kt-major).  NF = OT*KT*2 frags per half.
-//
-// acc[ot] (rows = output features, cols = tokens) += W[ot][kt] * X[kt] for ONE k-tile; weights are the A operand.
-template <int OT, int KT, class T16, bool SPLIT>
-DEV void mma_kt(f32x16 (&acc)[OT], const v8<T16>* __restrict__ w, int kt, const XFrag<T16, SPLIT>& x, int lane) {
-    constexpr int NF = OT * KT * 2;
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int fi = (kt * OT + ot) * 2 + s;
-            const v8<T16> a = w[fi * 64 + lane];
-            acc[ot] = mfma(a, x.hi[s], acc[ot]);
-            if constexpr (SPLIT) {
-                acc[ot] = mfma(a, x.lo[s], acc[ot]);
-                const v8<T16> al = w[(NF + fi) * 64 + lane];
-                acc[ot] = mfma(al, x.hi[s], acc[ot]);
-            }
-        }
-}
-template <int OT, int KT, class T16, bool SPLIT>
-DEV void gemm_wa(f32x16 (&acc)[OT], const v8<T16>* __restrict__ w, const XFrag<T16, SPLIT> (&x)[KT], int lane) {
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        mma_kt<OT, KT, T16, SPLIT>(acc, w, kt, x[kt], lane);
-        __builtin_amdgcn_sched_barrier(0);      // bounds the operand-read lookahead to one k-tile (register pressure)
-    }
-}
-
-// one output tile: acc (rows = output features of tile ot) += sum_kt W[ot][kt] * X[kt]
-template <int OT, int KT, class T16, bool SPLIT>
-DEV void mma_ot(f32x16& acc, const v8<T16>* __restrict__ w, int ot, const XFrag<T16, SPLIT> (&x)[KT], int lane) {
-    constexpr int NF = OT * KT * 2;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int fi = (kt * OT + ot) * 2 + s;
-            const v8<T16> a = w[fi * 64 + lane];
-            acc = mfma(a, x[kt].hi[s], acc);
-            if constexpr (SPLIT) {
-                acc = mfma(a, x[kt].lo[s], acc);
-                const v8<T16> al = w[(NF + fi) * 64 + lane];
-                acc = mfma(al, x[kt].hi[s], acc);
-            }
-        }
-}
-
-// acc (rows = tokens, cols = output features of tile oc) += X^T * W[oc] over all k-tiles; weights are the B operand.
-template <int OC, int KT, class T16, bool SPLIT>
-DEV void mmb_oc(f32x16& acc, const v8<T16>* __restrict__ w, int oc, const XFrag<T16, SPLIT> (&x)[KT], int lane) {
-    constexpr int NF = OC * KT * 2;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int fi = (kt * OC + oc) * 2 + s;
-            const v8<T16> b = w[fi * 64 + lane];
-            acc = mfma(x[kt].hi[s], b, acc);
-            if constexpr (SPLIT) {
-                acc = mfma(x[kt].lo[s], b, acc);
-                const v8<T16> bl = w[(NF + fi) * 64 + lane];
-                acc = mfma(x[kt].hi[s], bl, acc);
-            }
-        }
-}
-
-// two independent accumulator chains interleaved (non-split): tiles (wa, oca) and (wb, ocb) of the same operand x.
-// A single tile is a chain of 8 dependent MFMAs (~70 cycles each); two chains keep the matrix pipe busy.
-template <int OC, int KT, class T16>
-DEV void mmb_oc_pair(f32x16& acca, f32x16& accb, const v8<T16>* __restrict__ wa, int oca, const v8<T16>* __restrict__ wb, int ocb,
-                     const XFrag<T16, false> (&x)[KT], int lane) {
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const v8<T16> ba = wa[((kt * OC + oca) * 2 + s) * 64 + lane];
-            const v8<T16> bb = wb[((kt * OC + ocb) * 2 + s) * 64 + lane];
-            acca = mfma(x[kt].hi[s], ba, acca);
-            accb = mfma(x[kt].hi[s], bb, accb);
-        }
-}
-
-// all four output tiles of one 128 x 128 image at once: four independent chains (non-split)
-template <int OC, int KT, class T16>
-DEV void mmb_oc_quad(f32x16& a, f32x16& b, f32x16& c, f32x16& d, const v8<T16>* __restrict__ w, const XFrag<T16, false> (&x)[KT], int lane) {
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const v8<T16> fa = w[((kt * OC + 0) * 2 + s) * 64 + lane], fb = w[((kt * OC + 1) * 2 + s) * 64 + lane];
-            const v8<T16> fc = w[((kt * OC + 2) * 2 + s) * 64 + lane], fd = w[((kt * OC + 3) * 2 + s) * 64 + lane];
-            a = mfma(x[kt].hi[s], fa, a);
-            b = mfma(x[kt].hi[s], fb, b);
-            c = mfma(x[kt].hi[s], fc, c);
-            d = mfma(x[kt].hi[s], fd, d);
-        }
-}
-
-// per-feature vector stored as [tile][lane-half][16] so a lane reads its 16 values with one 64-B load
-DEV f32x16 ld_ft(const float* __restrict__ p, int tile, int hh) {
-    return *reinterpret_cast<const f32x16*>(p + (tile * 2 + hh) * 16);
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));   // operand of the packed-fp32 VALU ops (v_pk_add/mul/fma_f32)
-typedef __attribute__((ext_vector_type(8))) uint32_t u32x8;
-// nn.LayerNorm(128) over the feature axis of an FT activation (transformer.py:79,104,147)
-template <int NT>
-DEV void ln_stats(const f32x16 (&x)[NT], float& mean, float& rstd) {
-    // one pass: sum and sum of squares (fp32, 128 terms: the cancellation in E[x^2]-mean^2 stays ~1e-7*mean^2/var)
-    f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const f32x2 v = {x[t][2 * r], x[t][2 * r + 1]};
-            s2 += v;
-            q2 = __builtin_elementwise_fma(v, v, q2);
-        }
-    const float s = xhalf_sum(s2.x + s2.y);
-    const float q = xhalf_sum(q2.x + q2.y);
-    mean = s * (1.f / (32 * NT));
-    const float var = fmaxf(fmaf(-mean, mean, q * (1.f / (32 * NT))), 0.f);
-    rstd = rsqrtf(var + 1e-5f);
-}
-// operand fragments of the normalised x (the LayerNorm affine is folded into the projection that follows)
-template <class T16, bool SPLIT>
-DEV void ln_frags(XFrag<T16, SPLIT> (&nf)[4], const f32x16 (&x)[4]) {
-    float mean, rstd;
-    ln_stats<4>(x, mean, rstd);
-    const float shift = -mean * rstd;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        f32x16 n;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const f32x2 v = {x[kt][2 * r], x[kt][2 * r + 1]};
-            const f32x2 w = __builtin_elementwise_fma(v, (f32x2){rstd, rstd}, (f32x2){shift, shift});
-            n[2 * r] = w.x;
-            n[2 * r + 1] = w.y;
-        }
-        make_frag<T16, SPLIT>(n, nf[kt]);
-    }
-}
-
-// F.softmax(query.view(B,T,H,-1), dim=-1) (transformer.py:109,150): a head = 16 features
-// = registers 8p..8p+7 of this lane and of lane^32.
-DEV void softmax_heads_ft(f32x16 (&q)[4]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            float m = q[t][8 * p];
-#pragma unroll
-            for (int j = 1; j < 8; ++j) m = fmaxf(m, q[t][8 * p + j]);
-            m = xhalf_max(m);
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float e = exp2f_fast(q[t][8 * p + j] - m);     // q carries log2(e): folded into Wq, bq
-                q[t][8 * p + j] = e;
-                s += e;
-            }
-            const float inv = fast_rcp(xhalf_sum(s));
-#pragma unroll
-            for (int j = 0; j < 8; ++j) q[t][8 * p + j] *= inv;
-        }
-}
-
-DEV float silu(float z) { return z * fast_rcp(1.f + exp2f_fast(-1.4426950408889634f * z)); }
-// SiLU on log2(e)-scaled arguments, two elements at a time: u = log2(e) x  ->  u / (1 + 2^-u) = log2(e) SiLU(x).
-// The StylizationBlocks run in this scaling (the host folds log2(e) into the H' tiles and ln 2 into W_o; the caller scales
-// rstd / shift), which removes the per-element multiply in front of v_exp_f32; the add and the product are packed-fp32 ops.
-DEV f32x2 silu_pair(float x0, float x1) {          // plain SiLU of two elements, packed-fp32 products and sums
-    const f32x2 x = {x0, x1};
-    const f32x2 u = x * 1.4426950408889634f;
-    f32x2 e = {exp2f_fast(-u.x), exp2f_fast(-u.y)};
-    e = e + 1.f;
-    const f32x2 r = {fast_rcp(e.x), fast_rcp(e.y)};
-    return x * r;
-}
-DEV f32x2 silu_l2_pair(float u0, float u1) {
-    const f32x2 u = {u0, u1};
-    f32x2 e = {exp2f_fast(-u0), exp2f_fast(-u1)};
-    e = e + 1.f;
-    const f32x2 r = {fast_rcp(e.x), fast_rcp(e.y)};
-    return u * r;
-}
-// nn.GELU() (exact-erf form).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 noise of the
-// surrounding GEMMs): erf(a) = 1 - (a1 t + ... + a5 t^5) exp(-a^2), t = 1/(1 + p a), a >= 0.
-DEV float gelu_erf(float x) {
-    const float a = fabsf(x) * 0.70710678118654752440f;
-    const float t = fast_rcp(fmaf(0.3275911f, a, 1.f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float erfa = 1.f - poly * t * __expf(-a * a);
-    return 0.5f * x * (1.f + copysignf(erfa, x));
-}
-
-// XCD-aware workgroup index: blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so logical workgroup
-// ids are handed out in contiguous runs per XCD - the ~8 workgroups of a clip then share one L2 for the clip's unit
-// records and attention fragments.  Bijective for any grid size; affects speed only (placement is not guaranteed).
-DEV int wg_index() {
-    const int n = gridDim.x, b = blockIdx.x;
-    const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
-    return x * q + min(x, r) + i;
-}
-
-// token group geometry shared by the per-group kernels
-struct GroupCtx {
-    int g, lane, c, hh;
-    int tok;          // this lane's token (flat)
-    int b0, b1;       // first / last clip touched by the group
-    int boundary;     // first token of clip b1 (== (b0+1)*T when straddling)
-    bool straddle;
-    bool lane_in_b0;
-};
-
-DEV GroupCtx make_ctx(int g, int lane, int M, int T) {
-    GroupCtx x;
-    x.g = g;
-    x.lane = lane;
-    x.c = lane & 31;
-    x.hh = lane >> 5;
-    x.tok = 32 * g + x.c;
-    const int first = 32 * g;
-    const int last = min(first + 31, M - 1);
-    x.b0 = first / T;
-    x.b1 = last / T;
-    x.straddle = x.b1 != x.b0;
-    x.boundary = (x.b0 + 1) * T;
-    x.lane_in_b0 = x.tok < x.boundary;
-    return x;
-}
-
-// Rows (tokens, TF layout) of a group that belong to the slot's clip and are unmasked form one interval
-// [lo, lo + span) of group-local row indices (src_mask of transformer.py:107,114; `length` == nullptr means no
-// mask, as in cross-attention).  Stored per lane with the lane-half offset folded in: register r is valid
-// iff (unsigned)(crow(r) - lo) < span, crow(r) = (r&3) + 8*(r>>2).
-struct RowRange {
-    int lo;
-    unsigned span;      // wave-uniform; span == 32 means every row of the group is valid (the common case: no masking code)
-};
-DEV RowRange valid_rows(const GroupCtx& cx, int slot, int M, int T, const int* __restrict__ length) {
-    const int bs = slot == 0 ? cx.b0 : cx.b1;
-    const int len = length ? length[bs] : T;
-    const int first = max(bs * T, 32 * cx.g);                         // first valid token
-    const int end = min(min(bs * T + min(len, T), M), 32 * cx.g + 32);   // one past the last valid token
-    RowRange rr;
-    rr.lo = first - 32 * cx.g - 4 * cx.hh;
-    rr.span = end > first ? (unsigned)(end - first) : 0u;
-    return rr;
-}
-DEV bool row_ok(const RowRange& rr, int r) { return (unsigned)(((r & 3) + 8 * (r >> 2)) - rr.lo) < rr.span; }
-
-// lanes of the upper 16 columns keep registers 8..15 of an accumulator tile, the others 0..7.  Written as a bit-select:
-// as `up ? P[8+i] : P[i]` the compiler forms a dynamic vector index and expands it into a 16-way compare/select chain
-// per element (~400 instructions per tile; it was most of the record stage's time).
-DEV f32x8 keep_head_block(const f32x16& P, int c) {
-    const unsigned mask = (c >> 4) ? 0xffffffffu : 0u;
-    f32x8 k;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) k[i] = __uint_as_float((__float_as_uint(P[i]) & ~mask) | (__float_as_uint(P[8 + i]) & mask));
-    return k;
-}
-
-// One 32-feature tile of a group's partial record: column max m, column sum of exp(K-m), and
-// exp2(K-m)^T V (32x32; only the two diagonal 16x16 head blocks are stored).
-template <class T16, bool SPLIT>
-DEV void emit_partial(const f32x16& K, const f32x16& V, int oc, const RowRange& rr, float* __restrict__ R,
-                      const GroupCtx& cx) {
-    float m = -INFINITY;
-    const bool full = __builtin_amdgcn_readfirstlane(rr.span) == 32u;     // no predicates for whole groups (3 instructions per element)
-    if (full) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, K[r]);
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = row_ok(rr, r) ? fmaxf(m, K[r]) : m;
-    }
-    m = xhalf_max(m);
-    if (m == -INFINITY) m = 0.f;
-    f32x16 Ee, Vm;
-    float ssum = 0.f;
-    if (full) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            Ee[r] = exp2f_fast(K[r] - m);                           // K carries log2(e): folded into Wk, bk
-            ssum += Ee[r];
-        }
-        Vm = V;
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool ok = row_ok(rr, r);
-            const float e = ok ? exp2f_fast(K[r] - m) : 0.f;
-            Ee[r] = e;
-            ssum += e;
-            Vm[r] = ok ? V[r] : 0.f;
-        }
-    }
-    ssum = xhalf_sum(ssum);
-    XFrag<T16, SPLIT> ef, vf;
-    make_frag<T16, SPLIT>(Ee, ef);
-    make_frag<T16, SPLIT>(Vm, vf);
-    f32x16 P = splat(0.f);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        P = mfma(ef.hi[s], vf.hi[s], P);
-        if constexpr (SPLIT) {
-            P = mfma(ef.lo[s], vf.hi[s], P);
-            P = mfma(ef.hi[s], vf.lo[s], P);
-        }
-    }
-    if (cx.hh == 0) {
-        R[32 * oc + cx.c] = m;
-        R[128 + 32 * oc + cx.c] = ssum;
-    }
-    // keep the diagonal head blocks only: rows 16*(c>>4) .. +15 of this lane's column = registers 8*(c>>4) .. +7
-    reinterpret_cast<f32x8*>(R + 256)[oc * 64 + cx.lane] = keep_head_block(P, cx.c);
-}
-
-// fp32 fragment image of the step-invariant emb term: [g][ks][2 halves][64 lanes][4 floats] - element j of lane l in half
-// j>>2, so each 16-byte access of a wave covers one contiguous KiB
-DEV f32x8 ld_pp(const float* __restrict__ pp, size_t frag /* g*32 + ks */, int lane) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(pp) + frag * 128 + lane;
-    const f32x4 a = p[0], b = p[64];
-    f32x8 v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v[i] = a[i];
-        v[4 + i] = b[i];
-    }
-    return v;
-}
-
-// FiLM tile image: [2 halves][64 lanes][8 fp16] - registers 0..7 then 8..15 of each lane, so that both a
-// register load and an LDS-DMA copy of the tile are lane-linear 16-B accesses.
-DEV void store_etile(f16x16* __restrict__ E, size_t tile, int lane, const f16x16& v) {
-    f16x8* p = reinterpret_cast<f16x8*>(E) + tile * 128 + lane;
-    f16x8 lo8, hi8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        lo8[i] = v[i];
-        hi8[i] = v[8 + i];
-    }
-    // written once and read by a later kernel: non-temporal stores keep the 708 MB per step from evicting the FiLM
-    // weights (and later the layer kernels' own lines) from L2 - measured -1.8 % on the whole loop (tools/ab.sh)
-    __builtin_nontemporal_store(lo8, p);
-    __builtin_nontemporal_store(hi8, p + 64);
-}
-DEV f16x16 load_etile(const f16x8* __restrict__ p /* tile base + lane; global or LDS */) {
-    const f16x8 lo8 = p[0], hi8 = p[64];
-    f16x16 v;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        v[i] = lo8[i];
-        v[8 + i] = hi8[i];
-    }
-    return v;
-}
-
-// Residual-stream image: [group][tile t][quarter q][64 lanes][4 floats] - register 4q+i of tile t of lane l.  Each 16-byte
-// access of a wave covers one contiguous KiB (the former [t][lane][16] order made every store instruction touch 32
-// cache lines a quarter each: the eight waves' stores queued for ~7 us behind one another).
-DEV void load_h(f32x16 (&h)[4], const float* __restrict__ hbuf, int g, int lane) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(hbuf) + (size_t)g * 1024 + lane;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = p[(t * 4 + q) * 64];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) h[t][4 * q + i] = v[i];
-        }
-}
-DEV void store_h(const f32x16 (&h)[4], float* __restrict__ hbuf, int g, int lane) {
-    f32x4* p = reinterpret_cast<f32x4*>(hbuf) + (size_t)g * 1024 + lane;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = h[t][4 * q + i];
-            p[(t * 4 + q) * 64] = v;
-        }
-}
-
-// "Front half" of LinearTemporalSelfAttention (transformer.py:104-117) for one token group, given the operand
-// fragments nf of n = LN(h): K = Wk n + bk, V = Wv n + bv in TF form, then the group's partial record(s) of
-// softmax_T(K + mask) and K^T V - one per clip the group touches.  bk/bv: plain bias[128] (any address space).
-// (A workgroup-level pre-reduction of these records through LDS was measured: it shortened the combine by 30 %
-// but cost 2x that in this kernel - 8 waves x 128 live K/V registers - so records stay per group.)
-template <class T16, bool SPLIT>
-DEV void front_stage(const XFrag<T16, SPLIT> (&nf)[4], const v8<T16>* wk, const v8<T16>* wv, const float* bk,
-                     const float* bv, const GroupCtx& cx, int M, int T, const int* __restrict__ length,
-                     float* __restrict__ recs, bool active) {
-    float* rec = recs + (size_t)cx.g * 2 * DC_REC_FLOATS;
-    const RowRange valid0 = valid_rows(cx, 0, M, T, length);
-    const RowRange valid1 = valid_rows(cx, cx.straddle ? 1 : 0, M, T, length);
-#pragma unroll
-    for (int oc = 0; oc < 4; ++oc) {
-        f32x16 K = splat(bk[32 * oc + cx.c]);
-        f32x16 V = splat(bv[32 * oc + cx.c]);
-        mmb_oc<4, 4, T16, SPLIT>(K, wk, oc, nf, cx.lane);
-        mmb_oc<4, 4, T16, SPLIT>(V, wv, oc, nf, cx.lane);
-        if (active) {
-            emit_partial<T16, SPLIT>(K, V, oc, valid0, rec, cx);
-            if (cx.straddle) emit_partial<T16, SPLIT>(K, V, oc, valid1, rec + DC_REC_FLOATS, cx);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the four feature tiles sequential: bounds register pressure
-    }
-}
-
-
-// ------------------------------------------------------------------------------------
-// Workgroup-level partial records (non-split formats, T >= 256 so that the 256 tokens of a workgroup touch at most
-// two clips, "slots" 0/1 = clips ub0, ub0+1).  Instead of one record per 32-token group the 8 waves reduce theirs
-// through LDS: column maxima first (so every wave exponentiates against the workgroup's maximum and no rescaling is
-// needed), then the exp(K-m)^T V blocks and column sums are summed over the waves in wave order (deterministic).
-// One record per workgroup and slot: 8x fewer record bytes to write and to combine, and the combine itself moves into
-// the consuming kernel's prologue (wg_combine_attn) - no separate combine launch.
-// LDS: mx [4 oc][2 slots][32 cols][8 waves] floats; pst [8 waves][4 oc][64 lanes] f32x8 (each wave's primary slot);
-//      xp [4 oc][64 lanes] f32x8 (second slot of the one wave that straddles the clip edge); ss [(8+1)][4 oc][32] floats.
-// ------------------------------------------------------------------------------------
-DEV RowRange valid_rows_clip(const GroupCtx& cx, int clip, int B, int M, int T, const int* __restrict__ length, bool active) {
-    RowRange rr;
-    rr.lo = 0;
-    rr.span = 0u;
-    if (!active || clip >= B) return rr;
-    const int len = length ? length[clip] : T;
-    const int first = max(clip * T, 32 * cx.g);
-    const int end = min(min(clip * T + min(len, T), M), 32 * cx.g + 32);
-    rr.lo = first - 32 * cx.g - 4 * cx.hh;
-    rr.span = end > first ? (unsigned)(end - first) : 0u;
-    return rr;
-}
-DEV void wg_put_maxes(const f32x16 (&K)[4], const GroupCtx& cx, const RowRange (&vr)[2], float* mx, int wave) {
-#pragma unroll
-    for (int oc = 0; oc < 4; ++oc)
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            float m = -INFINITY;
-            const unsigned span = __builtin_amdgcn_readfirstlane(vr[sl].span);
-            if (span == 32u) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m = fmaxf(m, K[oc][r]);
-            } else if (span != 0u) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m = row_ok(vr[sl], r) ? fmaxf(m, K[oc][r]) : m;
-            }
-            m = xhalf_max(m);
-            if (cx.hh == 0) mx[((oc * 2 + sl) * 32 + cx.c) * 8 + wave] = m;
-        }
-}
-DEV float wg_colmax(const float* mx, int oc, int sl, int c) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(mx + ((oc * 2 + sl) * 32 + c) * 8);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(mx + ((oc * 2 + sl) * 32 + c) * 8 + 4);
-    const float m = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
-    return m == -INFINITY ? 0.f : m;
-}
-// one 32-feature tile against a GIVEN column maximum: column sums of exp2(K-m) and the kept head blocks of exp2(K-m)^T V
-template <class T16>
-DEV void partial_tile(const f32x16& K, const f32x16& V, const RowRange& rr, float m, const GroupCtx& cx, float& ssum, f32x8& keep) {
-    f32x16 Ee, Vm;
-    float s = 0.f;
-    if (__builtin_amdgcn_readfirstlane(rr.span) == 32u) {       // all 32 rows valid: no predicates (they cost 3 instructions per element)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            Ee[r] = exp2f_fast(K[r] - m);
-            s += Ee[r];
-        }
-        Vm = V;
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool ok = row_ok(rr, r);
-            const float e = ok ? exp2f_fast(K[r] - m) : 0.f;
-            Ee[r] = e;
-            s += e;
-            Vm[r] = ok ? V[r] : 0.f;
-        }
-    }
-    ssum = xhalf_sum(s);
-    XFrag<T16, false> ef, vf;
-    make_frag<T16, false>(Ee, ef);
-    make_frag<T16, false>(Vm, vf);
-    f32x16 P = splat(0.f);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) P = mfma(ef.hi[s2], vf.hi[s2], P);
-    keep = keep_head_block(P, cx.c);
-}
-// after the barrier that follows the last partial_tile: wave w sums tile oc = w & 3 of slot w >> 2 over the waves
-DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8* pst, const f32x8* xp, const float* ss,
-                         int wave, int lane, int ub0, int G, int M, int T, int wg) {
-    const int oc = wave & 3, sl = wave >> 2, c = lane & 31;
-    f32x8 acc;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    float ssum = 0.f;
-#pragma unroll
-    for (int v = 0; v < 8; ++v) {
-        const int gv = wg * 8 + v;
-        if (gv >= G) continue;
-        const int edge = (ub0 + 1) * T;                       // first token of slot 1's clip
-        const int s0v = 32 * gv >= edge ? 1 : 0;              // the wave's primary slot
-        const bool strad = !s0v && min(32 * gv + 31, M - 1) >= edge;
-        if (s0v == sl) {
-            const f32x8 p = pst[(v * 4 + oc) * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += p[i];
-            ssum += ss[(v * 4 + oc) * 32 + c];
-        }
-        if (strad && sl == 1) {
-            const f32x8 p = xp[oc * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += p[i];
-            ssum += ss[(8 * 4 + oc) * 32 + c];
-        }
-    }
-    float* R = recs + ((size_t)wg * 2 + sl) * DC_REC_FLOATS;
-    if (lane < 32) {
-        R[32 * oc + c] = wg_colmax(mx, oc, sl, c);
-        R[128 + 32 * oc + c] = ssum;
-    }
-    reinterpret_cast<f32x8*>(R + 256)[oc * 64 + lane] = acc;
-}
-// The workgroup's own combine (512 threads): attention operand fragments A[d][l] of clips ub0, ub0+1 from the unit
-// records of the previous kernel -> af [2 clips][8 frags][64 lanes] in LDS (the 8 hi fragments k_attn_combine makes).
-// scratch (LDS): w [2][NU][128] floats, z [2][128] floats.  Summation order is fixed.
-template <class T16>
-DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scratch, int ub0, int B, int M, int T, int tid, int wg,
-                         unsigned long long* st = nullptr) {
-#define CSTAMP(k) do { if (st && (tid & 63) == 0) st[(tid >> 6) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-    constexpr int NU = 17, PRE = 9;               // units per clip: T <= 4032; the first PRE are loaded before the weights exist
-    float* wsc = scratch;
-    float* zsc = scratch + 2 * NU * 128;
-    const int ci = tid >> 8, t = tid & 255, ln = t & 63, oc = t >> 6;
-    const int c = ln & 31, hh = ln >> 5;
-    const int b = ub0 + ci;
-    const int ub1 = (min((wg + 1) * 256, M) - 1) / T;          // last clip this workgroup touches
-    const bool live = b <= ub1;
-    const int u_lo = live ? (b * T) / 256 : 0;
-    const int u_hi = live ? (min((b + 1) * T, M) - 1) / 256 : -1;
-    const int nu = u_hi - u_lo + 1;
-    // unit u (tokens 256u..256u+255) intersects the clip; the clip is the unit's slot 0 iff the unit starts inside it
-    auto rec_of = [&](int clip, int u) { return recs + ((size_t)u * 2 + ((u * 256 >= clip * T) ? 0 : 1)) * DC_REC_FLOATS; };
-    // All loads of the combine are issued up front, branch-free (indices clamped to a valid unit, results predicated), so that
-    // one memory round trip covers them: phase A's scalars first (they are needed first), then the K^T V blocks.
-    const int ca = (tid >> 7) & 1, f = tid & 127, ba = ub0 + ca;
-    const bool la = ba <= ub1;
-    const int bav = la ? ba : ub0;                                   // a clip that certainly has units
-    const int a_lo = (bav * T) / 256, a_hi = (min((bav + 1) * T, M) - 1) / 256;
-    const int na = la ? a_hi - a_lo + 1 : 0;
-    float mr[PRE], sr[PRE];
-#pragma unroll
-    for (int k = 0; k < PRE; ++k) {
-        const float* R = rec_of(bav, min(a_lo + k, a_hi));
-        mr[k] = R[f];
-        sr[k] = R[128 + f];
-    }
-    const int bv = live ? b : ub0;
-    const int v_lo = (bv * T) / 256, v_hi = (min((bv + 1) * T, M) - 1) / 256;
-    f32x8 pre[PRE];
-    if (live) {                      // wave-uniform (ci is the wave's half of the workgroup): idle halves issue nothing
-#pragma unroll
-        for (int k = 0; k < PRE; ++k) pre[k] = reinterpret_cast<const f32x8*>(rec_of(bv, min(v_lo + k, v_hi)) + 256)[oc * 64 + ln];
-    }
-    CSTAMP(22);
-    if (tid < 256) {                              // phase A: per feature f of clip ca: m*, weights, normaliser
-#pragma unroll
-        for (int k = 0; k < PRE; ++k)
-            if (k >= na) sr[k] = 0.f;
-        float mstar = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < PRE; ++k)
-            if (sr[k] > 0.f) mstar = fmaxf(mstar, mr[k]);
-        for (int k = PRE; k < na; ++k) {          // clips longer than 9 workgroups (T > 2048)
-            const float* R = rec_of(ba, a_lo + k);
-            if (R[128 + f] > 0.f) mstar = fmaxf(mstar, R[f]);
-        }
-        float z = 0.f;
-#pragma unroll
-        for (int k = 0; k < PRE; ++k) {
-            const float ww = sr[k] > 0.f ? exp2f_fast(mr[k] - mstar) : 0.f;
-            if (k < na) wsc[(ca * NU + k) * 128 + f] = ww;
-            z += ww * sr[k];
-        }
-        for (int k = PRE; k < na; ++k) {
-            const float* R = rec_of(ba, a_lo + k);
-            const float su = R[128 + f];
-            const float ww = su > 0.f ? exp2f_fast(R[f] - mstar) : 0.f;
-            wsc[(ca * NU + k) * 128 + f] = ww;
-            z += ww * su;
-        }
-        zsc[ca * 128 + f] = z;
-    }
-    CSTAMP(23);
-    __syncthreads();
-    CSTAMP(24);
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    const int rowb = 32 * oc + 16 * (c >> 4) + 4 * hh;       // kept value j <-> feature row rowb + (j&3) + 8*(j>>2)
-    auto wrow = [&](const float* base, float (&w8)[8]) {       // rows rowb..+3 and rowb+8..+11: two 16-byte LDS reads
-        const f32x4 a = *reinterpret_cast<const f32x4*>(base + rowb), c2 = *reinterpret_cast<const f32x4*>(base + rowb + 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            w8[j] = a[j];
-            w8[4 + j] = c2[j];
-        }
-    };
-#pragma unroll
-    for (int k = 0; k < PRE; ++k)
-        if (k < nu) {
-            float w8[8];
-            wrow(wsc + (ci * NU + k) * 128, w8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], pre[k][j], acc[j]);
-        }
-    for (int k = PRE; k < nu; ++k) {
-        const f32x8 pv = reinterpret_cast<const f32x8*>(rec_of(b, u_lo + k) + 256)[oc * 64 + ln];
-        float w8[8];
-        wrow(wsc + (ci * NU + k) * 128, w8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], pv[j], acc[j]);
-    }
-    CSTAMP(25);
-    v8<T16> out, zero;
-    {
-        float z8[8];
-        wrow(zsc + ci * 128, z8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            out[j] = (T16)(z8[j] > 0.f ? acc[j] * fast_rcp(z8[j]) : 0.f);
-            zero[j] = (T16)0.f;
-        }
-    }
-    const int s = c >> 4;
-    af[(ci * 8 + oc * 2 + s) * 64 + ln] = out;
-    af[(ci * 8 + oc * 2 + (s ^ 1)) * 64 + ln] = zero;
-}
-
-
-// Grid-wide barrier between the layers of the persistent form of k_layer (all workgroups co-resident: the launcher
-// checks grid <= CU count at 1 workgroup per CU).  Release: the workgroup's record stores are written back
-// (__threadfence = agent-scope fence: L2 write-back + invalidate on gfx950's per-XCD L2s); acquire after the spin.
-// The spin is bounded: a workgroup that never sees the others arrive raises *err and goes on (wrong results, reported
-// by the host) instead of hanging the device.
-DEV void grid_barrier(unsigned* counter, unsigned target, int* err) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 21)) {
-                *err = 1;
-                break;
-            }
-        }
-        __threadfence();
-    }
-    __syncthreads();
-}
-
-}  // namespace dc
-using namespace dc;
 
 // ------------------------------------------------------------------------------------
 // per-step bookkeeping: iteration counter -> timestep per clip, DDIM scalars, snapshot slot
@@ -1199,19 +450,6 @@ DEV void film_shares(int& u0, int& u1, long long nunit, const float* __restrict_
     u1 = __builtin_amdgcn_readfirstlane((int)(nunit * (before + mine) / total));
 }
 
-// LDS-DMA of one 1-KiB fragment: lane i's 16 bytes at gsrc land at lds_dst + 16*i.  Issued through inline asm
-// on purpose: for the builtin form hipcc inserts `s_waitcnt vmcnt(0)` before the next LDS read of ANY address
-// (it assumes the DMA may alias), which would turn every "one stage ahead" prefetch into a synchronous copy.
-// All waits for these copies are explicit (stage_sync, the FiLM ring); M0 is saved/restored in the statement.
-DEV void lds_dma16(const void* gsrc /*per-lane*/, const char* lds_dst /*wave-uniform*/) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane(
-        (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_dst);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(dst)
-                 : "memory");
-}
 // ------------------------------------------------------------------------------------
 // FiLM GEMM v2 (non-split formats): S-stationary, persistent.  A workgroup = 8 waves works on 4 token groups (128 tokens):
 // its operand slab S[4 g][32 ks] (128 KiB) is copied once into LDS by LDS-DMA and stays there while the
@@ -1815,282 +1053,6 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
 // waves; each stage ends with vmcnt(0) + barrier.  All activations stay in registers, and the
 // residual stream h IS the accumulator of the three out-projections (h += W_o * a + b_o).
 // ------------------------------------------------------------------------------------
-template <int NW>
-DEV void stage_frags(const void* __restrict__ src, char* dst, int nfrags, int wave, int lane) {
-    const bf16x8* s = reinterpret_cast<const bf16x8*>(src);
-    for (int f = wave; f < nfrags; f += NW) lds_dma16(s + (size_t)f * 64 + lane, dst + f * 1024);
-}
-DEV void stage_sync(int abl = 0) {
-    __builtin_amdgcn_sched_barrier(0);           // stages do not interleave: keeps each stage's live set separate
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(abl & 0x1000)) __syncthreads();        // 0x1000: timing experiment only (results are garbage)
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <class T16, bool SPLIT>
-DEV void attn_apply_tile(f32x16& y, const v8<T16>* __restrict__ afrag, int oc, const XFrag<T16, SPLIT>& q, int lane) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const v8<T16> a = afrag[(oc * 2 + s) * 64 + lane];
-        y = mfma(a, q.hi[s], y);
-        if constexpr (SPLIT) {
-            y = mfma(a, q.lo[s], y);
-            const v8<T16> al = afrag[(8 + oc * 2 + s) * 64 + lane];
-            y = mfma(al, q.hi[s], y);
-        }
-    }
-}
-
-// The attention / FFN output y that feeds a StylizationBlock: its LayerNorm statistics are taken from the exact
-// fp32 accumulators as the tiles are produced; the tiles themselves are then held as packed f16 in the
-// non-split modes (32 instead of 64 VGPRs - y only ever passes through LayerNorm -> FiLM -> SiLU -> f16 operand).
-template <bool SPLIT> struct YT { using tile = f16x16; };
-template <> struct YT<true> { using tile = f32x16; };
-template <bool SPLIT> using ytile = typename YT<SPLIT>::tile;
-
-struct RowStats {
-    f32x2 s = {0.f, 0.f}, q = {0.f, 0.f};          // packed-fp32 partial sums (even / odd registers)
-    DEV void add(const f32x16& x) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const f32x2 v = {x[2 * r], x[2 * r + 1]};
-            s += v;
-            q = __builtin_elementwise_fma(v, v, q);
-        }
-    }
-    // LayerNorm(128) of a StylizationBlock input, in the log2(e) scaling of styl_tile: log2(e) nhat = x*rstd + shift
-    DEV void finish(float& rstd, float& shift) {
-        const float ss = xhalf_sum(s.x + s.y), qq = xhalf_sum(q.x + q.y);
-        const float mean = ss * (1.f / 128.f);
-        const float var = fmaxf(fmaf(-mean, mean, qq * (1.f / 128.f)), 0.f);
-        rstd = rsqrtf(var + 1e-5f) * 1.4426950408889634f;
-        shift = -mean * rstd;
-    }
-};
-template <bool SPLIT>
-DEV void put_y(ytile<SPLIT>& dst, const f32x16& x) {
-    if constexpr (SPLIT) {
-        dst = x;
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dst[r] = (_Float16)x[r];
-    }
-}
-
-// q = softmax_heads(Wq LN(h) + bq);  y = q . A per head  (weights image `w` in LDS, bias block behind it)
-template <class T16, bool SPLIT>
-DEV void query_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const f32x16 (&h)[4], const float* bq,
-                      const v8<T16>* w, const v8<T16>* a0, const v8<T16>* a1, const GroupCtx& cx) {
-    f32x16 q[4];
-    {
-        XFrag<T16, SPLIT> nf[4];
-        ln_frags<T16, SPLIT>(nf, h);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) q[t] = ld_ft(bq, t, cx.hh);
-        gemm_wa<4, 4, T16, SPLIT>(q, w, nf, cx.lane);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    softmax_heads_ft(q);
-    __builtin_amdgcn_sched_barrier(0);
-    RowStats st;
-#pragma unroll
-    for (int oc = 0; oc < 4; ++oc) {
-        f32x16 acc = splat(0.f);
-        XFrag<T16, SPLIT> qf;
-        make_frag<T16, SPLIT>(q[oc], qf);
-        if (!cx.straddle) {
-            attn_apply_tile<T16, SPLIT>(acc, a0, oc, qf, cx.lane);
-        } else {   // the group spans two clips: apply each clip's matrix to its own tokens (lanes)
-            XFrag<T16, SPLIT> qm = qf;
-            mask_frag<T16, SPLIT>(qm, cx.lane_in_b0);
-            attn_apply_tile<T16, SPLIT>(acc, a0, oc, qm, cx.lane);
-            mask_frag<T16, SPLIT>(qf, !cx.lane_in_b0);
-            attn_apply_tile<T16, SPLIT>(acc, a1, oc, qf, cx.lane);
-        }
-        st.add(acc);
-        put_y<SPLIT>(y[oc], acc);
-    }
-    st.finish(y_rstd, y_shift);
-}
-
-// v_fma_mix_f32: d = a * b + c with a read as the low / high fp16 half of a packed register - no separate conversion.
-// (hipcc does not form it from `fmaf((float)half, ...)`: the FiLM tiles and the packed y tiles cost 3 cvt per element.)
-template <int HI>
-DEV float fma_mix_h(uint32_t h2, float b, float c) {
-    float d;
-    if constexpr (HI)
-        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(b), "v"(c));
-    else
-        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(b), "v"(c));
-    return d;
-}
-template <int HI>
-DEV float add_mix_h(uint32_t h2, float c) {        // (float)half + c
-    float d;
-    if constexpr (HI)
-        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(c));
-    else
-        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(c));
-    return d;
-}
-
-// one k-tile of the FiLM-modulated, SiLU'ed operand: z = SiLU(nhat*G' + H'), gp = G' - 1; everything in the log2(e)
-// scaling of silu_l2_pair: rstd / shift arrive multiplied by log2(e), hp = log2(e) H', z = log2(e) SiLU(.)
-template <class T16, bool SPLIT, class YTile>
-DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shift, const f16x16& gp, const f16x16& hp) {
-    f32x16 z;
-    if constexpr (std::is_same<YTile, f16x16>::value) {      // packed y (non-split formats): three mixed-precision FMAs per element
-        const u32x8 yw = __builtin_bit_cast(u32x8, y), gw = __builtin_bit_cast(u32x8, gp), hw = __builtin_bit_cast(u32x8, hp);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float n0 = fma_mix_h<0>(yw[k], rstd, shift), n1 = fma_mix_h<1>(yw[k], rstd, shift);
-            const f32x2 zz = silu_l2_pair(add_mix_h<0>(hw[k], fma_mix_h<0>(gw[k], n0, n0)), add_mix_h<1>(hw[k], fma_mix_h<1>(gw[k], n1, n1)));
-            z[2 * k] = zz.x;
-            z[2 * k + 1] = zz.y;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float n0 = fmaf((float)y[2 * k], rstd, shift), n1 = fmaf((float)y[2 * k + 1], rstd, shift);
-            const f32x2 zz = silu_l2_pair(fmaf(n0, (float)gp[2 * k], n0 + (float)hp[2 * k]), fmaf(n1, (float)gp[2 * k + 1], n1 + (float)hp[2 * k + 1]));
-            z[2 * k] = zz.x;
-            z[2 * k + 1] = zz.y;
-        }
-    }
-    make_frag<T16, SPLIT>(z, zf);
-}
-
-// StylizationBlock (transformer.py:68-81) accumulated straight into the residual stream:
-//   h += W_o * SiLU( LN(y) * (1 + scale) + shift ) + b_o          (weights image `w` in LDS, b_o behind it)
-// with LN(y)*(1+scale)+shift = nhat*G' + H', nhat = (y-mean)*rstd; the FiLM GEMM delivers G'-1 and H' tiles.
-// E tiles come straight from global memory (Eg: this block's 8 tiles for this group).
-template <class T16, bool SPLIT>
-DEV void styl_accumulate(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd, float shift, const f16x8* __restrict__ Eg,
-                         const float* bo, const v8<T16>* w, int lane, int hh, int abl) {
-    XFrag<T16, SPLIT> zf[4];
-    {
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            f16x16 gp, hp;
-            if (abl & 0x100) {            // timing experiment: no FiLM tile loads
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gp[r] = hp[r] = (_Float16)0.f;
-            } else {
-                gp = load_etile(Eg + kt * 128 + lane);
-                hp = load_etile(Eg + (4 + kt) * 128 + lane);
-            }
-            styl_tile<T16, SPLIT, ytile<SPLIT>>(zf[kt], y[kt], rstd, shift, gp, hp);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const f32x16 bb = ld_ft(bo, t, hh);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h[t][r] += bb[r];
-    }
-    gemm_wa<4, 4, T16, SPLIT>(h, w, zf, lane);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// Per-wave FiLM tile ring in LDS: two 4-KiB slots, each holding one k-tile's (G'-1, H') tile pair.
-// FiLM tiles are read exactly once: non-temporal, so that 88 MB per layer do not flush the weights, attention fragments and
-// records the workgroups of an XCD share through L2 (same-box A/B: -4 % k_layer, -3.5 % loop)
-DEV void lds_dma16_nt(const void* gsrc, const char* lds_dst) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane(
-        (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_dst);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(dst)
-                 : "memory");
-}
-DEV void ering_issue(const f16x8* __restrict__ Eg, int kt, char* slot, int lane) {
-    const f16x8* gsrc = Eg + kt * 128 + lane;
-    const f16x8* hsrc = Eg + (4 + kt) * 128 + lane;
-    lds_dma16_nt(gsrc, slot);
-    lds_dma16_nt(gsrc + 64, slot + 1024);
-    lds_dma16_nt(hsrc, slot + 2048);
-    lds_dma16_nt(hsrc + 64, slot + 3072);
-}
-// same StylizationBlock with the FiLM tiles of k-tiles 0,1 arriving through the ring (issued a stage ago) and those of
-// k-tiles 2,3 prefetched into registers at the start of the preceding stage (EPre; they landed with that stage's closing
-// vmcnt(0)): nothing in this stage waits on HBM.  `prefetch_next` (the next stage's weight image and the next block's
-// ring tiles) is issued as soon as both ring slots have been read.
-struct EPre {
-    f16x8 glo[2], ghi[2], hlo[2], hhi[2];       // the 16-byte halves exactly as loaded: nothing may touch them before they land
-};
-// The loads are inline asm on purpose: hipcc would guard the first use of a load it knows about with a vmcnt wait that
-// also covers the LDS-DMAs issued (invisibly to it) just before that use; these tiles are complete at the preceding
-// stage's closing `s_waitcnt vmcnt(0)`, so no wait is wanted at the use.
-DEV f16x8 ld16_nowait(const f16x8* p) {
-    f16x8 v;
-    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-// SAFE: ordinary loads (the compiler tracks them and waits before any use, including a spill) - for the kernel variants
-// that spill registers (test hooks, persistent form): a register that an untracked load is still writing must never be
-// copied, so the no-wait form is only for the spill-free production instantiation.
-template <bool SAFE>
-DEV void epre_load(EPre& e, const f16x8* __restrict__ Eg, int lane) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const f16x8* pg = Eg + (2 + i) * 128 + lane;
-        const f16x8* ph = Eg + (4 + 2 + i) * 128 + lane;
-        if constexpr (SAFE) {
-            e.glo[i] = pg[0];
-            e.ghi[i] = pg[64];
-            e.hlo[i] = ph[0];
-            e.hhi[i] = ph[64];
-        } else {
-            e.glo[i] = ld16_nowait(pg);
-            e.ghi[i] = ld16_nowait(pg + 64);
-            e.hlo[i] = ld16_nowait(ph);
-            e.hhi[i] = ld16_nowait(ph + 64);
-        }
-    }
-}
-DEV f16x16 join16(const f16x8& lo8, const f16x8& hi8) {
-    f16x16 v;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        v[i] = lo8[i];
-        v[8 + i] = hi8[i];
-    }
-    return v;
-}
-template <class T16, bool SPLIT, class F>
-DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd, float shift, const EPre& ep,
-                              char* ring, const float* bo, const v8<T16>* w, int lane, int hh, F&& prefetch_next) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const f32x16 bb = ld_ft(bo, t, hh);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h[t][r] += bb[r];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        f16x16 gp, hp;
-        if (kt < 2) {
-            const f16x8* sp = reinterpret_cast<const f16x8*>(ring + kt * 4096) + lane;
-            gp = load_etile(sp);
-            hp = load_etile(sp + 128);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt == 1) prefetch_next();                                   // both slots have been read
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            gp = join16(ep.glo[kt - 2], ep.ghi[kt - 2]);
-            hp = join16(ep.hlo[kt - 2], ep.hhi[kt - 2]);
-        }
-        XFrag<T16, SPLIT> zf;
-        styl_tile<T16, SPLIT, ytile<SPLIT>>(zf, y[kt], rstd, shift, gp, hp);
-        mma_kt<4, 4, T16, SPLIT>(h, w, kt, zf, lane);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // DBG = true builds the test-hook variant (early exits after a stage, ablation switches, stage stamps); the
 // production instantiation has none of them - the extra exits alone cost 160 spilled registers.
 template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR, bool PERS>

@@ -35,19 +35,38 @@ class DcError(RuntimeError):
     pass
 
 
+SOURCES = ("dc_kernels.hip", "dc_fused.hip", "dc_api.hip", "dc_music.hip")
+HEADERS = ("dc_common.h", "dc_dev.h", "dc_launch.h", "dc_music.h")
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip for gfx950 into libdc_ddim.so (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("dc_kernels.hip", "dc_api.hip", "dc_music.hip")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("dc_common.h", "dc_launch.h", "dc_music.h")] + \
+    """Compile csrc/*.hip for gfx950 into libdc_ddim.so (hipcc cross-compiles without a GPU).  Each source becomes an
+    object under build/ (compiled in parallel, rebuilt only when it or a header changed), then one link."""
+    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    hdrs = [os.path.join(CSRC, f) for f in HEADERS if os.path.exists(os.path.join(CSRC, f))] + \
         [os.path.join(os.path.dirname(_HERE), "include", "dc_ddim.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    hmax = max(os.path.getmtime(h) for h in hdrs)
+    bdir = os.path.join(_HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           *srcs, "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+    objs, jobs = [], []
+    for src in srcs:
+        obj = os.path.join(bdir, os.path.basename(src).replace(".hip", ".o"))
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hmax):
+            cmd = [hipcc, *flags, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    if jobs or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     return LIB_PATH
 
 

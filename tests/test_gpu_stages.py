@@ -36,8 +36,33 @@ def test_block_golden(models, prec, name, first, last):
     out = nat.debug_layer(g["h"], g["t"], 2, first, last)
     err = rel_l2(out, g[name])
     d_err = rel_l2(out - g["h"], g[name] - g["h"])          # on what the block adds to the residual stream
-    print(f"G3 {name}[{prec}] rel-L2 {err:.3e} (block delta {d_err:.3e})")
+    print(f"G3 {name}[{prec}] rel-L2 {err:.3e} (block delta {d_err:.3e}; |delta| gpu {np.linalg.norm(out - g['h']):.3e} "
+          f"ref {np.linalg.norm(g[name] - g['h']):.3e})")
     assert np.isfinite(out).all() and err <= TOL[prec] and d_err <= 30 * TOL[prec]
+
+
+def test_block_chain_vs_oracle(models):
+    """Blocks 1..2 and 2..3 of layer 2 on the G3 residual stream against the oracle's composition of the same blocks."""
+    g = golden("g3_blocks.npz")
+    p = oracle_params()
+    h, xfp, xfo = (torch.from_numpy(g[k]) for k in ("h", "xf_proj", "xf_out"))
+    with torch.no_grad():
+        F = torch.nn.functional
+        te = O.timestep_embedding(torch.from_numpy(g["t"]), 128)
+        emb = F.linear(F.silu(F.linear(te, p["time_embed.0.weight"], p["time_embed.0.bias"])), p["time_embed.2.weight"],
+                       p["time_embed.2.bias"]).unsqueeze(1) + F.linear(xfp, p["linear.weight"], p["linear.bias"])
+        xo = F.linear(xfo, p["linear.weight"], p["linear.bias"])
+        mask = O.generate_src_mask(64, g["length"]).unsqueeze(-1)
+        pre = "temporal_decoder_blocks.2"
+        sa = O.linear_self_attention(p, pre + ".sa_block", h, emb, mask, 8)
+        sa_ca = O.linear_cross_attention(p, pre + ".ca_block", sa, xo, emb, 8)
+        ca = O.linear_cross_attention(p, pre + ".ca_block", h, xo, emb, 8)
+        ca_ffn = O.ffn(p, pre + ".ffn", ca, emb)
+    nat = models["bf16x3"].set_conditioning(xfp.cuda(), xfo.cuda(), g["length"])
+    e12 = rel_l2(nat.debug_layer(g["h"], g["t"], 2, 1, 2), sa_ca)
+    e23 = rel_l2(nat.debug_layer(g["h"], g["t"], 2, 2, 3), ca_ffn)
+    print(f"blocks 1..2 rel-L2 {e12:.3e}; blocks 2..3 rel-L2 {e23:.3e}")
+    assert e12 <= 1e-4 and e23 <= 1e-4
 
 
 # ---- every stage of every layer of the real pipeline against the oracle's taps -----------------------------------------

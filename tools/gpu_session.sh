@@ -3,7 +3,7 @@
 TAG="${1:-s1}"
 mkdir -p gpurun_out
 timeout 300 ./tools/probe_fused > gpurun_out/probe_$TAG.log 2>&1
-timeout 1500 python -m pytest tests/test_gpu_stages.py -m gpu -q -x -s > gpurun_out/t_stages_$TAG.log 2>&1
+timeout 1500 python -m pytest tests/test_gpu_stages.py -m gpu -q -s > gpurun_out/t_stages_$TAG.log 2>&1
 echo "stages rc=$?" >> gpurun_out/t_stages_$TAG.log
 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -s > gpurun_out/t_parity_$TAG.log 2>&1
 echo "parity rc=$?" >> gpurun_out/t_parity_$TAG.log

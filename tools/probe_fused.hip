@@ -74,11 +74,16 @@ __global__ __launch_bounds__(256, 2) void k_probe(const f16x8* __restrict__ W, c
     // prologue: S fragments of k-tiles 0, 1 and chunks 0 .. NSLOT-2.  Per iteration a wave issues 2 S loads, then 4 DMAs; at the
     // top of iteration c it needs S(c) (issued first in iteration c-2) and chunk c (iteration c-3): vmcnt(10) = "all but the 4
     // DMAs of iteration c-2 and the 6 operations of iteration c-1".
-    f16x8 sreg[3][2];
+    f16x8 sreg[4][2];        // ring of 4 k-tiles: 16 k-tiles per block keep the slot sequence continuous across blocks
 #pragma unroll
     for (int c = 0; c < NSLOT - 1; ++c) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) sreg[c][s2] = ld16_nowait_s(Sg + (size_t)(2 * (c & 1) + s2) * 64, soff);
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (c < 2)
+                sreg[c][s2] = ld16_nowait_s(Sg + (size_t)(2 * c + s2) * 64, soff);
+            else
+                lds_dma16(W + lane, lds + NSLOT * SLOT_BYTES + wave * 1024);
+        }
         issue(c);
     }
     int c = 0;
@@ -92,17 +97,22 @@ __global__ __launch_bounds__(256, 2) void k_probe(const f16x8* __restrict__ W, c
         for (int kt = 0; kt < 16; ++kt, ++c) {
             asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             __syncthreads();                                      // chunk c landed for every wave; everyone left slot (c-1) % NSLOT
-            {   // S fragments 2 k-tiles ahead (wraps into the next block's first k-tiles: same tokens, same image)
+            // S fragments 2 k-tiles ahead (wraps into the next block's first k-tiles: same tokens, same image).  A load without
+            // a wait must have a destination the compiler keeps alive until it has landed: none behind the last block.
+            if (kt < 14 || blk + 1 < nblk) {
                 const int kn = (kt + 2) & 15;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
-                    sreg[(kt + 2) % 3][s2] = ld16_nowait_s(Sg + (size_t)(WITH_S ? 2 * kn + s2 : 0) * 64, soff);
+                    sreg[(kt + 2) & 3][s2] = ld16_nowait_s(Sg + (size_t)(WITH_S ? 2 * kn + s2 : 0) * 64, soff);
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) lds_dma16(W + lane, lds + NSLOT * SLOT_BYTES + wave * 1024);
             }
             issue(c + NSLOT - 1);
             const f16x8* w = reinterpret_cast<const f16x8*>(lds + (c % NSLOT) * SLOT_BYTES) + lane;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const f16x8 b = sreg[kt % 3][s2];
+                const f16x8 b = sreg[kt & 3][s2];
 #pragma unroll
                 for (int tq = 0; tq < 2; ++tq) {
 #pragma unroll
@@ -120,11 +130,10 @@ __global__ __launch_bounds__(256, 2) void k_probe(const f16x8* __restrict__ W, c
         for (int cs = 0; cs < chain_slots; ++cs, ++c) {
             asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             __syncthreads();
-            {
-                f16x8 dummy[2];
+            // two placeholder operations keep the vmcnt arithmetic uniform (LDS-DMA into a scratch KiB: a register-destination
+            // load without a wait must never target a register the compiler considers dead - it lands later)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) dummy[s2] = ld16_nowait_s(Sg, soff);  // keeps vmcnt uniform
-            }
+            for (int s2 = 0; s2 < 2; ++s2) lds_dma16(W + lane, lds + NSLOT * SLOT_BYTES + wave * 1024);
             issue(c + NSLOT - 1);
             const f16x8* w = reinterpret_cast<const f16x8*>(lds + (c % NSLOT) * SLOT_BYTES) + lane;
             // 16 MFMAs in two chains of 8, operands converted from h one tile at a time; then VALU rounds on the two results
