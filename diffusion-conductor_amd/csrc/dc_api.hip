@@ -164,8 +164,8 @@ struct dc_sampler {
     float* d_film_rate = nullptr;  // FiLM GEMM: per-workgroup speeds measured by the previous launches, two buffers of 1024 (ping-pong)
     int film_rate_parity = 0;
     bool graph_folded = false;     // the captured steps look their timestep up through *d_iter (no k_begin_step launches)
-    unsigned* d_gbar = nullptr;   // grid-barrier arrival counter of the persistent layer kernel (zeroed before each launch)
-    int* d_gerr = nullptr;        // set by a workgroup whose grid-barrier spin ran out
+    unsigned* d_flags = nullptr;  // persistent layer kernel: per-unit progress flags (reset by k_embed_front every step)
+    int* d_gerr = nullptr;        // set by a workgroup whose bounded wait for its neighbours' flags ran out
     int num_cu = 0;
     int *d_iter = nullptr, *d_t_clip = nullptr, *d_snap_cur = nullptr, *d_t_of_iter = nullptr, *d_snap_of_iter = nullptr;
     float *d_coef_cur = nullptr, *d_coef_of_t = nullptr, *d_coef_of_iter = nullptr;   // DDIM scalars by timestep / by iteration
@@ -578,7 +578,8 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
     if (!s->d_iter) {
         int rc;
         if ((rc = dev_alloc(s, s->d_stamps, (8 * 32 + 8 + 1024 + 1024 + 256 + 8) * 8))) return rc;
-        if ((rc = dev_alloc(s, s->d_gbar, 16))) return rc;
+        if ((rc = dev_alloc(s, s->d_flags, 4096 * sizeof(unsigned)))) return rc;
+        HIP_TRY(hipMemset(s->d_flags, 0, 4096 * sizeof(unsigned)));
         if ((rc = dev_alloc(s, s->d_film_rate, 2 * 1024 * sizeof(float)))) return rc;
         HIP_TRY(hipMemset(s->d_film_rate, 0, 2 * 1024 * sizeof(float)));      // 0 = not measured yet: equal shares
         if ((rc = dev_alloc(s, s->d_gerr, 16))) return rc;
@@ -650,8 +651,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     // remains for the split formats, for the v1 kernel, and under the test hooks that read the operand image back
     static const bool film_v1 = getenv("DC_FILM_V1") != nullptr, unfused = getenv("DC_UNFUSED_SILU") != nullptr;
     const bool fuse_silu = !sf && !film_v1 && !unfused && s->dbg_layers < 0;
-    const bool folded = loop_mode && graph_step >= 0 && fuse_silu && !s->cfg.no_eff && !getenv("DC_PERSIST") &&
-                        !getenv("DC_BEGIN_STEP") && s->dbg_stage == 0;
+    const bool folded = loop_mode && graph_step >= 0 && fuse_silu && !s->cfg.no_eff && !getenv("DC_BEGIN_STEP") && s->dbg_stage == 0;
     const int* iter_base = folded ? s->d_iter : nullptr;
     const int* t_src = folded ? s->d_t_of_iter + graph_step : s->d_t_clip;
     const float* coef_src = folded ? s->d_coef_of_iter + 4 * (size_t)graph_step : s->d_coef_cur;
@@ -710,24 +710,23 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     if (s->dbg_first >= 0)
         LAUNCH(K_EMBED, dc_launch_front_from_h(st, fs, ss, s->d_model, s->d_h, s->d_recs, s->d_length, M, T, G, B, s->dbg_first));
     else
-        LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
-                                              want_stamps_film ? s->d_stamps + 256 : nullptr));
+            LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
+                                              want_stamps_film ? s->d_stamps + 256 : nullptr, s->d_flags));
     static const int ablate = getenv("DC_ABLATE") ? (int)strtol(getenv("DC_ABLATE"), nullptr, 0) : 0;   // timing experiments
     static const bool want_stamps = getenv("DC_STAMPS") != nullptr;
-    const bool no_persist = false;
     const int nwg = (G + 7) / 8;
     const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
-    // persistent form: all layers in one launch (grid barriers between them) when every workgroup gets its own CU
-    // (measured at bs=32 x 1800: ~2 ms per DDIM-50 loop SLOWER than per-layer launches - the grid barrier costs more than
-    // the residual stream's HBM round trip and the launch edges it saves - so it is opt-in: DC_PERSIST=1)
-    const bool want_persist = getenv("DC_PERSIST") != nullptr;      // (read per call: the tests toggle it)
-    const bool persistent = want_persist && chunks == 1 && wgr && nwg <= s->num_cu && nl_run == L && s->dbg_stage == 0 && !ablate && !no_persist && L > 1;
+    // Persistent form: all layers in ONE launch, the workgroups synchronising through per-unit progress flags (dc_kernels.hip
+    // k_layer, PERS) - no launch edges, no wait for the slowest of all workgroups, no grid barrier.  Needs every workgroup on
+    // its own CU (1 per CU at 152 KiB of LDS) and the layer count the kernel is compiled for.  DC_NO_PERSIST=1: per-layer
+    // launches (read per call: the tests toggle it).
+    const bool persistent = !getenv("DC_NO_PERSIST") && chunks == 1 && wgr && nwg <= s->num_cu && nwg <= 4096 && L == DC_PERS_LAYERS &&
+                            nl_run == L && s->dbg_stage == 0 && !ablate && !want_stamps && s->dbg_first < 0;
     if (persistent) {
         s->pers_used = true;
-        HIP_TRY(hipMemsetAsync(s->d_gbar, 0, 4, st));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, 0, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
-                                        s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur, s->d_snap_cur, s->d_snaps,
-                                        M, T, G, B, 0, want_stamps ? s->d_stamps : nullptr, L, rec_stride, s->d_gbar, s->d_gerr, nullptr));
+                                        s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src, s->d_snaps,
+                                        M, T, G, B, 0, nullptr, L, rec_stride, s->d_flags, s->d_gerr, iter_base));
         return DC_OK;
     }
     for (int l = s->dbg_first >= 0 ? s->dbg_first : 0; l < nl_run; ++l) {
@@ -737,7 +736,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, e_for_layer(l), NTe, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src,
                                         s->d_snaps, M, T, G, B, dbg, ((l == 3 || l == 4) && want_stamps) ? s->d_stamps : nullptr, l + 1, rec_stride,
-                                        s->d_gbar, s->d_gerr, iter_base));
+                                        s->d_flags, s->d_gerr, iter_base));
     }
     return DC_OK;
 }
@@ -812,8 +811,8 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
         s->pers_used = false;
         if (gerr) {
             HIP_TRY(hipMemset(s->d_gerr, 0, 4));
-            return fail(DC_ERR_HIP, "an earlier persistent layer launch timed out in its grid barrier (workgroups not co-resident?); "
-                                    "its results were invalid - unset DC_PERSIST to use per-layer launches (the default)");
+            return fail(DC_ERR_HIP, "an earlier persistent layer launch timed out waiting for its neighbours' progress flags (workgroups "
+                                    "not co-resident?); its results were invalid - set DC_NO_PERSIST=1 to use per-layer launches");
         }
     }
 
@@ -953,7 +952,7 @@ void dc_sampler_destroy(dc_sampler* s) {
     void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_y, s->d_mean, s->d_rstd, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
                     s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t, s->d_coef_of_iter,
-                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_gbar, s->d_gerr, s->d_film_rate};
+                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_flags, s->d_gerr, s->d_film_rate};
     for (void* p : ptrs)
         if (p) hipFree(p);
     dc_music_destroy(s->music);

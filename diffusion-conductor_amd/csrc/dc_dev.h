@@ -575,7 +575,60 @@ DEV void partial_tile(const f32x16& K, const f32x16& V, const RowRange& rr, floa
     for (int s2 = 0; s2 < 2; ++s2) P = mfma(ef.hi[s2], vf.hi[s2], P);
     keep = keep_head_block(P, cx.c);
 }
+
+// ---- records that cross workgroups INSIDE one launch (persistent layer kernel): every byte is stored and loaded `sc1`
+// (write-through to / read from the memory side, past the per-XCD L2s), the producer's waves wait for their stores, and one
+// lane publishes a per-unit flag; the consumer polls the flags with sc1 loads (MI355X_MICROARCH.md, cross-workgroup hand-offs,
+// first row of the sc1 table).  SC1 = false: plain accesses (records handed over at a kernel boundary).
+template <bool SC1>
+DEV float ld_rec(const float* p) {
+    if constexpr (SC1)
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        return *p;
+}
+template <bool SC1>
+DEV void st_rec(float* p, float v) {
+    if constexpr (SC1)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+// 32-byte block as two 16-byte halves (kept as two 4-register values: assembled into one 8-register tuple, every sc1
+// load needed a copy and the combine's nine blocks in flight spilled); the sc1 loads are not tracked by the compiler: the
+// caller waits (vmcnt) before use
+struct Rec8 {
+    f32x4 a, b;
+    DEV float operator[](int j) const { return j < 4 ? a[j] : b[j - 4]; }
+};
+template <bool SC1>
+DEV Rec8 ld_rec8(const f32x8* p) {
+    Rec8 v;
+    if constexpr (SC1) {
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1" : "=&v"(v.a), "=&v"(v.b) : "v"(p) : "memory");
+    } else {
+        const f32x4* q = reinterpret_cast<const f32x4*>(p);
+        v.a = q[0];
+        v.b = q[1];
+    }
+    return v;
+}
+template <bool SC1>
+DEV void st_rec8(f32x8* p, const f32x8& v) {
+    if constexpr (SC1) {
+        f32x4 a, b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = v[i];
+            b[i] = v[4 + i];
+        }
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(p), "v"(a), "v"(b) : "memory");
+    } else {
+        *p = v;
+    }
+}
 // after the barrier that follows the last partial_tile: wave w sums tile oc = w & 3 of slot w >> 2 over the waves
+template <bool SC1 = false>
 DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8* pst, const f32x8* xp, const float* ss,
                          int wave, int lane, int ub0, int G, int M, int T, int wg) {
     const int oc = wave & 3, sl = wave >> 2, c = lane & 31;
@@ -605,15 +658,15 @@ DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8*
     }
     float* R = recs + ((size_t)wg * 2 + sl) * DC_REC_FLOATS;
     if (lane < 32) {
-        R[32 * oc + c] = wg_colmax(mx, oc, sl, c);
-        R[128 + 32 * oc + c] = ssum;
+        st_rec<SC1>(R + 32 * oc + c, wg_colmax(mx, oc, sl, c));
+        st_rec<SC1>(R + 128 + 32 * oc + c, ssum);
     }
-    reinterpret_cast<f32x8*>(R + 256)[oc * 64 + lane] = acc;
+    st_rec8<SC1>(reinterpret_cast<f32x8*>(R + 256) + oc * 64 + lane, acc);
 }
 // The workgroup's own combine (512 threads): attention operand fragments A[d][l] of clips ub0, ub0+1 from the unit
 // records of the previous kernel -> af [2 clips][8 frags][64 lanes] in LDS (the 8 hi fragments k_attn_combine makes).
 // scratch (LDS): w [2][NU][128] floats, z [2][128] floats.  Summation order is fixed.
-template <class T16>
+template <class T16, bool SC1 = false>
 DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scratch, int ub0, int B, int M, int T, int tid, int wg,
                          unsigned long long* st = nullptr) {
 #define CSTAMP(k) do { if (st && (tid & 63) == 0) st[(tid >> 6) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -641,15 +694,15 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
         const float* R = rec_of(bav, min(a_lo + k, a_hi));
-        mr[k] = R[f];
-        sr[k] = R[128 + f];
+        mr[k] = ld_rec<SC1>(R + f);
+        sr[k] = ld_rec<SC1>(R + 128 + f);
     }
     const int bv = live ? b : ub0;
     const int v_lo = (bv * T) / 256, v_hi = (min((bv + 1) * T, M) - 1) / 256;
-    f32x8 pre[PRE];
+    Rec8 pre[PRE];
     if (live) {                      // wave-uniform (ci is the wave's half of the workgroup): idle halves issue nothing
 #pragma unroll
-        for (int k = 0; k < PRE; ++k) pre[k] = reinterpret_cast<const f32x8*>(rec_of(bv, min(v_lo + k, v_hi)) + 256)[oc * 64 + ln];
+        for (int k = 0; k < PRE; ++k) pre[k] = ld_rec8<SC1>(reinterpret_cast<const f32x8*>(rec_of(bv, min(v_lo + k, v_hi)) + 256) + oc * 64 + ln);
     }
     CSTAMP(22);
     if (tid < 256) {                              // phase A: per feature f of clip ca: m*, weights, normaliser
@@ -662,7 +715,7 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
             if (sr[k] > 0.f) mstar = fmaxf(mstar, mr[k]);
         for (int k = PRE; k < na; ++k) {          // clips longer than 9 workgroups (T > 2048)
             const float* R = rec_of(ba, a_lo + k);
-            if (R[128 + f] > 0.f) mstar = fmaxf(mstar, R[f]);
+            if (ld_rec<SC1>(R + 128 + f) > 0.f) mstar = fmaxf(mstar, ld_rec<SC1>(R + f));
         }
         float z = 0.f;
 #pragma unroll
@@ -673,14 +726,15 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
         }
         for (int k = PRE; k < na; ++k) {
             const float* R = rec_of(ba, a_lo + k);
-            const float su = R[128 + f];
-            const float ww = su > 0.f ? exp2f_fast(R[f] - mstar) : 0.f;
+            const float su = ld_rec<SC1>(R + 128 + f);
+            const float ww = su > 0.f ? exp2f_fast(ld_rec<SC1>(R + f) - mstar) : 0.f;
             wsc[(ca * NU + k) * 128 + f] = ww;
             z += ww * su;
         }
         zsc[ca * 128 + f] = z;
     }
     CSTAMP(23);
+    if constexpr (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the untracked sc1 block loads have landed
     __syncthreads();
     CSTAMP(24);
     float acc[8];
@@ -704,7 +758,8 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], pre[k][j], acc[j]);
         }
     for (int k = PRE; k < nu; ++k) {
-        const f32x8 pv = reinterpret_cast<const f32x8*>(rec_of(b, u_lo + k) + 256)[oc * 64 + ln];
+        const Rec8 pv = ld_rec8<SC1>(reinterpret_cast<const f32x8*>(rec_of(b, u_lo + k) + 256) + oc * 64 + ln);
+        if constexpr (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float w8[8];
         wrow(wsc + (ci * NU + k) * 128, w8);
 #pragma unroll
@@ -727,25 +782,29 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
 }
 
 
-// Grid-wide barrier between the layers of the persistent form of k_layer (all workgroups co-resident: the launcher
-// checks grid <= CU count at 1 workgroup per CU).  Release: the workgroup's record stores are written back
-// (__threadfence = agent-scope fence: L2 write-back + invalidate on gfx950's per-XCD L2s); acquire after the spin.
-// The spin is bounded: a workgroup that never sees the others arrive raises *err and goes on (wrong results, reported
-// by the host) instead of hanging the device.
-DEV void grid_barrier(unsigned* counter, unsigned target, int* err) {
+// Persistent layer kernel: per-unit progress flags instead of a grid barrier.  A workgroup publishes flags[unit] = layer + 1
+// once its record of that layer is stored (sc1 stores, every storing wave waited, workgroup barrier, then ONE sc1 flag store);
+// before combining, a workgroup waits until the units that overlap its <= 2 clips have published the layer it needs.  One
+// wave polls (a lane per unit, sc1 loads); the spin is bounded: a workgroup that never sees its neighbours arrive raises *err
+// and goes on (wrong results, reported by the host) instead of hanging the device.  Needs every workgroup co-resident.
+DEV void unit_publish(unsigned* flags, int unit, unsigned value) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's record stores have left
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(flags + unit, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEV void units_wait(const unsigned* flags, int u_lo, int u_hi, unsigned target, int* err) {
+    if (threadIdx.x < 64) {
+        const int u = min(u_lo + (int)threadIdx.x, u_hi);
         unsigned spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 21)) {
+        for (;;) {
+            const unsigned v = __hip_atomic_load(flags + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_ballot_w64(v < target) == 0) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) {
                 *err = 1;
                 break;
             }
         }
-        __threadfence();
     }
     __syncthreads();
 }

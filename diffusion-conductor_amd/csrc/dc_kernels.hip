@@ -317,14 +317,16 @@ __global__ __launch_bounds__(1024) void k_attn_combine(const float* __restrict__
 template <class T16, bool SPLIT>
 __global__ void k_silu_emb(const float* __restrict__ pp /*frag-major fp32*/, const float* __restrict__ temb,
                            const int* __restrict__ t_clip, v8<T16>* __restrict__ s_hi, v8<T16>* __restrict__ s_lo,
-                           int G, int T, int B) {
+                           int G, int T, int B, const int* __restrict__ iter_base) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)G * 32 * 64) return;
     const int lane = idx & 63, ks = (idx >> 6) & 31;
     const int g = (int)(idx >> 11);
     const int tok = g * 32 + (lane & 31);
     const int b = min(tok / T, B - 1);
-    const float* te = temb + (size_t)t_clip[b] * 512 + 16 * ks + 8 * (lane >> 5);
+    // graph-captured loop: one timestep for all clips, t_clip = this step's slot of the iteration table, *iter_base = the
+    // iteration at which the replay began
+    const float* te = temb + (size_t)t_clip[iter_base ? *iter_base : b] * 512 + 16 * ks + 8 * (lane >> 5);
     const f32x8 p = ld_pp(pp, idx >> 6, lane);
     const f32x8 tv = *reinterpret_cast<const f32x8*>(te);
     v8<T16> hi, lo;
@@ -887,7 +889,8 @@ template <class T16, bool SPLIT, bool WGR, bool FROMH = false>
 __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
 void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /*[M][P]*/, float* __restrict__ hbuf,
                    float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G, int B,
-                   unsigned long long* __restrict__ clk /* diagnostic: 100-MHz stamps of one wave, or nullptr */, int l0 = 0) {
+                   unsigned long long* __restrict__ clk /* diagnostic: 100-MHz stamps of one wave, or nullptr */, int l0 = 0,
+                   unsigned* __restrict__ flags = nullptr /* WGR: progress flag of this unit for the persistent layer kernel, reset here */) {
     static_assert(!(FROMH && WGR), "the h-injection hook exists for the per-group-record form only");
     constexpr int NW = SPLIT ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;
@@ -899,6 +902,7 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
     using W = v8<T16>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wg = WGR ? wg_index() : (int)blockIdx.x;
+    if (WGR && flags && threadIdx.x == 0) flags[wg] = 0u;
     int g = wg * NW + wave;
     const bool active = g < G;
     if (!active) g = G - 1;
@@ -1062,12 +1066,13 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
              float* __restrict__ recs, const int* __restrict__ length, const float* __restrict__ xin,
              float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur, const int* __restrict__ snap_cur,
              float* __restrict__ snaps, int M, int T, int G, int B, int dbg,
-             unsigned long long* __restrict__ stamps, int l_end, size_t rec_stride, unsigned* __restrict__ gbar,
+             unsigned long long* __restrict__ stamps, int l_end, size_t rec_stride, unsigned* __restrict__ flags,
              int* __restrict__ gerr, const int* __restrict__ iter_base) {
-    // Layers l .. l_end-1 in one launch when l_end > l + 1 (persistent form, WGR only): the residual stream stays in
-    // registers, a grid barrier separates the layers, and the unit records alternate between two buffers
-    // (recs + parity * rec_stride) so that a fast workgroup's records for layer l+1 never overwrite what a slow one
-    // still combines for layer l.
+    // PERS (WGR only): all DC_PERS_LAYERS layers in one launch.  Between the layers a workgroup parks its residual stream in
+    // hbuf (own stores, own loads), publishes flags[unit] = layer + 1 behind its unit record (sc1 stores) and waits only for
+    // the units that overlap its own clips (units_wait) - no grid-wide barrier, no L2 write-back / invalidate.  The unit
+    // records alternate between two buffers (recs + parity * rec_stride): a workgroup can only be one layer ahead of the
+    // units it shares a clip with, so a record is never overwritten while a neighbour still combines it.
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int NW = SPLIT ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;            // operand images per matrix (hi [+ lo])
@@ -1090,14 +1095,16 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     constexpr int OFF_SS = OFF_ER + 8 * 8192;    // non-split: column sums of the workgroup record (4.5 KiB)
     using W = v8<T16>;
     const int nl = dm->num_layers;
-    const int l_first = l;
     f32x16 h[4];
     {
         const int g0 = min((int)((WGR ? wg_index() : (int)blockIdx.x) * NW + (threadIdx.x >> 6)), G - 1);
         load_h(h, hbuf, g0, threadIdx.x & 63);      // in flight across the first prologue
     }
-#pragma nounroll
-  for (;; ++l) {                       // layer loop (one iteration unless persistent)
+  // PERS: all DC_PERS_LAYERS layers in this launch, as straight-line code (the loop is unrolled at compile time: as a run-time
+  // loop the body's address arithmetic stayed live next to the loop-carried residual stream and spilled ~85 VGPRs)
+  constexpr int NLP = PERS ? DC_PERS_LAYERS : 1;
+#pragma unroll
+  for (int li = 0; li < NLP; ++li, ++l) {
     // Everything derived from the thread index is re-derived per layer from an opaque copy: hoisted out of the loop
     // these values would stay live across the whole body next to the loop-carried residual stream (it spilled ~100 VGPRs).
     int tid_ = threadIdx.x;
@@ -1125,9 +1132,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     };
     const W* af = reinterpret_cast<const W*>(lds + OFF_AF);
     const DcLayer& L = dm->layer[l];
-    const bool last = l + 1 >= nl;
-    const bool more = PERS && l + 1 < l_end;     // the next layer runs in this launch (compile-time false otherwise: the
-                                                 // residual stream is then dead after its store and the loop has no back edge)
+    const bool last = PERS ? li + 1 == NLP : l + 1 >= nl;
+    const bool more = PERS && li + 1 < NLP;      // the next layer runs in this launch (compile-time)
     const f16x8* Eg = reinterpret_cast<const f16x8*>(E) + ((size_t)g * NT + (size_t)l * 24) * 128;   // 3 blocks x 8 tiles
     const W* acl = a_ca + (size_t)l * B * 16 * 64;
     const float* recs_in = recs + (size_t)(l & 1) * rec_stride;
@@ -1136,10 +1142,19 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(0);
     if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0 && l == 3) stamps[(threadIdx.x >> 6) * 32 + 26] = __builtin_amdgcn_s_memtime();
     DC_WGSTAMP(0);
+    if constexpr (PERS)
+        if (li > 0) load_h(h, hbuf, g, lane);           // parked by this wave at the previous layer's tail
     stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
-    if constexpr (WGR)      // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
-        wg_combine_attn<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, M, T, tid_, wg,
-                             (STAMP && stamps && blockIdx.x == 3 && l == 3) ? stamps : nullptr);
+    if constexpr (WGR) {    // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
+        if constexpr (PERS) {
+            if (li > 0) {
+                const int ub1 = (min((wg + 1) * NW * 32, M) - 1) / T;
+                units_wait(flags, (ub0 * T) / (NW * 32), (min((ub1 + 1) * T, M) - 1) / (NW * 32), (unsigned)li, gerr);
+            }
+        }
+        wg_combine_attn<T16, PERS>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, M, T, tid_, wg,
+                                   (STAMP && stamps && blockIdx.x == 3 && l == 3) ? stamps : nullptr);
+    }
     else if (wg_lds)
         stage_attn(a_sa);
     DC_STAMP(14);
@@ -1285,7 +1300,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         // youngest operations (the 16 dwordx4 stores of h) are outstanding means "the image has landed" while the
         // stores keep draining behind the K/V projections.
         __builtin_amdgcn_sched_barrier(0);
-        const bool st_h = active && !more;               // the residual stream only leaves the registers at a launch edge
+        const bool st_h = active;                        // (the persistent form parks it here too: held through the record tail it spilled)
         if (st_h) store_h(h, hbuf, g, lane);
         __builtin_amdgcn_sched_barrier(0);
         XFrag<T16, SPLIT> nf[4];
@@ -1421,7 +1436,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             DC_STAMP(16);
             __syncthreads();
             DC_STAMP(17);
-            wg_write_record(recs_out, mx, pst, xp, ss, wave, lane, ub0, G, M, T, wg);
+            wg_write_record<PERS>(recs_out, mx, pst, xp, ss, wave, lane, ub0, G, M, T, wg);
         } else {
             f32x16 K[4];                  // keys from buf0 while the value image lands in buf1
 #pragma unroll
@@ -1455,7 +1470,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0 && l == 3) stamps[(threadIdx.x >> 6) * 32 + 27] = __builtin_amdgcn_s_memtime();
         DC_WGSTAMP(1);
         if (more) {
-            grid_barrier(gbar, (unsigned)gridDim.x * (unsigned)(l - l_first + 1), gerr);
+            unit_publish(flags, wg, (unsigned)(li + 1));
             continue;
         }
         return;
@@ -2018,14 +2033,14 @@ hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, vo
 
 template <class T16, bool SP>
 static void launch_silu_t(hipStream_t st, const float* pp, const float* temb, const int* t_clip, void* s_hi, void* s_lo,
-                          int G, int T, int B) {
+                          int G, int T, int B, const int* iter_base) {
     const size_t n = (size_t)G * 32 * 64;
     k_silu_emb<T16, SP><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(pp, temb, t_clip, (v8<T16>*)s_hi,
-                                                                                 (v8<T16>*)s_lo, G, T, B);
+                                                                                 (v8<T16>*)s_lo, G, T, B, iter_base);
 }
 hipError_t dc_launch_silu_emb(hipStream_t st, int fmt, bool split, const float* pp, const float* temb, const int* t_clip,
-                              void* s_hi, void* s_lo, int G, int T, int B) {
-    DISPATCH(fmt, split, (launch_silu_t<T16, SP>(st, pp, temb, t_clip, s_hi, s_lo, G, T, B)));
+                              void* s_hi, void* s_lo, int G, int T, int B, const int* iter_base) {
+    DISPATCH(fmt, split, (launch_silu_t<T16, SP>(st, pp, temb, t_clip, s_hi, s_lo, G, T, B, iter_base)));
     return LAUNCH_CHECK();
 }
 
@@ -2096,25 +2111,25 @@ hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcM
 
 template <class T16, bool SP, bool WGR>
 static hipError_t launch_embed_t(hipStream_t st, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
-                                 int M, int T, int G, int B, unsigned long long* clk) {
+                                 int M, int T, int G, int B, unsigned long long* clk, unsigned* flags) {
     constexpr int NW = SP ? 4 : 8;
     const size_t shm = WGR ? 8192 + 65536 + 8192 + 9 * 4 * 32 * 4 + 33 * 1024 : 0;
     if (WGR) {
         static unsigned long long optin_done = 0;
         if (hipError_t e = lds_optin((const void*)k_embed_front<T16, SP, WGR>, (int)shm, optin_done)) return e;
     }
-    k_embed_front<T16, SP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, B, clk);
+    k_embed_front<T16, SP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, B, clk, 0, flags);
     return hipGetLastError();
 }
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf,
-                                 float* recs, const int* length, int M, int T, int G, int B, unsigned long long* clk) {
+                                 float* recs, const int* length, int M, int T, int G, int B, unsigned long long* clk, unsigned* flags) {
     hipError_t e = hipSuccess;
     if (wgr && !split) {
-        e = fmt == 1 ? launch_embed_t<_Float16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk)
-                     : launch_embed_t<__bf16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk);
+        e = fmt == 1 ? launch_embed_t<_Float16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, flags)
+                     : launch_embed_t<__bf16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, flags);
         return e;
     }
-    DISPATCH(fmt, split, (e = launch_embed_t<T16, SP, false>(st, dm, x, hbuf, recs, length, M, T, G, B, clk)));
+    DISPATCH(fmt, split, (e = launch_embed_t<T16, SP, false>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, nullptr)));
     return e;
 }
 
@@ -2123,7 +2138,7 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                                  int M, int T, int G, int B, int dbg, unsigned long long* stamps, int l_end, size_t rec_stride,
-                                 unsigned* gbar, int* gerr, const int* iter_base) {
+                                 unsigned* flags, int* gerr, const int* iter_base) {
     constexpr int NW = SP ? 4 : 8;
     // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
     const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
@@ -2131,7 +2146,7 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
     if (hipError_t e = lds_optin((const void*)k_layer<T16, SP, DBG, STAMP, WGR, PERS>, (int)shm, optin_done)) return e;
     k_layer<T16, SP, DBG, STAMP, WGR, PERS><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
                        (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
-                       snaps, M, T, G, B, dbg, stamps, l_end, rec_stride, gbar, gerr, iter_base);
+                       snaps, M, T, G, B, dbg, stamps, l_end, rec_stride, flags, gerr, iter_base);
     return hipGetLastError();
 }
 
@@ -2139,18 +2154,15 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps, int l_end, size_t rec_stride,
-                           unsigned* gbar, int* gerr, const int* iter_base) {
+                           unsigned* flags, int* gerr, const int* iter_base) {
     hipError_t e = hipSuccess;
 #define LAYER_ARGS st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps, \
-                   l_end, rec_stride, gbar, gerr, iter_base
+                   l_end, rec_stride, flags, gerr, iter_base
     if (wgr && !split) {        // workgroup-level records + in-kernel combine (non-split formats, T >= 256)
         if (dbg != 0)
             e = fmt == 1 ? launch_layer_t<_Float16, false, true, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, true, false, true>(LAYER_ARGS);
-        else if (stamps != nullptr)
-            e = l_end > l + 1 ? (fmt == 1 ? launch_layer_t<_Float16, false, false, true, true, true>(LAYER_ARGS)
-                                          : launch_layer_t<__bf16, false, false, true, true, true>(LAYER_ARGS))
-                              : (fmt == 1 ? launch_layer_t<_Float16, false, false, true, true>(LAYER_ARGS)
-                                          : launch_layer_t<__bf16, false, false, true, true>(LAYER_ARGS));
+        else if (stamps != nullptr && l_end == l + 1)
+            e = fmt == 1 ? launch_layer_t<_Float16, false, false, true, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, false, true, true>(LAYER_ARGS);
         else if (l_end > l + 1)       // persistent form: its own instantiation (loop-carried residual stream)
             e = fmt == 1 ? launch_layer_t<_Float16, false, false, false, true, true>(LAYER_ARGS)
                          : launch_layer_t<__bf16, false, false, false, true, true>(LAYER_ARGS);

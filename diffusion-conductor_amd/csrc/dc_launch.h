@@ -16,7 +16,8 @@ hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* 
 hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, void* afrag, int T, int NU, int B, int nset,
                                   int gran);
 hipError_t dc_launch_silu_emb(hipStream_t st, int fmt, bool split, const float* pp, const float* temb, const int* t_clip,
-                              void* s_hi, void* s_lo, int G, int T, int B);
+                              void* s_hi, void* s_lo, int G, int T, int B,
+                              const int* iter_base = nullptr /* captured loop: t_clip = &t_of_iter[step], indexed by *iter_base */);
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
                                int nround, const float* pp, const float* temb, const int* t_clip, int T, int B,
                                unsigned long long* clk /* diagnostic clock stamps or nullptr */,
@@ -28,7 +29,8 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
 // no dc_launch_attn_combine between the layers then)
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf, float* recs,
                                  const int* length, int M, int T, int G, int B,
-                                 unsigned long long* clk /* diagnostic stamps (8 slots) or nullptr */);
+                                 unsigned long long* clk /* diagnostic stamps (8 slots) or nullptr */,
+                                 unsigned* flags = nullptr /* wgr: per-unit progress flags of the persistent layer kernel, reset here */);
 // test hook: front half of layer l0 from the residual stream as it stands in hbuf (per-group records)
 hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcModel* dm, float* hbuf, float* recs, const int* length,
                                   int M, int T, int G, int B, int l0);
@@ -36,13 +38,14 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps, int l_end, size_t rec_stride,
-                           unsigned* gbar, int* gerr,
+                           unsigned* flags, int* gerr,
                            const int* iter_base /* captured loop: coef_cur / snap_cur = this step's slots of the per-iteration tables,
                                                    indexed by *iter_base; else nullptr (scalars prepared by k_begin_step) */);
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);
-// l_end > l + 1 (wgr only): layers l .. l_end-1 in ONE launch with grid barriers in between - the caller guarantees that all
-// ceil(G/8) workgroups are co-resident (<= CU count) and that *gbar == 0 at launch; rec_stride: floats between the two
-// alternating unit-record buffers (0 = single buffer, non-wgr)
+// l == 0 and l_end == DC_PERS_LAYERS == num_layers (wgr only): ALL layers in ONE launch, synchronised through per-unit
+// progress flags (`flags`, one unsigned per 256-token unit, reset by dc_launch_embed_front) - the caller guarantees that all
+// ceil(G/8) workgroups are co-resident (<= CU count); rec_stride: floats between the two alternating unit-record buffers
+// (0 = single buffer, non-wgr); *gerr is raised if a workgroup's bounded wait for its neighbours ran out
 
 // ---- no_eff variant (full T x T attention); non-split formats only.  KT = key tiles per clip array.
 hipError_t dc_launch_ca_kv(hipStream_t st, int fmt, const DcModel* dm, const void* nh_hi, const void* nh_lo, void* kv_ca,
@@ -56,3 +59,14 @@ hipError_t dc_launch_layer_full(hipStream_t st, int fmt, const DcModel* dm, int 
 
 // Savitzky-Golay smoothing along time of [B][T][P] fp32 (coef: hat matrix [win][win]); y != x
 hipError_t dc_launch_savgol(hipStream_t st, const float* x, float* y, const float* coef, int B, int T, int P, int win);
+
+// ---- fused path (dc_fused.hip): non-split formats, T >= dc_fused_unit_tokens(), <= dc_fused_max_units_per_clip() units per clip.
+// S = the f16/bf16 fragment image of SiLU(emb) that k_silu_emb writes ([G][32 ks][64][8]); recs: [2 parities][units][2][DC_REC_FLOATS]
+hipError_t dc_launch_fembed(hipStream_t st, int fmt, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
+                            int M, int T, int G, int B);
+hipError_t dc_launch_flayer(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* S, const void* a_ca, float* recs,
+                            const int* length, const float* xin, float* xout, int out_mode, const float* coef_cur,
+                            const int* snap_cur, float* snaps, int M, int T, int G, int B, int dbg, size_t rec_stride,
+                            const int* iter_base);
+int dc_fused_max_units_per_clip(void);
+int dc_fused_unit_tokens(void);

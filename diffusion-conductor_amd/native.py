@@ -37,6 +37,8 @@ class DcError(RuntimeError):
 
 SOURCES = ("dc_kernels.hip", "dc_fused.hip", "dc_api.hip", "dc_music.hip")
 HEADERS = ("dc_common.h", "dc_dev.h", "dc_launch.h", "dc_music.h")
+# the persistent layer kernel unrolls its 8-layer loop at compile time: far beyond clang's default size limit for `#pragma unroll`
+EXTRA_FLAGS = {"dc_kernels.hip": ["-mllvm", "-pragma-unroll-threshold=4000000"]}
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
@@ -55,7 +57,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(bdir, os.path.basename(src).replace(".hip", ".o"))
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hmax):
-            cmd = [hipcc, *flags, "-c", src, "-o", obj]
+            cmd = [hipcc, *flags, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             jobs.append((cmd, subprocess.Popen(cmd)))

@@ -144,17 +144,36 @@ def test_captured_loop_table_lookup_equals_begin_step_launches(models):
 
 
 def test_persistent_layer_kernel_equals_per_layer_launches(models):
-    """DC_PERSIST=1: all 8 layers in one launch with grid barriers between them (opt-in; needs one CU per
-    256-token workgroup).  Same arithmetic in the same order as the per-layer launches: bit-identical."""
+    """Default: all 8 layers in one launch, the workgroups synchronised through per-unit progress flags (needs one CU per
+    256-token workgroup); DC_NO_PERSIST=1: one launch per layer.  Same arithmetic in the same order: bit-identical, in the
+    captured graph and with eager launches, with clip edges inside workgroups and ragged lengths."""
     xfp, xfo = xf_pair(3, 900, first=40)
     noise = torch.from_numpy(batch_noise(3, 900, first=40))
     a = _ddim(models["fp16"], 25, noise, xfp, xfo, [900, 512, 333])
-    os.environ["DC_PERSIST"] = "1"
     os.environ["DC_DISABLE_GRAPH"] = "1"
     try:
+        a2 = _ddim(models["fp16"], 25, noise, xfp, xfo, [900, 512, 333])
+        os.environ["DC_NO_PERSIST"] = "1"
         b = _ddim(models["fp16"], 25, noise, xfp, xfo, [900, 512, 333])
     finally:
-        del os.environ["DC_PERSIST"], os.environ["DC_DISABLE_GRAPH"]
+        del os.environ["DC_DISABLE_GRAPH"]
+        os.environ.pop("DC_NO_PERSIST", None)
+    assert torch.isfinite(a).all() and torch.equal(a, a2) and torch.equal(a, b)
+
+
+def test_persistent_layer_kernel_full_batch(models):
+    """bs=32 x 1800 (225 co-resident workgroups, 7-8 units per clip, every clip edge inside a workgroup): the persistent
+    form equals per-layer launches bit for bit on the whole batch."""
+    B, T = 32, 1800
+    xfp, xfo = xf_pair(B, T)
+    noise = torch.from_numpy(batch_noise(B, T))
+    a = _ddim(models["fp16"], 25, noise, xfp, xfo, [T - 13 * (b % 5) for b in range(B)])
+    os.environ["DC_NO_PERSIST"] = "1"
+    os.environ["DC_DISABLE_GRAPH"] = "1"
+    try:
+        b = _ddim(models["fp16"], 25, noise, xfp, xfo, [T - 13 * (b % 5) for b in range(B)])
+    finally:
+        del os.environ["DC_NO_PERSIST"], os.environ["DC_DISABLE_GRAPH"]
     assert torch.isfinite(a).all() and torch.equal(a, b)
 
 

@@ -34,36 +34,75 @@ DEV f16x8 ld16_nowait(const f16x8* p) {
     return v;
 }
 // uniform base in SGPRs + per-lane byte offset in one VGPR: distinct fragments cost scalar adds, not VGPR address pairs
+#ifndef S_MODE
+#define S_MODE 1       // 1 = compiler-tracked loads, 2 = saddr asm without waits, 3 = 64-bit vaddr asm without waits
+#endif
 DEV f16x8 ld16_nowait_s(const void* sbase, unsigned voff) {
     f16x8 v;
+#if S_MODE == 1
+    v = *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(sbase) + voff);
+#elif S_MODE == 2
     asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+#else
+    const char* p = reinterpret_cast<const char*>(sbase) + voff;
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+#endif
     return v;
 }
 DEV f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-constexpr int NSLOT = 4;             // ring slots of 16 KiB
+#ifndef NSLOT_
+#define NSLOT_ 4
+#endif
+#ifndef NWAVES
+#define NWAVES 4
+#endif
+#ifndef S_MODE
+#define S_MODE 1
+#endif
+constexpr int NSLOT = NSLOT_;        // ring slots of 16 KiB
+constexpr int FPW = 16 / NWAVES;     // fragments each wave copies per chunk
 constexpr int SLOT_BYTES = 16384;
 
+// wait until only the DMAs of the newest NSLOT-2 iterations (+ their S operations in the untracked modes) are outstanding
+#if S_MODE == 1
+#define VM_N ((NSLOT - 2) * FPW)
+#else
+#define VM_N ((NSLOT - 2) * (FPW + 2) + FPW)
+#endif
+#ifdef NO_DMA
+#define RING_WAITVM()
+#else
+#define RING_WAITVM() asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_N) : "memory")
+#endif
+#ifdef NO_BAR
+#define RING_SYNC() do { RING_WAITVM(); } while (0)
+#else
+#define RING_SYNC() do { RING_WAITVM(); __syncthreads(); } while (0)
+#endif
 // one launch = `nblk` FiLM blocks, each followed by `chain_slots` chunks of chain work
 template <int WITH_S>
-__global__ __launch_bounds__(256, 2) void k_probe(const f16x8* __restrict__ W, const f16x8* __restrict__ S, float* __restrict__ out,
+__global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void k_probe(const f16x8* __restrict__ W, const f16x8* __restrict__ S, float* __restrict__ out,
                                                   int G, int nblk, int chain_slots, int valu_iters) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int g = min((int)blockIdx.x * 4 + wave, G - 1);
+    const int g = min((int)blockIdx.x * NWAVES + wave, G - 1);
     const int slots_per_blk = 16 + chain_slots;
     const int total = nblk * slots_per_blk;
     const f16x8* Sg = S + (size_t)g * 32 * 64;                   // this wave's 32 fragments (wave-uniform base)
     const unsigned soff = lane * 16;
     auto issue = [&](int c) {                                   // chunk c of the stream -> slot c % NSLOT; 4 fragments per wave
+#ifdef NO_DMA
+        return;
+#endif
         if (c < total) {
             const f16x8* src = W + (size_t)c * 16 * 64 + lane;
             char* dst = lds + (c % NSLOT) * SLOT_BYTES;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lds_dma16(src + (size_t)(wave * 4 + i) * 64, dst + (wave * 4 + i) * 1024);
-        } else {                                                // keep the vmcnt arithmetic uniform: 4 dummy loads
+            for (int i = 0; i < FPW; ++i) lds_dma16(src + (size_t)(wave * FPW + i) * 64, dst + (wave * FPW + i) * 1024);
+        } else {                                                // keep the vmcnt arithmetic uniform: dummy loads
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lds_dma16(W + lane, lds + NSLOT * SLOT_BYTES + wave * 1024);
+            for (int i = 0; i < FPW; ++i) lds_dma16(W + lane, lds + NSLOT * SLOT_BYTES + wave * 1024);
         }
     };
     f32x16 h[4];
@@ -81,8 +120,10 @@ __global__ __launch_bounds__(256, 2) void k_probe(const f16x8* __restrict__ W, c
         for (int s2 = 0; s2 < 2; ++s2) {
             if (c < 2)
                 sreg[c][s2] = ld16_nowait_s(Sg + (size_t)(2 * c + s2) * 64, soff);
+#if S_MODE != 1
             else
                 lds_dma16(W + lane, lds + NSLOT * SLOT_BYTES + wave * 1024);
+#endif
         }
         issue(c);
     }
@@ -95,8 +136,7 @@ __global__ __launch_bounds__(256, 2) void k_probe(const f16x8* __restrict__ W, c
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 16; ++kt, ++c) {
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            __syncthreads();                                      // chunk c landed for every wave; everyone left slot (c-1) % NSLOT
+            RING_SYNC();                                          // chunk c landed for every wave; everyone left slot (c-1) % NSLOT
             // S fragments 2 k-tiles ahead (wraps into the next block's first k-tiles: same tokens, same image).  A load without
             // a wait must have a destination the compiler keeps alive until it has landed: none behind the last block.
             if (kt < 14 || blk + 1 < nblk) {
@@ -105,8 +145,10 @@ __global__ __launch_bounds__(256, 2) void k_probe(const f16x8* __restrict__ W, c
                 for (int s2 = 0; s2 < 2; ++s2)
                     sreg[(kt + 2) & 3][s2] = ld16_nowait_s(Sg + (size_t)(WITH_S ? 2 * kn + s2 : 0) * 64, soff);
             } else {
+#if S_MODE != 1
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) lds_dma16(W + lane, lds + NSLOT * SLOT_BYTES + wave * 1024);
+#endif
             }
             issue(c + NSLOT - 1);
             const f16x8* w = reinterpret_cast<const f16x8*>(lds + (c % NSLOT) * SLOT_BYTES) + lane;
@@ -128,12 +170,13 @@ __global__ __launch_bounds__(256, 2) void k_probe(const f16x8* __restrict__ W, c
             for (int r = 0; r < 16; ++r) h[t][r] += (float)(_Float16)acc[2 * t][r] * (float)(_Float16)acc[2 * t + 1][r];
         // chain stand-in: chunks of 128-wide GEMM work (4 chains x 4 k-tiles x ... = 16 MFMAs per chunk) + VALU rounds
         for (int cs = 0; cs < chain_slots; ++cs, ++c) {
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            __syncthreads();
+            RING_SYNC();
             // two placeholder operations keep the vmcnt arithmetic uniform (LDS-DMA into a scratch KiB: a register-destination
             // load without a wait must never target a register the compiler considers dead - it lands later)
+#if S_MODE != 1
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) lds_dma16(W + lane, lds + NSLOT * SLOT_BYTES + wave * 1024);
+#endif
             issue(c + NSLOT - 1);
             const f16x8* w = reinterpret_cast<const f16x8*>(lds + (c % NSLOT) * SLOT_BYTES) + lane;
             // 16 MFMAs in two chains of 8, operands converted from h one tile at a time; then VALU rounds on the two results
@@ -174,10 +217,23 @@ __global__ __launch_bounds__(256, 2) void k_probe(const f16x8* __restrict__ W, c
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += h[t][r];
-    if (blockIdx.x * 4 + wave < G) out[(size_t)(blockIdx.x * 4 + wave) * 64 + lane] = s;
+    if (blockIdx.x * NWAVES + wave < G) out[(size_t)(blockIdx.x * NWAVES + wave) * 64 + lane] = s;
 }
 
 int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    printf("S_MODE %d NWAVES %d NSLOT %d%s%s\n", S_MODE, NWAVES, NSLOT,
+#ifdef NO_DMA
+           " NO_DMA",
+#else
+           "",
+#endif
+#ifdef NO_BAR
+           " NO_BAR"
+#else
+           ""
+#endif
+    );
     const int G = argc > 1 ? atoi(argv[1]) : 1800;            // 32 clips x 1800 frames / 32
     const int reps = 20;
     const size_t wbytes = (size_t)8 * 64 * SLOT_BYTES;        // 8 layers x 64 chunks
@@ -194,13 +250,13 @@ int main(int argc, char** argv) {
         CHECK(hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
         CHECK(hipMemcpy(S, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
     }
-    const int shm = NSLOT * SLOT_BYTES + 4096;
+    const int shm = NSLOT * SLOT_BYTES + NWAVES * 1024;
     CHECK(hipFuncSetAttribute((const void*)k_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, shm));
     CHECK(hipFuncSetAttribute((const void*)k_probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, shm));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    const int nwg = (G + 3) / 4;
+    const int nwg = (G + NWAVES - 1) / NWAVES;
     struct Cfg { const char* name; int with_s, nblk, chain, valu; };
     const Cfg cfgs[] = {
         {"FiLM only, no S loads, 3 blocks/launch", 0, 3, 0, 0},
@@ -213,13 +269,14 @@ int main(int argc, char** argv) {
     };
     for (const Cfg& cf : cfgs) {
         float best = 1e30f, tot = 0.f;
+        printf("%s ...\n", cf.name);
         for (int r = 0; r < reps + 2; ++r) {
             const f16x8* w = W + (size_t)(r % 8) * 64 * SLOT_BYTES / 16 * (cf.nblk > 3 ? 0 : 1);
             CHECK(hipEventRecord(e0, 0));
             if (cf.with_s)
-                hipLaunchKernelGGL(k_probe<1>, dim3(nwg), dim3(256), shm, 0, w, S, out, G, cf.nblk, cf.chain, cf.valu);
+                hipLaunchKernelGGL(k_probe<1>, dim3(nwg), dim3(NWAVES * 64), shm, 0, w, S, out, G, cf.nblk, cf.chain, cf.valu);
             else
-                hipLaunchKernelGGL(k_probe<0>, dim3(nwg), dim3(256), shm, 0, w, S, out, G, cf.nblk, cf.chain, cf.valu);
+                hipLaunchKernelGGL(k_probe<0>, dim3(nwg), dim3(NWAVES * 64), shm, 0, w, S, out, G, cf.nblk, cf.chain, cf.valu);
             CHECK(hipEventRecord(e1, 0));
             CHECK(hipEventSynchronize(e1));
             float ms;
