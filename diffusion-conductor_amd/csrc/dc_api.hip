@@ -164,8 +164,6 @@ struct dc_sampler {
     float* d_film_rate = nullptr;  // FiLM GEMM: per-workgroup speeds measured by the previous launches, two buffers of 1024 (ping-pong)
     int film_rate_parity = 0;
     bool graph_folded = false;     // the captured steps look their timestep up through *d_iter (no k_begin_step launches)
-    unsigned* d_flags = nullptr;  // persistent layer kernel: per-unit progress flags (reset by k_embed_front every step)
-    int* d_gerr = nullptr;        // set by a workgroup whose bounded wait for its neighbours' flags ran out
     int num_cu = 0;
     int *d_iter = nullptr, *d_t_clip = nullptr, *d_snap_cur = nullptr, *d_t_of_iter = nullptr, *d_snap_of_iter = nullptr;
     float *d_coef_cur = nullptr, *d_coef_of_t = nullptr, *d_coef_of_iter = nullptr;   // DDIM scalars by timestep / by iteration
@@ -176,7 +174,6 @@ struct dc_sampler {
     int tables_S = 0;
     std::vector<int> tab_t, tab_snap;
     std::vector<float> tab_coef, tab_coef_iter;
-    bool pers_used = false;                // a persistent layer launch ran since d_gerr was last read
 
     // graph cache: one per (B,T,steps_per_graph)
     hipGraphExec_t graph = nullptr;
@@ -578,12 +575,8 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
     if (!s->d_iter) {
         int rc;
         if ((rc = dev_alloc(s, s->d_stamps, (8 * 32 + 8 + 1024 + 1024 + 256 + 8) * 8))) return rc;
-        if ((rc = dev_alloc(s, s->d_flags, 4096 * sizeof(unsigned)))) return rc;
-        HIP_TRY(hipMemset(s->d_flags, 0, 4096 * sizeof(unsigned)));
         if ((rc = dev_alloc(s, s->d_film_rate, 2 * 1024 * sizeof(float)))) return rc;
         HIP_TRY(hipMemset(s->d_film_rate, 0, 2 * 1024 * sizeof(float)));      // 0 = not measured yet: equal shares
-        if ((rc = dev_alloc(s, s->d_gerr, 16))) return rc;
-        HIP_TRY(hipMemset(s->d_gerr, 0, 16));
         if ((rc = dev_alloc(s, s->d_iter, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_snap_cur, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_coef_cur, 16))) return rc;
@@ -649,8 +642,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const int fs = s->small_fmt, ff = s->film_fmt;
     // non-split formats: the FiLM GEMM produces its own operand from pp + temb (no k_silu_emb pass); the separate pass
     // remains for the split formats, for the v1 kernel, and under the test hooks that read the operand image back
-    static const bool film_v1 = getenv("DC_FILM_V1") != nullptr, unfused = getenv("DC_UNFUSED_SILU") != nullptr;
-    const bool fuse_silu = !sf && !film_v1 && !unfused && s->dbg_layers < 0;
+    const bool fuse_silu = !sf && s->dbg_layers < 0;
     const bool folded = loop_mode && graph_step >= 0 && fuse_silu && !s->cfg.no_eff && !getenv("DC_BEGIN_STEP") && s->dbg_stage == 0;
     const int* iter_base = folded ? s->d_iter : nullptr;
     const int* t_src = folded ? s->d_t_of_iter + graph_step : s->d_t_clip;
@@ -662,41 +654,21 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
                                              s->d_t_clip, s->d_coef_cur, s->d_snap_cur, B));
     if (!fuse_silu)
         LAUNCH(K_SILU, dc_launch_silu_emb(st, ff, sf, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, G, T, B));
-    // FiLM GEMM in `chunks` launches, each covering the feature tiles of L / chunks consecutive layers and issued right
-    // before the first of them: its output (88 MB per layer at bs=32 x 1800) is consumed while still cache-resident
-    static const int film_chunks_env = getenv("DC_FILM_CHUNKS") ? atoi(getenv("DC_FILM_CHUNKS")) : 1;
-    const int nround_all = s->NT / 16;                       // a layer owns 12 tile pairs = 1.5 rounds of 8
-    int chunks = (sf || film_chunks_env < 1 || L % film_chunks_env || ((L / film_chunks_env) & 1)) ? 1 : film_chunks_env;
-    const int lpc = L / chunks;                              // layers per chunk (even)
     static const bool want_stamps_film = getenv("DC_STAMPS") != nullptr;       // clock stamps land in stamp slots 28..31 of wave 7
-    // DC_FILM_ALIAS=1 (with DC_FILM_CHUNKS > 1): every chunk writes the SAME buffer region (tiles of lpc layers per group), so the
-    // FiLM tiles are overwritten in place chunk after chunk and can live in the 256-MB Infinity Cache instead of streaming
-    // 708 MB per step through HBM
-    static const bool alias = getenv("DC_FILM_ALIAS") != nullptr;
-    const bool aliased = alias && chunks > 1;
-    const int NTe = aliased ? s->NT / chunks : s->NT;
-    auto e_for_layer = [&](int l) -> void* { return aliased ? (void*)((char*)s->d_E - (size_t)(l - l % lpc) * 24 * 2048) : s->d_E; };
-    // adaptive work shares of the persistent FiLM GEMM (dc_kernels.hip, k_film_gemm2); DC_FILM_STATIC=1 keeps equal shares
+    // adaptive work shares of the persistent FiLM GEMM (dc_kernels.hip, film_shares); DC_FILM_STATIC=1 keeps equal shares
     const bool film_static = getenv("DC_FILM_STATIC") != nullptr;           // (read per call: the tests toggle it)
     const bool adapt = !film_static && s->num_cu <= 1024;
-    auto film_chunk = [&](int c) -> int {
-        LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b,
-                                           s->d_s_hi, s->d_s_lo, aliased ? (void*)((char*)s->d_E - (size_t)c * lpc * 3 * 8 * 2048) : s->d_E, G, NTe,
-                                           c * lpc * 3 / 2, chunks == 1 ? nround_all : lpc * 3 / 2,
-                                           fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
-                                           want_stamps_film ? s->d_stamps + 252 : nullptr,
-                                           adapt ? s->d_film_rate + 1024 * s->film_rate_parity : nullptr,
-                                           adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr, iter_base,
-                                           s->h_model.film_w16, s->h_model.film_b16));
-        s->film_rate_parity ^= 1;
-        return DC_OK;
-    };
-    { int rc = film_chunk(0); if (rc) return rc; }
+    LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
+                                       s->NT / 16, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
+                                       want_stamps_film ? s->d_stamps + 252 : nullptr,
+                                       adapt ? s->d_film_rate + 1024 * s->film_rate_parity : nullptr,
+                                       adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr, iter_base,
+                                       s->h_model.film_w16, s->h_model.film_b16));
+    s->film_rate_parity ^= 1;
     const int nl_run = (s->dbg_layers >= 0 && s->dbg_layers < L) ? s->dbg_layers : L;
     if (s->cfg.no_eff) {
         LAUNCH(K_EMBED, dc_launch_embed_front_full(st, fs, s->d_model, x_src, s->d_h, s->d_kv_sa[0], M, T, B, s->KT));
         for (int l = 0; l < nl_run; ++l) {
-            if (l > 0 && l % lpc == 0) { int rc = film_chunk(l / lpc); if (rc) return rc; }
             LAUNCH(K_LAYER, dc_launch_layer_full(st, fs, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_kv_sa[l & 1], s->d_kv_sa[(l + 1) & 1],
                                                  s->d_kv_ca, s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur,
                                                  s->d_snap_cur, s->d_snaps, M, T, B, s->KT,
@@ -710,33 +682,18 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     if (s->dbg_first >= 0)
         LAUNCH(K_EMBED, dc_launch_front_from_h(st, fs, ss, s->d_model, s->d_h, s->d_recs, s->d_length, M, T, G, B, s->dbg_first));
     else
-            LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
-                                              want_stamps_film ? s->d_stamps + 256 : nullptr, s->d_flags));
-    static const int ablate = getenv("DC_ABLATE") ? (int)strtol(getenv("DC_ABLATE"), nullptr, 0) : 0;   // timing experiments
+        LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
+                                              want_stamps_film ? s->d_stamps + 256 : nullptr));
     static const bool want_stamps = getenv("DC_STAMPS") != nullptr;
     const int nwg = (G + 7) / 8;
     const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
-    // Persistent form: all layers in ONE launch, the workgroups synchronising through per-unit progress flags (dc_kernels.hip
-    // k_layer, PERS) - no launch edges, no wait for the slowest of all workgroups, no grid barrier.  Needs every workgroup on
-    // its own CU (1 per CU at 152 KiB of LDS) and the layer count the kernel is compiled for.  DC_NO_PERSIST=1: per-layer
-    // launches (read per call: the tests toggle it).
-    const bool persistent = !getenv("DC_NO_PERSIST") && chunks == 1 && wgr && nwg <= s->num_cu && nwg <= 4096 && L == DC_PERS_LAYERS &&
-                            nl_run == L && s->dbg_stage == 0 && !ablate && !want_stamps && s->dbg_first < 0;
-    if (persistent) {
-        s->pers_used = true;
-        LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, 0, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
-                                        s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src, s->d_snaps,
-                                        M, T, G, B, 0, nullptr, L, rec_stride, s->d_flags, s->d_gerr, iter_base));
-        return DC_OK;
-    }
     for (int l = s->dbg_first >= 0 ? s->dbg_first : 0; l < nl_run; ++l) {
-        if (l > 0 && l % lpc == 0) { int rc = film_chunk(l / lpc); if (rc) return rc; }
-        const int dbg = ((l == nl_run - 1) ? s->dbg_stage : 0) | ablate;
+        const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
-        LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, e_for_layer(l), NTe, s->d_a_sa, s->d_a_ca, s->d_recs,
+        LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src,
-                                        s->d_snaps, M, T, G, B, dbg, ((l == 3 || l == 4) && want_stamps) ? s->d_stamps : nullptr, l + 1, rec_stride,
-                                        s->d_flags, s->d_gerr, iter_base));
+                                        s->d_snaps, M, T, G, B, dbg, ((l == 3 || l == 4) && want_stamps) ? s->d_stamps : nullptr, rec_stride,
+                                        iter_base));
     }
     return DC_OK;
 }
@@ -804,18 +761,6 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     }
     HIP_TRY(hipMemsetAsync(s->d_iter, 0, 16, st));
     HIP_TRY(hipMemcpyAsync(s->d_x, d_noise, MP * 4, hipMemcpyDeviceToDevice, st));
-    if (s->pers_used) {       // only the opt-in persistent layer form can raise the grid-barrier flag
-        int gerr = 0;
-        HIP_TRY(hipMemcpyAsync(&gerr, s->d_gerr, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        s->pers_used = false;
-        if (gerr) {
-            HIP_TRY(hipMemset(s->d_gerr, 0, 4));
-            return fail(DC_ERR_HIP, "an earlier persistent layer launch timed out waiting for its neighbours' progress flags (workgroups "
-                                    "not co-resident?); its results were invalid - set DC_NO_PERSIST=1 to use per-layer launches");
-        }
-    }
-
     const bool no_graph = getenv("DC_DISABLE_GRAPH") != nullptr;
     if (profile || no_graph) {
         s->prof.on = profile;
@@ -952,7 +897,7 @@ void dc_sampler_destroy(dc_sampler* s) {
     void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_y, s->d_mean, s->d_rstd, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
                     s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t, s->d_coef_of_iter,
-                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_flags, s->d_gerr, s->d_film_rate};
+                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate};
     for (void* p : ptrs)
         if (p) hipFree(p);
     dc_music_destroy(s->music);

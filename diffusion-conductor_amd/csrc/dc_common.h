@@ -19,7 +19,6 @@
 #define DC_C 64         // music feature channels
 #define DC_PMAX 32      // input_feats padded to one MFMA tile
 #define DC_MAX_LAYERS 16
-#define DC_PERS_LAYERS 8  // the persistent layer kernel is compiled for exactly this many layers (the reference's default)
 #define DC_FILM_TILES_PER_BLOCK 8   // 256 FiLM outputs = 4 scale tiles + 4 shift tiles
 #define DC_KS_E (DC_E / 16)         // 32 k-steps of 16 over the 512-wide embedding
 
@@ -56,39 +55,8 @@ struct DcLayer {
     const float *ca_bk, *ca_bv;                // plain [128]
 };
 
-// ---- fused layer kernel (dc_fused.hip): per layer ONE stream of 16-KiB chunks (16 fragments each, consumption order) and
-// one 8-KiB block of fp32 constants.  Chunk indices inside a layer's stream:
-#define DCF_CH_F0 0      // FiLM block 3l+0: 16 chunks; chunk kt = fragments [tile it 0..7 (G'0,H'0,G'1,H'1,..)][s 0..1], natural-k pack,
-                         //   element j of lane (i, hh) = W[32 it + i][32 kt + 16 s + 8 hh + j]
-#define DCF_CH_Q 16      // sa query image by output-tile pairs: chunk 0 = tiles 0,1, chunk 1 = tiles 2,3; fragment [kt][ot2][s] (chained k order)
-#define DCF_CH_O 18      // sa out-projection image
-#define DCF_CH_F1 20
-#define DCF_CH_CQ 36
-#define DCF_CH_CO 38
-#define DCF_CH_F2 40
-#define DCF_CH_FFN 56    // W1 (16 fragments) | W2 (16 fragments)
-#define DCF_CH_FO 58
-#define DCF_CH_NEXT 60   // next layer's key image (2 chunks) and value image (2); last layer: `out` image (8 hi + 8 lo fragments)
-#define DCF_NCHUNK 64
-// constants block (floats): FiLM accumulator initial values as ftvec [3 blocks][8 tiles][2][16], then the biases
-#define DCF_C_FILM 0
-#define DCF_C_BQ_SA 768      // ftvec[4]
-#define DCF_C_BO_SA 896
-#define DCF_C_BQ_CA 1024
-#define DCF_C_BO_CA 1152
-#define DCF_C_B1 1280        // ftvec[2]
-#define DCF_C_B2 1344        // ftvec[4]
-#define DCF_C_BO_FFN 1472
-#define DCF_C_BK 1600        // plain[128]: next layer's key bias   (last layer: `out` bias as ftvec[1])
-#define DCF_C_BV 1728        // plain[128]
-#define DCF_C_FLOATS 2048
-
 struct DcModel {
     DcLayer layer[DC_MAX_LAYERS];
-    const void* fl_stream[DC_MAX_LAYERS];    // fused path: weight stream of layer l (nullptr in the split precision modes)
-    const float* fl_consts[DC_MAX_LAYERS];   // fused path: constants block of layer l
-    const void* fe_stream;                   // step prologue: joint_embed image | layer 0 key image (2 chunks) | value image (2)
-    const float* fe_consts;                  // joint_embed bias ftvec[4] | bk plain[128] | bv plain[128]  (512 floats)
     const bf16x8* img_je;    // joint_embed: chained pack OT=4 KT=1 (8 frags/half, always used split) + bias ftvec[4]
     const float* seq_emb;    // row-major [num_frames][128]
     const bf16x8* img_out;   // out: chained pack OT=1 KT=4 (8 frags/half, always used split) + bias ftvec[1]

@@ -576,59 +576,7 @@ DEV void partial_tile(const f32x16& K, const f32x16& V, const RowRange& rr, floa
     keep = keep_head_block(P, cx.c);
 }
 
-// ---- records that cross workgroups INSIDE one launch (persistent layer kernel): every byte is stored and loaded `sc1`
-// (write-through to / read from the memory side, past the per-XCD L2s), the producer's waves wait for their stores, and one
-// lane publishes a per-unit flag; the consumer polls the flags with sc1 loads (MI355X_MICROARCH.md, cross-workgroup hand-offs,
-// first row of the sc1 table).  SC1 = false: plain accesses (records handed over at a kernel boundary).
-template <bool SC1>
-DEV float ld_rec(const float* p) {
-    if constexpr (SC1)
-        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-        return *p;
-}
-template <bool SC1>
-DEV void st_rec(float* p, float v) {
-    if constexpr (SC1)
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-        *p = v;
-}
-// 32-byte block as two 16-byte halves (kept as two 4-register values: assembled into one 8-register tuple, every sc1
-// load needed a copy and the combine's nine blocks in flight spilled); the sc1 loads are not tracked by the compiler: the
-// caller waits (vmcnt) before use
-struct Rec8 {
-    f32x4 a, b;
-    DEV float operator[](int j) const { return j < 4 ? a[j] : b[j - 4]; }
-};
-template <bool SC1>
-DEV Rec8 ld_rec8(const f32x8* p) {
-    Rec8 v;
-    if constexpr (SC1) {
-        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1" : "=&v"(v.a), "=&v"(v.b) : "v"(p) : "memory");
-    } else {
-        const f32x4* q = reinterpret_cast<const f32x4*>(p);
-        v.a = q[0];
-        v.b = q[1];
-    }
-    return v;
-}
-template <bool SC1>
-DEV void st_rec8(f32x8* p, const f32x8& v) {
-    if constexpr (SC1) {
-        f32x4 a, b;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a[i] = v[i];
-            b[i] = v[4 + i];
-        }
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(p), "v"(a), "v"(b) : "memory");
-    } else {
-        *p = v;
-    }
-}
 // after the barrier that follows the last partial_tile: wave w sums tile oc = w & 3 of slot w >> 2 over the waves
-template <bool SC1 = false>
 DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8* pst, const f32x8* xp, const float* ss,
                          int wave, int lane, int ub0, int G, int M, int T, int wg) {
     const int oc = wave & 3, sl = wave >> 2, c = lane & 31;
@@ -658,15 +606,15 @@ DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8*
     }
     float* R = recs + ((size_t)wg * 2 + sl) * DC_REC_FLOATS;
     if (lane < 32) {
-        st_rec<SC1>(R + 32 * oc + c, wg_colmax(mx, oc, sl, c));
-        st_rec<SC1>(R + 128 + 32 * oc + c, ssum);
+        R[32 * oc + c] = wg_colmax(mx, oc, sl, c);
+        R[128 + 32 * oc + c] = ssum;
     }
-    st_rec8<SC1>(reinterpret_cast<f32x8*>(R + 256) + oc * 64 + lane, acc);
+    reinterpret_cast<f32x8*>(R + 256)[oc * 64 + lane] = acc;
 }
 // The workgroup's own combine (512 threads): attention operand fragments A[d][l] of clips ub0, ub0+1 from the unit
 // records of the previous kernel -> af [2 clips][8 frags][64 lanes] in LDS (the 8 hi fragments k_attn_combine makes).
 // scratch (LDS): w [2][NU][128] floats, z [2][128] floats.  Summation order is fixed.
-template <class T16, bool SC1 = false>
+template <class T16>
 DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scratch, int ub0, int B, int M, int T, int tid, int wg,
                          unsigned long long* st = nullptr) {
 #define CSTAMP(k) do { if (st && (tid & 63) == 0) st[(tid >> 6) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -694,15 +642,15 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
         const float* R = rec_of(bav, min(a_lo + k, a_hi));
-        mr[k] = ld_rec<SC1>(R + f);
-        sr[k] = ld_rec<SC1>(R + 128 + f);
+        mr[k] = R[f];
+        sr[k] = R[128 + f];
     }
     const int bv = live ? b : ub0;
     const int v_lo = (bv * T) / 256, v_hi = (min((bv + 1) * T, M) - 1) / 256;
-    Rec8 pre[PRE];
+    f32x8 pre[PRE];
     if (live) {                      // wave-uniform (ci is the wave's half of the workgroup): idle halves issue nothing
 #pragma unroll
-        for (int k = 0; k < PRE; ++k) pre[k] = ld_rec8<SC1>(reinterpret_cast<const f32x8*>(rec_of(bv, min(v_lo + k, v_hi)) + 256) + oc * 64 + ln);
+        for (int k = 0; k < PRE; ++k) pre[k] = reinterpret_cast<const f32x8*>(rec_of(bv, min(v_lo + k, v_hi)) + 256)[oc * 64 + ln];
     }
     CSTAMP(22);
     if (tid < 256) {                              // phase A: per feature f of clip ca: m*, weights, normaliser
@@ -715,7 +663,7 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
             if (sr[k] > 0.f) mstar = fmaxf(mstar, mr[k]);
         for (int k = PRE; k < na; ++k) {          // clips longer than 9 workgroups (T > 2048)
             const float* R = rec_of(ba, a_lo + k);
-            if (ld_rec<SC1>(R + 128 + f) > 0.f) mstar = fmaxf(mstar, ld_rec<SC1>(R + f));
+            if (R[128 + f] > 0.f) mstar = fmaxf(mstar, R[f]);
         }
         float z = 0.f;
 #pragma unroll
@@ -726,15 +674,14 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
         }
         for (int k = PRE; k < na; ++k) {
             const float* R = rec_of(ba, a_lo + k);
-            const float su = ld_rec<SC1>(R + 128 + f);
-            const float ww = su > 0.f ? exp2f_fast(ld_rec<SC1>(R + f) - mstar) : 0.f;
+            const float su = R[128 + f];
+            const float ww = su > 0.f ? exp2f_fast(R[f] - mstar) : 0.f;
             wsc[(ca * NU + k) * 128 + f] = ww;
             z += ww * su;
         }
         zsc[ca * 128 + f] = z;
     }
     CSTAMP(23);
-    if constexpr (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the untracked sc1 block loads have landed
     __syncthreads();
     CSTAMP(24);
     float acc[8];
@@ -758,8 +705,7 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], pre[k][j], acc[j]);
         }
     for (int k = PRE; k < nu; ++k) {
-        const Rec8 pv = ld_rec8<SC1>(reinterpret_cast<const f32x8*>(rec_of(b, u_lo + k) + 256) + oc * 64 + ln);
-        if constexpr (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const f32x8 pv = reinterpret_cast<const f32x8*>(rec_of(b, u_lo + k) + 256)[oc * 64 + ln];
         float w8[8];
         wrow(wsc + (ci * NU + k) * 128, w8);
 #pragma unroll
@@ -781,33 +727,6 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
     af[(ci * 8 + oc * 2 + (s ^ 1)) * 64 + ln] = zero;
 }
 
-
-// Persistent layer kernel: per-unit progress flags instead of a grid barrier.  A workgroup publishes flags[unit] = layer + 1
-// once its record of that layer is stored (sc1 stores, every storing wave waited, workgroup barrier, then ONE sc1 flag store);
-// before combining, a workgroup waits until the units that overlap its <= 2 clips have published the layer it needs.  One
-// wave polls (a lane per unit, sc1 loads); the spin is bounded: a workgroup that never sees its neighbours arrive raises *err
-// and goes on (wrong results, reported by the host) instead of hanging the device.  Needs every workgroup co-resident.
-DEV void unit_publish(unsigned* flags, int unit, unsigned value) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's record stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flags + unit, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-DEV void units_wait(const unsigned* flags, int u_lo, int u_hi, unsigned target, int* err) {
-    if (threadIdx.x < 64) {
-        const int u = min(u_lo + (int)threadIdx.x, u_hi);
-        unsigned spins = 0;
-        for (;;) {
-            const unsigned v = __hip_atomic_load(flags + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__builtin_amdgcn_ballot_w64(v < target) == 0) break;
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22)) {
-                *err = 1;
-                break;
-            }
-        }
-    }
-    __syncthreads();
-}
 
 }  // namespace dc
 using namespace dc;
@@ -831,10 +750,10 @@ DEV void stage_frags(const void* __restrict__ src, char* dst, int nfrags, int wa
     const bf16x8* s = reinterpret_cast<const bf16x8*>(src);
     for (int f = wave; f < nfrags; f += NW) lds_dma16(s + (size_t)f * 64 + lane, dst + f * 1024);
 }
-DEV void stage_sync(int abl = 0) {
+DEV void stage_sync() {
     __builtin_amdgcn_sched_barrier(0);           // stages do not interleave: keeps each stage's live set separate
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(abl & 0x1000)) __syncthreads();        // 0x1000: timing experiment only (results are garbage)
+    __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -977,19 +896,14 @@ DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shif
 // E tiles come straight from global memory (Eg: this block's 8 tiles for this group).
 template <class T16, bool SPLIT>
 DEV void styl_accumulate(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd, float shift, const f16x8* __restrict__ Eg,
-                         const float* bo, const v8<T16>* w, int lane, int hh, int abl) {
+                         const float* bo, const v8<T16>* w, int lane, int hh) {
     XFrag<T16, SPLIT> zf[4];
     {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             f16x16 gp, hp;
-            if (abl & 0x100) {            // timing experiment: no FiLM tile loads
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gp[r] = hp[r] = (_Float16)0.f;
-            } else {
-                gp = load_etile(Eg + kt * 128 + lane);
-                hp = load_etile(Eg + (4 + kt) * 128 + lane);
-            }
+            gp = load_etile(Eg + kt * 128 + lane);
+            hp = load_etile(Eg + (4 + kt) * 128 + lane);
             styl_tile<T16, SPLIT, ytile<SPLIT>>(zf[kt], y[kt], rstd, shift, gp, hp);
         }
     }

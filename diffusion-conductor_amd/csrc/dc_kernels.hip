@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void k_film_gemm(const v8<T16>* __restrict__ W
 }
 
 
-// Work shares of the persistent FiLM GEMMs: every wave derives the same integer boundaries (see k_film_gemm2).
+// Work shares of the persistent FiLM GEMM: every wave derives the same integer boundaries (see k_film_gemm3).
 DEV void film_shares(int& u0, int& u1, long long nunit, const float* __restrict__ rate_in, int lane) {
     const int nw = gridDim.x, b = blockIdx.x;
     float xs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // lane i covers workgroups i, i + 64, ...: all on XCD i & 7
@@ -453,235 +453,13 @@ DEV void film_shares(int& u0, int& u1, long long nunit, const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------
-// FiLM GEMM v2 (non-split formats): S-stationary, persistent.  A workgroup = 8 waves works on 4 token groups (128 tokens):
-// its operand slab S[4 g][32 ks] (128 KiB) is copied once into LDS by LDS-DMA and stays there while the
-// waves sweep all 3L*4*... feature-tile PAIRS (scale tile, shift tile): wave w takes pairs w, w+8, ...
-// Weight fragments stream L2 -> registers through a PF-deep software prefetch ring (each fragment is used
-// by exactly one wave, so LDS staging would buy nothing); there is no barrier in the sweep.
-// Per k-step and wave: 2 weight loads + 4 LDS reads feed 8 MFMAs (accumulators 2 x 4 tiles = 128 VGPRs).
-// ------------------------------------------------------------------------------------
-template <class T16>
-__global__ __launch_bounds__(512, 2) void k_film_gemm2(const v8<T16>* __restrict__ W, const float* __restrict__ bias_ft,
-                                                       const v8<T16>* __restrict__ S, f16x16* __restrict__ E, int G, int NT, int round0,
-                                                       int nround, const float* __restrict__ pp, const float* __restrict__ temb,
-                                                       const int* __restrict__ t_clip, int T, int B, int abl,
-                                                       unsigned long long* __restrict__ clk, const float* __restrict__ rate_in,
-                                                       float* __restrict__ rate_out, const int* __restrict__ iter_base) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    using OP = v8<T16>;
-    constexpr int PF = 4;       // measured: 8 (with the 256-register budget it needs) is 25 % slower
-    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
-    // diagnostic (clk == nullptr normally): core-clock and 100-MHz stamps around one workgroup's whole sweep give the
-    // clock the chip actually holds under this kernel (MI355X_MICROARCH.md, DVFS give-back item 6)
-    if (clk && blockIdx.x == 5 && threadIdx.x == 0) {
-        clk[0] = __builtin_amdgcn_s_memtime();
-        clk[1] = __builtin_amdgcn_s_memrealtime();
-    }
-    // ... and for every workgroup (slots 1036.. relative to clk = stamps + 252): clock and finish time per XCD
-    if (clk && threadIdx.x == 0 && blockIdx.x < 256) {
-        clk[1036 + blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
-        clk[1036 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-    }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int hh = lane >> 5;
-    const OP* slab = reinterpret_cast<const OP*>(lds);
-    // Persistent workgroups: the work is (token block of 4 groups) x (round of 8 feature-tile pairs, one pair per
-    // wave); each workgroup owns a contiguous, equal share of those units so that all CUs finish together, and
-    // reloads its slab only when it crosses into the next token block.
-    // this launch covers rounds [round0, round0 + nround) of the NT / 16 rounds of 8 feature-tile pairs
-    const int nblk = (G + 3) / 4;
-    const long long nunit = (long long)nblk * nround;
-    // (measured alternatives: whole token blocks per workgroup sweeping the weight rounds in lock-step for L2 locality -
-    // 5 % faster per sweep, but 450 blocks on 256 CUs need 2 full sweeps instead of 1.76; and a balanced lock-step
-    // form, 7-8 groups per workgroup as a 4-group + 3-group sweep - fabric re-fetches of the weights gone, yet 2 %
-    // slower overall; a single-wave-per-SIMD form - 4 waves, 2 pairs x 4 groups each, the 256 accumulator registers in
-    // AGPRs, half the LDS reads per MFMA - ran 33 % slower: two waves per SIMD hide each other's waits far better than
-    // a deeper prefetch ring does.)
-    // Shares: equal on the first launch, then proportional to the speed (units per 100-MHz tick, smoothed) that the
-    // workgroups of each XCD measured in the previous launches.  The XCDs of one MI355X hold clocks 10-12 % apart under
-    // this kernel, and with equal shares the slowest XCD's workgroups finish up to 30 us after the fastest's.  Only the
-    // per-XCD mean is used: a single workgroup's speed depends on how many slab fills its range happens to contain, and
-    // feeding that back makes the boundaries oscillate.  The partition does not change any result (a unit's tiles do not
-    // depend on who computes them).  Every wave derives the same integer boundaries.
-    int u0, u1;
-    film_shares(u0, u1, nunit, rate_in, lane);
-    int cur_blk = -1;
-    // diagnostic: where a slab fill's time goes (summed over this workgroup's fills, wave 0): wait for the slowest wave of the
-    // previous slab | SiLU + slab writes + second half | last loads + closing barrier
-    const bool ftime = clk && blockIdx.x == 5 && threadIdx.x == 0;
-    unsigned long long fill_t[3] = {0, 0, 0}, fill_n = 0;
-    OP a0[PF], a1[PF];
-    // abl & 1 (timing experiment, garbage results): every round reads the same 8 tile pairs - weights always cache-resident
-    auto wbase = [&](int u) { return W + (size_t)(2 * ((abl & 1 ? 0 : (round0 + u % nround)) * 8 + wave)) * DC_KS_E * 64 + lane; };
-    if (u0 < u1) {
-        const OP* w0 = wbase(u0);
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            a0[i] = w0[i * 64];
-            a1[i] = w0[(DC_KS_E + i) * 64];
-        }
-    }
-    for (int u = u0; u < u1; ++u) {
-        const int tb = u / nround, p = (round0 + u % nround) * 8 + wave;
-        const int g0 = tb * 4;
-        if (tb != cur_blk) {
-            const unsigned long long tf0 = ftime ? __builtin_amdgcn_s_memrealtime() : 0;
-            unsigned long long tf1 = tf0;
-            // slab: frag (g, ks) at [(g*32 + ks)]; groups past the end alias the last one (their stores are skipped)
-            if (abl & 8) {
-                __syncthreads();                                  // timing experiment: no slab fill at all
-            } else if (pp) {
-                // fused operand production (was k_silu_emb): S = SiLU(temb[t_clip] + linear(xf_proj)) (transformer.py:73-74,482)
-                // straight from the fp32 fragment image into the slab - saves the 16-bit image's HBM round trip
-                v8<T16>* slab_w = reinterpret_cast<v8<T16>*>(lds);
-                // a wave fills fragments f = wave + 8i, i < 16 (group i >> 2, k-step (wave + 8i) & 31).  The loads of 8 fragments
-                // are issued before the first SiLU: one by one (load, SiLU, write) the fill exposed 16 HBM latencies per slab
-                // = 16 % of the kernel.  The timestep rows of the four groups are looked up first, so that the only dependent
-                // load chain is t_clip -> temb once per slab, and the first half's loads are in flight while the workgroup
-                // waits for its slowest wave to leave the previous slab.
-                const float* trow[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int gg = min(g0 + g, G - 1);
-                    const int b = min((gg * 32 + (lane & 31)) / T, B - 1);
-                    // graph-captured loop: one timestep for all clips, t_clip = this step's slot of the iteration table and
-                    // *iter_base = the iteration at which the graph replay began (no per-step bookkeeping launch)
-                    trow[g] = temb + (size_t)t_clip[iter_base ? *iter_base : b] * 512 + 8 * (lane >> 5);
-                }
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    f32x8 pv[8], tv[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int f = wave + 8 * (8 * half + i);
-                        const int gg = min(g0 + 2 * half + (i >> 2), G - 1), ks = f & 31;
-                        pv[i] = ld_pp(pp, (size_t)gg * DC_KS_E + ks, lane);
-                        tv[i] = *reinterpret_cast<const f32x8*>(trow[2 * half + (i >> 2)] + 16 * ks);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (half == 0) {
-                        __syncthreads();               // everyone is done with the previous slab
-                        if (ftime) tf1 = __builtin_amdgcn_s_memrealtime();
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int f = wave + 8 * (8 * half + i);
-                        v8<T16> hi;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const f32x2 z = silu_pair(pv[i][2 * j] + tv[i][2 * j], pv[i][2 * j + 1] + tv[i][2 * j + 1]);
-                            hi[2 * j] = (T16)z.x;
-                            hi[2 * j + 1] = (T16)z.y;
-                        }
-                        slab_w[f * 64 + lane] = hi;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                __syncthreads();                                  // everyone is done with the previous slab
-                for (int f = wave; f < 4 * DC_KS_E; f += 8) {
-                    const int gg = min(g0 + (f >> 5), G - 1);
-                    lds_dma16(S + ((size_t)gg * DC_KS_E + (f & 31)) * 64 + lane, lds + f * 1024);
-                }
-            }
-            const unsigned long long tf2 = ftime ? __builtin_amdgcn_s_memrealtime() : 0;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (ftime) {
-                const unsigned long long tf3 = __builtin_amdgcn_s_memrealtime();
-                fill_t[0] += tf1 - tf0;
-                fill_t[1] += tf2 - tf1;
-                fill_t[2] += tf3 - tf2;
-                ++fill_n;
-            }
-            cur_blk = tb;
-        }
-        const OP* w0 = wbase(u);                                  // scale tile of the pair; the shift tile follows
-        const OP* wn = wbase(u + 1 < u1 ? u + 1 : u);             // next unit's pair (prefetch target)
-        f32x16 acc[2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const f32x16 c = ld_ft(bias_ft, 2 * p + i, hh);      // folded constants (see the header comment)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[i][g] = c;
-        }
-        // slab operand fragments are read one k-step ahead (bA/bB alternate), weight fragments PF k-steps ahead
-        OP bA[4], bB[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bA[g] = slab[(g * DC_KS_E) * 64 + lane];
-#pragma unroll 1
-        for (int ks0 = 0; ks0 < DC_KS_E; ks0 += PF) {
-            const bool tail = ks0 + PF >= DC_KS_E;                          // ring rolls over into the next pair
-            const OP* wsrc = tail ? wn + (size_t)(ks0 + PF - DC_KS_E) * 64 : w0 + (size_t)(ks0 + PF) * 64;
-#pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                const int ksn = (ks0 + q + 1) & (DC_KS_E - 1);              // next k-step (wraps harmlessly at the end)
-                if ((q & 1) == 0) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) bB[g] = slab[(g * DC_KS_E + ((abl & 2) ? 0 : ksn)) * 64 + lane];
-                    // (hipcc sinks these reads behind the 7th MFMA and reuses the registers; fencing them up here, one whole
-                    //  k-step ahead in distinct registers, measured 4 % slower)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        acc[0][g] = mfma(a0[q], bA[g], acc[0][g]);
-                        acc[1][g] = mfma(a1[q], bA[g], acc[1][g]);
-                    }
-                } else {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) bA[g] = slab[(g * DC_KS_E + ((abl & 2) ? 0 : ksn)) * 64 + lane];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        acc[0][g] = mfma(a0[q], bB[g], acc[0][g]);
-                        acc[1][g] = mfma(a1[q], bB[g], acc[1][g]);
-                    }
-                }
-                // refill this ring slot for k-step +PF right after its last use; the fences keep the loads here
-                // (hipcc otherwise sinks all of them to the end of the body and waits vmcnt(0) on the spot)
-                __builtin_amdgcn_sched_barrier(0);
-                a0[q] = wsrc[q * 64];
-                a1[q] = wsrc[(DC_KS_E + q) * 64];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // epilogue: fp16, store (tile p of the interleaved order = features 32t.. of block blk)
-        const int blk = p >> 2, t = p & 3;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g0 + g >= G) continue;
-            f16x16 og, oh;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                og[r] = (_Float16)acc[0][g][r];
-                oh[r] = (_Float16)acc[1][g][r];
-            }
-            if (abl & 4) continue;                                  // timing experiment: no output stores
-            store_etile(E, (size_t)(g0 + g) * NT + blk * 8 + t, lane, og);
-            store_etile(E, (size_t)(g0 + g) * NT + blk * 8 + 4 + t, lane, oh);
-        }
-    }
-    if (clk && blockIdx.x == 5 && threadIdx.x == 0) {
-        clk[2] = __builtin_amdgcn_s_memtime();
-        clk[3] = __builtin_amdgcn_s_memrealtime();
-        clk[1036 + 1024 + 256 + 0] = fill_t[0];
-        clk[1036 + 1024 + 256 + 1] = fill_t[1];
-        clk[1036 + 1024 + 256 + 2] = fill_t[2];
-        clk[1036 + 1024 + 256 + 3] = fill_n;
-    }
-    if (clk && threadIdx.x == 0 && blockIdx.x < 256) {
-        clk[1036 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime();
-        clk[1036 + blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
-        clk[1036 + 1024 + blockIdx.x] = (unsigned long long)(u1 - u0);
-    }
-    if (rate_out && threadIdx.x == 0) {
-        const float ticks = (float)(long long)(__builtin_amdgcn_s_memrealtime() - t_begin);
-        const float old = rate_in ? rate_in[blockIdx.x] : 0.f;
-        const float now = (u1 > u0 && ticks > 0.f) ? (float)(u1 - u0) / ticks : 0.f;
-        rate_out[blockIdx.x] = now > 0.f ? (old > 0.f ? 0.5f * old + 0.5f * now : now) : old;
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// FiLM GEMM v3: the same S-stationary persistent schedule as v2 on v_mfma_f32_16x16x32 instead of 32x32x16.
+// FiLM GEMM (non-split formats), S-stationary and persistent, on v_mfma_f32_16x16x32.  A workgroup = 8 waves works on 4 token
+// groups (128 tokens): their operand slab S = SiLU(temb[t] + linear(xf_proj)) (128 KiB as f16) is built once in LDS and stays
+// there while the waves sweep the feature-tile PAIRS (scale tile, shift tile); weight fragments stream L2 -> registers through
+// a PF-deep software prefetch ring (each fragment is used by exactly one wave, so LDS staging would buy nothing); there is
+// no barrier in the sweep.  Every workgroup owns a contiguous share of the (token block x round of 8 pairs) units, sized by
+// the per-XCD speeds measured in earlier launches (film_shares), and refills its slab when it crosses into the next block.
+// (The 32x32x16 form of the same schedule, k_film_gemm2 of round 1, measured 6.4 % slower: see DESIGN.md.)
 // Why: this kernel is power-limited (it holds 1.6-1.8 GHz), and on this part a loop of 16x16x32 MFMAs sustains a
 // higher clock than the same FLOPs issued as 32x32x16 (MI355X_MICROARCH.md, DVFS item 7).  Same bytes, same cycles:
 // per 32-deep k-step a wave feeds 32 MFMAs (4 weight fragments x 8 slab fragments) from 4 weight loads + 8 LDS reads.
@@ -704,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
 #ifndef DC_FILM3_PF
 #define DC_FILM3_PF 2
 #endif
-    constexpr int PF = DC_FILM3_PF;        // weight ring depth in 32-deep k-steps (2 = v2's 4 x 16)
+    constexpr int PF = DC_FILM3_PF;        // weight ring depth in 32-deep k-steps
     constexpr int KS = DC_E / 32;          // 16 k-steps
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     if (clk && blockIdx.x == 5 && threadIdx.x == 0) {
@@ -744,7 +522,7 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
         const bool next_seg = useg + nr < u1;                     // (its first round is round 0 of the next block)
         const int g0 = tb * 4;
         {
-            // slab fill (see k_film_gemm2): S = SiLU(temb[t] + linear(xf_proj)) from the fp32 fragment image, which is in
+            // slab fill: S = SiLU(temb[t] + linear(xf_proj)) (transformer.py:73-74,482) from the fp32 fragment image, which is in
             // the 32x32x16 operand order [g][ks16][2][64][4]: this lane's 8 values of (token, 32 ks32 + 8 (l >> 4) ..) are
             // the two 16-byte pieces of lane' = 32 ((l >> 4) & 1) + 16 tb16 + (l & 15) in fragment ks16 = 2 ks32 + (l >> 5)
             v8<T16>* slab_w = reinterpret_cast<v8<T16>*>(lds);
@@ -889,8 +667,7 @@ template <class T16, bool SPLIT, bool WGR, bool FROMH = false>
 __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
 void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /*[M][P]*/, float* __restrict__ hbuf,
                    float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G, int B,
-                   unsigned long long* __restrict__ clk /* diagnostic: 100-MHz stamps of one wave, or nullptr */, int l0 = 0,
-                   unsigned* __restrict__ flags = nullptr /* WGR: progress flag of this unit for the persistent layer kernel, reset here */) {
+                   unsigned long long* __restrict__ clk /* diagnostic: 100-MHz stamps of one wave, or nullptr */, int l0 = 0) {
     static_assert(!(FROMH && WGR), "the h-injection hook exists for the per-group-record form only");
     constexpr int NW = SPLIT ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;
@@ -902,7 +679,6 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
     using W = v8<T16>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wg = WGR ? wg_index() : (int)blockIdx.x;
-    if (WGR && flags && threadIdx.x == 0) flags[wg] = 0u;
     int g = wg * NW + wave;
     const bool active = g < G;
     if (!active) g = G - 1;
@@ -1057,22 +833,16 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
 // waves; each stage ends with vmcnt(0) + barrier.  All activations stay in registers, and the
 // residual stream h IS the accumulator of the three out-projections (h += W_o * a + b_o).
 // ------------------------------------------------------------------------------------
-// DBG = true builds the test-hook variant (early exits after a stage, ablation switches, stage stamps); the
+// DBG = true builds the test-hook variant (early exits after a block, leading blocks skipped); the
 // production instantiation has none of them - the extra exits alone cost 160 spilled registers.
-template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR, bool PERS>
+template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR>
 __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
 void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
              const v8<T16>* __restrict__ a_sa /*[B][16][64]*/, const v8<T16>* __restrict__ a_ca /*[L][B][16][64]*/,
              float* __restrict__ recs, const int* __restrict__ length, const float* __restrict__ xin,
              float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur, const int* __restrict__ snap_cur,
              float* __restrict__ snaps, int M, int T, int G, int B, int dbg,
-             unsigned long long* __restrict__ stamps, int l_end, size_t rec_stride, unsigned* __restrict__ flags,
-             int* __restrict__ gerr, const int* __restrict__ iter_base) {
-    // PERS (WGR only): all DC_PERS_LAYERS layers in one launch.  Between the layers a workgroup parks its residual stream in
-    // hbuf (own stores, own loads), publishes flags[unit] = layer + 1 behind its unit record (sc1 stores) and waits only for
-    // the units that overlap its own clips (units_wait) - no grid-wide barrier, no L2 write-back / invalidate.  The unit
-    // records alternate between two buffers (recs + parity * rec_stride): a workgroup can only be one layer ahead of the
-    // units it shares a clip with, so a record is never overwritten while a neighbour still combines it.
+             unsigned long long* __restrict__ stamps, size_t rec_stride, const int* __restrict__ iter_base) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int NW = SPLIT ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;            // operand images per matrix (hi [+ lo])
@@ -1100,15 +870,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         const int g0 = min((int)((WGR ? wg_index() : (int)blockIdx.x) * NW + (threadIdx.x >> 6)), G - 1);
         load_h(h, hbuf, g0, threadIdx.x & 63);      // in flight across the first prologue
     }
-  // PERS: all DC_PERS_LAYERS layers in this launch, as straight-line code (the loop is unrolled at compile time: as a run-time
-  // loop the body's address arithmetic stayed live next to the loop-carried residual stream and spilled ~85 VGPRs)
-  constexpr int NLP = PERS ? DC_PERS_LAYERS : 1;
-#pragma unroll
-  for (int li = 0; li < NLP; ++li, ++l) {
-    // Everything derived from the thread index is re-derived per layer from an opaque copy: hoisted out of the loop
-    // these values would stay live across the whole body next to the loop-carried residual stream (it spilled ~100 VGPRs).
-    int tid_ = threadIdx.x;
-    asm volatile("" : "+v"(tid_));
+  {
+    const int tid_ = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), lane = tid_ & 63;
     const int wg = WGR ? wg_index() : (int)blockIdx.x;
     int g = wg * NW + wave;
@@ -1132,8 +895,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     };
     const W* af = reinterpret_cast<const W*>(lds + OFF_AF);
     const DcLayer& L = dm->layer[l];
-    const bool last = PERS ? li + 1 == NLP : l + 1 >= nl;
-    const bool more = PERS && li + 1 < NLP;      // the next layer runs in this launch (compile-time)
+    const bool last = l + 1 >= nl;
     const f16x8* Eg = reinterpret_cast<const f16x8*>(E) + ((size_t)g * NT + (size_t)l * 24) * 128;   // 3 blocks x 8 tiles
     const W* acl = a_ca + (size_t)l * B * 16 * 64;
     const float* recs_in = recs + (size_t)(l & 1) * rec_stride;
@@ -1142,19 +904,10 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(0);
     if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0 && l == 3) stamps[(threadIdx.x >> 6) * 32 + 26] = __builtin_amdgcn_s_memtime();
     DC_WGSTAMP(0);
-    if constexpr (PERS)
-        if (li > 0) load_h(h, hbuf, g, lane);           // parked by this wave at the previous layer's tail
     stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
-    if constexpr (WGR) {    // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
-        if constexpr (PERS) {
-            if (li > 0) {
-                const int ub1 = (min((wg + 1) * NW * 32, M) - 1) / T;
-                units_wait(flags, (ub0 * T) / (NW * 32), (min((ub1 + 1) * T, M) - 1) / (NW * 32), (unsigned)li, gerr);
-            }
-        }
-        wg_combine_attn<T16, PERS>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, M, T, tid_, wg,
-                                   (STAMP && stamps && blockIdx.x == 3 && l == 3) ? stamps : nullptr);
-    }
+    if constexpr (WGR)      // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
+        wg_combine_attn<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, M, T, tid_, wg,
+                             (STAMP && stamps && blockIdx.x == 3 && l == 3) ? stamps : nullptr);
     else if (wg_lds)
         stage_attn(a_sa);
     DC_STAMP(14);
@@ -1165,13 +918,13 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DC_STAMP(15);
-    stage_sync(DBG ? dbg : 0);
+    stage_sync();
     DC_STAMP(1);
 
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
     stage_frags<NW>(L.img_sa_o, buf1, NFW + 1, wave, lane);
     EPre ep;
-    if constexpr (use_ring) epre_load<DBG || PERS>(ep, Eg, lane);
+    if constexpr (use_ring) epre_load<DBG>(ep, Eg, lane);
     ytile<SPLIT> y[4];
     float y_rstd, y_shift;
     // test hook (DBG builds): (dbg >> 16) & 3 = number of leading blocks of the layer to skip (1: no self-attention,
@@ -1185,13 +938,13 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, a_sa + (size_t)cx.b0 * 16 * 64,
                                  a_sa + (size_t)cx.b1 * 16 * 64, cx);
     DC_STAMP(2);
-    stage_sync(DBG ? dbg : 0);
+    stage_sync();
     DC_STAMP(3);
     // ---- stage 2: SA stylization [buf1]; prefetch CA query -> buf0 (+ cross-attention frags)
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
         if (wg_lds) stage_attn(acl);
-        if (!(DBG && skip_blocks >= 1)) styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh, dbg);
+        if (!(DBG && skip_blocks >= 1)) styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh);
     } else {
         auto next2 = [&]() {
             stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
@@ -1206,11 +959,11 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     }
     if constexpr (DBG) if ((dbg & 0xff) == 1) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after self-attention
     DC_STAMP(4);
-    stage_sync(DBG ? dbg : 0);
+    stage_sync();
     DC_STAMP(5);
     // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
     stage_frags<NW>(L.img_ca_o, buf1, NFW + 1, wave, lane);
-    if constexpr (use_ring) epre_load<DBG || PERS>(ep, Eg + 8 * 128, lane);
+    if constexpr (use_ring) epre_load<DBG>(ep, Eg + 8 * 128, lane);
     if (DBG && skip_blocks >= 2) {
     } else if (wg_lds)
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (size_t)(cx.b0 - ub0) * 8 * 64,
@@ -1219,12 +972,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, acl + (size_t)cx.b0 * 16 * 64,
                                  acl + (size_t)cx.b1 * 16 * 64, cx);
     DC_STAMP(6);
-    stage_sync(DBG ? dbg : 0);
+    stage_sync();
     // ---- stage 4: CA stylization [buf1]; prefetch FFN W1|W2 (+ b1|b2) -> buf0
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
         stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
-        if (!(DBG && skip_blocks >= 2)) styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh, dbg);
+        if (!(DBG && skip_blocks >= 2)) styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh);
     } else {
         auto next4 = [&]() {
             stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
@@ -1239,11 +992,11 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     }
     if constexpr (DBG) if ((dbg & 0xff) == 2) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after cross-attention
     DC_STAMP(7);
-    stage_sync(DBG ? dbg : 0);
+    stage_sync();
     DC_STAMP(8);
     // ---- stage 5: FFN [buf0]; prefetch FFN out-proj -> buf1
     stage_frags<NW>(L.img_ffn_o, buf1, NFW + 1, wave, lane);
-    if constexpr (use_ring) epre_load<DBG || PERS>(ep, Eg + 16 * 128, lane);
+    if constexpr (use_ring) epre_load<DBG>(ep, Eg + 16 * 128, lane);
     {
         f32x16 u[2];
         {
@@ -1272,7 +1025,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         st.finish(y_rstd, y_shift);
     }
     DC_STAMP(9);
-    stage_sync(DBG ? dbg : 0);
+    stage_sync();
     // ---- stage 6: FFN stylization [buf1]; prefetch next layer's key projection (or the output projection) -> buf0
     {
         auto next_w = [&]() {
@@ -1283,14 +1036,14 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         };
         if constexpr (!use_ring) {
             next_w();
-            styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, c1, w1, lane, cx.hh, dbg);
+            styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, c1, w1, lane, cx.hh);
         } else {
             styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, next_w);
         }
     }
     if constexpr (DBG) if ((dbg & 0xff) == 3) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
     DC_STAMP(10);
-    stage_sync(DBG ? dbg : 0);
+    stage_sync();
     DC_STAMP(11);
 
     if (!last) {
@@ -1300,13 +1053,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         // youngest operations (the 16 dwordx4 stores of h) are outstanding means "the image has landed" while the
         // stores keep draining behind the K/V projections.
         __builtin_amdgcn_sched_barrier(0);
-        const bool st_h = active;                        // (the persistent form parks it here too: held through the record tail it spilled)
+        const bool st_h = active;
         if (st_h) store_h(h, hbuf, g, lane);
         __builtin_amdgcn_sched_barrier(0);
         XFrag<T16, SPLIT> nf[4];
         ln_frags<T16, SPLIT>(nf, h);
         DC_STAMP(19);
-        if constexpr (DBG) if (dbg & 0x400) return;      // timing experiment: no front stage
         if constexpr (WGR) {
             // Workgroup record in one pass over each image.  While the value image is still landing in buf1: keys of all
             // four feature tiles (pairs of MFMA chains), exponentiated against THIS WAVE's column maxima and kept as
@@ -1436,7 +1188,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             DC_STAMP(16);
             __syncthreads();
             DC_STAMP(17);
-            wg_write_record<PERS>(recs_out, mx, pst, xp, ss, wave, lane, ub0, G, M, T, wg);
+            wg_write_record(recs_out, mx, pst, xp, ss, wave, lane, ub0, G, M, T, wg);
         } else {
             f32x16 K[4];                  // keys from buf0 while the value image lands in buf1
 #pragma unroll
@@ -1469,10 +1221,6 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         DC_STAMP(13);
         if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0 && l == 3) stamps[(threadIdx.x >> 6) * 32 + 27] = __builtin_amdgcn_s_memtime();
         DC_WGSTAMP(1);
-        if (more) {
-            unit_publish(flags, wg, (unsigned)(li + 1));
-            continue;
-        }
         return;
     }
     // ---- output projection [buf0, split] + DDIM update
@@ -1513,7 +1261,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         }
     }
     return;
-  }   // layer loop
+  }
 }
 
 // ====================================================================================
@@ -1793,7 +1541,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
     full_attend<T16>(y, y_rstd, y_shift, h, reinterpret_cast<const W*>(L.img_sa_q), kv_cur + (size_t)cx.b * KT * 16 * 64, cx.nkt,
                      cx.g_lo * 32, key_lo, key_hi, q_pad, any_pad, lds, cx.active, wave, lane, cx.hh);
     load_h(h, hbuf, cx.g, lane);           // not kept live across the key loop
-    styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg, consts(L.img_sa_o), reinterpret_cast<const W*>(L.img_sa_o), lane, cx.hh, 0);
+    styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg, consts(L.img_sa_o), reinterpret_cast<const W*>(L.img_sa_o), lane, cx.hh);
     if (stop_after == 1) { store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok); return; }
     // ---- cross-attention (no mask, transformer.py:244-264)
     store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok);
@@ -1801,7 +1549,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
                      cx.nkt, cx.g_lo * 32, key_lo, key_hi, false, false, lds, cx.active, wave, lane, cx.hh);
     load_h(h, hbuf, cx.g, lane);
     styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg + 8 * 128, consts(L.img_ca_o), reinterpret_cast<const W*>(L.img_ca_o), lane,
-                                cx.hh, 0);
+                                cx.hh);
     if (stop_after == 2) { store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok); return; }
     // ---- FFN
     {
@@ -1835,7 +1583,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
         st.finish(y_rstd, y_shift);
     }
     styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg + 16 * 128, consts(L.img_ffn_o), reinterpret_cast<const W*>(L.img_ffn_o), lane,
-                                cx.hh, 0);
+                                cx.hh);
     if (!cx.active) return;
     if (!last || stop_after == 3) {
         store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok);
@@ -2052,21 +1800,6 @@ static void launch_film_t(hipStream_t st, const void* W, const float* bias_ft,
                                                                          (f16x16*)E, G, NT);
 }
 template <class T16>
-static hipError_t launch_film2_t(hipStream_t st, const void* W, const float* bias_ft,
-                                 const void* s_hi, void* E, int G, int NT, int round0, int nround, const float* pp, const float* temb,
-                                 const int* t_clip, int T, int B, unsigned long long* clk, const float* rate_in, float* rate_out,
-                                 const int* iter_base) {
-    const size_t shm = 4 * DC_KS_E * 1024;
-    static unsigned long long optin_done = 0;
-    if (hipError_t e = lds_optin((const void*)k_film_gemm2<T16>, (int)shm, optin_done)) return e;
-    const int ncu = cu_count();
-    const int nblk = (G + 3) / 4;
-    k_film_gemm2<T16><<<dim3(nblk < ncu ? nblk : ncu), dim3(512), shm, st>>>((const v8<T16>*)W, bias_ft,
-                                                                (const v8<T16>*)s_hi, (f16x16*)E, G, NT, round0, nround, pp, temb, t_clip, T, B,
-                                                                getenv("DC_FILM_ABL") ? atoi(getenv("DC_FILM_ABL")) : 0, clk, rate_in, rate_out, iter_base);
-    return hipGetLastError();
-}
-template <class T16>
 static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* bias16, void* E, int G, int NT, int round0, int nround,
                                  const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk,
                                  const float* rate_in, float* rate_out, const int* iter_base) {
@@ -2082,15 +1815,12 @@ static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* b
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
                                int nround, const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk,
                                const float* rate_in, float* rate_out, const int* iter_base, const void* W16, const float* bias16) {
-    static const bool use_v1 = getenv("DC_FILM_V1") != nullptr;
-    const bool mfma32 = getenv("DC_FILM_MFMA32") != nullptr;          // (read per call: A/B within one process)
-    if (!split && !use_v1 && pp && W16 && !mfma32)
+    // non-split formats with the fp32 emb image at hand: the S-stationary 16x16x32 kernel builds its operand itself; the split
+    // formats (and the test hooks, which read the 16-bit operand image back) use the plain tiled kernel on S_hi / S_lo
+    if (!split && pp && W16)
         return fmt == 1 ? launch_film3_t<_Float16>(st, W16, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base)
                         : launch_film3_t<__bf16>(st, W16, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base);
-    if (!split && !use_v1)
-        return fmt == 1 ? launch_film2_t<_Float16>(st, W, bias_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base)
-                        : launch_film2_t<__bf16>(st, W, bias_ft, s_hi, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base);
-    if (round0 != 0) return hipSuccess;        // the v1 / split kernels compute all rounds in their first launch
+    if (round0 != 0) return hipSuccess;        // the plain kernel computes all rounds in its first launch
     DISPATCH(fmt, split, (launch_film_t<T16, SP>(st, W, bias_ft, s_hi, s_lo, E, G, NT)));
     return LAUNCH_CHECK();
 }
@@ -2111,61 +1841,57 @@ hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcM
 
 template <class T16, bool SP, bool WGR>
 static hipError_t launch_embed_t(hipStream_t st, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
-                                 int M, int T, int G, int B, unsigned long long* clk, unsigned* flags) {
+                                 int M, int T, int G, int B, unsigned long long* clk) {
     constexpr int NW = SP ? 4 : 8;
     const size_t shm = WGR ? 8192 + 65536 + 8192 + 9 * 4 * 32 * 4 + 33 * 1024 : 0;
     if (WGR) {
         static unsigned long long optin_done = 0;
         if (hipError_t e = lds_optin((const void*)k_embed_front<T16, SP, WGR>, (int)shm, optin_done)) return e;
     }
-    k_embed_front<T16, SP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, B, clk, 0, flags);
+    k_embed_front<T16, SP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, B, clk);
     return hipGetLastError();
 }
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf,
-                                 float* recs, const int* length, int M, int T, int G, int B, unsigned long long* clk, unsigned* flags) {
+                                 float* recs, const int* length, int M, int T, int G, int B, unsigned long long* clk) {
     hipError_t e = hipSuccess;
     if (wgr && !split) {
-        e = fmt == 1 ? launch_embed_t<_Float16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, flags)
-                     : launch_embed_t<__bf16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, flags);
+        e = fmt == 1 ? launch_embed_t<_Float16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk)
+                     : launch_embed_t<__bf16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk);
         return e;
     }
-    DISPATCH(fmt, split, (e = launch_embed_t<T16, SP, false>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, nullptr)));
+    DISPATCH(fmt, split, (e = launch_embed_t<T16, SP, false>(st, dm, x, hbuf, recs, length, M, T, G, B, clk)));
     return e;
 }
 
-template <class T16, bool SP, bool DBG, bool STAMP, bool WGR, bool PERS = false>
+template <class T16, bool SP, bool DBG, bool STAMP, bool WGR>
 static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                                 int M, int T, int G, int B, int dbg, unsigned long long* stamps, int l_end, size_t rec_stride,
-                                 unsigned* flags, int* gerr, const int* iter_base) {
+                                 int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride,
+                                 const int* iter_base) {
     constexpr int NW = SP ? 4 : 8;
     // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
     const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
     static unsigned long long optin_done = 0;   // > 64 KiB of dynamic LDS needs the opt-in
-    if (hipError_t e = lds_optin((const void*)k_layer<T16, SP, DBG, STAMP, WGR, PERS>, (int)shm, optin_done)) return e;
-    k_layer<T16, SP, DBG, STAMP, WGR, PERS><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
+    if (hipError_t e = lds_optin((const void*)k_layer<T16, SP, DBG, STAMP, WGR>, (int)shm, optin_done)) return e;
+    k_layer<T16, SP, DBG, STAMP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
                        (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
-                       snaps, M, T, G, B, dbg, stamps, l_end, rec_stride, flags, gerr, iter_base);
+                       snaps, M, T, G, B, dbg, stamps, rec_stride, iter_base);
     return hipGetLastError();
 }
 
 hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                           int M, int T, int G, int B, int dbg, unsigned long long* stamps, int l_end, size_t rec_stride,
-                           unsigned* flags, int* gerr, const int* iter_base) {
+                           int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride, const int* iter_base) {
     hipError_t e = hipSuccess;
 #define LAYER_ARGS st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps, \
-                   l_end, rec_stride, flags, gerr, iter_base
+                   rec_stride, iter_base
     if (wgr && !split) {        // workgroup-level records + in-kernel combine (non-split formats, T >= 256)
         if (dbg != 0)
             e = fmt == 1 ? launch_layer_t<_Float16, false, true, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, true, false, true>(LAYER_ARGS);
-        else if (stamps != nullptr && l_end == l + 1)
+        else if (stamps != nullptr)
             e = fmt == 1 ? launch_layer_t<_Float16, false, false, true, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, false, true, true>(LAYER_ARGS);
-        else if (l_end > l + 1)       // persistent form: its own instantiation (loop-carried residual stream)
-            e = fmt == 1 ? launch_layer_t<_Float16, false, false, false, true, true>(LAYER_ARGS)
-                         : launch_layer_t<__bf16, false, false, false, true, true>(LAYER_ARGS);
         else
             e = fmt == 1 ? launch_layer_t<_Float16, false, false, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, false, false, true>(LAYER_ARGS);
         return e;

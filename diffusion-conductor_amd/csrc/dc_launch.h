@@ -29,23 +29,18 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
 // no dc_launch_attn_combine between the layers then)
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf, float* recs,
                                  const int* length, int M, int T, int G, int B,
-                                 unsigned long long* clk /* diagnostic stamps (8 slots) or nullptr */,
-                                 unsigned* flags = nullptr /* wgr: per-unit progress flags of the persistent layer kernel, reset here */);
+                                 unsigned long long* clk /* diagnostic stamps (8 slots) or nullptr */);
 // test hook: front half of layer l0 from the residual stream as it stands in hbuf (per-group records)
 hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcModel* dm, float* hbuf, float* recs, const int* length,
                                   int M, int T, int G, int B, int l0);
 hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                           int M, int T, int G, int B, int dbg, unsigned long long* stamps, int l_end, size_t rec_stride,
-                           unsigned* flags, int* gerr,
+                           int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride,
                            const int* iter_base /* captured loop: coef_cur / snap_cur = this step's slots of the per-iteration tables,
                                                    indexed by *iter_base; else nullptr (scalars prepared by k_begin_step) */);
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);
-// l == 0 and l_end == DC_PERS_LAYERS == num_layers (wgr only): ALL layers in ONE launch, synchronised through per-unit
-// progress flags (`flags`, one unsigned per 256-token unit, reset by dc_launch_embed_front) - the caller guarantees that all
-// ceil(G/8) workgroups are co-resident (<= CU count); rec_stride: floats between the two alternating unit-record buffers
-// (0 = single buffer, non-wgr); *gerr is raised if a workgroup's bounded wait for its neighbours ran out
+// rec_stride: floats between the two alternating unit-record buffers (0 = single buffer, non-wgr)
 
 // ---- no_eff variant (full T x T attention); non-split formats only.  KT = key tiles per clip array.
 hipError_t dc_launch_ca_kv(hipStream_t st, int fmt, const DcModel* dm, const void* nh_hi, const void* nh_lo, void* kv_ca,
@@ -59,14 +54,3 @@ hipError_t dc_launch_layer_full(hipStream_t st, int fmt, const DcModel* dm, int 
 
 // Savitzky-Golay smoothing along time of [B][T][P] fp32 (coef: hat matrix [win][win]); y != x
 hipError_t dc_launch_savgol(hipStream_t st, const float* x, float* y, const float* coef, int B, int T, int P, int win);
-
-// ---- fused path (dc_fused.hip): non-split formats, T >= dc_fused_unit_tokens(), <= dc_fused_max_units_per_clip() units per clip.
-// S = the f16/bf16 fragment image of SiLU(emb) that k_silu_emb writes ([G][32 ks][64][8]); recs: [2 parities][units][2][DC_REC_FLOATS]
-hipError_t dc_launch_fembed(hipStream_t st, int fmt, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
-                            int M, int T, int G, int B);
-hipError_t dc_launch_flayer(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* S, const void* a_ca, float* recs,
-                            const int* length, const float* xin, float* xout, int out_mode, const float* coef_cur,
-                            const int* snap_cur, float* snaps, int M, int T, int G, int B, int dbg, size_t rec_stride,
-                            const int* iter_base);
-int dc_fused_max_units_per_clip(void);
-int dc_fused_unit_tokens(void);

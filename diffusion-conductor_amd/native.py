@@ -35,10 +35,9 @@ class DcError(RuntimeError):
     pass
 
 
-SOURCES = ("dc_kernels.hip", "dc_fused.hip", "dc_api.hip", "dc_music.hip")
+SOURCES = ("dc_kernels.hip", "dc_api.hip", "dc_music.hip")
 HEADERS = ("dc_common.h", "dc_dev.h", "dc_launch.h", "dc_music.h")
-# the persistent layer kernel unrolls its 8-layer loop at compile time: far beyond clang's default size limit for `#pragma unroll`
-EXTRA_FLAGS = {"dc_kernels.hip": ["-mllvm", "-pragma-unroll-threshold=4000000"]}
+EXTRA_FLAGS = {}      # per-source compiler flags
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:

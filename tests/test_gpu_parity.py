@@ -143,40 +143,6 @@ def test_captured_loop_table_lookup_equals_begin_step_launches(models):
     assert sorted(a.keys()) == [0, 60, 99, 100] and all(torch.equal(a[k], b[k]) for k in a)
 
 
-def test_persistent_layer_kernel_equals_per_layer_launches(models):
-    """Default: all 8 layers in one launch, the workgroups synchronised through per-unit progress flags (needs one CU per
-    256-token workgroup); DC_NO_PERSIST=1: one launch per layer.  Same arithmetic in the same order: bit-identical, in the
-    captured graph and with eager launches, with clip edges inside workgroups and ragged lengths."""
-    xfp, xfo = xf_pair(3, 900, first=40)
-    noise = torch.from_numpy(batch_noise(3, 900, first=40))
-    a = _ddim(models["fp16"], 25, noise, xfp, xfo, [900, 512, 333])
-    os.environ["DC_DISABLE_GRAPH"] = "1"
-    try:
-        a2 = _ddim(models["fp16"], 25, noise, xfp, xfo, [900, 512, 333])
-        os.environ["DC_NO_PERSIST"] = "1"
-        b = _ddim(models["fp16"], 25, noise, xfp, xfo, [900, 512, 333])
-    finally:
-        del os.environ["DC_DISABLE_GRAPH"]
-        os.environ.pop("DC_NO_PERSIST", None)
-    assert torch.isfinite(a).all() and torch.equal(a, a2) and torch.equal(a, b)
-
-
-def test_persistent_layer_kernel_full_batch(models):
-    """bs=32 x 1800 (225 co-resident workgroups, 7-8 units per clip, every clip edge inside a workgroup): the persistent
-    form equals per-layer launches bit for bit on the whole batch."""
-    B, T = 32, 1800
-    xfp, xfo = xf_pair(B, T)
-    noise = torch.from_numpy(batch_noise(B, T))
-    a = _ddim(models["fp16"], 25, noise, xfp, xfo, [T - 13 * (b % 5) for b in range(B)])
-    os.environ["DC_NO_PERSIST"] = "1"
-    os.environ["DC_DISABLE_GRAPH"] = "1"
-    try:
-        b = _ddim(models["fp16"], 25, noise, xfp, xfo, [T - 13 * (b % 5) for b in range(B)])
-    finally:
-        del os.environ["DC_NO_PERSIST"], os.environ["DC_DISABLE_GRAPH"]
-    assert torch.isfinite(a).all() and torch.equal(a, b)
-
-
 def test_film_adaptive_shares_do_not_change_results(models):
     """The persistent FiLM GEMM sizes its workgroups' shares by the per-XCD speeds measured in earlier launches (>= 64
     workgroups); which workgroup computes a tile must not matter: bit-identical to equal shares (DC_FILM_STATIC=1) and
@@ -193,26 +159,6 @@ def test_film_adaptive_shares_do_not_change_results(models):
     finally:
         del os.environ["DC_FILM_STATIC"], os.environ["DC_DISABLE_GRAPH"]
     assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, a2)
-
-
-def test_film_gemm_mfma_shapes_agree(models):
-    """The FiLM GEMM runs on v_mfma_f32_16x16x32 (k_film_gemm3); DC_FILM_MFMA32=1 selects the 32x32x16 form (k_film_gemm2).
-    Same operands, different accumulation grouping: the two agree to fp32-accumulation noise on the fp16 E tiles, and both
-    meet the parity bound against the golden."""
-    g = golden("g6_variants.npz")
-    xfp, xfo = xf_pair(2, 900, first=10)
-    noise = torch.from_numpy(batch_noise(2, 900, first=10))
-    a = _ddim(models["fp16"], 50, noise, xfp, xfo, [900, 700])
-    os.environ["DC_FILM_MFMA32"] = "1"
-    os.environ["DC_DISABLE_GRAPH"] = "1"          # eager launches: the switch is read when a launch is enqueued
-    try:
-        b = _ddim(models["fp16"], 50, noise, xfp, xfo, [900, 700])
-    finally:
-        del os.environ["DC_FILM_MFMA32"], os.environ["DC_DISABLE_GRAPH"]
-    d = rel_l2(a, b.cpu().numpy())
-    eb = rel_l2(b, g["t900_x0"])
-    print(f"film gemm 16x16x32 vs 32x32x16: rel-L2 {d:.2e}; 32x32x16 vs golden {eb:.3e}")
-    assert d <= 2e-4 and eb <= TOL_PARITY
 
 
 def test_progressive_matches_fast_path(models):
