@@ -430,8 +430,13 @@ DEV void store_etile(f16x16* __restrict__ E, size_t tile, int lane, const f16x16
     }
     // written once and read by a later kernel: non-temporal stores keep the 708 MB per step from evicting the FiLM
     // weights (and later the layer kernels' own lines) from L2 - measured -1.8 % on the whole loop (tools/ab.sh)
+#ifdef DC_E_SC1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(lo8) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p + 64), "v"(hi8) : "memory");
+#else
     __builtin_nontemporal_store(lo8, p);
     __builtin_nontemporal_store(hi8, p + 64);
+#endif
 }
 DEV f16x16 load_etile(const f16x8* __restrict__ p /* tile base + lane; global or LDS */) {
     const f16x8 lo8 = p[0], hi8 = p[64];
@@ -467,7 +472,12 @@ DEV void store_h(const f32x16 (&h)[4], float* __restrict__ hbuf, int g, int lane
             f32x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = h[t][4 * q + i];
+#ifdef DC_H_SC1
+            // write-through: the 29 MB of residual stream are not left dirty in the L2s for the end-of-kernel write-back
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p + (t * 4 + q) * 64), "v"(v) : "memory");
+#else
             p[(t * 4 + q) * 64] = v;
+#endif
         }
 }
 

@@ -19,7 +19,7 @@ case "$1" in
       for v in "" $VARIANTS; do
         if [ -n "$v" ]; then export DC_DDIM_LIB="$R/diffusion-conductor_amd/libdc_ddim_$v.alt"; else unset DC_DDIM_LIB; fi
         echo -n "variant ${v:-default}: "
-        python bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>&1 | grep -o "k_film_gemm [0-9.]*ms\|k_embed_front [0-9.]*ms\|k_layer [0-9.]*ms\|ms_per_step\": [0-9.]*" | tr "\n" " "; echo
+        python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras 2>&1 | grep -o "k_film_gemm [0-9.]*ms\|k_embed_front [0-9.]*ms\|k_layer [0-9.]*ms\|ms_per_step\": [0-9.]*" | tr "\n" " "; echo
       done
     done ;;
 esac

@@ -10,7 +10,7 @@ OUT="$R/gpurun_out/profiles_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="/usr/bin/python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+BENCH="/usr/bin/python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH > "$OUT/kt.log" 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES \
     --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- $BENCH > "$OUT/pmc_sq.log" 2>&1
