@@ -67,122 +67,173 @@ __global__ __launch_bounds__(512) void k_temb_table(const float* __restrict__ fr
 // ------------------------------------------------------------------------------------
 // conditioning (step-invariant, once per batch)
 // ------------------------------------------------------------------------------------
-// y[tok][k] = b[k] + sum_i xf[tok][i] * Wt[i][k]   (`self.linear`, transformer.py:479-480)
-__global__ void k_cond_linear(const float* __restrict__ xf /*[M][64]*/, const float* __restrict__ wt,
-                              const float* __restrict__ b, float* __restrict__ y /*[Mpad][512]*/, int M, int Mpad) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)Mpad * 512) return;
-    const int k = idx & 511;
-    const size_t tok = idx >> 9;
-    if (tok >= (size_t)M) {
-        y[idx] = 0.f;
-        return;
-    }
-    float acc = b[k];
-    const float* x = xf + tok * 64;
-#pragma unroll 8
-    for (int i = 0; i < 64; ++i) acc = fmaf(x[i], wt[i * 512 + k], acc);
-    y[idx] = acc;
-}
-
-// per-row mean / rstd over 512 (text_norm without its affine, transformer.py:149); one wave per token
-__global__ void k_row_stats512(const float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int Mpad) {
-    const int tok = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (tok >= Mpad) return;
-    const float* r = y + (size_t)tok * 512;
-    float v[8], s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        v[i] = r[lane + 64 * i];
-        s += v[i];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mu = s * (1.f / 512.f);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) q += (v[i] - mu) * (v[i] - mu);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    if (lane == 0) {
-        mean[tok] = mu;
-        rstd[tok] = rsqrtf(q * (1.f / 512.f) + 1e-5f);
-    }
-}
-
-// row-major [Mpad][512] fp32 -> fragment-major: element (g, ks, lane, j) = y[32g + (lane&31)][16ks + 8(lane>>5) + j]
-// MODE 0: fp32 image (the xf_proj' term of emb);  MODE 1: normalised, bf16 hi + lo operand images.
+// `self.linear` (64 -> 512, transformer.py:479-480) of one 32-token group, straight into the fragment-major operand images the
+// step kernels read - one kernel instead of linear + row statistics + pack with a [M][512] fp32 round trip in between:
+//   MODE 0 (xf_proj): the fp32 image of emb's step-invariant term (layout: ld_pp);
+//   MODE 1 (xf_out):  text_norm without its affine (transformer.py:149; folded into the K/V projections) as bf16 hi + lo
+//                     operand images [g][32 ks][64 lanes][8]: lane (c, hh), element j = nhat[32 g + c][16 ks + 8 hh + j].
+// 256 threads: thread t owns output features t and t + 256 for all 32 tokens (64 accumulators), the weight rows it needs
+// are coalesced L2 reads, x comes from LDS as broadcasts; the [32][512] result tile is turned through LDS (rows padded to
+// 516 floats: a lane's 32-byte reads of 16 different rows then fall on different banks).
 template <int MODE>
-__global__ void k_cond_pack(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ rstd,
-                            float* __restrict__ out_f32, bf16x8* __restrict__ out_hi, bf16x8* __restrict__ out_lo, int G) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (g*32+ks)*64 + lane
-    if (idx >= (size_t)G * 32 * 64) return;
-    const int lane = idx & 63, ks = (idx >> 6) & 31;
-    const size_t g = idx >> 11;
-    const size_t tok = g * 32 + (lane & 31);
-    const float* src = y + tok * 512 + 16 * ks + 8 * (lane >> 5);
-    f32x8 v = *reinterpret_cast<const f32x8*>(src);
-    if constexpr (MODE == 0) {
-        f32x4* o = reinterpret_cast<f32x4*>(out_f32) + (idx >> 6) * 128 + lane;      // layout: ld_pp
-        f32x4 a, b;
+__global__ __launch_bounds__(256, 2)
+void k_cond_embed(const float* __restrict__ xf /*[M][64]*/, const float* __restrict__ wt /*[64][512]*/, const float* __restrict__ b,
+                  float* __restrict__ out_f32, bf16x8* __restrict__ out_hi, bf16x8* __restrict__ out_lo, int M) {
+    constexpr int YS = 516;
+    __shared__ __attribute__((aligned(16))) float xs[32 * 64];
+    __shared__ __attribute__((aligned(16))) float ys[32 * YS];
+    __shared__ float mu_s[32], rs_s[32];
+    const int g = blockIdx.x, t = threadIdx.x;
+    {   // x tile: 32 tokens x 64 floats = 512 16-byte pieces; tokens past M read as zeros
+        const f32x4* src = reinterpret_cast<const f32x4*>(xf) + (size_t)g * 512;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = t + 256 * i;
+            const int tok = 32 * g + (p >> 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (tok < M) v = src[p];
+            reinterpret_cast<f32x4*>(xs)[p] = v;
+        }
+    }
+    __syncthreads();
+    float acc0[32], acc1[32];
+    const float b0 = b[t], b1 = b[t + 256];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        acc0[k] = b0;
+        acc1[k] = b1;
+    }
+#pragma unroll 2
+    for (int i4 = 0; i4 < 16; ++i4) {
+        float w0[4], w1[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            a[i] = v[i];
-            b[i] = v[4 + i];
+            w0[i] = wt[(4 * i4 + i) * 512 + t];
+            w1[i] = wt[(4 * i4 + i) * 512 + t + 256];
         }
-        o[0] = a;
-        o[64] = b;
-    } else {
-        const float mu = mean[tok], rs = rstd[tok];
-        bf16x8 hi, lo;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float n = (v[j] - mu) * rs;
-            hi[j] = (__bf16)n;
-            lo[j] = (__bf16)(n - (float)hi[j]);
+        for (int k = 0; k < 32; ++k) {
+            const f32x4 x4 = reinterpret_cast<const f32x4*>(xs)[k * 16 + i4];       // broadcast
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc0[k] = fmaf(x4[i], w0[i], acc0[k]);
+                acc1[k] = fmaf(x4[i], w1[i], acc1[k]);
+            }
         }
-        out_hi[idx] = hi;
-        out_lo[idx] = lo;
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const bool live = 32 * g + k < M;               // rows past M: zeros (as the unfused path wrote them)
+        ys[k * YS + t] = live ? acc0[k] : 0.f;
+        ys[k * YS + t + 256] = live ? acc1[k] : 0.f;
+    }
+    __syncthreads();
+    const int wave = t >> 6, lane = t & 63;
+    if constexpr (MODE == 1) {      // per-token mean / rstd over the 512 features (two passes, as nn.LayerNorm): a wave per 8 tokens
+        for (int k = wave * 8; k < wave * 8 + 8; ++k) {
+            float v[8], sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = ys[k * YS + lane + 64 * i];
+                sum += v[i];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mu = sum * (1.f / 512.f);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q += (v[i] - mu) * (v[i] - mu);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            if (lane == 0) {
+                mu_s[k] = mu;
+                rs_s[k] = rsqrtf(q * (1.f / 512.f) + 1e-5f);
+            }
+        }
+        __syncthreads();
+    }
+    // copy-out: fragment (g, ks), lane (c = token, hh): the 8 features 16 ks + 8 hh .. + 7 of row c; a wave writes 1-KiB pieces
+    const int c = lane & 31, hh = lane >> 5;
+    for (int ks = wave; ks < 32; ks += 4) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(ys + c * YS + 16 * ks + 8 * hh);
+        const f32x4 a = src[0], d = src[1];
+        if constexpr (MODE == 0) {
+            f32x4* o = reinterpret_cast<f32x4*>(out_f32) + ((size_t)g * 32 + ks) * 128 + lane;
+            o[0] = a;
+            o[64] = d;
+        } else {
+            const float mu = mu_s[c], rs = rs_s[c];
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float n = ((j < 4 ? a[j] : d[j - 4]) - mu) * rs;
+                hi[j] = (__bf16)n;
+                lo[j] = (__bf16)(n - (float)hi[j]);
+            }
+            out_hi[((size_t)g * 32 + ks) * 64 + lane] = hi;
+            out_lo[((size_t)g * 32 + ks) * 64 + lane] = lo;
+        }
     }
 }
 
 // Cross-attention K/V for every layer + their partial records (transformer.py:149-155):
 // K = Wk' nhat + bk', V = Wv' nhat + bv' with text_norm's affine folded into Wk'/Wv'.
-// grid (ceil(G/4), L); one wave per (group, layer).  CA has no mask: every real token is valid.
-// One-time cost per batch, so always split-bf16 (plain bf16 here alone costs ~2e-3 on the matrices).
-__global__ __launch_bounds__(256) void k_cond_ca_partials(const DcModel* __restrict__ dm, const bf16x8* __restrict__ nh_hi,
-                                                          const bf16x8* __restrict__ nh_lo, float* __restrict__ recs,
-                                                          int M, int T, int G) {
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= G) return;
-    const int lane = threadIdx.x & 63;
+// grid (ceil(G/8), L), 512 threads: one wave per (group, layer); the 16 weight fragments of a k-step (K hi, K lo, V hi, V lo x
+// 4 feature tiles) are copied L2 -> LDS once per workgroup by LDS-DMA (double-buffered, one barrier per k-step) and serve
+// all 8 waves - read straight from L2 by every wave they were 8.3 GB of traffic per batch and the kernel took 1.66 ms.
+// CA has no mask: every real token is valid.  One-time cost per batch, so always split-bf16 (plain bf16 here alone costs
+// ~2e-3 on the matrices).
+__global__ __launch_bounds__(512, 1) void k_cond_ca_partials(const DcModel* __restrict__ dm, const bf16x8* __restrict__ nh_hi,
+                                                             const bf16x8* __restrict__ nh_lo, float* __restrict__ recs,
+                                                             int M, int T, int G) {
+    __shared__ __attribute__((aligned(16))) char wbuf[2 * 16384];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int g = blockIdx.x * 8 + wave;
+    const bool active = g < G;
+    if (!active) g = G - 1;
     const int l = blockIdx.y;
     const DcLayer& L = dm->layer[l];
     const GroupCtx cx = make_ctx(g, lane, M, T);
+    constexpr int NF = 4 * DC_KS_E;
+    // fragment f of k-step ks: f = which * 4 + oc, which = 0 K hi, 1 K lo, 2 V hi, 3 V lo; natural pack index oc * 32 + ks
+    auto stage = [&](int ks, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = 2 * wave + i, which = f >> 2, oc = f & 3;
+            const bf16x8* src = ((which & 2) ? L.ca_wv : L.ca_wk) + (size_t)(((which & 1) ? NF : 0) + oc * DC_KS_E + ks) * 64 + lane;
+            lds_dma16(src, wbuf + buf * 16384 + f * 1024);
+        }
+    };
     f32x16 K[4], V[4];
 #pragma unroll
     for (int oc = 0; oc < 4; ++oc) {
         K[oc] = splat(L.ca_bk[32 * oc + cx.c]);
         V[oc] = splat(L.ca_bv[32 * oc + cx.c]);
     }
-    constexpr int NF = 4 * DC_KS_E;
+    stage(0, 0);
+    bf16x8 a = nh_hi[((size_t)g * DC_KS_E) * 64 + lane], al = nh_lo[((size_t)g * DC_KS_E) * 64 + lane];
     for (int ks = 0; ks < DC_KS_E; ++ks) {
-        const bf16x8 a = nh_hi[((size_t)g * DC_KS_E + ks) * 64 + lane];
-        const bf16x8 al = nh_lo[((size_t)g * DC_KS_E + ks) * 64 + lane];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                          // k-step ks has landed for every wave; everyone left buffer (ks + 1) & 1
+        const bf16x8 a_cur = a, al_cur = al;
+        if (ks + 1 < DC_KS_E) {
+            stage(ks + 1, (ks + 1) & 1);
+            a = nh_hi[((size_t)g * DC_KS_E + ks + 1) * 64 + lane];
+            al = nh_lo[((size_t)g * DC_KS_E + ks + 1) * 64 + lane];
+        }
+        const bf16x8* w = reinterpret_cast<const bf16x8*>(wbuf + (ks & 1) * 16384) + lane;
 #pragma unroll
         for (int oc = 0; oc < 4; ++oc) {
-            const int fi = oc * DC_KS_E + ks;                      // natural pack: [ot][ks]
-            const bf16x8 bk = L.ca_wk[fi * 64 + lane];
-            const bf16x8 bv = L.ca_wv[fi * 64 + lane];
-            K[oc] = mfma(a, bk, K[oc]);
-            V[oc] = mfma(a, bv, V[oc]);
-            K[oc] = mfma(al, bk, K[oc]);
-            V[oc] = mfma(al, bv, V[oc]);
-            K[oc] = mfma(a, L.ca_wk[(NF + fi) * 64 + lane], K[oc]);
-            V[oc] = mfma(a, L.ca_wv[(NF + fi) * 64 + lane], V[oc]);
+            const bf16x8 bk = w[(0 + oc) * 64], bkl = w[(4 + oc) * 64], bv = w[(8 + oc) * 64], bvl = w[(12 + oc) * 64];
+            K[oc] = mfma(a_cur, bk, K[oc]);
+            V[oc] = mfma(a_cur, bv, V[oc]);
+            K[oc] = mfma(al_cur, bk, K[oc]);
+            V[oc] = mfma(al_cur, bv, V[oc]);
+            K[oc] = mfma(a_cur, bkl, K[oc]);
+            V[oc] = mfma(a_cur, bvl, V[oc]);
         }
     }
+    if (!active) return;
     float* rec = recs + ((size_t)l * G + g) * 2 * DC_REC_FLOATS;
     const int nslot = cx.straddle ? 2 : 1;
     for (int slot = 0; slot < nslot; ++slot) {
@@ -1738,31 +1789,18 @@ hipError_t dc_launch_temb_table(hipStream_t st, const float* freqs, const float*
     return LAUNCH_CHECK();
 }
 
-hipError_t dc_launch_cond_linear(hipStream_t st, const float* xf, const float* wt, const float* b, float* y, int M, int Mpad) {
-    const size_t n = (size_t)Mpad * 512;
-    hipLaunchKernelGGL(k_cond_linear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xf, wt, b, y, M, Mpad);
-    return LAUNCH_CHECK();
-}
-
-hipError_t dc_launch_row_stats(hipStream_t st, const float* y, float* mean, float* rstd, int Mpad) {
-    hipLaunchKernelGGL(k_row_stats512, dim3((Mpad + 3) / 4), dim3(256), 0, st, y, mean, rstd, Mpad);
-    return LAUNCH_CHECK();
-}
-
-hipError_t dc_launch_cond_pack(hipStream_t st, int mode, const float* y, const float* mean, const float* rstd,
-                               float* out_f32, void* out_hi, void* out_lo, int G) {
-    const size_t n = (size_t)G * 32 * 64;
-    const dim3 grid((unsigned)((n + 255) / 256));
+hipError_t dc_launch_cond_embed(hipStream_t st, int mode, const float* xf, const float* wt, const float* b, float* out_f32,
+                                void* out_hi, void* out_lo, int M, int G) {
     if (mode == 0)
-        hipLaunchKernelGGL(k_cond_pack<0>, grid, dim3(256), 0, st, y, mean, rstd, out_f32, (bf16x8*)out_hi, (bf16x8*)out_lo, G);
+        hipLaunchKernelGGL(k_cond_embed<0>, dim3(G), dim3(256), 0, st, xf, wt, b, out_f32, (bf16x8*)out_hi, (bf16x8*)out_lo, M);
     else
-        hipLaunchKernelGGL(k_cond_pack<1>, grid, dim3(256), 0, st, y, mean, rstd, out_f32, (bf16x8*)out_hi, (bf16x8*)out_lo, G);
+        hipLaunchKernelGGL(k_cond_embed<1>, dim3(G), dim3(256), 0, st, xf, wt, b, out_f32, (bf16x8*)out_hi, (bf16x8*)out_lo, M);
     return LAUNCH_CHECK();
 }
 
 hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* nh_hi, const void* nh_lo,
                                  float* recs, int M, int T, int G, int L) {
-    hipLaunchKernelGGL(k_cond_ca_partials, dim3((G + 3) / 4, L), dim3(256), 0, st, dm, (const bf16x8*)nh_hi,
+    hipLaunchKernelGGL(k_cond_ca_partials, dim3((G + 7) / 8, L), dim3(512), 0, st, dm, (const bf16x8*)nh_hi,
                        (const bf16x8*)nh_lo, recs, M, T, G);
     return LAUNCH_CHECK();
 }

@@ -7,10 +7,10 @@ hipError_t dc_launch_begin_step(hipStream_t st, int* iter, const int* t_of_iter,
                                 const int* snap_of_iter, int* t_clip, float* coef_cur, int* snap_cur, int B);
 hipError_t dc_launch_temb_table(hipStream_t st, const float* freqs, const float* w0t, const float* b0,
                                 const float* w2t, const float* b2, float* temb, int nt);
-hipError_t dc_launch_cond_linear(hipStream_t st, const float* xf, const float* wt, const float* b, float* y, int M, int Mpad);
-hipError_t dc_launch_row_stats(hipStream_t st, const float* y, float* mean, float* rstd, int Mpad);
-hipError_t dc_launch_cond_pack(hipStream_t st, int mode, const float* y, const float* mean, const float* rstd,
-                               float* out_f32, void* out_hi, void* out_lo, int G);
+// `self.linear` of one conditioning tensor [M][64] into a fragment-major operand image: mode 0 = fp32 image of emb's
+// step-invariant term (out_f32), mode 1 = text_norm'ed bf16 hi / lo images (out_hi, out_lo) for the cross-attention pre-pass
+hipError_t dc_launch_cond_embed(hipStream_t st, int mode, const float* xf, const float* wt, const float* b, float* out_f32,
+                                void* out_hi, void* out_lo, int M, int G);
 hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* nh_hi, const void* nh_lo,
                                  float* recs, int M, int T, int G, int L);
 hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, void* afrag, int T, int NU, int B, int nset,
