@@ -127,6 +127,11 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void k_probe(cons
         }
         issue(c);
     }
+#ifdef NO_LDS
+    f16x8 wreg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wreg[i] = W[lane + 64 * i];
+#endif
     int c = 0;
     for (int blk = 0; blk < nblk; ++blk) {
         f32x16 acc[8];
@@ -134,6 +139,13 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void k_probe(cons
         for (int t = 0; t < 8; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#ifdef TWO_B
+        f32x16 acc2[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+#endif
 #pragma unroll
         for (int kt = 0; kt < 16; ++kt, ++c) {
             RING_SYNC();                                          // chunk c landed for every wave; everyone left slot (c-1) % NSLOT
@@ -158,7 +170,23 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void k_probe(cons
 #pragma unroll
                 for (int tq = 0; tq < 2; ++tq) {
 #pragma unroll
+#if defined(NO_LDS) && defined(LDS_DUMMY)
+                    for (int t = 4 * tq; t < 4 * tq + 4; ++t) {      // the LDS reads are issued and waited for, but feed nothing
+                        const f16x8 tmp = w[(t * 2 + s2) * 64];
+                        asm volatile("" ::"v"(tmp));
+                        acc[t] = mfma(wreg[t & 3], b, acc[t]);
+                    }
+#elif defined(NO_LDS)
+                    for (int t = 4 * tq; t < 4 * tq + 4; ++t) acc[t] = mfma(wreg[t & 3], b, acc[t]);      // operands never leave the registers
+#elif defined(TWO_B)
+                    for (int t = 4 * tq; t < 4 * tq + 4; ++t) {      // each LDS fragment feeds two MFMAs (a second token group)
+                        const f16x8 a = w[(t * 2 + s2) * 64];
+                        acc[t] = mfma(a, b, acc[t]);
+                        acc2[t] = mfma(a, sreg[(kt + 1) & 3][s2], acc2[t]);
+                    }
+#else
                     for (int t = 4 * tq; t < 4 * tq + 4; ++t) acc[t] = mfma(w[(t * 2 + s2) * 64], b, acc[t]);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -167,7 +195,12 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void k_probe(cons
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h[t][r] += (float)(_Float16)acc[2 * t][r] * (float)(_Float16)acc[2 * t + 1][r];
+            for (int r = 0; r < 16; ++r) {
+                h[t][r] += (float)(_Float16)acc[2 * t][r] * (float)(_Float16)acc[2 * t + 1][r];
+#ifdef TWO_B
+                h[t][r] += (float)(_Float16)acc2[2 * t][r] * (float)(_Float16)acc2[2 * t + 1][r];
+#endif
+            }
         // chain stand-in: chunks of 128-wide GEMM work (4 chains x 4 k-tiles x ... = 16 MFMAs per chunk) + VALU rounds
         for (int cs = 0; cs < chain_slots; ++cs, ++c) {
             RING_SYNC();
