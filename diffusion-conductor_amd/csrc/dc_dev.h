@@ -227,26 +227,57 @@ DEV void ln_frags(XFrag<T16, SPLIT> (&nf)[4], const f32x16 (&x)[4]) {
 
 // F.softmax(query.view(B,T,H,-1), dim=-1) (transformer.py:109,150): a head = 16 features
 // = registers 8p..8p+7 of this lane and of lane^32.
+// Packed-fp32 formulation (v_pk_add / v_pk_mul_f32 on register pairs, 3-input maxima): 29 instead of 43 VALU instructions per
+// head half - the layer kernel is bound by instruction issue.
+DEV float max3(float a, float b, float c) {       // (the compiler forms v_max3_f32 from nested fmaxf only now and then)
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+DEV float max8(const f32x16& q, int o) {
+    return max3(max3(q[o], q[o + 1], q[o + 2]), max3(q[o + 3], q[o + 4], q[o + 5]), fmaxf(q[o + 6], q[o + 7]));
+}
 DEV void softmax_heads_ft(f32x16 (&q)[4]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            float m = q[t][8 * p];
+            const float m = xhalf_max(max8(q[t], 8 * p));
+            const f32x2 nm = {-m, -m};
+            f32x2 e[4], s2 = {0.f, 0.f};
 #pragma unroll
-            for (int j = 1; j < 8; ++j) m = fmaxf(m, q[t][8 * p + j]);
-            m = xhalf_max(m);
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float e = exp2f_fast(q[t][8 * p + j] - m);     // q carries log2(e): folded into Wq, bq
-                q[t][8 * p + j] = e;
-                s += e;
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 d = (f32x2){q[t][8 * p + 2 * j], q[t][8 * p + 2 * j + 1]} + nm;
+                e[j] = (f32x2){exp2f_fast(d.x), exp2f_fast(d.y)};      // q carries log2(e): folded into Wq, bq
+                s2 += e[j];
             }
-            const float inv = fast_rcp(xhalf_sum(s));
+            const float inv = fast_rcp(xhalf_sum(s2.x + s2.y));
 #pragma unroll
-            for (int j = 0; j < 8; ++j) q[t][8 * p + j] *= inv;
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 r = e[j] * inv;
+                q[t][8 * p + 2 * j] = r.x;
+                q[t][8 * p + 2 * j + 1] = r.y;
+            }
         }
+}
+// column maximum of a 32-row tile held in 16 registers (this lane's half of the rows)
+DEV float max16(const f32x16& k) {
+    return max3(max3(max3(k[0], k[1], k[2]), max3(k[3], k[4], k[5]), max3(k[6], k[7], k[8])),
+                max3(k[9], k[10], k[11]), max3(max3(k[12], k[13], k[14]), k[15], k[15]));
+}
+// e[r] = exp2(k[r] - m) for the 16 registers, and their sum (packed subtractions / additions)
+DEV float exp_rows(f32x16& e, const f32x16& k, float m) {
+    const f32x2 nm = {-m, -m};
+    f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const f32x2 d = (f32x2){k[2 * j], k[2 * j + 1]} + nm;
+        const f32x2 x = {exp2f_fast(d.x), exp2f_fast(d.y)};
+        e[2 * j] = x.x;
+        e[2 * j + 1] = x.y;
+        s2 += x;
+    }
+    return s2.x + s2.y;
 }
 
 DEV float silu(float z) { return z * fast_rcp(1.f + exp2f_fast(-1.4426950408889634f * z)); }
@@ -279,6 +310,25 @@ DEV float gelu_erf(float x) {
     poly = fmaf(poly, t, 0.254829592f);
     const float erfa = 1.f - poly * t * __expf(-a * a);
     return 0.5f * x * (1.f + copysignf(erfa, x));
+}
+// the same on two elements with packed-fp32 arithmetic: gelu(x) = x/2 + |x|/2 * erf(|x| / sqrt 2)  (x sign(x) = |x|),
+// exp(-a^2) = 2^(-x^2 log2(e) / 2)
+DEV f32x2 gelu_erf_pair(float x0, float x1) {
+    const f32x2 x = {x0, x1};
+    const f32x2 ax = {fabsf(x0), fabsf(x1)};
+    const f32x2 den = __builtin_elementwise_fma(ax, (f32x2){0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f},
+                                                (f32x2){1.f, 1.f});
+    const f32x2 t = {fast_rcp(den.x), fast_rcp(den.y)};
+    f32x2 poly = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2){1.421413741f, 1.421413741f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2){-0.284496736f, -0.284496736f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2){0.254829592f, 0.254829592f});
+    const f32x2 xx = x * x * (-0.5f * 1.4426950408889634f);
+    const f32x2 ex = {exp2f_fast(xx.x), exp2f_fast(xx.y)};
+    const f32x2 pe = poly * t * ex;                                    // 1 - erf(a)
+    const f32x2 half_ax = ax * 0.5f;
+    // x/2 + |x|/2 (1 - pe)
+    return __builtin_elementwise_fma(half_ax, (f32x2){1.f, 1.f} - pe, x * 0.5f);
 }
 
 // XCD-aware workgroup index: blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so logical workgroup
@@ -356,8 +406,7 @@ DEV void emit_partial(const f32x16& K, const f32x16& V, int oc, const RowRange& 
     float m = -INFINITY;
     const bool full = __builtin_amdgcn_readfirstlane(rr.span) == 32u;     // no predicates for whole groups (3 instructions per element)
     if (full) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, K[r]);
+        m = max16(K);
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) m = row_ok(rr, r) ? fmaxf(m, K[r]) : m;
@@ -367,11 +416,7 @@ DEV void emit_partial(const f32x16& K, const f32x16& V, int oc, const RowRange& 
     f32x16 Ee, Vm;
     float ssum = 0.f;
     if (full) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            Ee[r] = exp2f_fast(K[r] - m);                           // K carries log2(e): folded into Wk, bk
-            ssum += Ee[r];
-        }
+        ssum = exp_rows(Ee, K, m);                                  // K carries log2(e): folded into Wk, bk
         Vm = V;
     } else {
 #pragma unroll
@@ -538,8 +583,7 @@ DEV void wg_put_maxes(const f32x16 (&K)[4], const GroupCtx& cx, const RowRange (
             float m = -INFINITY;
             const unsigned span = __builtin_amdgcn_readfirstlane(vr[sl].span);
             if (span == 32u) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m = fmaxf(m, K[oc][r]);
+                m = max16(K[oc]);
             } else if (span != 0u) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) m = row_ok(vr[sl], r) ? fmaxf(m, K[oc][r]) : m;
@@ -560,11 +604,7 @@ DEV void partial_tile(const f32x16& K, const f32x16& V, const RowRange& rr, floa
     f32x16 Ee, Vm;
     float s = 0.f;
     if (__builtin_amdgcn_readfirstlane(rr.span) == 32u) {       // all 32 rows valid: no predicates (they cost 3 instructions per element)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            Ee[r] = exp2f_fast(K[r] - m);
-            s += Ee[r];
-        }
+        s = exp_rows(Ee, K, m);
         Vm = V;
     } else {
 #pragma unroll
@@ -922,7 +962,11 @@ DEV void styl_accumulate(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd,
     for (int t = 0; t < 4; ++t) {
         const f32x16 bb = ld_ft(bo, t, hh);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h[t][r] += bb[r];
+        for (int r = 0; r < 8; ++r) {                                  // v_pk_add_f32
+            const f32x2 v = (f32x2){h[t][2 * r], h[t][2 * r + 1]} + (f32x2){bb[2 * r], bb[2 * r + 1]};
+            h[t][2 * r] = v.x;
+            h[t][2 * r + 1] = v.y;
+        }
     }
     gemm_wa<4, 4, T16, SPLIT>(h, w, zf, lane);
     __builtin_amdgcn_sched_barrier(0);
@@ -1001,7 +1045,11 @@ DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float 
     for (int t = 0; t < 4; ++t) {
         const f32x16 bb = ld_ft(bo, t, hh);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h[t][r] += bb[r];
+        for (int r = 0; r < 8; ++r) {                                  // v_pk_add_f32
+            const f32x2 v = (f32x2){h[t][2 * r], h[t][2 * r + 1]} + (f32x2){bb[2 * r], bb[2 * r + 1]};
+            h[t][2 * r] = v.x;
+            h[t][2 * r + 1] = v.y;
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

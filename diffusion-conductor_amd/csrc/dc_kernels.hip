@@ -1062,7 +1062,11 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) u[kt][r] = gelu_erf(u[kt][r]);
+            for (int r = 0; r < 8; ++r) {
+                const f32x2 gg = gelu_erf_pair(u[kt][2 * r], u[kt][2 * r + 1]);
+                u[kt][2 * r] = gg.x;
+                u[kt][2 * r + 1] = gg.y;
+            }
             make_frag<T16, SPLIT>(u[kt], uf[kt]);
         }
         RowStats st;
@@ -1133,8 +1137,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 float m = -INFINITY;
                 const bool full = __builtin_amdgcn_readfirstlane(rr.span) == 32u;
                 if (full) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) m = fmaxf(m, K[r]);
+                    m = max16(K);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) m = row_ok(rr, r) ? fmaxf(m, K[r]) : m;
@@ -1145,11 +1148,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 f32x16 Ee;
                 float sacc = 0.f;
                 if (full) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        Ee[r] = exp2f_fast(K[r] - mz);
-                        sacc += Ee[r];
-                    }
+                    sacc = exp_rows(Ee, K, mz);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -1620,7 +1619,11 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) u[kt][r] = gelu_erf(u[kt][r]);
+            for (int r = 0; r < 8; ++r) {
+                const f32x2 gg = gelu_erf_pair(u[kt][2 * r], u[kt][2 * r + 1]);
+                u[kt][2 * r] = gg.x;
+                u[kt][2 * r + 1] = gg.y;
+            }
             make_frag<T16, false>(u[kt], uf[kt]);
         }
         RowStats st;
