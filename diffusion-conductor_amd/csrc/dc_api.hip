@@ -676,13 +676,18 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     // workgroup-level records (no combine launches) whenever a workgroup's 256 tokens cannot touch more than two clips
     static const bool no_wgr = getenv("DC_NO_WGREC") != nullptr;
     const bool wgr = !ss && T >= 256 && !no_wgr && s->dbg_first < 0;
+    // Narrow workgroups (4 waves = 128-token units, one wave per SIMD) while every unit still gets a CU of its own: the layer
+    // kernel is bound by instruction issue, so a wave alone on its SIMD runs a layer in about half the time (DESIGN.md
+    // section 4).  T <= 3840: the narrow combine holds 32 units per clip.  DC_NO_NARROW=1 keeps the 8-wave form (read per call).
+    const bool narrow = wgr && (G + 3) / 4 <= s->num_cu && T <= 3840 && s->dbg_layers < 0 && s->dbg_stage == 0 &&
+                        !getenv("DC_NO_NARROW") && !getenv("DC_STAMPS");
     if (s->dbg_first >= 0)
         LAUNCH(K_EMBED, dc_launch_front_from_h(st, fs, ss, s->d_model, s->d_h, s->d_recs, s->d_length, M, T, G, B, s->dbg_first));
     else
         LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
-                                              want_stamps_film ? s->d_stamps + 256 : nullptr));
+                                              want_stamps_film ? s->d_stamps + 256 : nullptr, narrow));
     static const bool want_stamps = getenv("DC_STAMPS") != nullptr;
-    const int nwg = (G + 7) / 8;
+    const int nwg = narrow ? (G + 3) / 4 : (G + 7) / 8;
     const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
     for (int l = s->dbg_first >= 0 ? s->dbg_first : 0; l < nl_run; ++l) {
         const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
@@ -690,7 +695,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src,
                                         s->d_snaps, M, T, G, B, dbg, ((l == 3 || l == 4) && want_stamps) ? s->d_stamps : nullptr, rec_stride,
-                                        iter_base));
+                                        iter_base, narrow));
     }
     return DC_OK;
 }

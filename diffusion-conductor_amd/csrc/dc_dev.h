@@ -575,6 +575,7 @@ DEV RowRange valid_rows_clip(const GroupCtx& cx, int clip, int B, int M, int T, 
     rr.span = end > first ? (unsigned)(end - first) : 0u;
     return rr;
 }
+template <int NW = 8>
 DEV void wg_put_maxes(const f32x16 (&K)[4], const GroupCtx& cx, const RowRange (&vr)[2], float* mx, int wave) {
 #pragma unroll
     for (int oc = 0; oc < 4; ++oc)
@@ -589,13 +590,17 @@ DEV void wg_put_maxes(const f32x16 (&K)[4], const GroupCtx& cx, const RowRange (
                 for (int r = 0; r < 16; ++r) m = row_ok(vr[sl], r) ? fmaxf(m, K[oc][r]) : m;
             }
             m = xhalf_max(m);
-            if (cx.hh == 0) mx[((oc * 2 + sl) * 32 + cx.c) * 8 + wave] = m;
+            if (cx.hh == 0) mx[((oc * 2 + sl) * 32 + cx.c) * NW + wave] = m;
         }
 }
+template <int NW = 8>
 DEV float wg_colmax(const float* mx, int oc, int sl, int c) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(mx + ((oc * 2 + sl) * 32 + c) * 8);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(mx + ((oc * 2 + sl) * 32 + c) * 8 + 4);
-    const float m = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+    const f32x4 a = *reinterpret_cast<const f32x4*>(mx + ((oc * 2 + sl) * 32 + c) * NW);
+    float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+    if constexpr (NW == 8) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(mx + ((oc * 2 + sl) * 32 + c) * 8 + 4);
+        m = fmaxf(m, fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+    }
     return m == -INFINITY ? 0.f : m;
 }
 // one 32-feature tile against a GIVEN column maximum: column sums of exp2(K-m) and the kept head blocks of exp2(K-m)^T V
@@ -627,39 +632,45 @@ DEV void partial_tile(const f32x16& K, const f32x16& V, const RowRange& rr, floa
 }
 
 // after the barrier that follows the last partial_tile: wave w sums tile oc = w & 3 of slot w >> 2 over the waves
+// NW = 8: wave w sums tile oc = w & 3 of slot w >> 2; NW = 4 (narrow workgroups): wave w sums tile oc = w of both slots in turn.
+template <int NW = 8>
 DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8* pst, const f32x8* xp, const float* ss,
                          int wave, int lane, int ub0, int G, int M, int T, int wg) {
-    const int oc = wave & 3, sl = wave >> 2, c = lane & 31;
-    f32x8 acc;
+    const int oc = wave & 3, c = lane & 31;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    float ssum = 0.f;
+    for (int pass = 0; pass < (NW == 8 ? 1 : 2); ++pass) {
+        const int sl = NW == 8 ? wave >> 2 : pass;
+        f32x8 acc;
 #pragma unroll
-    for (int v = 0; v < 8; ++v) {
-        const int gv = wg * 8 + v;
-        if (gv >= G) continue;
-        const int edge = (ub0 + 1) * T;                       // first token of slot 1's clip
-        const int s0v = 32 * gv >= edge ? 1 : 0;              // the wave's primary slot
-        const bool strad = !s0v && min(32 * gv + 31, M - 1) >= edge;
-        if (s0v == sl) {
-            const f32x8 p = pst[(v * 4 + oc) * 64 + lane];
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        float ssum = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += p[i];
-            ssum += ss[(v * 4 + oc) * 32 + c];
+        for (int v = 0; v < NW; ++v) {
+            const int gv = wg * NW + v;
+            if (gv >= G) continue;
+            const int edge = (ub0 + 1) * T;                       // first token of slot 1's clip
+            const int s0v = 32 * gv >= edge ? 1 : 0;              // the wave's primary slot
+            const bool strad = !s0v && min(32 * gv + 31, M - 1) >= edge;
+            if (s0v == sl) {
+                const f32x8 p = pst[(v * 4 + oc) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += p[i];
+                ssum += ss[(v * 4 + oc) * 32 + c];
+            }
+            if (strad && sl == 1) {
+                const f32x8 p = xp[oc * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += p[i];
+                ssum += ss[(NW * 4 + oc) * 32 + c];
+            }
         }
-        if (strad && sl == 1) {
-            const f32x8 p = xp[oc * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += p[i];
-            ssum += ss[(8 * 4 + oc) * 32 + c];
+        float* R = recs + ((size_t)wg * 2 + sl) * DC_REC_FLOATS;
+        if (lane < 32) {
+            R[32 * oc + c] = wg_colmax<NW>(mx, oc, sl, c);
+            R[128 + 32 * oc + c] = ssum;
         }
+        reinterpret_cast<f32x8*>(R + 256)[oc * 64 + lane] = acc;
     }
-    float* R = recs + ((size_t)wg * 2 + sl) * DC_REC_FLOATS;
-    if (lane < 32) {
-        R[32 * oc + c] = wg_colmax(mx, oc, sl, c);
-        R[128 + 32 * oc + c] = ssum;
-    }
-    reinterpret_cast<f32x8*>(R + 256)[oc * 64 + lane] = acc;
 }
 // The workgroup's own combine (512 threads): attention operand fragments A[d][l] of clips ub0, ub0+1 from the unit
 // records of the previous kernel -> af [2 clips][8 frags][64 lanes] in LDS (the 8 hi fragments k_attn_combine makes).
@@ -777,6 +788,133 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
     af[(ci * 8 + oc * 2 + (s ^ 1)) * 64 + ln] = zero;
 }
 
+
+// The same combine for NARROW workgroups (4 waves = 128-token units, 256 threads; small batches, one wave per SIMD).
+// scratch (LDS): w [2][32][128] floats, z [2][128] floats: <= 32 units per clip (T <= 3840).  The K^T V blocks of the
+// workgroup's first clip are loaded up front (one memory round trip together with phase A's scalars); a second clip
+// (the one unit per clip that contains a clip edge) is loaded in batches behind the barrier.
+template <class T16>
+DEV void wg_combine_attn_narrow(const float* __restrict__ recs, v8<T16>* af, float* scratch, int ub0, int M, int T, int tid, int wg) {
+    constexpr int UT = 128, NU = 32, PRE = 16;
+    float* wsc = scratch;
+    float* zsc = scratch + 2 * NU * 128;
+    const int ub1 = (min((wg + 1) * UT, M) - 1) / T;          // last clip this unit touches
+    auto rec_of = [&](int clip, int u) { return recs + ((size_t)u * 2 + ((u * UT >= clip * T) ? 0 : 1)) * DC_REC_FLOATS; };
+    const int ca = tid >> 7, f = tid & 127, ba = ub0 + ca;
+    const bool la = ba <= ub1;
+    const int bav = la ? ba : ub0;
+    const int a_lo = (bav * T) / UT, a_hi = (min((bav + 1) * T, M) - 1) / UT;
+    const int na = la ? a_hi - a_lo + 1 : 0;
+    float mr[PRE], sr[PRE];
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {                            // branch-free: indices clamped, results predicated
+        const float* R = rec_of(bav, min(a_lo + k, a_hi));
+        mr[k] = R[f];
+        sr[k] = R[128 + f];
+    }
+    const int oc = tid >> 6, ln = tid & 63, c = ln & 31, hh = ln >> 5;
+    const int v_lo = (ub0 * T) / UT, v_hi = (min((ub0 + 1) * T, M) - 1) / UT;
+    f32x8 pre[PRE];
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) pre[k] = reinterpret_cast<const f32x8*>(rec_of(ub0, min(v_lo + k, v_hi)) + 256)[oc * 64 + ln];
+    {   // phase A: per feature f of clip ca: m*, weights, normaliser
+#pragma unroll
+        for (int k = 0; k < PRE; ++k)
+            if (k >= na) sr[k] = 0.f;
+        float mstar = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < PRE; ++k)
+            if (sr[k] > 0.f) mstar = fmaxf(mstar, mr[k]);
+        for (int k = PRE; k < na; ++k) {                       // clips longer than 16 units (T > 1920)
+            const float* R = rec_of(ba, a_lo + k);
+            if (R[128 + f] > 0.f) mstar = fmaxf(mstar, R[f]);
+        }
+        float z = 0.f;
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            const float ww = sr[k] > 0.f ? exp2f_fast(mr[k] - mstar) : 0.f;
+            if (k < na) wsc[(ca * NU + k) * 128 + f] = ww;
+            z += ww * sr[k];
+        }
+        for (int k = PRE; k < na; ++k) {
+            const float* R = rec_of(ba, a_lo + k);
+            const float su = R[128 + f];
+            const float ww = su > 0.f ? exp2f_fast(R[f] - mstar) : 0.f;
+            wsc[(ca * NU + k) * 128 + f] = ww;
+            z += ww * su;
+        }
+        zsc[ca * 128 + f] = z;
+    }
+    __syncthreads();
+    const int rowb = 32 * oc + 16 * (c >> 4) + 4 * hh;        // kept value j <-> feature row rowb + (j&3) + 8*(j>>2)
+    auto wrow = [&](const float* base, float (&w8)[8]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(base + rowb), c2 = *reinterpret_cast<const f32x4*>(base + rowb + 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w8[j] = a[j];
+            w8[4 + j] = c2[j];
+        }
+    };
+    auto emit = [&](int ci, const float (&acc)[8], bool live) {
+        v8<T16> out, zero;
+        float z8[8];
+        wrow(zsc + ci * 128, z8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            out[j] = (T16)((live && z8[j] > 0.f) ? acc[j] * fast_rcp(z8[j]) : 0.f);
+            zero[j] = (T16)0.f;
+        }
+        const int s = c >> 4;
+        af[(ci * 8 + oc * 2 + s) * 64 + ln] = out;
+        af[(ci * 8 + oc * 2 + (s ^ 1)) * 64 + ln] = zero;
+    };
+    {   // clip ub0 (always live)
+        const int nu = v_hi - v_lo + 1;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < PRE; ++k)
+            if (k < nu) {
+                float w8[8];
+                wrow(wsc + k * 128, w8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], pre[k][j], acc[j]);
+            }
+        for (int k = PRE; k < nu; ++k) {
+            const f32x8 pv = reinterpret_cast<const f32x8*>(rec_of(ub0, v_lo + k) + 256)[oc * 64 + ln];
+            float w8[8];
+            wrow(wsc + k * 128, w8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], pv[j], acc[j]);
+        }
+        emit(0, acc, true);
+    }
+    {   // clip ub0 + 1: only the unit that contains a clip edge
+        const bool live = ub0 + 1 <= ub1;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        if (live) {
+            const int b = ub0 + 1;
+            const int u_lo = (b * T) / UT, u_hi = (min((b + 1) * T, M) - 1) / UT, nu = u_hi - u_lo + 1;
+            for (int k0 = 0; k0 < nu; k0 += 8) {
+                f32x8 pb[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pb[k] = reinterpret_cast<const f32x8*>(rec_of(b, min(u_lo + k0 + k, u_hi)) + 256)[oc * 64 + ln];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k0 + k < nu) {
+                        float w8[8];
+                        wrow(wsc + (NU + k0 + k) * 128, w8);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], pb[k][j], acc[j]);
+                    }
+            }
+        }
+        emit(1, acc, live);
+    }
+}
 
 }  // namespace dc
 using namespace dc;

@@ -714,13 +714,16 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
 // ------------------------------------------------------------------------------------
 // FROMH (test hook, per-group records only): the residual stream is taken from hbuf as it stands instead of being embedded
 // from x, and the front half is that of layer l0 - lets a test start a single decoder layer from a given h.
-template <class T16, bool SPLIT, bool WGR, bool FROMH = false>
-__global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
+// NARROW (WGR, non-split): 4-wave workgroups = 128-token units, one wave per SIMD - for batches small enough that every
+// unit gets a CU of its own (see k_layer).
+template <class T16, bool SPLIT, bool WGR, bool FROMH = false, bool NARROW = false>
+__global__ __launch_bounds__((SPLIT || NARROW) ? 256 : 512, (SPLIT || NARROW) ? 1 : 2)
 void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /*[M][P]*/, float* __restrict__ hbuf,
                    float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G, int B,
                    unsigned long long* __restrict__ clk /* diagnostic: 100-MHz stamps of one wave, or nullptr */, int l0 = 0) {
     static_assert(!(FROMH && WGR), "the h-injection hook exists for the per-group-record form only");
-    constexpr int NW = SPLIT ? 4 : 8;
+    static_assert(!NARROW || (WGR && !SPLIT), "narrow workgroups exist for the workgroup-record form of the non-split formats");
+    constexpr int NW = (SPLIT || NARROW) ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;
     const bool stamping = clk && blockIdx.x == 100 && threadIdx.x == 0;
     auto stamp = [&](int i) {
@@ -841,7 +844,7 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
             K[oc] = splat(bk[32 * oc + cx.c]);
             mmb_oc<4, 4, T16, false>(K[oc], lk, oc, nf, lane);
         }
-        wg_put_maxes(K, cx, vr, mx, wave);
+        wg_put_maxes<NW>(K, cx, vr, mx, wave);
         __syncthreads();
         stamp(4);
         const int s0 = cx.b0 - ub0;
@@ -853,20 +856,20 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
             mmb_oc<4, 4, T16, false>(V, lv, oc, nf, lane);
             float ssum;
             f32x8 keep;
-            partial_tile<T16>(K[oc], V, vr_own, wg_colmax(mx, oc, s0, cx.c), cx, ssum, keep);
+            partial_tile<T16>(K[oc], V, vr_own, wg_colmax<NW>(mx, oc, s0, cx.c), cx, ssum, keep);
             pst[(wave * 4 + oc) * 64 + lane] = keep;
             if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssum;
             if (active && cx.straddle) {
-                partial_tile<T16>(K[oc], V, vr[1], wg_colmax(mx, oc, 1, cx.c), cx, ssum, keep);
+                partial_tile<T16>(K[oc], V, vr[1], wg_colmax<NW>(mx, oc, 1, cx.c), cx, ssum, keep);
                 xp[oc * 64 + lane] = keep;
-                if (cx.hh == 0) ss[(8 * 4 + oc) * 32 + cx.c] = ssum;
+                if (cx.hh == 0) ss[(NW * 4 + oc) * 32 + cx.c] = ssum;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp(5);
         __syncthreads();
         stamp(6);
-        wg_write_record(recs, mx, pst, xp, ss, wave, lane, ub0, G, M, T, wg);
+        wg_write_record<NW>(recs, mx, pst, xp, ss, wave, lane, ub0, G, M, T, wg);
         stamp(7);
     }
 }
@@ -886,8 +889,11 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
 // ------------------------------------------------------------------------------------
 // DBG = true builds the test-hook variant (early exits after a block, leading blocks skipped); the
 // production instantiation has none of them - the extra exits alone cost 160 spilled registers.
-template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR>
-__global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2)
+// NARROW (WGR, non-split, production build only): 4 waves per workgroup = 128-token units, ONE wave per SIMD.  The kernel is
+// bound by instruction issue, so a wave that has its SIMD to itself runs the layer in about half the time; worth it
+// whenever the batch is small enough for every unit to get its own CU (<= 32 K tokens: e.g. the reference's one clip per call).
+template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR, bool NARROW = false>
+__global__ __launch_bounds__((SPLIT || NARROW) ? 256 : 512, (SPLIT || NARROW) ? 1 : 2)
 void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
              const v8<T16>* __restrict__ a_sa /*[B][16][64]*/, const v8<T16>* __restrict__ a_ca /*[L][B][16][64]*/,
              float* __restrict__ recs, const int* __restrict__ length, const float* __restrict__ xin,
@@ -895,7 +901,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
              float* __restrict__ snaps, int M, int T, int G, int B, int dbg,
              unsigned long long* __restrict__ stamps, size_t rec_stride, const int* __restrict__ iter_base) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int NW = SPLIT ? 4 : 8;
+    static_assert(!NARROW || (WGR && !SPLIT && !DBG), "narrow workgroups: workgroup-record form, non-split formats, no test hooks");
+    constexpr int NW = (SPLIT || NARROW) ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;            // operand images per matrix (hi [+ lo])
     constexpr int NFW = 32 * WM;
     // diagnostic build aid: 100 MHz timestamps per stage for the waves of workgroup 3 (stamps == nullptr normally)
@@ -956,7 +963,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0 && l == 3) stamps[(threadIdx.x >> 6) * 32 + 26] = __builtin_amdgcn_s_memtime();
     DC_WGSTAMP(0);
     stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
-    if constexpr (WGR)      // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
+    if constexpr (NARROW)
+        wg_combine_attn_narrow<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, M, T, tid_, wg);
+    else if constexpr (WGR)      // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
         wg_combine_attn<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, M, T, tid_, wg,
                              (STAMP && stamps && blockIdx.x == 3 && l == 3) ? stamps : nullptr);
     else if (wg_lds)
@@ -1169,8 +1178,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                     mB[oc] = -INFINITY;
                     if (strad) keys_of(Kp[q], vr1, efB[oc], ssB[oc], mB[oc]);
                     if (cx.hh == 0) {
-                        mx[((oc * 2 + s0) * 32 + cx.c) * 8 + wave] = mA[oc];
-                        mx[((oc * 2 + (s0 ^ 1)) * 32 + cx.c) * 8 + wave] = s0 ? -INFINITY : mB[oc];
+                        mx[((oc * 2 + s0) * 32 + cx.c) * NW + wave] = mA[oc];
+                        mx[((oc * 2 + (s0 ^ 1)) * 32 + cx.c) * NW + wave] = s0 ? -INFINITY : mB[oc];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1187,11 +1196,11 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             // rescale factors of this wave's columns, through its own LDS strip (each lane needs 8 of them as row factors)
 #pragma unroll
             for (int oc = 0; oc < 4; ++oc) {
-                const float fa = mA[oc] == -INFINITY ? 0.f : exp2f_fast(mA[oc] - wg_colmax(mx, oc, s0, cx.c));
+                const float fa = mA[oc] == -INFINITY ? 0.f : exp2f_fast(mA[oc] - wg_colmax<NW>(mx, oc, s0, cx.c));
                 ssA[oc] *= fa;
                 if (cx.hh == 0) scw[(0 * 4 + oc) * 32 + cx.c] = fa;
                 if (strad) {
-                    const float fb = mB[oc] == -INFINITY ? 0.f : exp2f_fast(mB[oc] - wg_colmax(mx, oc, 1, cx.c));
+                    const float fb = mB[oc] == -INFINITY ? 0.f : exp2f_fast(mB[oc] - wg_colmax<NW>(mx, oc, 1, cx.c));
                     ssB[oc] *= fb;
                     if (cx.hh == 0) scw[(1 * 4 + oc) * 32 + cx.c] = fb;
                 }
@@ -1230,7 +1239,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                     if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssA[oc];
                     if (strad) {
                         xp[oc * 64 + lane] = block_of(efB[oc], Vp[q], vr1, scw + (1 * 4 + oc) * 32);
-                        if (cx.hh == 0) ss[(8 * 4 + oc) * 32 + cx.c] = ssB[oc];
+                        if (cx.hh == 0) ss[(NW * 4 + oc) * 32 + cx.c] = ssB[oc];
                     }
                 }
             }
@@ -1238,7 +1247,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             DC_STAMP(16);
             __syncthreads();
             DC_STAMP(17);
-            wg_write_record(recs_out, mx, pst, xp, ss, wave, lane, ub0, G, M, T, wg);
+            wg_write_record<NW>(recs_out, mx, pst, xp, ss, wave, lane, ub0, G, M, T, wg);
         } else {
             f32x16 K[4];                  // keys from buf0 while the value image lands in buf1
 #pragma unroll
@@ -1887,21 +1896,24 @@ hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcM
     return e;
 }
 
-template <class T16, bool SP, bool WGR>
+template <class T16, bool SP, bool WGR, bool NARROW = false>
 static hipError_t launch_embed_t(hipStream_t st, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
                                  int M, int T, int G, int B, unsigned long long* clk) {
-    constexpr int NW = SP ? 4 : 8;
+    constexpr int NW = (SP || NARROW) ? 4 : 8;
     const size_t shm = WGR ? 8192 + 65536 + 8192 + 9 * 4 * 32 * 4 + 33 * 1024 : 0;
     if (WGR) {
         static unsigned long long optin_done = 0;
-        if (hipError_t e = lds_optin((const void*)k_embed_front<T16, SP, WGR>, (int)shm, optin_done)) return e;
+        if (hipError_t e = lds_optin((const void*)k_embed_front<T16, SP, WGR, false, NARROW>, (int)shm, optin_done)) return e;
     }
-    k_embed_front<T16, SP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, B, clk);
+    k_embed_front<T16, SP, WGR, false, NARROW><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, B, clk);
     return hipGetLastError();
 }
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf,
-                                 float* recs, const int* length, int M, int T, int G, int B, unsigned long long* clk) {
+                                 float* recs, const int* length, int M, int T, int G, int B, unsigned long long* clk, bool narrow) {
     hipError_t e = hipSuccess;
+    if (wgr && !split && narrow)
+        return fmt == 1 ? launch_embed_t<_Float16, false, true, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk)
+                        : launch_embed_t<__bf16, false, true, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk);
     if (wgr && !split) {
         e = fmt == 1 ? launch_embed_t<_Float16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk)
                      : launch_embed_t<__bf16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk);
@@ -1911,18 +1923,18 @@ hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, 
     return e;
 }
 
-template <class T16, bool SP, bool DBG, bool STAMP, bool WGR>
+template <class T16, bool SP, bool DBG, bool STAMP, bool WGR, bool NARROW = false>
 static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                                  int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride,
                                  const int* iter_base) {
-    constexpr int NW = SP ? 4 : 8;
+    constexpr int NW = (SP || NARROW) ? 4 : 8;
     // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
     const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
     static unsigned long long optin_done = 0;   // > 64 KiB of dynamic LDS needs the opt-in
-    if (hipError_t e = lds_optin((const void*)k_layer<T16, SP, DBG, STAMP, WGR>, (int)shm, optin_done)) return e;
-    k_layer<T16, SP, DBG, STAMP, WGR><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
+    if (hipError_t e = lds_optin((const void*)k_layer<T16, SP, DBG, STAMP, WGR, NARROW>, (int)shm, optin_done)) return e;
+    k_layer<T16, SP, DBG, STAMP, WGR, NARROW><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
                        (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
                        snaps, M, T, G, B, dbg, stamps, rec_stride, iter_base);
     return hipGetLastError();
@@ -1931,10 +1943,14 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
 hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
-                           int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride, const int* iter_base) {
+                           int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride, const int* iter_base,
+                           bool narrow) {
     hipError_t e = hipSuccess;
 #define LAYER_ARGS st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps, \
                    rec_stride, iter_base
+    if (wgr && !split && narrow && dbg == 0 && stamps == nullptr)      // narrow workgroups: production build only
+        return fmt == 1 ? launch_layer_t<_Float16, false, false, false, true, true>(LAYER_ARGS)
+                        : launch_layer_t<__bf16, false, false, false, true, true>(LAYER_ARGS);
     if (wgr && !split) {        // workgroup-level records + in-kernel combine (non-split formats, T >= 256)
         if (dbg != 0)
             e = fmt == 1 ? launch_layer_t<_Float16, false, true, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, true, false, true>(LAYER_ARGS);

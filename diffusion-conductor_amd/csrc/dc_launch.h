@@ -29,7 +29,8 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
 // no dc_launch_attn_combine between the layers then)
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf, float* recs,
                                  const int* length, int M, int T, int G, int B,
-                                 unsigned long long* clk /* diagnostic stamps (8 slots) or nullptr */);
+                                 unsigned long long* clk /* diagnostic stamps (8 slots) or nullptr */,
+                                 bool narrow = false /* wgr, non-split: 4-wave workgroups = 128-token units (small batches) */);
 // test hook: front half of layer l0 from the residual stream as it stands in hbuf (per-group records)
 hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcModel* dm, float* hbuf, float* recs, const int* length,
                                   int M, int T, int G, int B, int l0);
@@ -38,7 +39,8 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride,
                            const int* iter_base /* captured loop: coef_cur / snap_cur = this step's slots of the per-iteration tables,
-                                                   indexed by *iter_base; else nullptr (scalars prepared by k_begin_step) */);
+                                                   indexed by *iter_base; else nullptr (scalars prepared by k_begin_step) */,
+                           bool narrow = false /* wgr, non-split, dbg == 0: 4-wave workgroups; recs / rec_stride then count 128-token units */);
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);
 // rec_stride: floats between the two alternating unit-record buffers (0 = single buffer, non-wgr)
 

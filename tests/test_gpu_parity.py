@@ -143,6 +143,29 @@ def test_captured_loop_table_lookup_equals_begin_step_launches(models):
     assert sorted(a.keys()) == [0, 60, 99, 100] and all(torch.equal(a[k], b[k]) for k in a)
 
 
+def test_narrow_workgroups_agree_with_wide_ones(models):
+    """Small batches run the layer kernels with 4-wave workgroups (128-token units, one wave per SIMD; default whenever every
+    unit gets its own CU), DC_NO_NARROW=1 keeps the 8-wave form.  The two exponentiate the keys against different unit maxima
+    before the f16 operand rounding, so they agree at the precision mode's noise level - and both meet the parity bound."""
+    B, T = 3, 900
+    xfp, xfo = xf_pair(B, T, first=40)
+    noise = torch.from_numpy(batch_noise(B, T, first=40))
+    length = [900, 512, 333]
+    with torch.no_grad():
+        ref = O.ddim_sample_loop(oracle_params(), noise, xfp, xfo, length, 25)
+    os.environ["DC_DISABLE_GRAPH"] = "1"
+    try:
+        a = _ddim(models["fp16"], 25, noise, xfp, xfo, length)
+        os.environ["DC_NO_NARROW"] = "1"
+        b = _ddim(models["fp16"], 25, noise, xfp, xfo, length)
+    finally:
+        del os.environ["DC_DISABLE_GRAPH"]
+        os.environ.pop("DC_NO_NARROW", None)
+    ea, eb, d = rel_l2(a, ref), rel_l2(b, ref), rel_l2(a, b.cpu().numpy())
+    print(f"narrow vs oracle {ea:.3e}; wide vs oracle {eb:.3e}; narrow vs wide {d:.3e}")
+    assert torch.isfinite(a).all() and ea <= TOL_PARITY and eb <= TOL_PARITY and d <= TOL_PARITY
+
+
 def test_film_adaptive_shares_do_not_change_results(models):
     """The persistent FiLM GEMM sizes its workgroups' shares by the per-XCD speeds measured in earlier launches (>= 64
     workgroups); which workgroup computes a tile must not matter: bit-identical to equal shares (DC_FILM_STATIC=1) and
