@@ -90,22 +90,6 @@ void pack_weight(const float* w, int n_out, int k_in, bool chained, uint16_t* hi
                         lo[o] = f16 ? f2h(v - h2f(h)) : f2bf(v - bf2f(h));
                     }
 }
-// v_mfma_f32_16x16x32 operand image of the 16-token layer kernel (DcLayer16 in dc_common.h): [m][rb][64][8]
-void pack_weight16(const float* w, int n_out, int k_in, uint16_t* hi, uint16_t* lo, bool f16) {
-    const int RB = cdiv(n_out, 16), KM = cdiv(k_in, 32);
-    for (int m = 0; m < KM; ++m)
-        for (int rb = 0; rb < RB; ++rb)
-            for (int l = 0; l < 64; ++l)
-                for (int j = 0; j < 8; ++j) {
-                    const int row = 16 * rb + (l & 15), col = 32 * m + 16 * (j >> 2) + 4 * (l >> 4) + (j & 3);
-                    const float v = (row < n_out && col < k_in) ? w[(size_t)row * k_in + col] : 0.f;
-                    const size_t o = (((size_t)m * RB + rb) * 64 + l) * 8 + j;
-                    const uint16_t h = f16 ? f2h(v) : f2bf(v);
-                    hi[o] = h;
-                    if (lo) lo[o] = f16 ? f2h(v - h2f(h)) : f2bf(v - bf2f(h));
-                }
-}
-size_t packed_elems16(int n_out, int k_in) { return (size_t)cdiv(n_out, 16) * cdiv(k_in, 32) * 64 * 8; }
 size_t packed_elems(int n_out, int k_in) { return (size_t)cdiv(n_out, 32) * cdiv(k_in, 32) * 2 * 64 * 8; }
 
 // per-feature vector in FT register order: out[(t*2+hh)*16 + r] = v[32t + tile_row(r,hh)]
@@ -168,7 +152,6 @@ struct dc_sampler {
     float* d_h = nullptr;
     float* d_recs = nullptr;
     void *d_a_sa = nullptr, *d_a_ca = nullptr;
-    void* d_a_ca16 = nullptr;             // cross-attention fragments in the 16-token layer kernel's form
     void *d_kv_sa[2] = {nullptr, nullptr}, *d_kv_ca = nullptr;   // no_eff: key-tile arrays (dc_kernels.hip, full attention)
     int KT = 0;                                                   // key tiles per clip array
     float* d_x = nullptr;
@@ -347,31 +330,14 @@ int build_model(dc_sampler* s) {
         return buf;
     };
     const bool ssp = s->split_small;
-    // 16-token layer kernel (non-split formats, linear attention): up to two matrices + constants per stage image
-    const bool want16 = !ssp && !c.no_eff;
-    auto add_image16 = [&](const bf16x8** dst, const float* wa, int na_out, int ka, const float* wb, int nb_out, int kb, bool with_lo,
-                           const std::vector<float>& consts) {
-        if (!want16) return;
-        const size_t ea = packed_elems16(na_out, ka), eb = wb ? packed_elems16(nb_out, kb) : 0;
-        std::vector<uint16_t> hi(ea + eb), lo(ea + eb);
-        pack_weight16(wa, na_out, ka, hi.data(), lo.data(), sf16);
-        if (wb) pack_weight16(wb, nb_out, kb, hi.data() + ea, lo.data() + ea, sf16);
-        std::vector<uint8_t> blob((ea + eb) * 2 * (with_lo ? 2 : 1) + 1024, 0);
-        memcpy(blob.data(), hi.data(), (ea + eb) * 2);
-        if (with_lo) memcpy(blob.data() + (ea + eb) * 2, lo.data(), (ea + eb) * 2);
-        memcpy(blob.data() + (ea + eb) * 2 * (with_lo ? 2 : 1), consts.data(), consts.size() * 4);
-        O.fix.push_back({(const void**)dst, A.add(blob.data(), blob.size())});
-    };
-    auto add_styl = [&](const bf16x8** dst, const std::string& p) -> std::vector<float> {
+    auto add_styl = [&](const bf16x8** dst, const std::string& p) {
         const std::vector<float> bo = ftvec(P_(p + ".out_layers.2.bias"), D, 4);
         // the kernels hand over log2(e) * SiLU(.) (silu_l2_pair in dc_kernels.hip): ln 2 goes into the weights
         const float* w = P_(p + ".out_layers.2.weight");
         std::vector<float> ws((size_t)D * D);
         for (size_t i = 0; i < ws.size(); ++i) ws[i] = (float)((double)w[i] * 0.6931471805599453);
         add_image(dst, ws.data(), D, D, ssp, bo.data(), bo.size());
-        return ws;
     };
-    auto vec = [](const float* p, size_t n) { return std::vector<float>(p, p + n); };
     // W' = W diag(g), c' = c + W b  (LayerNorm affine folded into the projection that consumes it)
     // `scale` additionally multiplies the whole projection: log2(e) for the query / key projections, whose
     // outputs only ever feed exp() (softmax), so the kernels can use the native exp2.
@@ -401,7 +367,6 @@ int build_model(dc_sampler* s) {
     for (int i = 0; i < L; ++i) {
         const std::string p = "temporal_decoder_blocks." + std::to_string(i);
         DcLayer& y = m.layer[i];
-        DcLayer16& y16 = m.l16[i];
         std::vector<float> wf, cf;
         const float* sg = P_(p + ".sa_block.norm.weight");
         const float* sb = P_(p + ".sa_block.norm.bias");
@@ -409,24 +374,17 @@ int build_model(dc_sampler* s) {
         {
             const std::vector<float> c = ftvec(cf.data(), D, 4);
             add_image(&y.img_sa_q, wf.data(), D, D, ssp, c.data(), c.size());
-            add_image16(&y16.sa_q, wf.data(), D, D, nullptr, 0, 0, false, cf);
         }
         fold_ln(P_(p + ".sa_block.key.weight"), P_(p + ".sa_block.key.bias"), sg, sb, D, D, wf, cf, KS);
         add_image(&y.img_sa_k, wf.data(), D, D, ssp, cf.data(), cf.size());          // plain bias[128]
-        add_image16(&y16.sa_k, wf.data(), D, D, nullptr, 0, 0, false, cf);
         fold_ln(P_(p + ".sa_block.value.weight"), P_(p + ".sa_block.value.bias"), sg, sb, D, D, wf, cf);
         add_image(&y.img_sa_v, wf.data(), D, D, ssp, cf.data(), cf.size());
-        add_image16(&y16.sa_v, wf.data(), D, D, nullptr, 0, 0, false, cf);
-        {
-            const std::vector<float> ws = add_styl(&y.img_sa_o, p + ".sa_block.proj_out");
-            add_image16(&y16.sa_o, ws.data(), D, D, nullptr, 0, 0, false, vec(P_(p + ".sa_block.proj_out.out_layers.2.bias"), D));
-        }
+        add_styl(&y.img_sa_o, p + ".sa_block.proj_out");
         fold_ln(P_(p + ".ca_block.query.weight"), P_(p + ".ca_block.query.bias"), P_(p + ".ca_block.norm.weight"),
                 P_(p + ".ca_block.norm.bias"), D, D, wf, cf, QS);
         {
             const std::vector<float> c = ftvec(cf.data(), D, 4);
             add_image(&y.img_ca_q, wf.data(), D, D, ssp, c.data(), c.size());
-            add_image16(&y16.ca_q, wf.data(), D, D, nullptr, 0, 0, false, cf);
         }
         // fold text_norm's affine (transformer.py:149,153) into the K/V projections:
         //   W (g*n + b) + c = (W*g) n + (W b + c)
@@ -451,25 +409,15 @@ int build_model(dc_sampler* s) {
                 add_raw(kv ? &y.ca_bv : &y.ca_bk, bf.data(), D);
             }
         }
-        {
-            const std::vector<float> ws = add_styl(&y.img_ca_o, p + ".ca_block.proj_out");
-            add_image16(&y16.ca_o, ws.data(), D, D, nullptr, 0, 0, false, vec(P_(p + ".ca_block.proj_out.out_layers.2.bias"), D));
-        }
+        add_styl(&y.img_ca_o, p + ".ca_block.proj_out");
         add_image(&y.img_ffn_w1, P_(p + ".ffn.linear1.weight"), DC_F, D, ssp, nullptr, 0);
         {
             std::vector<float> c = ftvec(P_(p + ".ffn.linear1.bias"), DC_F, 2);       // 64 floats, then b2
             const std::vector<float> c2 = ftvec(P_(p + ".ffn.linear2.bias"), D, 4);
             c.insert(c.end(), c2.begin(), c2.end());
             add_image(&y.img_ffn_w2, P_(p + ".ffn.linear2.weight"), D, DC_F, ssp, c.data(), c.size());
-            std::vector<float> pc = vec(P_(p + ".ffn.linear1.bias"), DC_F);
-            const std::vector<float> pb2 = vec(P_(p + ".ffn.linear2.bias"), D);
-            pc.insert(pc.end(), pb2.begin(), pb2.end());
-            add_image16(&y16.ffn_w, P_(p + ".ffn.linear1.weight"), DC_F, D, P_(p + ".ffn.linear2.weight"), D, DC_F, false, pc);
         }
-        {
-            const std::vector<float> ws = add_styl(&y.img_ffn_o, p + ".ffn.proj_out");
-            add_image16(&y16.ffn_o, ws.data(), D, D, nullptr, 0, 0, false, vec(P_(p + ".ffn.proj_out.out_layers.2.bias"), D));
-        }
+        add_styl(&y.img_ffn_o, p + ".ffn.proj_out");
         const char* blk[3] = {".sa_block.proj_out", ".ca_block.proj_out", ".ffn.proj_out"};
         for (int j = 0; j < 3; ++j) {
             const size_t row0 = (size_t)(3 * i + j) * 256;
@@ -523,9 +471,6 @@ int build_model(dc_sampler* s) {
         add_image(&m.img_je, P_("joint_embed.weight"), D, P, true, jb.data(), jb.size());
         const std::vector<float> ob = ftvec(P_("out.bias"), P, 1);
         add_image(&m.img_out, P_("out.weight"), P, D, true, ob.data(), ob.size());
-        std::vector<float> ob16(32, 0.f);
-        for (int i = 0; i < P; ++i) ob16[i] = P_("out.bias")[i];
-        add_image16(&m.out16, P_("out.weight"), P, D, nullptr, 0, 0, true, ob16);
     }
     add_raw(&m.seq_emb, P_("sequence_embedding"), (size_t)c.num_frames * D);
     {
@@ -615,7 +560,6 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
         if ((rc = dev_alloc(s, s->d_t_clip, (size_t)B * 4))) return rc;
         if ((rc = dev_alloc(s, s->d_a_sa, (size_t)B * 16 * 1024))) return rc;
         if ((rc = dev_alloc(s, s->d_a_ca, (size_t)L * B * 16 * 1024))) return rc;
-        if ((rc = dev_alloc(s, s->d_a_ca16, (size_t)L * B * 8 * 1024))) return rc;
         s->cap_B = (size_t)B;
     }
     if ((size_t)M * P > s->cap_MP) {
@@ -743,18 +687,11 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
                                               want_stamps_film ? s->d_stamps + 256 : nullptr, narrow));
     static const bool want_stamps = getenv("DC_STAMPS") != nullptr;
-    // 16-token waves (dc_layer16.hip): DC_LAYER16=1 (read per call)
-    const bool layer16 = wgr && !narrow && !want_stamps && getenv("DC_LAYER16") != nullptr;
     const int nwg = narrow ? (G + 3) / 4 : (G + 7) / 8;
     const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
     for (int l = s->dbg_first >= 0 ? s->dbg_first : 0; l < nl_run; ++l) {
         const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
-        if (layer16 && (dbg >> 8) == 0) {
-            LAUNCH(K_LAYER, dc_launch_layer16(st, fs, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_ca16, s->d_recs, s->d_length, x_src, x_dst,
-                                              loop_mode ? 1 : 0, coef_src, snap_src, s->d_snaps, M, T, G, B, dbg, rec_stride, iter_base));
-            continue;
-        }
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src,
                                         s->d_snaps, M, T, G, B, dbg, ((l == 3 || l == 4) && want_stamps) ? s->d_stamps : nullptr, rec_stride,
@@ -1049,7 +986,6 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
     } else {
         HIP_TRY(dc_launch_ca_partials(st, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_recs_ca, M, T, G, L));
         HIP_TRY(dc_launch_attn_combine(st, s->small_fmt, s->d_recs_ca, s->d_a_ca, T, G, B, L, 32));
-        if (!s->split_small) HIP_TRY(dc_launch_cond_af16(st, s->small_fmt, s->d_a_ca, s->d_a_ca16, L * B));
     }
     HIP_TRY(hipStreamSynchronize(st));   // `len` is host memory
     s->cond_set = true;

@@ -41,13 +41,6 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            const int* iter_base /* captured loop: coef_cur / snap_cur = this step's slots of the per-iteration tables,
                                                    indexed by *iter_base; else nullptr (scalars prepared by k_begin_step) */,
                            bool narrow = false /* wgr, non-split, dbg == 0: 4-wave workgroups; recs / rec_stride then count 128-token units */);
-// the same layer on 16-token waves (dc_layer16.hip): wgr, non-split formats, 256-token units; a_ca16 = the cross-attention
-// fragments in that kernel's form (dc_launch_cond_af16, once per conditioning); stop_after: 0 or the 1 / 2 / 3 of `dbg`
-hipError_t dc_launch_layer16(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* E, int NT, const void* a_ca16,
-                             float* recs, const int* length, const float* xin, float* xout, int out_mode, const float* coef_cur,
-                             const int* snap_cur, float* snaps, int M, int T, int G, int B, int stop_after, size_t rec_stride,
-                             const int* iter_base);
-hipError_t dc_launch_cond_af16(hipStream_t st, int fmt, const void* a_ca, void* a_ca16, int n_matrices);
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);
 // rec_stride: floats between the two alternating unit-record buffers (0 = single buffer, non-wgr)
 

@@ -384,16 +384,25 @@ DEV void wg_combine_attn16(const float* __restrict__ recs, v8<T16>* af, float* s
 // k_layer16: one decoder layer for one 256-token unit, 16 waves x 16 tokens.  Same stages, staging and barriers as k_layer.
 // stop_after (test hook, wave-uniform): 1 / 2 / 3 = leave after the self-attention / cross-attention / FFN block.
 // ------------------------------------------------------------------------------------------------------------------
-template <class T16>
+template <class T16, bool STAMP>
 __global__ __launch_bounds__(1024, 1)
 void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
                const v8<T16>* __restrict__ a_ca /*[L][B][16][64] 32-token form*/, float* __restrict__ recs, const int* __restrict__ length,
                const float* __restrict__ xin, float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur,
                const int* __restrict__ snap_cur, float* __restrict__ snaps, int M, int T, int G, int B, int stop_after,
-               size_t rec_stride, const int* __restrict__ iter_base) {
+               size_t rec_stride, const int* __restrict__ iter_base, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using W = v8<T16>;
     constexpr int NW = 16;
+    // diagnostic build: 100 MHz timestamps per stage for the 16 waves of workgroup 3 of layer 3 (tools/stage_stamps16.py)
+    auto stamp = [&](int k) {
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0 && l == 3)
+                stamps[264 + (threadIdx.x >> 6) * 32 + k] = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wg = wg_index();
@@ -417,17 +426,21 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
     float* recs_out = recs + (size_t)((l + 1) & 1) * rec_stride;
 
     f32x4 h[8];
+    stamp(0);
     load_h16(h, hbuf, c);
     stage_frags<NW>(L.sa_q, buf0, 33, wave, lane);
     wg_combine_attn16<T16>(recs_in, reinterpret_cast<W*>(lds + L16_OFF_AF), reinterpret_cast<float*>(buf1), ub0, M, T, tid, wg);
     stage_sync();
+    stamp(1);
 
     // ---- self-attention
     stage_frags<NW>(L.sa_o, buf1, 33, wave, lane);
     Y16 y[8];
     float y_rstd, y_shift;
     query_attend16<T16>(y, y_rstd, y_shift, h, c0, w0, af + (size_t)(c.b0 - ub0) * 8 * 64, af + (size_t)(c.b1 - ub0) * 8 * 64, c);
+    stamp(2);
     stage_sync();
+    stamp(3);
     {   // cross-attention query image + the cross-attention fragments of clips ub0, ub0+1 (built from the 32-token form by
         // k_cond_af16 into dm-independent storage: a_ca here IS that 16-token form: [L][B][8 heads][64 lanes])
         stage_frags<NW>(L.ca_q, buf0, 33, wave, lane);
@@ -437,24 +450,30 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
         stage_frags<NW>(acl + (size_t)c1i * 8 * 64, lds + L16_OFF_AF + 8192, 8, wave, lane);
     }
     styl_accumulate16<T16>(h, y, y_rstd, y_shift, Eg, c1, w1, c);
+    stamp(4);
     if (stop_after == 1) {
         if (active) store_h16(h, hbuf, c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
     stage_sync();
+    stamp(5);
     // ---- cross-attention
     stage_frags<NW>(L.ca_o, buf1, 33, wave, lane);
     query_attend16<T16>(y, y_rstd, y_shift, h, c0, w0, af + (size_t)(c.b0 - ub0) * 8 * 64, af + (size_t)(c.b1 - ub0) * 8 * 64, c);
+    stamp(6);
     stage_sync();
+    stamp(7);
     stage_frags<NW>(L.ffn_w, buf0, 33, wave, lane);          // W1 (16 fragments) | W2 (16) | b1[64], b2[128]
     styl_accumulate16<T16>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, c);
+    stamp(8);
     if (stop_after == 2) {
         if (active) store_h16(h, hbuf, c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
     stage_sync();
+    stamp(9);
     // ---- FFN
     stage_frags<NW>(L.ffn_o, buf1, 33, wave, lane);
     {
@@ -493,18 +512,22 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
         }
         st.finish(y_rstd, y_shift);
     }
+    stamp(10);
     stage_sync();
+    stamp(11);
     if (!last)
         stage_frags<NW>(dm->l16[l + 1].sa_k, buf0, 33, wave, lane);
     else
         stage_frags<NW>(dm->out16, buf0, 17, wave, lane);        // 8 hi + 8 lo fragments + bias: always runs split
     styl_accumulate16<T16>(h, y, y_rstd, y_shift, Eg + 16 * 128, c1, w1, c);
+    stamp(12);
     if (stop_after == 3) {
         if (active) store_h16(h, hbuf, c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
     stage_sync();
+    stamp(13);
 
     if (!last) {
         // ---- next layer's self-attention front half: K [buf0], V [buf1] in TF form (token on the ROW: lane = feature), unit record
@@ -569,6 +592,7 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
             }
             if (cb & 1) __builtin_amdgcn_sched_barrier(0);
         }
+        stamp(14);
         __builtin_amdgcn_sched_barrier(0);
         if (active)
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // all but the 8 stores of h: the value image has landed
@@ -576,6 +600,7 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
+        stamp(15);
         auto unit_max = [&](int feat, int sl) {
             const f32x4* p = reinterpret_cast<const f32x4*>(mx + (feat * 2 + sl) * 16);
             const f32x4 a = p[0], b = p[1], cc = p[2], d = p[3];
@@ -601,6 +626,7 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(16);
         // two rounds of four heads: every wave stages its K^T V blocks, the waves 0..7 sum block (round * 4 + (w & 3)) of slot w >> 2
         // over the 16 contributors in wave order and write the unit record in the 32-token kernels' format
         f32x4* mine = reinterpret_cast<f32x4*>(pst) + (size_t)wave * 4 * 64 + lane;
@@ -642,7 +668,9 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
                 }
                 if (k & 1) __builtin_amdgcn_sched_barrier(0);
             }
+            stamp(17 + 3 * rnd);
             __syncthreads();
+            stamp(18 + 3 * rnd);
             if (wave < 8) {
                 const int k = wave & 3, cb = 4 * rnd + k, sl = wave >> 2;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -672,6 +700,7 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
                 // 16 (cb & 1) + l + 32 (q4 & 1), values 4 (q4 >> 1) + i
                 reinterpret_cast<f32x4*>(R + 256 + ((cb >> 1) * 64 + 16 * (cb & 1) + f + 32 * (c.q4 & 1)) * 8)[c.q4 >> 1] = acc;
             }
+            stamp(19 + 3 * rnd);
         }
         return;
     }
@@ -755,12 +784,13 @@ __global__ void k_cond_af16(const v8<T16>* __restrict__ src, v8<T16>* __restrict
 }
 
 static hipError_t l16_optin(const void* fn) {
-    static unsigned long long done[2] = {0, 0};
-    static const void* fns[2] = {nullptr, nullptr};
+    static unsigned long long done[3] = {0, 0, 0};
+    static const void* fns[3] = {nullptr, nullptr, nullptr};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    int slot = fns[0] == fn || fns[0] == nullptr ? 0 : 1;
+    int slot = 0;
+    while (slot < 2 && fns[slot] != fn && fns[slot] != nullptr) ++slot;
     fns[slot] = fn;
     if (dev < 64 && ((done[slot] >> dev) & 1ull)) return hipSuccess;
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, L16_LDS);
@@ -771,16 +801,24 @@ static hipError_t l16_optin(const void* fn) {
 hipError_t dc_launch_layer16(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* E, int NT, const void* a_ca16,
                              float* recs, const int* length, const float* xin, float* xout, int out_mode, const float* coef_cur,
                              const int* snap_cur, float* snaps, int M, int T, int G, int B, int stop_after, size_t rec_stride,
-                             const int* iter_base) {
+                             const int* iter_base, unsigned long long* stamps) {
     const dim3 grid((G + 7) / 8), block(1024);
+    if (stamps) {      // diagnostic build (DC_STAMPS=1)
+        if (fmt != 1) return hipErrorInvalidValue;
+        if (hipError_t e = l16_optin((const void*)k_layer16<_Float16, true>)) return e;
+        k_layer16<_Float16, true><<<grid, block, L16_LDS, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const f16x8*)a_ca16, recs, length, xin, xout,
+                                                                out_mode, coef_cur, snap_cur, snaps, M, T, G, B, stop_after, rec_stride, iter_base,
+                                                                stamps);
+        return hipGetLastError();
+    }
     if (fmt == 1) {
-        if (hipError_t e = l16_optin((const void*)k_layer16<_Float16>)) return e;
-        k_layer16<_Float16><<<grid, block, L16_LDS, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const f16x8*)a_ca16, recs, length, xin, xout,
-                                                          out_mode, coef_cur, snap_cur, snaps, M, T, G, B, stop_after, rec_stride, iter_base);
+        if (hipError_t e = l16_optin((const void*)k_layer16<_Float16, false>)) return e;
+        k_layer16<_Float16, false><<<grid, block, L16_LDS, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const f16x8*)a_ca16, recs, length, xin, xout,
+                                                          out_mode, coef_cur, snap_cur, snaps, M, T, G, B, stop_after, rec_stride, iter_base, nullptr);
     } else {
-        if (hipError_t e = l16_optin((const void*)k_layer16<__bf16>)) return e;
-        k_layer16<__bf16><<<grid, block, L16_LDS, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const bf16x8*)a_ca16, recs, length, xin, xout,
-                                                        out_mode, coef_cur, snap_cur, snaps, M, T, G, B, stop_after, rec_stride, iter_base);
+        if (hipError_t e = l16_optin((const void*)k_layer16<__bf16, false>)) return e;
+        k_layer16<__bf16, false><<<grid, block, L16_LDS, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const bf16x8*)a_ca16, recs, length, xin, xout,
+                                                        out_mode, coef_cur, snap_cur, snaps, M, T, G, B, stop_after, rec_stride, iter_base, nullptr);
     }
     return hipGetLastError();
 }
