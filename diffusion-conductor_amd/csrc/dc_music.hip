@@ -155,6 +155,127 @@ __global__ __launch_bounds__(256) void k_me_conv(const float* __restrict__ mel, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The same convolution for CIN >= 16 from an LDS-resident input tile.  k_me_conv reads every tap of every pixel from
+// L1 / L2 (18 KiB of loads per 2 KiB of unique input: 2.3 TB/s of HBM at best); here a persistent 4-wave workgroup
+// copies a (ROWS + 2) x (32 NXS + 2)-pixel halo tile of both planes into LDS by LDS-DMA (reflect padding by index) once
+// and feeds all nine taps from there.  LDS piece order [plane][16-channel chunk][channel half][row][pixel] x 16 B: the
+// B operand of one tap is 32 consecutive pieces per channel half - conflict-free ds_read_b128 - and a tap shift is a
+// piece offset.  The weight fragments of a k-step are read once per wave for its ROWS NXS / 4 wave tiles; the identity
+// residual and the 1x1 residual convolution take the centre pixels from the same tile.  Two workgroups per CU: one
+// fills while the other computes.
+// ---------------------------------------------------------------------------------------------------------
+DEV void me_dma16(const void* gsrc /*per-lane*/, const char* lds_dst /*wave-uniform*/) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+template <int CIN, int COUT, int RES, int ROWS, int NXS>
+__global__ __launch_bounds__(256, 2) void k_me_conv_t(const bf16x8* __restrict__ in_hi, const bf16x8* __restrict__ in_lo,
+                                                      __bf16* __restrict__ out_hi, __bf16* __restrict__ out_lo,
+                                                      const bf16x8* __restrict__ w, const float* __restrict__ bias_ft,
+                                                      const float* __restrict__ rbias_ft, int H, int W, int ntiles) {
+    constexpr int KC = CIN / 16, NKS = 9 * KC, NF = 2 * NKS + (RES == 2 ? 2 * KC : 0);
+    constexpr int TX = 32 * NXS, PXW = TX + 2, RH = ROWS + 2;
+    constexpr int SEL = RH * PXW;                    // pieces per (plane, chunk, half)
+    constexpr int NP = 2 * KC * 2 * SEL;
+    constexpr int NDMA = (NP + 63) / 64;
+    constexpr int TPW = ROWS * NXS / 4;
+    static_assert(ROWS * NXS % 4 == 0, "wave tiles divide over 4 waves");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    bf16x8* wl = reinterpret_cast<bf16x8*>(lds);
+    bf16x8* tl = wl + NF * 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = lane & 31, kh = lane >> 5;
+    for (int f = wave; f < NF; f += 4) wl[f * 64 + lane] = w[f * 64 + lane];
+    f32x16 bias, rbias;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        bias[r] = bias_ft[kh * 16 + r];
+        rbias[r] = RES == 2 ? rbias_ft[kh * 16 + r] : 0.f;
+    }
+    const int txn = W / TX, tyn = (H + ROWS - 1) / ROWS;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = t % txn, ty = (t / txn) % tyn, b = t / (txn * tyn);
+        const int x0 = tx * TX, y0 = ty * ROWS;
+        for (int j = wave; j < NDMA; j += 4) {
+            const int p = 64 * j + lane;
+            if (p < NP) {
+                const int px = p % PXW, row = (p / PXW) % RH, sel = p / SEL;
+                const int yy = reflect(y0 - 1 + row, H), xx = reflect(x0 - 1 + px, W);
+                const bf16x8* src = ((sel >= 2 * KC) ? in_lo : in_hi) + (((size_t)b * H + yy) * W + xx) * (CIN / 8) + (sel % (2 * KC));
+                me_dma16(src, reinterpret_cast<const char*>(tl + 64 * j));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x16 acc[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = zero16();
+        // piece of (plane, chunk kc, this lane's half, tile row r + dy, pixel 32 seg + n + dx), halo coordinates
+        auto piece = [&](int plane, int kc, int r, int seg, int dy, int dx) {
+            return tl[((plane * KC + kc) * 2 + kh) * SEL + (r + dy) * PXW + seg * 32 + n + dx];
+        };
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const int ks = tap * KC + kc;
+                const bf16x8 ah = wl[ks * 64 + lane], al = wl[(NKS + ks) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const int wt = wave * TPW + i, r = wt / NXS, seg = wt % NXS;
+                    acc[i] = mma3(ah, al, piece(0, kc, r, seg, tap / 3, tap % 3), piece(1, kc, r, seg, tap / 3, tap % 3), acc[i]);
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int wt = wave * TPW + i, r = wt / NXS, seg = wt % NXS;
+            const int y = y0 + r, x = x0 + seg * 32 + n;
+            f32x16 res = zero16();
+            if constexpr (RES == 2) {
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc)
+                    res = mma3(wl[(2 * NKS + kc) * 64 + lane], wl[(2 * NKS + KC + kc) * 64 + lane], piece(0, kc, r, seg, 1, 1),
+                               piece(1, kc, r, seg, 1, 1), res);
+            }
+            if (y >= H) continue;
+            const size_t pix = ((size_t)b * H + y) * W + x;
+#pragma unroll
+            for (int q = 0; q < COUT / 8; ++q) {
+                const int c0 = 8 * q + 4 * kh;          // this lane's 4 consecutive output channels of register group q
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][4 * q + e] + bias[4 * q + e], 0.f);
+                if constexpr (RES == 1) {               // input channels c0 .. c0+3 of the centre pixel: half kh of piece (q >> 1, q & 1)
+                    const int pc = ((q >> 1) * 2 + (q & 1)) * SEL + (r + 1) * PXW + seg * 32 + n + 1;
+                    const bf16x4 xh = reinterpret_cast<const bf16x4*>(tl + pc)[kh];
+                    const bf16x4 xl = reinterpret_cast<const bf16x4*>(tl + 2 * KC * SEL + pc)[kh];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)xh[e] + (float)xl[e];
+                }
+                if constexpr (RES == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += res[4 * q + e] + rbias[4 * q + e];
+                }
+                bf16x4 oh, ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const __bf16 h = (__bf16)v[e];
+                    oh[e] = h;
+                    ol[e] = (__bf16)(v[e] - (float)h);
+                }
+                *reinterpret_cast<bf16x4*>(out_hi + pix * COUT + c0) = oh;
+                *reinterpret_cast<bf16x4*>(out_lo + pix * COUT + c0) = ol;
+            }
+        }
+        __syncthreads();          // everyone is done with the tile before the next fill lands
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // max_pool2d on the plane pair; padding never wins (torch pads with -inf).  One thread per (pixel, 8 channels).
 // hi + lo is exact in fp32 (<= 17 significant bits), so the maximum re-splits into the very planes it came from.
 // ---------------------------------------------------------------------------------------------------------
@@ -513,6 +634,33 @@ hipError_t launch_conv(hipStream_t st, const ConvDev& c, const float* mel, const
                                                                       TPW);
     return hipGetLastError();
 }
+// LDS-tiled form (CIN >= 16); W must be a multiple of the tile width
+template <int CIN, int COUT, int RES, int ROWS, int NXS>
+hipError_t launch_conv_t(hipStream_t st, const ConvDev& c, const bf16x8* ih, const bf16x8* il, bf16x8* oh, bf16x8* ol, int Bc, int H,
+                         int W) {
+    constexpr int KC = CIN / 16, NKS = 9 * KC, NF = 2 * NKS + (RES == 2 ? 2 * KC : 0);
+    constexpr int NP = 2 * KC * 2 * (ROWS + 2) * (32 * NXS + 2), NDMA = (NP + 63) / 64;
+    constexpr int SHM = (NF + NDMA) * 1024;
+    if (W % (32 * NXS) != 0) return launch_conv<CIN, COUT, RES>(st, c, nullptr, ih, il, oh, ol, Bc, H, W);
+    static int ncu = 0;
+    static bool optin = false;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return hipErrorUnknown;
+        ncu = pr.multiProcessorCount;
+    }
+    const auto fn = k_me_conv_t<CIN, COUT, RES, ROWS, NXS>;
+    if (!optin) {
+        if (hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, SHM)) return e;
+        optin = true;
+    }
+    const long long ntiles = (long long)Bc * ((H + ROWS - 1) / ROWS) * (W / (32 * NXS));
+    const unsigned grid = (unsigned)std::min<long long>(ntiles, 2LL * ncu);
+    fn<<<dim3(grid), dim3(256), SHM, st>>>(ih, il, reinterpret_cast<__bf16*>(oh), reinterpret_cast<__bf16*>(ol), c.w, c.bias, c.rbias, H, W,
+                                           (int)ntiles);
+    return hipGetLastError();
+}
 template <int KH, int KW, int SH, int SW, int PH, int PW>
 hipError_t launch_pool(hipStream_t st, const bf16x8* ih, const bf16x8* il, bf16x8* oh, bf16x8* ol, int Bc, int H, int W, int C,
                        int Ho, int Wo) {
@@ -557,14 +705,14 @@ hipError_t dc_music_encode(dc_music* m, const float* d_mel, int B, int Tm, float
         const int Bc = std::min(chunk, B - b0);
         const float* mel = d_mel + (size_t)b0 * Tm * 128;
         ME_TRY((launch_conv<1, 16, 0>(st, m->conv[0], mel, nullptr, nullptr, ah, al, Bc, Tm, 128)));
-        ME_TRY((launch_conv<16, 16, 1>(st, m->conv[1], nullptr, ah, al, bh, bl, Bc, Tm, 128)));
-        ME_TRY((launch_conv<16, 16, 1>(st, m->conv[2], nullptr, bh, bl, ah, al, Bc, Tm, 128)));
+        ME_TRY((launch_conv_t<16, 16, 1, 8, 2>(st, m->conv[1], ah, al, bh, bl, Bc, Tm, 128)));
+        ME_TRY((launch_conv_t<16, 16, 1, 8, 2>(st, m->conv[2], bh, bl, ah, al, Bc, Tm, 128)));
         ME_TRY((launch_pool<5, 5, 1, 2, 2, 2>(st, ah, al, bh, bl, Bc, Tm, 128, 16, Tm, 64)));
-        ME_TRY((launch_conv<16, 32, 2>(st, m->conv[3], nullptr, bh, bl, ah, al, Bc, Tm, 64)));
-        ME_TRY((launch_conv<32, 32, 1>(st, m->conv[4], nullptr, ah, al, bh, bl, Bc, Tm, 64)));
+        ME_TRY((launch_conv_t<16, 32, 2, 8, 2>(st, m->conv[3], bh, bl, ah, al, Bc, Tm, 64)));
+        ME_TRY((launch_conv_t<32, 32, 1, 8, 1>(st, m->conv[4], ah, al, bh, bl, Bc, Tm, 64)));
         ME_TRY((launch_pool<5, 5, 3, 2, 2, 2>(st, bh, bl, ah, al, Bc, Tm, 64, 32, T, 32)));
-        ME_TRY((launch_conv<32, 32, 1>(st, m->conv[5], nullptr, ah, al, bh, bl, Bc, T, 32)));
-        ME_TRY((launch_conv<32, 32, 1>(st, m->conv[6], nullptr, bh, bl, ah, al, Bc, T, 32)));
+        ME_TRY((launch_conv_t<32, 32, 1, 8, 1>(st, m->conv[5], ah, al, bh, bl, Bc, T, 32)));
+        ME_TRY((launch_conv_t<32, 32, 1, 8, 1>(st, m->conv[6], bh, bl, ah, al, Bc, T, 32)));
         ME_TRY((launch_pool<3, 3, 1, 2, 1, 1>(st, ah, al, bh, bl, Bc, T, 32, 32, T, 16)));
         const int M = Bc * T;
         const unsigned grid = (unsigned)((M + 127) / 128);
