@@ -276,6 +276,201 @@ __global__ __launch_bounds__(256, 2) void k_me_conv_t(const bf16x8* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// conv1 (1 -> 16 -> 16 -> 16 at full mel resolution) as ONE kernel: the three layers' activations of an 8 x 64-pixel
+// output tile never leave the CU.  Separately they write / read 708 MB each per 16 clips (3.9 GB for the three layers);
+// fused, HBM sees the mel (44 MB) and the third layer's output.  A persistent 8-wave workgroup per CU:
+//   A: conv1.0 on the tile grown by 2 pixels (12 x 68), from mel (global, 9 taps per lane)       -> LDS tile TA
+//   B: conv1.1 on the tile grown by 1 (10 x 66), taps + identity residual from TA                -> LDS tile TB
+//   C: conv1.2 on the tile, taps + residual from TB                                              -> HBM
+// Reflect padding: a position outside the image holds the layer's value AT THE REFLECTED POSITION, so the grown tiles are
+// computed at reflected coordinates (a lane reads its taps around the reflected position's place in the tile below).
+// 16 output channels = one v_mfma_f32_16x16x32_bf16 row block; a k-step holds two taps x 16 channels (lane group q4: tap
+// 2 ks + (q4 >> 1), channels 8 (q4 & 1) ..): 5 k-steps x 3 split products per 16 pixels, none of it padding rows.
+// The D tile has the pixel on the lane and channels 4 q4 .. 4 q4 + 3 in registers: one 8-byte piece per plane, the four
+// lane groups complete a pixel's 32 bytes in one store instruction.
+// ---------------------------------------------------------------------------------------------------------
+DEV f32x4 mfma16b(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+DEV f32x4 mma3_16(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4 acc) {
+    acc = mfma16b(ah, bh, acc);
+    acc = mfma16b(al, bh, acc);
+    return mfma16b(ah, bl, acc);
+}
+template <int ROWS, int TX>
+__global__ __launch_bounds__(512, 1) void k_me_stem(const float* __restrict__ mel, __bf16* __restrict__ out_hi, __bf16* __restrict__ out_lo,
+                                                    const bf16x8* __restrict__ w /* 22 fragments */, const float* __restrict__ bias /*[3][16]*/,
+                                                    const float* __restrict__ wa32 /* conv1.0 folded weights [16][9] */, int H, int W, int ntiles) {
+    constexpr int RAH = ROWS + 4, RAW = TX + 4, NA = RAH * RAW;       // conv1.0 region
+    constexpr int RBH = ROWS + 2, RBW = TX + 2, NB = RBH * RBW;       // conv1.1 region
+    constexpr int NBP = (NB + 15) / 16 * 16;                          // plane stride of TB: a multiple of 256 B keeps the reads conflict-free
+    constexpr int NC = ROWS * TX;
+    constexpr int MH = ROWS + 6, MW = TX + 6, NM = MH * MW;           // mel region; positions outside the image hold the reflected values
+    static_assert(NA % 16 == 0, "plane stride of TA");
+    static_assert(NM <= 1024, "two mel values per thread");
+    static_assert(TX == 64 && NC % 128 == 0, "phase C walks two rows per step");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* TA = lds;                                // pieces [plane][half][NA] x 16 B
+    char* TB = TA + 4 * NA * 16;                   // pieces [plane][half][NBP] x 16 B
+    float* MT = reinterpret_cast<float*>(TB + 4 * NBP * 16);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = lane & 15, q4 = lane >> 4;
+    // conv1.1 / conv1.2 weight fragments stay in registers (the B operands are the only LDS reads of the MFMA phases)
+    bf16x8 wb_h[5], wb_l[5], wc_h[5], wc_l[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        wb_h[ks] = w[(2 + ks) * 64 + lane];
+        wb_l[ks] = w[(7 + ks) * 64 + lane];
+        wc_h[ks] = w[(12 + ks) * 64 + lane];
+        wc_l[ks] = w[(17 + ks) * 64 + lane];
+    }
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + 16 + 4 * q4), bc = *reinterpret_cast<const f32x4*>(bias + 32 + 4 * q4);
+    // phase A runs on the vector ALU in fp32: thread = (pixel, channel quad); its quad's 36 weights in registers
+    const int quad = tid & 3;
+    float wa[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wa[c][k] = wa32[(4 * quad + c) * 9 + k];
+    const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + 4 * quad);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto split4 = [](const f32x4& v, bf16x4& oh, bf16x4& ol) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 h = (__bf16)v[e];
+            oh[e] = h;
+            ol[e] = (__bf16)(v[e] - (float)h);
+        }
+    };
+    // k-step ks of this lane: tap 2 ks + (q4 >> 1) (the ninth tap's partner slot has zero weights: it re-reads tap 8), channel half q4 & 1
+    int ckA[5], ckB[5];          // piece offsets relative to the centre piece (TA: centre = the position itself; TB: centre = tile origin)
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const int tap = min(2 * ks + (q4 >> 1), 8);
+        ckA[ks] = ((q4 & 1) * NA + (tap / 3 - 1) * RAW + tap % 3 - 1) * 16;
+        ckB[ks] = ((q4 & 1) * NBP + (tap / 3) * RBW + tap % 3) * 16;
+    }
+    const int hp = (q4 >> 1), ho = (q4 & 1) * 8;         // this lane's output channels 4 q4 .. +3: half hp, byte offset ho of the piece
+    const int txn = W / TX, tyn = (H + ROWS - 1) / ROWS;
+    // mel region of tile t: thread i holds elements i and i + 512
+    auto mel_fetch = [&](int t, float (&mv)[2]) {
+        const int tx = t % txn, ty = (t / txn) % tyn, b = t / (txn * tyn);
+        const float* mb = mel + (size_t)b * H * W;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + 512 * k;
+            mv[k] = 0.f;
+            if (i < NM) mv[k] = mb[(size_t)reflect(ty * ROWS - 3 + i / MW, H) * W + reflect(tx * TX - 3 + i % MW, W)];
+        }
+    };
+    float mv[2];
+    if ((int)blockIdx.x < ntiles) mel_fetch(blockIdx.x, mv);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = t % txn, ty = (t / txn) % tyn, b = t / (txn * tyn);
+        const int x0 = tx * TX, y0 = ty * ROWS;
+        MT[tid] = mv[0];
+        if (tid + 512 < NM) MT[tid + 512] = mv[1];
+        __syncthreads();            // also: everyone has left the previous tile's phase C (TB) and phase A (MT)
+        if (t + (int)gridDim.x < ntiles) mel_fetch(t + gridDim.x, mv);      // lands during the three phases
+        // local coordinate of image position (tile origin - g + i) reflected into the image, in a region that starts at origin - G
+        auto local = [](int i, int o0, int g, int G, int size, int lim) {
+            const int r = reflect(o0 - g + i, size) - (o0 - G);
+            return min(max(r, 1), lim - 2);
+        };
+        // ---- A: conv1.0 at the reflected positions of the 2-pixel-grown tile (fp32 FMAs; taps are plain neighbours in MT)
+        {
+            int row = (tid >> 2) / RAW, px = (tid >> 2) % RAW;
+            for (int p = tid >> 2; p < NA; p += 128) {
+                const int cy = local(row, y0, 2, 3, H, MH), cx = local(px, x0, 2, 3, W, MW);
+                const float* m0 = MT + cy * MW + cx;
+                f32x4 acc = ba;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const float mval = m0[(k / 3 - 1) * MW + k % 3 - 1];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = fmaf(wa[c][k], mval, acc[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = fmaxf(acc[c], 0.f);
+                bf16x4 oh, ol;
+                split4(acc, oh, ol);
+                char* dst = TA + (size_t)(((quad >> 1) * NA + p) * 16 + (quad & 1) * 8);
+                *reinterpret_cast<bf16x4*>(dst) = oh;
+                *reinterpret_cast<bf16x4*>(dst + 2 * NA * 16) = ol;
+                px += 128 - RAW;
+                row += 1;
+                if (px >= RAW) {
+                    px -= RAW;
+                    row += 1;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- B: conv1.1 at the reflected positions of the 1-pixel-grown tile, from TA
+        {
+            int row = (wave * 16 + n) / RBW, px = (wave * 16 + n) % RBW;
+            for (int f = wave * 16 + n; f < NBP; f += 128) {
+                const int rr = min(row, RBH - 1);
+                const int ly = local(rr, y0, 1, 2, H, RAH), lx = local(px, x0, 1, 2, W, RAW);
+                const char* ctr = TA + (size_t)(ly * RAW + lx) * 16;
+                f32x4 acc = z4;
+#pragma unroll
+                for (int ks = 0; ks < 5; ++ks) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(ctr + ckA[ks]);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(ctr + ckA[ks] + 2 * NA * 16);
+                    acc = mma3_16(wb_h[ks], wb_l[ks], bh, bl, acc);
+                }
+                const bf16x4 rh = *reinterpret_cast<const bf16x4*>(ctr + hp * NA * 16 + ho);
+                const bf16x4 rl = *reinterpret_cast<const bf16x4*>(ctr + (2 + hp) * NA * 16 + ho);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e] + bb[e], 0.f) + ((float)rh[e] + (float)rl[e]);
+                bf16x4 oh, ol;
+                split4(acc, oh, ol);
+                if (f < NB) {
+                    char* dst = TB + (size_t)((hp * NBP + f) * 16 + ho);
+                    *reinterpret_cast<bf16x4*>(dst) = oh;
+                    *reinterpret_cast<bf16x4*>(dst + 2 * NBP * 16) = ol;
+                }
+                px += 128 - RBW;
+                row += 1;
+                if (px >= RBW) {
+                    px -= RBW;
+                    row += 1;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- C: conv1.2 on the tile, from TB (its halo already holds the reflected values); two tile rows per step
+        {
+            const int row0 = wave >> 2, px = (wave & 3) * 16 + n;
+            const char* org = TB + (size_t)(row0 * RBW + px) * 16;
+            size_t pix = ((size_t)b * H + y0 + row0) * W + x0 + px;
+#pragma unroll
+            for (int k = 0; k < ROWS / 2; ++k) {
+                f32x4 acc = z4;
+#pragma unroll
+                for (int ks = 0; ks < 5; ++ks) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(org + ckB[ks]);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(org + ckB[ks] + 2 * NBP * 16);
+                    acc = mma3_16(wc_h[ks], wc_l[ks], bh, bl, acc);
+                }
+                const char* ctr = org + (RBW + 1) * 16;
+                const bf16x4 rh = *reinterpret_cast<const bf16x4*>(ctr + hp * NBP * 16 + ho);
+                const bf16x4 rl = *reinterpret_cast<const bf16x4*>(ctr + (2 + hp) * NBP * 16 + ho);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e] + bc[e], 0.f) + ((float)rh[e] + (float)rl[e]);
+                bf16x4 oh, ol;
+                split4(acc, oh, ol);
+                if (y0 + row0 + 2 * k < H) {
+                    *reinterpret_cast<bf16x4*>(out_hi + pix * 16 + 4 * q4) = oh;
+                    *reinterpret_cast<bf16x4*>(out_lo + pix * 16 + 4 * q4) = ol;
+                }
+                org += 2 * RBW * 16;
+                pix += 2 * (size_t)W;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // max_pool2d on the plane pair; padding never wins (torch pads with -inf).  One thread per (pixel, 8 channels).
 // hi + lo is exact in fp32 (<= 17 significant bits), so the maximum re-splits into the very planes it came from.
 // ---------------------------------------------------------------------------------------------------------
@@ -461,6 +656,9 @@ struct dc_music {
     ConvDev conv[7];
     const bf16x8 *w4 = nullptr, *wp = nullptr;
     const float *b4 = nullptr, *bp = nullptr;
+    const bf16x8* stem_w = nullptr;       // k_me_stem: 22 fragments (conv1.0: hi, lo; conv1.1: 5 hi, 5 lo; conv1.2: 5 hi, 5 lo)
+    const float* stem_b = nullptr;        // [3][16] folded biases
+    const float* stem_wa = nullptr;       // conv1.0 folded weights [16][9] fp32 (that layer runs on the vector ALU)
     // ping-pong plane pairs, sized for `cap` clips of `cap_tm` mel frames
     bf16x8 *a_hi = nullptr, *a_lo = nullptr, *b_hi = nullptr, *b_lo = nullptr;
     int cap = 0, cap_tm = 0;
@@ -541,6 +739,30 @@ dc_music* dc_music_build(const std::map<std::string, std::vector<float>>& params
     struct Off {
         size_t w, bias, rbias;
     } off[7];
+    // v_mfma_f32_16x16x32 A fragments of the fused conv1 kernel: lane (co = l & 15, q4 = l >> 4), element j
+    std::vector<uint16_t> stem_hi[3], stem_lo[3];
+    std::vector<float> stem_bias, stem_wa32;
+    auto stem_pack = [&](int layer, const std::vector<float>& Wm, int K, int cin) {
+        const int nks = cin == 1 ? 1 : 5;
+        stem_hi[layer].assign((size_t)nks * 512, 0);
+        stem_lo[layer].assign((size_t)nks * 512, 0);
+        for (int ks = 0; ks < nks; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = l & 15, q4 = l >> 4;
+                    float v = 0.f;
+                    if (cin == 1) {
+                        const int k = 8 * q4 + j;
+                        if (k < 9) v = Wm[(size_t)co * K + k];
+                    } else {
+                        const int tap = 2 * ks + (q4 >> 1), ci = 8 * (q4 & 1) + j;
+                        if (tap < 9) v = Wm[(size_t)co * K + tap * 16 + ci];
+                    }
+                    const uint16_t h = f2bf(v);
+                    stem_hi[layer][((size_t)ks * 64 + l) * 8 + j] = h;
+                    stem_lo[layer][((size_t)ks * 64 + l) * 8 + j] = f2bf(v - bf2f(h));
+                }
+    };
     const std::string me = "music_encoder.";
     for (int i = 0; i < 7; ++i) {
         const ConvSpec& c = kConvs[i];
@@ -555,6 +777,15 @@ dc_music* dc_music_build(const std::map<std::string, std::vector<float>>& params
                 for (int tap = 0; tap < 9; ++tap)
                     Wm[(size_t)co * K + tap * c.cin + ci] = w[((size_t)co * c.cin + ci) * 9 + tap] * sc[co];
         std::vector<uint16_t> frags = pack_nat(Wm, c.cout, K, 1, KS);
+        if (i == 0) {
+            stem_wa32.resize(16 * 9);
+            for (int co = 0; co < 16; ++co)
+                for (int tap = 0; tap < 9; ++tap) stem_wa32[co * 9 + tap] = Wm[(size_t)co * K + tap];
+        }
+        if (i < 3) {
+            stem_pack(i, Wm, K, c.cin);
+            stem_bias.insert(stem_bias.end(), bi.begin(), bi.end());
+        }
         off[i].rbias = (size_t)-1;
         std::vector<float> rb_ft;
         if (c.res_conv) {
@@ -585,6 +816,14 @@ dc_music* dc_music_build(const std::map<std::string, std::vector<float>>& params
     const size_t o_w4 = add(f4.data(), f4.size() * 2);
     const std::vector<float> b4_ft = ftvec(b4, 2);
     const size_t o_b4 = add(b4_ft.data(), b4_ft.size() * 4);
+    std::vector<uint16_t> stem_frags;
+    for (int i = 0; i < 3; ++i) {
+        stem_frags.insert(stem_frags.end(), stem_hi[i].begin(), stem_hi[i].end());
+        stem_frags.insert(stem_frags.end(), stem_lo[i].begin(), stem_lo[i].end());
+    }
+    const size_t o_stem_w = add(stem_frags.data(), stem_frags.size() * 2);
+    const size_t o_stem_b = add(stem_bias.data(), stem_bias.size() * 4);
+    const size_t o_stem_wa = add(stem_wa32.data(), stem_wa32.size() * 4);
     const std::vector<uint16_t> fp = pack_nat(P("proj.weight"), 64, 64, 2, 4);
     const size_t o_wp = add(fp.data(), fp.size() * 2);
     const std::vector<float> bp_ft = ftvec(P("proj.bias"), 2);
@@ -603,6 +842,9 @@ dc_music* dc_music_build(const std::map<std::string, std::vector<float>>& params
         m->conv[i].bias = reinterpret_cast<const float*>(m->arena + off[i].bias);
         m->conv[i].rbias = off[i].rbias == (size_t)-1 ? nullptr : reinterpret_cast<const float*>(m->arena + off[i].rbias);
     }
+    m->stem_w = reinterpret_cast<const bf16x8*>(m->arena + o_stem_w);
+    m->stem_b = reinterpret_cast<const float*>(m->arena + o_stem_b);
+    m->stem_wa = reinterpret_cast<const float*>(m->arena + o_stem_wa);
     m->w4 = reinterpret_cast<const bf16x8*>(m->arena + o_w4);
     m->b4 = reinterpret_cast<const float*>(m->arena + o_b4);
     m->wp = reinterpret_cast<const bf16x8*>(m->arena + o_wp);
@@ -661,10 +903,30 @@ hipError_t launch_conv_t(hipStream_t st, const ConvDev& c, const bf16x8* ih, con
                                            (int)ntiles);
     return hipGetLastError();
 }
+// conv1.0 -> conv1.1 -> conv1.2 fused (W a multiple of 64); DC_ME_NO_STEM=1 keeps the three separate launches
+hipError_t launch_stem(hipStream_t st, const dc_music* m, const float* mel, bf16x8* oh, bf16x8* ol, int Bc, int H, int W) {
+    constexpr int ROWS = 8, TX = 64;
+    constexpr int NBP = ((ROWS + 2) * (TX + 2) + 15) / 16 * 16;
+    constexpr int SHM = 4 * (ROWS + 4) * (TX + 4) * 16 + 4 * NBP * 16 + (ROWS + 6) * (TX + 6) * 4;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return hipErrorUnknown;
+        ncu = pr.multiProcessorCount;
+        if (hipError_t e = hipFuncSetAttribute((const void*)k_me_stem<ROWS, TX>, hipFuncAttributeMaxDynamicSharedMemorySize, SHM)) return e;
+    }
+    const long long ntiles = (long long)Bc * ((H + ROWS - 1) / ROWS) * (W / TX);
+    const unsigned grid = (unsigned)std::min<long long>(ntiles, ncu);
+    k_me_stem<ROWS, TX><<<dim3(grid), dim3(512), SHM, st>>>(mel, reinterpret_cast<__bf16*>(oh), reinterpret_cast<__bf16*>(ol), m->stem_w,
+                                                            m->stem_b, m->stem_wa, H, W, (int)ntiles);
+    return hipGetLastError();
+}
 template <int KH, int KW, int SH, int SW, int PH, int PW>
 hipError_t launch_pool(hipStream_t st, const bf16x8* ih, const bf16x8* il, bf16x8* oh, bf16x8* ol, int Bc, int H, int W, int C,
                        int Ho, int Wo) {
-    constexpr int NY = 24;                 // output rows per thread: (NY + KH - 1) / NY of the minimum input traffic
+    int NY = 24;                 // output rows per thread: (NY + KH - 1) / NY of the minimum input traffic
+    if (const char* e = getenv("DC_ME_POOL_NY")) NY = std::max(1, atoi(e));
     const long long total = (long long)Bc * ((Ho + NY - 1) / NY) * Wo * (C / 8);
     k_me_pool<KH, KW, SH, SW, PH, PW><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(ih, il, oh, ol, Bc, H, W, C / 8, Ho, Wo, NY);
     return hipGetLastError();
@@ -675,8 +937,9 @@ hipError_t launch_pool(hipStream_t st, const bf16x8* ih, const bf16x8* il, bf16x
 hipError_t dc_music_encode(dc_music* m, const float* d_mel, int B, int Tm, float* d_xf_proj, float* d_xf_out, hipStream_t st,
                            std::string* err) {
     const int T = dc_music_frames(Tm);
-    // chunk of clips whose largest activation (16 channels x Tm x 128 bins, two bf16 planes) stays under ~0.4 GB per buffer
-    const int chunk = std::max(1, std::min(B, 8 * 5400 / std::max(Tm, 1)));
+    // chunk of clips whose largest activation (16 channels x Tm x 128 bins, two bf16 planes) stays under ~0.7 GB per buffer (16 clips of 60 s: 5.2 ms for 32 clips; 8: 5.8 ms, 32: no faster)
+    int chunk = std::max(1, std::min(B, 16 * 5400 / std::max(Tm, 1)));
+    if (const char* e = getenv("DC_ME_CHUNK")) chunk = std::max(1, std::min(B, atoi(e)));
     if (chunk > m->cap || Tm > m->cap_tm) {
         hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) return e;
@@ -704,9 +967,13 @@ hipError_t dc_music_encode(dc_music* m, const float* d_mel, int B, int Tm, float
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = std::min(chunk, B - b0);
         const float* mel = d_mel + (size_t)b0 * Tm * 128;
-        ME_TRY((launch_conv<1, 16, 0>(st, m->conv[0], mel, nullptr, nullptr, ah, al, Bc, Tm, 128)));
-        ME_TRY((launch_conv_t<16, 16, 1, 8, 2>(st, m->conv[1], ah, al, bh, bl, Bc, Tm, 128)));
-        ME_TRY((launch_conv_t<16, 16, 1, 8, 2>(st, m->conv[2], bh, bl, ah, al, Bc, Tm, 128)));
+        if (!getenv("DC_ME_NO_STEM")) {
+            ME_TRY(launch_stem(st, m, mel, ah, al, Bc, Tm, 128));
+        } else {
+            ME_TRY((launch_conv<1, 16, 0>(st, m->conv[0], mel, nullptr, nullptr, ah, al, Bc, Tm, 128)));
+            ME_TRY((launch_conv_t<16, 16, 1, 8, 2>(st, m->conv[1], ah, al, bh, bl, Bc, Tm, 128)));
+            ME_TRY((launch_conv_t<16, 16, 1, 8, 2>(st, m->conv[2], bh, bl, ah, al, Bc, Tm, 128)));
+        }
         ME_TRY((launch_pool<5, 5, 1, 2, 2, 2>(st, ah, al, bh, bl, Bc, Tm, 128, 16, Tm, 64)));
         ME_TRY((launch_conv_t<16, 32, 2, 8, 2>(st, m->conv[3], bh, bl, ah, al, Bc, Tm, 64)));
         ME_TRY((launch_conv_t<32, 32, 1, 8, 1>(st, m->conv[4], ah, al, bh, bl, Bc, Tm, 64)));
