@@ -937,8 +937,8 @@ hipError_t launch_pool(hipStream_t st, const bf16x8* ih, const bf16x8* il, bf16x
 hipError_t dc_music_encode(dc_music* m, const float* d_mel, int B, int Tm, float* d_xf_proj, float* d_xf_out, hipStream_t st,
                            std::string* err) {
     const int T = dc_music_frames(Tm);
-    // chunk of clips whose largest activation (16 channels x Tm x 128 bins, two bf16 planes) stays under ~0.7 GB per buffer (16 clips of 60 s: 5.2 ms for 32 clips; 8: 5.8 ms, 32: no faster)
-    int chunk = std::max(1, std::min(B, 16 * 5400 / std::max(Tm, 1)));
+    // chunk of clips whose largest activation (16 channels x Tm x 128 bins, two bf16 planes) stays under ~1.4 GB per buffer (32 clips of 60 s in one pass: 4.5 ms; 16 per pass: 4.7 ms, 8: 5.0 ms)
+    int chunk = std::max(1, std::min(B, 32 * 5400 / std::max(Tm, 1)));
     if (const char* e = getenv("DC_ME_CHUNK")) chunk = std::max(1, std::min(B, atoi(e)));
     if (chunk > m->cap || Tm > m->cap_tm) {
         hipError_t e = hipStreamSynchronize(st);

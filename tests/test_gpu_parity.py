@@ -269,20 +269,27 @@ def test_encode_music_golden(models):
 
 
 def test_encode_music_batched_vs_oracle(models):
-    """Clips are encoded in chunks of 8 at full length; a batch of 9 crosses the chunk edge.  30-s clips
-    (Tm = 2700 -> T = 900) and an odd frame count exercise the stride-3 pool's floor."""
+    """Clips are encoded in chunks (32 at full length; DC_ME_CHUNK=4 makes a batch of 9 cross two chunk edges).  30-s clips
+    (Tm = 2700 -> T = 900) and an odd frame count (271 = 33 x 8 + 7: partial row tiles of the LDS-tiled convolutions, the
+    stride-3 pool's floor) against the oracle; the fused conv1 kernel and the three separate launches (DC_ME_NO_STEM=1) both."""
     from oracle import ddim_oracle as O
     m = models["fp16"]
     p = oracle_params()
-    for B, Tm in ((9, 5400), (3, 2700), (2, 271)):
+    for B, Tm, env in ((9, 5400, {"DC_ME_CHUNK": "4"}), (3, 2700, {}), (2, 271, {}), (2, 271, {"DC_ME_NO_STEM": "1"}),
+                       (2, 2700, {"DC_ME_NO_STEM": "1"})):
         mel = torch.from_numpy(batch_mel(B, Tm))
-        xp, x = m.encode_music(mel.cuda(), "cuda:0")
-        torch.cuda.synchronize()
+        os.environ.update(env)
+        try:
+            xp, x = m.encode_music(mel.cuda(), "cuda:0")
+            torch.cuda.synchronize()
+        finally:
+            for k in env:
+                del os.environ[k]
         with torch.no_grad():
             rxp, rx = O.encode_music(p, mel)
         assert tuple(x.shape) == tuple(rx.shape)
         e1, e2 = rel_l2(xp, rxp), rel_l2(x, rx)
-        print(f"encode_music B={B} Tm={Tm}: rel-L2 x_proj {e1:.2e} x {e2:.2e}")
+        print(f"encode_music B={B} Tm={Tm} {env}: rel-L2 x_proj {e1:.2e} x {e2:.2e}")
         assert e1 <= 1e-4 and e2 <= 1e-4
 
 
