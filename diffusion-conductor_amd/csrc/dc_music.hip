@@ -925,8 +925,7 @@ hipError_t launch_stem(hipStream_t st, const dc_music* m, const float* mel, bf16
 template <int KH, int KW, int SH, int SW, int PH, int PW>
 hipError_t launch_pool(hipStream_t st, const bf16x8* ih, const bf16x8* il, bf16x8* oh, bf16x8* ol, int Bc, int H, int W, int C,
                        int Ho, int Wo) {
-    int NY = 24;                 // output rows per thread: (NY + KH - 1) / NY of the minimum input traffic
-    if (const char* e = getenv("DC_ME_POOL_NY")) NY = std::max(1, atoi(e));
+    constexpr int NY = 24;                 // output rows per thread: (NY + KH - 1) / NY of the minimum input traffic (3 ... 24: same time)
     const long long total = (long long)Bc * ((Ho + NY - 1) / NY) * Wo * (C / 8);
     k_me_pool<KH, KW, SH, SW, PH, PW><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(ih, il, oh, ol, Bc, H, W, C / 8, Ho, Wo, NY);
     return hipGetLastError();
