@@ -876,6 +876,25 @@ hipError_t launch_conv(hipStream_t st, const ConvDev& c, const float* mel, const
                                                                       TPW);
     return hipGetLastError();
 }
+// per-device state of the launchers: CU count and the large-LDS opt-in (hipFuncSetAttribute applies per device)
+struct MeDev {
+    int dev = 0, ncu = 0;
+};
+hipError_t me_device(MeDev& d) {
+    static int ncu_of[64] = {0};
+    if (hipError_t e = hipGetDevice(&d.dev)) return e;
+    int& n = ncu_of[d.dev & 63];
+    if (!n)
+        if (hipError_t e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d.dev)) return e;
+    d.ncu = n;
+    return hipSuccess;
+}
+hipError_t me_optin(const void* fn, int bytes, unsigned long long& done, int dev) {
+    if (dev < 64 && ((done >> dev) & 1ull)) return hipSuccess;
+    if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) return e;
+    if (dev < 64) done |= 1ull << dev;
+    return hipSuccess;
+}
 // LDS-tiled form (CIN >= 16); W must be a multiple of the tile width
 template <int CIN, int COUT, int RES, int ROWS, int NXS>
 hipError_t launch_conv_t(hipStream_t st, const ConvDev& c, const bf16x8* ih, const bf16x8* il, bf16x8* oh, bf16x8* ol, int Bc, int H,
@@ -884,19 +903,12 @@ hipError_t launch_conv_t(hipStream_t st, const ConvDev& c, const bf16x8* ih, con
     constexpr int NP = 2 * KC * 2 * (ROWS + 2) * (32 * NXS + 2), NDMA = (NP + 63) / 64;
     constexpr int SHM = (NF + NDMA) * 1024;
     if (W % (32 * NXS) != 0) return launch_conv<CIN, COUT, RES>(st, c, nullptr, ih, il, oh, ol, Bc, H, W);
-    static int ncu = 0;
-    static bool optin = false;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return hipErrorUnknown;
-        ncu = pr.multiProcessorCount;
-    }
+    static unsigned long long optin = 0;
+    MeDev d;
+    if (hipError_t e = me_device(d)) return e;
+    const int ncu = d.ncu;
     const auto fn = k_me_conv_t<CIN, COUT, RES, ROWS, NXS>;
-    if (!optin) {
-        if (hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, SHM)) return e;
-        optin = true;
-    }
+    if (hipError_t e = me_optin((const void*)fn, SHM, optin, d.dev)) return e;
     const long long ntiles = (long long)Bc * ((H + ROWS - 1) / ROWS) * (W / (32 * NXS));
     const unsigned grid = (unsigned)std::min<long long>(ntiles, 2LL * ncu);
     fn<<<dim3(grid), dim3(256), SHM, st>>>(ih, il, reinterpret_cast<__bf16*>(oh), reinterpret_cast<__bf16*>(ol), c.w, c.bias, c.rbias, H, W,
@@ -908,14 +920,11 @@ hipError_t launch_stem(hipStream_t st, const dc_music* m, const float* mel, bf16
     constexpr int ROWS = 8, TX = 64;
     constexpr int NBP = ((ROWS + 2) * (TX + 2) + 15) / 16 * 16;
     constexpr int SHM = 4 * (ROWS + 4) * (TX + 4) * 16 + 4 * NBP * 16 + (ROWS + 6) * (TX + 6) * 4;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return hipErrorUnknown;
-        ncu = pr.multiProcessorCount;
-        if (hipError_t e = hipFuncSetAttribute((const void*)k_me_stem<ROWS, TX>, hipFuncAttributeMaxDynamicSharedMemorySize, SHM)) return e;
-    }
+    static unsigned long long optin = 0;
+    MeDev d;
+    if (hipError_t e = me_device(d)) return e;
+    const int ncu = d.ncu;
+    if (hipError_t e = me_optin((const void*)k_me_stem<ROWS, TX>, SHM, optin, d.dev)) return e;
     const long long ntiles = (long long)Bc * ((H + ROWS - 1) / ROWS) * (W / TX);
     const unsigned grid = (unsigned)std::min<long long>(ntiles, ncu);
     k_me_stem<ROWS, TX><<<dim3(grid), dim3(512), SHM, st>>>(mel, reinterpret_cast<__bf16*>(oh), reinterpret_cast<__bf16*>(ol), m->stem_w,
