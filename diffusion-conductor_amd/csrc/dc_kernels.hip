@@ -1858,11 +1858,12 @@ static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* b
     if (hipError_t e = lds_optin((const void*)k_film_gemm3<T16>, (int)shm, optin_done)) return e;
     const int ncu = cu_count();
     // One workgroup per CU for big batches; for small ones (the reference samples ONE clip per call: 15 token blocks) the
-    // (token block x round) units are spread over more workgroups than there are token blocks - several workgroups then
-    // build the same slab, but a slab fill costs ~6 us and a block's 48 rounds ~60 us when one workgroup sweeps them alone.
+    // (token block x round) units are spread over more workgroups than there are token blocks, down to one unit each - several
+    // workgroups then build the same slab, but a slab fill costs ~6 us and a block's 12 rounds ~60 us when one workgroup sweeps them
+    // alone (B=1: 49 -> 36 us per step with one unit per workgroup instead of four).
     const int nblk = (G + 3) / 4;
     const long long nunit = (long long)nblk * nround;
-    int nwg = (int)(nunit / 4 < ncu ? nunit / 4 : ncu);
+    int nwg = (int)(nunit < ncu ? nunit : ncu);
     if (nwg < nblk) nwg = nblk < ncu ? nblk : ncu;
     if (nwg < 1) nwg = 1;
     k_film_gemm3<T16><<<dim3(nwg), dim3(512), shm, st>>>((const v8<T16>*)W16, bias16, (f16x16*)E, G, NT, round0, nround,
