@@ -143,7 +143,8 @@ struct dc_sampler {
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
 
     // workspace (capacity-tracked)
-    int B = 0, T = 0, M = 0, G = 0;
+    int B = 0, T = 0, M = 0, G = 0;          // T: clip stride of the token space (the caller's frames per clip, padded: below)
+    int Tx = 0;                              // the caller's frames per clip: x, xf, snapshots are [B][Tx][..]
     size_t cap_G = 0, cap_B = 0, cap_MP = 0, cap_steps = 0, cap_snap = 0, cap_kv = 0;
     int* d_length = nullptr;
     float* d_pp = nullptr;
@@ -519,7 +520,18 @@ int build_model(dc_sampler* s) {
     return DC_OK;
 }
 
-int ensure_workspace(dc_sampler* s, int B, int T) {
+// Clip stride of the internal token space.  Where the workgroup-record kernels can run (non-split formats, linear attention,
+// Tx >= 256) a clip may be padded to whole 32-token groups, so that no group spans two clips (the padding frames behave like
+// frames past `length`).  Measured (same box): bs=32 x 1800 (+1.3 % tokens) -1.6 % per loop; bs=128 x 900
+// (+3.1 %) +0.2 %; small batches, which then also run clip-aligned units (enqueue_step), -9 % at bs=4 x 1800.
+int clip_stride(const dc_sampler* s, int B, int Tx) {
+    if (s->split_small || s->cfg.no_eff || Tx < 256 || Tx % 32 == 0 || getenv("DC_NO_PAD")) return Tx;
+    const int Tp = (Tx + 31) / 32 * 32;
+    const bool small_batch = (long long)B * ((Tp + 127) / 128) <= s->num_cu;       // narrow, clip-aligned workgroups
+    return (small_batch || (Tp - Tx) * 50 <= Tx) ? Tp : Tx;
+}
+int ensure_workspace(dc_sampler* s, int B, int Tx) {
+    const int T = clip_stride(s, B, Tx);
     const int M = B * T, G = cdiv(M, 32), L = s->cfg.num_layers, P = s->cfg.input_feats;
     if ((size_t)G > s->cap_G) {
         drop_graph(s);
@@ -578,9 +590,10 @@ int ensure_workspace(dc_sampler* s, int B, int T) {
         if ((rc = dev_alloc(s, s->d_snap_cur, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_coef_cur, 16))) return rc;
     }
-    if (s->B != B || s->T != T) drop_graph(s);
+    if (s->B != B || s->T != T || s->Tx != Tx) drop_graph(s);
     s->B = B;
     s->T = T;
+    s->Tx = Tx;
     s->M = M;
     s->G = G;
     {   // per-workgroup partial records when a workgroup (NW groups) cannot span more than two clips
@@ -679,15 +692,24 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     // Narrow workgroups (4 waves = 128-token units, one wave per SIMD) while every unit still gets a CU of its own: the layer
     // kernel is bound by instruction issue, so a wave alone on its SIMD runs a layer in about half the time (DESIGN.md
     // section 4).  T <= 3840: the narrow combine holds 32 units per clip.  DC_NO_NARROW=1 keeps the 8-wave form (read per call).
-    const bool narrow = wgr && (G + 3) / 4 <= s->num_cu && T <= 3840 && s->dbg_layers < 0 && s->dbg_stage == 0 &&
+    // Clip-aligned units (WgMap in dc_dev.h; needs a clip stride of whole groups): upc workgroups per clip, no workgroup spans two
+    // clips.  Default for the narrow (small-batch) form; with the chip full (bs=32 x 1800: 256 workgroups instead of 228 flat
+    // units) it measured 1.2 % slower than flat units - DC_ALIGN=1 forces it there.
+    const bool can_align = wgr && T % 32 == 0 && !getenv("DC_NO_ALIGN");
+    const int upc_wide = (T + 255) / 256, upc_narrow = (T + 127) / 128;
+    const int nwg_narrow = can_align ? B * upc_narrow : (G + 3) / 4;
+    const bool narrow = wgr && nwg_narrow <= s->num_cu && T <= 3840 && s->dbg_layers < 0 && s->dbg_stage == 0 &&
                         !getenv("DC_NO_NARROW") && !getenv("DC_STAMPS");
+    const bool aligned = can_align && (narrow || getenv("DC_ALIGN") != nullptr);
+    const int upc = aligned ? (narrow ? upc_narrow : upc_wide) : 0;
+    const int Tx = s->Tx;
     if (s->dbg_first >= 0)
         LAUNCH(K_EMBED, dc_launch_front_from_h(st, fs, ss, s->d_model, s->d_h, s->d_recs, s->d_length, M, T, G, B, s->dbg_first));
     else
         LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
-                                              want_stamps_film ? s->d_stamps + 256 : nullptr, narrow));
+                                              want_stamps_film ? s->d_stamps + 256 : nullptr, narrow, Tx, upc));
     static const bool want_stamps = getenv("DC_STAMPS") != nullptr;
-    const int nwg = narrow ? (G + 3) / 4 : (G + 7) / 8;
+    const int nwg = aligned ? B * upc : (narrow ? (G + 3) / 4 : (G + 7) / 8);
     const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
     for (int l = s->dbg_first >= 0 ? s->dbg_first : 0; l < nl_run; ++l) {
         const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
@@ -695,7 +717,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src,
                                         s->d_snaps, M, T, G, B, dbg, ((l == 3 || l == 4) && want_stamps) ? s->d_stamps : nullptr, rec_stride,
-                                        iter_base, narrow));
+                                        iter_base, narrow, Tx, upc));
     }
     return DC_OK;
 }
@@ -726,12 +748,12 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     if (!d_noise || !d_out || !h_coef) return fail(DC_ERR_INVALID, "null pointer argument");
     int rc;
     if ((rc = ensure_steps(s, S))) return rc;
-    const size_t MP = (size_t)s->M * s->cfg.input_feats;
-    if ((size_t)n_snap > s->cap_snap) {
+    const size_t MP = (size_t)s->B * s->Tx * s->cfg.input_feats;          // x, snapshots: the caller's layout
+    if ((size_t)n_snap * MP > s->cap_snap) {          // (capacity in elements: the batch may have grown since the last call)
         drop_graph(s);
         s->cap_snap = 0;
         if ((rc = dev_alloc(s, s->d_snaps, (size_t)n_snap * MP * 4))) return rc;
-        s->cap_snap = (size_t)n_snap;
+        s->cap_snap = (size_t)n_snap * MP;
     }
     // Per-iteration tables on the device: uploaded only when (S, coefficients, snapshot iterations) differ from the
     // previous call - a sampling service calls the loop with the same schedule every time, and the four small H2D
@@ -975,16 +997,18 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
     hipStream_t user = (hipStream_t)stream, st = s->stream;
     if ((rc = sync_in(s, user))) return rc;
     const int M = s->M, G = s->G, L = s->cfg.num_layers;
+    const int Tx = T;
+    T = s->T;                         // clip stride of the token space from here on (>= Tx)
     HIP_TRY(hipMemcpyAsync(s->d_length, len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     // emb's step-invariant term: linear(xf_proj) as fp32 operand image
-    HIP_TRY(dc_launch_cond_embed(st, 0, d_xf_proj, s->h_model.lin_wt, s->h_model.lin_b, s->d_pp, nullptr, nullptr, M, G));
+    HIP_TRY(dc_launch_cond_embed(st, 0, d_xf_proj, s->h_model.lin_wt, s->h_model.lin_b, s->d_pp, nullptr, nullptr, M, G, T, Tx));
     // cross-attention: linear(xf_out) -> text_norm (affine folded into K/V) as bf16 hi / lo operand images -> per-layer K,V -> A_ca
-    HIP_TRY(dc_launch_cond_embed(st, 1, d_xf_out, s->h_model.lin_wt, s->h_model.lin_b, nullptr, s->d_nh_hi, s->d_nh_lo, M, G));
+    HIP_TRY(dc_launch_cond_embed(st, 1, d_xf_out, s->h_model.lin_wt, s->h_model.lin_b, nullptr, s->d_nh_hi, s->d_nh_lo, M, G, T, Tx));
     // one-time cost: always split precision (plain bf16 here alone costs ~2e-3 on A_cross)
     if (s->cfg.no_eff) {
         HIP_TRY(dc_launch_ca_kv(st, s->small_fmt, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_kv_ca, M, T, G, B, s->KT, L));
     } else {
-        HIP_TRY(dc_launch_ca_partials(st, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_recs_ca, M, T, G, L));
+        HIP_TRY(dc_launch_ca_partials(st, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_recs_ca, M, T, G, L, Tx));
         HIP_TRY(dc_launch_attn_combine(st, s->small_fmt, s->d_recs_ca, s->d_a_ca, T, G, B, L, 32));
     }
     HIP_TRY(hipStreamSynchronize(st));   // `len` is host memory
@@ -1162,9 +1186,11 @@ int dc_sampler_debug_layer(dc_sampler* s, const float* h_h, const int32_t* h_tim
             for (int q = 0; q < 4; ++q)
                 for (int l = 0; l < 64; ++l)
                     for (int i = 0; i < 4; ++i) {
-                        const size_t tok = g * 32 + (l & 31);
+                        const size_t tok = g * 32 + (l & 31);             // token space: clip stride s->T; h_h rows: [B][Tx]
+                        const size_t bb = tok / s->T, nn = tok % s->T;
                         const int f = 32 * t + tile_row(4 * q + i, l >> 5);
-                        if (tok < (size_t)s->M) img[(((g * 4 + t) * 4 + q) * 64 + l) * 4 + i] = h_h[tok * DC_D + f];
+                        if (tok < (size_t)s->M && nn < (size_t)s->Tx)
+                            img[(((g * 4 + t) * 4 + q) * 64 + l) * 4 + i] = h_h[(bb * s->Tx + nn) * DC_D + f];
                     }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(s->d_h, img.data(), img.size() * 4, hipMemcpyHostToDevice));
@@ -1202,6 +1228,8 @@ int dc_sampler_debug_read(dc_sampler* s, const char* what, void* h_out, int64_t 
     HIP_TRY(hipMemcpy(h_out, src, (size_t)nbytes, hipMemcpyDeviceToHost));
     return DC_OK;
 }
+
+int32_t dc_sampler_clip_stride(const dc_sampler* s) { return s ? s->T : 0; }
 
 const char* dc_kernel_name(int32_t id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
 int32_t dc_kernel_count(void) { return K_COUNT; }

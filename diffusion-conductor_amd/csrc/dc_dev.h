@@ -375,9 +375,9 @@ struct RowRange {
     int lo;
     unsigned span;      // wave-uniform; span == 32 means every row of the group is valid (the common case: no masking code)
 };
-DEV RowRange valid_rows(const GroupCtx& cx, int slot, int M, int T, const int* __restrict__ length) {
+DEV RowRange valid_rows(const GroupCtx& cx, int slot, int M, int T, const int* __restrict__ length, int len_all = -1) {
     const int bs = slot == 0 ? cx.b0 : cx.b1;
-    const int len = length ? length[bs] : T;
+    const int len = length ? length[bs] : (len_all >= 0 ? len_all : T);      // len_all: frames per clip when the clip stride T is padded
     const int first = max(bs * T, 32 * cx.g);                         // first valid token
     const int end = min(min(bs * T + min(len, T), M), 32 * cx.g + 32);   // one past the last valid token
     RowRange rr;
@@ -575,6 +575,40 @@ DEV RowRange valid_rows_clip(const GroupCtx& cx, int clip, int B, int M, int T, 
     rr.span = end > first ? (unsigned)(end - first) : 0u;
     return rr;
 }
+// Workgroup -> token groups of the workgroup-record kernels.
+// Flat (upc == 0): workgroup wg owns groups wg*NW .. of the flat token space; a unit (and a group) may span two clips.
+// Clip-aligned (upc > 0; the clip stride T is a multiple of 32): clip b = wg / upc owns upc workgroups = units of NW*32 tokens, the
+// last one partial - no unit and no group spans two clips, and a clip's result no longer depends on its place in the batch.
+// The unit arithmetic of the wg_* helpers (which units make up a clip, record slots) runs in a "unit space" in which every clip is
+// Tu = upc*NW*32 tokens long; group / token indices of h, E, pp stay compact (clip stride T).
+struct WgMap {
+    int g;            // this wave's group (clamped to a valid one when the wave is idle)
+    bool active;
+    int ub0;          // first clip of the unit
+    int nact;         // active waves of the workgroup (a prefix)
+    int Mu, Tu;       // unit space: total tokens, clip stride
+};
+DEV WgMap wg_map(int wg, int wave, int NW, int G, int M, int T, int B, int upc) {
+    WgMap w;
+    if (upc == 0) {
+        w.g = wg * NW + wave;
+        w.active = w.g < G;
+        if (!w.active) w.g = G - 1;
+        w.ub0 = (wg * NW * 32) / T;
+        w.nact = min(NW, G - wg * NW);
+        w.Mu = M;
+        w.Tu = T;
+    } else {
+        const int gc = T >> 5, b = wg / upc, u = wg - b * upc, gl = NW * u + wave;
+        w.active = gl < gc;
+        w.g = b * gc + min(gl, gc - 1);
+        w.ub0 = b;
+        w.nact = min(NW, gc - NW * u);
+        w.Tu = upc * NW * 32;
+        w.Mu = B * w.Tu;
+    }
+    return w;
+}
 template <int NW = 8>
 DEV void wg_put_maxes(const f32x16 (&K)[4], const GroupCtx& cx, const RowRange (&vr)[2], float* mx, int wave) {
 #pragma unroll
@@ -635,7 +669,7 @@ DEV void partial_tile(const f32x16& K, const f32x16& V, const RowRange& rr, floa
 // NW = 8: wave w sums tile oc = w & 3 of slot w >> 2; NW = 4 (narrow workgroups): wave w sums tile oc = w of both slots in turn.
 template <int NW = 8>
 DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8* pst, const f32x8* xp, const float* ss,
-                         int wave, int lane, int ub0, int G, int M, int T, int wg) {
+                         int wave, int lane, int ub0, int nact /* active waves of the workgroup (a prefix) */, int M, int T, int wg) {
     const int oc = wave & 3, c = lane & 31;
 #pragma unroll
     for (int pass = 0; pass < (NW == 8 ? 1 : 2); ++pass) {
@@ -646,8 +680,8 @@ DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8*
         float ssum = 0.f;
 #pragma unroll
         for (int v = 0; v < NW; ++v) {
-            const int gv = wg * NW + v;
-            if (gv >= G) continue;
+            const int gv = wg * NW + v;                           // (M, T: the unit space of WgMap)
+            if (v >= nact) continue;
             const int edge = (ub0 + 1) * T;                       // first token of slot 1's clip
             const int s0v = 32 * gv >= edge ? 1 : 0;              // the wave's primary slot
             const bool strad = !s0v && min(32 * gv + 31, M - 1) >= edge;

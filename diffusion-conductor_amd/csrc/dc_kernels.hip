@@ -78,20 +78,22 @@ __global__ __launch_bounds__(512) void k_temb_table(const float* __restrict__ fr
 template <int MODE>
 __global__ __launch_bounds__(256, 2)
 void k_cond_embed(const float* __restrict__ xf /*[M][64]*/, const float* __restrict__ wt /*[64][512]*/, const float* __restrict__ b,
-                  float* __restrict__ out_f32, bf16x8* __restrict__ out_hi, bf16x8* __restrict__ out_lo, int M) {
+                  float* __restrict__ out_f32, bf16x8* __restrict__ out_hi, bf16x8* __restrict__ out_lo, int M, int T, int Tx) {
+    // T: clip stride of the operand images (a multiple of 32 when the clips are padded), Tx <= T: frames per clip of xf; rows of the
+    // padding (n >= Tx) and past M read as zeros
     constexpr int YS = 516;
     __shared__ __attribute__((aligned(16))) float xs[32 * 64];
     __shared__ __attribute__((aligned(16))) float ys[32 * YS];
     __shared__ float mu_s[32], rs_s[32];
     const int g = blockIdx.x, t = threadIdx.x;
     {   // x tile: 32 tokens x 64 floats = 512 16-byte pieces; tokens past M read as zeros
-        const f32x4* src = reinterpret_cast<const f32x4*>(xf) + (size_t)g * 512;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int p = t + 256 * i;
             const int tok = 32 * g + (p >> 4);
+            const int bb = tok / T, nn = tok - bb * T;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (tok < M) v = src[p];
+            if (tok < M && nn < Tx) v = reinterpret_cast<const f32x4*>(xf)[((size_t)bb * Tx + nn) * 16 + (p & 15)];
             reinterpret_cast<f32x4*>(xs)[p] = v;
         }
     }
@@ -123,7 +125,7 @@ void k_cond_embed(const float* __restrict__ xf /*[M][64]*/, const float* __restr
     }
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
-        const bool live = 32 * g + k < M;               // rows past M: zeros (as the unfused path wrote them)
+        const bool live = 32 * g + k < M && (32 * g + k) % T < Tx;      // rows past M and padding rows: zeros
         ys[k * YS + t] = live ? acc0[k] : 0.f;
         ys[k * YS + t + 256] = live ? acc1[k] : 0.f;
     }
@@ -185,7 +187,7 @@ void k_cond_embed(const float* __restrict__ xf /*[M][64]*/, const float* __restr
 // ~2e-3 on the matrices).
 __global__ __launch_bounds__(512, 1) void k_cond_ca_partials(const DcModel* __restrict__ dm, const bf16x8* __restrict__ nh_hi,
                                                              const bf16x8* __restrict__ nh_lo, float* __restrict__ recs,
-                                                             int M, int T, int G) {
+                                                             int M, int T, int G, int Tx /* frames per clip (<= the clip stride T) */) {
     __shared__ __attribute__((aligned(16))) char wbuf[2 * 16384];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int g = blockIdx.x * 8 + wave;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(512, 1) void k_cond_ca_partials(const DcModel* __re
     float* rec = recs + ((size_t)l * G + g) * 2 * DC_REC_FLOATS;
     const int nslot = cx.straddle ? 2 : 1;
     for (int slot = 0; slot < nslot; ++slot) {
-        const RowRange valid = valid_rows(cx, slot, M, T, nullptr);
+        const RowRange valid = valid_rows(cx, slot, M, T, nullptr, Tx);
         float* R = rec + (size_t)slot * DC_REC_FLOATS;
 #pragma unroll
         for (int oc = 0; oc < 4; ++oc) emit_partial<__bf16, true>(K[oc], V[oc], oc, valid, R, cx);
@@ -720,7 +722,8 @@ template <class T16, bool SPLIT, bool WGR, bool FROMH = false, bool NARROW = fal
 __global__ __launch_bounds__((SPLIT || NARROW) ? 256 : 512, (SPLIT || NARROW) ? 1 : 2)
 void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /*[M][P]*/, float* __restrict__ hbuf,
                    float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G, int B,
-                   unsigned long long* __restrict__ clk /* diagnostic: 100-MHz stamps of one wave, or nullptr */, int l0 = 0) {
+                   unsigned long long* __restrict__ clk /* diagnostic: 100-MHz stamps of one wave, or nullptr */, int l0, int Tx /* frames per
+                   clip of x (<= the clip stride T) */, int upc /* workgroups per clip (clip-aligned units, WgMap) or 0 */) {
     static_assert(!(FROMH && WGR), "the h-injection hook exists for the per-group-record form only");
     static_assert(!NARROW || (WGR && !SPLIT), "narrow workgroups exist for the workgroup-record form of the non-split formats");
     constexpr int NW = (SPLIT || NARROW) ? 4 : 8;
@@ -733,13 +736,15 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
     using W = v8<T16>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wg = WGR ? wg_index() : (int)blockIdx.x;
-    int g = wg * NW + wave;
-    const bool active = g < G;
-    if (!active) g = G - 1;
+    const WgMap wm = wg_map(wg, wave, NW, G, M, T, B, WGR ? upc : 0);
+    const int g = wm.g;
+    const bool active = wm.active;
     const GroupCtx cx = make_ctx(g, lane, M, T);
     const int P = dm->input_feats;
-    const bool live = cx.tok < M;
-    const int n = live ? cx.tok % T : 0;
+    const int xb = min(cx.tok, M - 1) / T, xn = cx.tok - xb * T;              // clip / frame of this lane's token
+    const bool live = cx.tok < M && xn < Tx;                                     // (frames Tx .. T-1 are padding)
+    const int n = live ? xn : 0;
+    const size_t xrow = (size_t)xb * Tx + n;                                     // row of x
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int OFF_IMG_K = 8192, OFF_IMG_V = 8192 + 65536 + 8192 + 9 * 4 * 32 * 4;
     if constexpr (WGR) {
@@ -772,10 +777,12 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
             // wave-private LDS patch.  (Per-element loads touch 32+ cache lines per instruction; the 8 waves' 128 such
             // instructions queue in the CU's address unit for ~4 us.)  The last, partial group keeps the element loads.
             constexpr int OFF_XS = 8192 + 34 * 1024;               // inside pst, behind the key image; 3.5 KiB per wave
-            staged = active && 32 * g + 32 <= M;                   // wave-uniform
-            if (staged) {
+            const int gb = (32 * g) / T, gn = 32 * g - gb * T;      // the group's first token
+            const size_t row0 = (size_t)gb * Tx + gn;
+            staged = active && 32 * g + 32 <= M && gn + 32 <= Tx && (row0 * P) % 4 == 0;     // wave-uniform: 32 real
+            if (staged) {                                                                                       // frames of one clip, 16-B aligned
                 float* xs = reinterpret_cast<float*>(lds + OFF_XS + wave * 3584);
-                const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)g * 32 * P);
+                const f32x4* src = reinterpret_cast<const f32x4*>(x + row0 * P);
                 f32x4 ch[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -795,7 +802,7 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int f = tile_row(r, cx.hh);
-                xv[r] = (live && f < P) ? x[(size_t)cx.tok * P + f] : 0.f;
+                xv[r] = (live && f < P) ? x[xrow * P + f] : 0.f;
             }
         }
         make_frag<T16, true>(xv, xf[0]);
@@ -829,7 +836,7 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
         f32x8* pst = reinterpret_cast<f32x8*>(lds + 8192);
         f32x8* xp = reinterpret_cast<f32x8*>(lds + 8192 + 65536);
         float* ss = reinterpret_cast<float*>(lds + 8192 + 65536 + 8192);
-        const int ub0 = (wg * NW * 32) / T;
+        const int ub0 = wm.ub0;
         const W* lk = reinterpret_cast<const W*>(lds + OFF_IMG_K);
         const W* lv = reinterpret_cast<const W*>(lds + OFF_IMG_V);
         const float* bk = reinterpret_cast<const float*>(lk + 32 * 64);
@@ -869,7 +876,7 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
         stamp(5);
         __syncthreads();
         stamp(6);
-        wg_write_record<NW>(recs, mx, pst, xp, ss, wave, lane, ub0, G, M, T, wg);
+        wg_write_record<NW>(recs, mx, pst, xp, ss, wave, lane, ub0, wm.nact, wm.Mu, wm.Tu, wg);
         stamp(7);
     }
 }
@@ -899,7 +906,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
              float* __restrict__ recs, const int* __restrict__ length, const float* __restrict__ xin,
              float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur, const int* __restrict__ snap_cur,
              float* __restrict__ snaps, int M, int T, int G, int B, int dbg,
-             unsigned long long* __restrict__ stamps, size_t rec_stride, const int* __restrict__ iter_base) {
+             unsigned long long* __restrict__ stamps, size_t rec_stride, const int* __restrict__ iter_base,
+             int Tx /* frames per clip of xin / xout / snaps (<= the clip stride T) */, int upc /* workgroups per clip (WgMap) or 0 */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     static_assert(!NARROW || (WGR && !SPLIT && !DBG), "narrow workgroups: workgroup-record form, non-split formats, no test hooks");
     constexpr int NW = (SPLIT || NARROW) ? 4 : 8;
@@ -925,16 +933,16 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const int nl = dm->num_layers;
     f32x16 h[4];
     {
-        const int g0 = min((int)((WGR ? wg_index() : (int)blockIdx.x) * NW + (threadIdx.x >> 6)), G - 1);
+        const int g0 = wg_map(WGR ? wg_index() : (int)blockIdx.x, threadIdx.x >> 6, NW, G, M, T, B, WGR ? upc : 0).g;
         load_h(h, hbuf, g0, threadIdx.x & 63);      // in flight across the first prologue
     }
   {
     const int tid_ = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), lane = tid_ & 63;
     const int wg = WGR ? wg_index() : (int)blockIdx.x;
-    int g = wg * NW + wave;
-    const bool active = g < G;                   // idle waves still take part in the staging and barriers
-    if (!active) g = G - 1;
+    const WgMap wm = wg_map(wg, wave, NW, G, M, T, B, WGR ? upc : 0);
+    const int g = wm.g;
+    const bool active = wm.active;               // idle waves still take part in the staging and barriers
     const GroupCtx cx = make_ctx(g, lane, M, T);
     char* buf0 = lds;
     char* buf1 = lds + WSZ;
@@ -944,7 +952,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const float* c1 = reinterpret_cast<const float*>(buf1 + NFW * 1024);
     // attention frags come through LDS when the workgroup can span at most 2 clips, else straight from L2
     const bool wg_lds = WGR || (!SPLIT && T >= NW * 32);       // WGR is only launched with T >= NW * 32
-    const int ub0 = (wg * NW * 32) / T;
+    const int ub0 = wm.ub0;
     char* ring = lds + OFF_ER + wave * 8192;
     auto stage_attn = [&](const W* a) {          // frags of clips ub0, ub0+1 -> AF region
         const int c1i = min(ub0 + 1, B - 1);
@@ -964,9 +972,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_WGSTAMP(0);
     stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
     if constexpr (NARROW)
-        wg_combine_attn_narrow<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, M, T, tid_, wg);
+        wg_combine_attn_narrow<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, wm.Mu, wm.Tu, tid_, wg);
     else if constexpr (WGR)      // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
-        wg_combine_attn<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, M, T, tid_, wg,
+        wg_combine_attn<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, wm.Mu, wm.Tu, tid_, wg,
                              (STAMP && stamps && blockIdx.x == 3 && l == 3) ? stamps : nullptr);
     else if (wg_lds)
         stage_attn(a_sa);
@@ -1247,7 +1255,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             DC_STAMP(16);
             __syncthreads();
             DC_STAMP(17);
-            wg_write_record<NW>(recs_out, mx, pst, xp, ss, wave, lane, ub0, G, M, T, wg);
+            wg_write_record<NW>(recs_out, mx, pst, xp, ss, wave, lane, ub0, wm.nact, wm.Mu, wm.Tu, wg);
         } else {
             f32x16 K[4];                  // keys from buf0 while the value image lands in buf1
 #pragma unroll
@@ -1293,11 +1301,14 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     }
     if (!active || cx.tok >= M) return;
     const int P = dm->input_feats;
+    const int xb = cx.tok / T, xn = cx.tok - xb * T;
+    if (xn >= Tx) return;                                           // padding frame
+    const size_t xrow = (size_t)xb * Tx + xn;                       // row of xin / xout / snaps
     if (out_mode == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = tile_row(r, cx.hh);
-            if (f < P) xout[(size_t)cx.tok * P + f] = x0[0][r];
+            if (f < P) xout[xrow * P + f] = x0[0][r];
         }
     } else {
         // graph-captured loop: coef_cur / snap_cur point at this step's slot of the per-iteration tables and *iter_base is
@@ -1310,12 +1321,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         for (int r = 0; r < 16; ++r) {
             const int f = tile_row(r, cx.hh);
             if (f < P) {
-                const size_t o = (size_t)cx.tok * P + f;
+                const size_t o = xrow * P + f;
                 const float xt = xin[o];
                 const float eps = (sr * xt - x0[0][r]) / srm1;
-                const float xn = x0[0][r] * cx0 + ceps * eps;
-                xout[o] = xn;
-                if (snap >= 0) snaps[(size_t)snap * M * P + o] = xn;
+                const float xnew = x0[0][r] * cx0 + ceps * eps;
+                xout[o] = xnew;
+                if (snap >= 0) snaps[(size_t)snap * B * Tx * P + o] = xnew;
             }
         }
     }
@@ -1802,18 +1813,18 @@ hipError_t dc_launch_temb_table(hipStream_t st, const float* freqs, const float*
 }
 
 hipError_t dc_launch_cond_embed(hipStream_t st, int mode, const float* xf, const float* wt, const float* b, float* out_f32,
-                                void* out_hi, void* out_lo, int M, int G) {
+                                void* out_hi, void* out_lo, int M, int G, int T, int Tx) {
     if (mode == 0)
-        hipLaunchKernelGGL(k_cond_embed<0>, dim3(G), dim3(256), 0, st, xf, wt, b, out_f32, (bf16x8*)out_hi, (bf16x8*)out_lo, M);
+        hipLaunchKernelGGL(k_cond_embed<0>, dim3(G), dim3(256), 0, st, xf, wt, b, out_f32, (bf16x8*)out_hi, (bf16x8*)out_lo, M, T, Tx);
     else
-        hipLaunchKernelGGL(k_cond_embed<1>, dim3(G), dim3(256), 0, st, xf, wt, b, out_f32, (bf16x8*)out_hi, (bf16x8*)out_lo, M);
+        hipLaunchKernelGGL(k_cond_embed<1>, dim3(G), dim3(256), 0, st, xf, wt, b, out_f32, (bf16x8*)out_hi, (bf16x8*)out_lo, M, T, Tx);
     return LAUNCH_CHECK();
 }
 
 hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* nh_hi, const void* nh_lo,
-                                 float* recs, int M, int T, int G, int L) {
+                                 float* recs, int M, int T, int G, int L, int Tx) {
     hipLaunchKernelGGL(k_cond_ca_partials, dim3((G + 7) / 8, L), dim3(512), 0, st, dm, (const bf16x8*)nh_hi,
-                       (const bf16x8*)nh_lo, recs, M, T, G);
+                       (const bf16x8*)nh_lo, recs, M, T, G, Tx);
     return LAUNCH_CHECK();
 }
 
@@ -1887,7 +1898,7 @@ template <class T16, bool SP>
 static hipError_t launch_front_from_h_t(hipStream_t st, const DcModel* dm, float* hbuf, float* recs, const int* length,
                                         int M, int T, int G, int B, int l0) {
     constexpr int NW = SP ? 4 : 8;
-    k_embed_front<T16, SP, false, true><<<dim3((G + NW - 1) / NW), dim3(NW * 64), 0, st>>>(dm, nullptr, hbuf, recs, length, M, T, G, B, nullptr, l0);
+    k_embed_front<T16, SP, false, true><<<dim3((G + NW - 1) / NW), dim3(NW * 64), 0, st>>>(dm, nullptr, hbuf, recs, length, M, T, G, B, nullptr, l0, T, 0);
     return hipGetLastError();
 }
 hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcModel* dm, float* hbuf, float* recs, const int* length,
@@ -1899,28 +1910,29 @@ hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcM
 
 template <class T16, bool SP, bool WGR, bool NARROW = false>
 static hipError_t launch_embed_t(hipStream_t st, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
-                                 int M, int T, int G, int B, unsigned long long* clk) {
+                                 int M, int T, int G, int B, unsigned long long* clk, int Tx, int upc) {
     constexpr int NW = (SP || NARROW) ? 4 : 8;
     const size_t shm = WGR ? 8192 + 65536 + 8192 + 9 * 4 * 32 * 4 + 33 * 1024 : 0;
     if (WGR) {
         static unsigned long long optin_done = 0;
         if (hipError_t e = lds_optin((const void*)k_embed_front<T16, SP, WGR, false, NARROW>, (int)shm, optin_done)) return e;
     }
-    k_embed_front<T16, SP, WGR, false, NARROW><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, B, clk);
+    k_embed_front<T16, SP, WGR, false, NARROW><<<dim3((WGR && upc) ? B * upc : (G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, B,
+                                                                                                                         clk, 0, Tx, WGR ? upc : 0);
     return hipGetLastError();
 }
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf,
-                                 float* recs, const int* length, int M, int T, int G, int B, unsigned long long* clk, bool narrow) {
+                                 float* recs, const int* length, int M, int T, int G, int B, unsigned long long* clk, bool narrow, int Tx, int upc) {
     hipError_t e = hipSuccess;
     if (wgr && !split && narrow)
-        return fmt == 1 ? launch_embed_t<_Float16, false, true, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk)
-                        : launch_embed_t<__bf16, false, true, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk);
+        return fmt == 1 ? launch_embed_t<_Float16, false, true, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc)
+                        : launch_embed_t<__bf16, false, true, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc);
     if (wgr && !split) {
-        e = fmt == 1 ? launch_embed_t<_Float16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk)
-                     : launch_embed_t<__bf16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk);
+        e = fmt == 1 ? launch_embed_t<_Float16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc)
+                     : launch_embed_t<__bf16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc);
         return e;
     }
-    DISPATCH(fmt, split, (e = launch_embed_t<T16, SP, false>(st, dm, x, hbuf, recs, length, M, T, G, B, clk)));
+    DISPATCH(fmt, split, (e = launch_embed_t<T16, SP, false>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc)));
     return e;
 }
 
@@ -1929,15 +1941,15 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                                  int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride,
-                                 const int* iter_base) {
+                                 const int* iter_base, int Tx, int upc) {
     constexpr int NW = (SP || NARROW) ? 4 : 8;
     // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
     const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
     static unsigned long long optin_done = 0;   // > 64 KiB of dynamic LDS needs the opt-in
     if (hipError_t e = lds_optin((const void*)k_layer<T16, SP, DBG, STAMP, WGR, NARROW>, (int)shm, optin_done)) return e;
-    k_layer<T16, SP, DBG, STAMP, WGR, NARROW><<<dim3((G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, l, hbuf, (const f16x16*)E, NT,
-                       (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
-                       snaps, M, T, G, B, dbg, stamps, rec_stride, iter_base);
+    k_layer<T16, SP, DBG, STAMP, WGR, NARROW><<<dim3((WGR && upc) ? B * upc : (G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(
+        dm, l, hbuf, (const f16x16*)E, NT, (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
+        snaps, M, T, G, B, dbg, stamps, rec_stride, iter_base, Tx, WGR ? upc : 0);
     return hipGetLastError();
 }
 
@@ -1945,10 +1957,10 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride, const int* iter_base,
-                           bool narrow) {
+                           bool narrow, int Tx, int upc) {
     hipError_t e = hipSuccess;
 #define LAYER_ARGS st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps, \
-                   rec_stride, iter_base
+                   rec_stride, iter_base, Tx, upc
     if (wgr && !split && narrow && dbg == 0 && stamps == nullptr)      // narrow workgroups: production build only
         return fmt == 1 ? launch_layer_t<_Float16, false, false, false, true, true>(LAYER_ARGS)
                         : launch_layer_t<__bf16, false, false, false, true, true>(LAYER_ARGS);

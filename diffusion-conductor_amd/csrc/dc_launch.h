@@ -10,9 +10,10 @@ hipError_t dc_launch_temb_table(hipStream_t st, const float* freqs, const float*
 // `self.linear` of one conditioning tensor [M][64] into a fragment-major operand image: mode 0 = fp32 image of emb's
 // step-invariant term (out_f32), mode 1 = text_norm'ed bf16 hi / lo images (out_hi, out_lo) for the cross-attention pre-pass
 hipError_t dc_launch_cond_embed(hipStream_t st, int mode, const float* xf, const float* wt, const float* b, float* out_f32,
-                                void* out_hi, void* out_lo, int M, int G);
+                                void* out_hi, void* out_lo, int M, int G, int T /* clip stride of the images */,
+                                int Tx /* frames per clip of xf (<= T; the rest of a clip's stride is padding) */);
 hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* nh_hi, const void* nh_lo,
-                                 float* recs, int M, int T, int G, int L);
+                                 float* recs, int M, int T, int G, int L, int Tx /* frames per clip (<= the clip stride T) */);
 hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, void* afrag, int T, int NU, int B, int nset,
                                   int gran);
 hipError_t dc_launch_silu_emb(hipStream_t st, int fmt, bool split, const float* pp, const float* temb, const int* t_clip,
@@ -30,7 +31,9 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf, float* recs,
                                  const int* length, int M, int T, int G, int B,
                                  unsigned long long* clk /* diagnostic stamps (8 slots) or nullptr */,
-                                 bool narrow = false /* wgr, non-split: 4-wave workgroups = 128-token units (small batches) */);
+                                 bool narrow /* wgr, non-split: 4-wave workgroups = 128-token units (small batches) */,
+                                 int Tx /* frames per clip of x (<= the clip stride T) */,
+                                 int upc /* wgr: workgroups per clip (clip-aligned units, WgMap in dc_dev.h), grid = B * upc; else 0 */);
 // test hook: front half of layer l0 from the residual stream as it stands in hbuf (per-group records)
 hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcModel* dm, float* hbuf, float* recs, const int* length,
                                   int M, int T, int G, int B, int l0);
@@ -40,7 +43,8 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride,
                            const int* iter_base /* captured loop: coef_cur / snap_cur = this step's slots of the per-iteration tables,
                                                    indexed by *iter_base; else nullptr (scalars prepared by k_begin_step) */,
-                           bool narrow = false /* wgr, non-split, dbg == 0: 4-wave workgroups; recs / rec_stride then count 128-token units */);
+                           bool narrow /* wgr, non-split, dbg == 0: 4-wave workgroups; recs / rec_stride then count 128-token units */,
+                           int Tx /* frames per clip of xin / xout / snaps */, int upc /* as dc_launch_embed_front */);
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);
 // rec_stride: floats between the two alternating unit-record buffers (0 = single buffer, non-wgr)
 

@@ -21,7 +21,7 @@ EXPORTS = [
     "dc_last_error", "dc_version", "dc_linear_beta_schedule", "dc_ddim_coefficients", "dc_pack_weight",
     "dc_sampler_create", "dc_sampler_destroy", "dc_sampler_set_param", "dc_sampler_finalize_params",
     "dc_sampler_set_conditioning", "dc_sampler_encode_music", "dc_sampler_denoise", "dc_sampler_ddim_loop", "dc_sampler_profile_loop",
-    "dc_kernel_name", "dc_kernel_count", "dc_sampler_workspace_bytes", "dc_sampler_debug_denoise",
+    "dc_kernel_name", "dc_kernel_count", "dc_sampler_workspace_bytes", "dc_sampler_clip_stride", "dc_sampler_debug_denoise",
     "dc_sampler_debug_read", "dc_sampler_debug_layer", "dc_savgol_coefficients", "dc_savgol_filter",
 ]
 
@@ -91,6 +91,8 @@ def lib():
     L.dc_kernel_count.restype = C.c_int32
     L.dc_sampler_workspace_bytes.restype = C.c_int64
     L.dc_sampler_workspace_bytes.argtypes = [C.c_void_p]
+    L.dc_sampler_clip_stride.restype = C.c_int32
+    L.dc_sampler_clip_stride.argtypes = [C.c_void_p]
     dp, fp, ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
     L.dc_linear_beta_schedule.argtypes = [C.c_int32, dp, dp, dp, dp, dp]
     L.dc_ddim_coefficients.argtypes = [C.c_int32, dp, fp]
@@ -327,12 +329,20 @@ class NativeSampler:
         _check(lib().dc_sampler_debug_read(self._h, what.encode(), a.ctypes.data_as(C.c_void_p), a.nbytes))
         return a
 
+    def clip_stride(self):
+        """Frames per clip of the internal token space (T, padded to whole 32-frame groups where the clip-aligned kernels run)."""
+        return int(lib().dc_sampler_clip_stride(self._h))
+
     def read_h(self):
-        """Residual stream [M_pad, 128] unpacked from the FT-tile image [G][4][64][16]."""
-        G = (self.B * self.T + 31) // 32
+        """Residual stream [>= B*T, 128] (rows b*T + n) unpacked from the FT-tile image [G][4][64][16]."""
+        Tp = self.clip_stride()
+        G = (self.B * Tp + 31) // 32
         # device order [G][tile][quarter][lane][4] -> [G][tile][lane][16 regs]
         raw = self.debug_read("h", np.float32, G * 4 * 64 * 16).reshape(G, 4, 4, 64, 4)
-        return unpack_ft(raw.transpose(0, 1, 3, 2, 4).reshape(G, 4, 64, 16))
+        rows = unpack_ft(raw.transpose(0, 1, 3, 2, 4).reshape(G, 4, 64, 16))
+        if Tp != self.T:       # drop the padding frames of every clip
+            rows = rows[:self.B * Tp].reshape(self.B, Tp, 128)[:, :self.T].reshape(self.B * self.T, 128)
+        return rows
 
     def workspace_bytes(self):
         return int(lib().dc_sampler_workspace_bytes(self._h))

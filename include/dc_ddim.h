@@ -186,8 +186,11 @@ int dc_savgol_coefficients(int32_t window, int32_t order, float* h_coef);
 int dc_savgol_filter(const float* d_in, float* d_out, int32_t B, int32_t T, int32_t P, int32_t window, int32_t order,
                      void* stream);
 
-/* Introspection used by tests: bytes of device workspace currently held. */
+/* Introspection used by tests: bytes of device workspace currently held; frames per clip of the sampler's internal token space
+ * (the T of dc_sampler_set_conditioning, padded to whole 32-frame groups where the clip-aligned kernels run): the layout of the
+ * buffers dc_sampler_debug_read returns. */
 int64_t dc_sampler_workspace_bytes(const dc_sampler* s);
+int32_t dc_sampler_clip_stride(const dc_sampler* s);
 
 #ifdef __cplusplus
 }

@@ -166,6 +166,39 @@ def test_narrow_workgroups_agree_with_wide_ones(models):
     assert torch.isfinite(a).all() and ea <= TOL_PARITY and eb <= TOL_PARITY and d <= TOL_PARITY
 
 
+def test_clip_layouts_agree_and_small_batches_are_batch_invariant(models):
+    """Where the workgroup-record kernels run, a clip's stride in the token space is padded to whole 32-frame groups (T = 900 -> 928
+    for a small batch) and small batches run clip-aligned 4-wave workgroups: no group and no workgroup spans two clips.  The
+    layouts (padded + aligned, padded + flat units, unpadded; DC_ALIGN=1 with 8-wave workgroups) differ only by which unit
+    maxima the keys are exponentiated against: all within the parity bound, 2e-4 apart.  With aligned units a clip never
+    shares a workgroup, so its result does not depend on the batch around it: bit-identical to sampling it alone."""
+    B, T = 3, 900
+    xfp, xfo = xf_pair(B, T, first=50)
+    noise = torch.from_numpy(batch_noise(B, T, first=50))
+    length = [900, 611, 333]
+    with torch.no_grad():
+        ref = O.ddim_sample_loop(oracle_params(), noise, xfp, xfo, length, 25)
+    outs = {}
+    os.environ["DC_DISABLE_GRAPH"] = "1"          # eager launches: the switches are read when a launch is enqueued
+    try:
+        for name, env in (("aligned", {}), ("flat", {"DC_NO_ALIGN": "1"}), ("unpadded", {"DC_NO_PAD": "1"}),
+                          ("aligned-wide", {"DC_NO_NARROW": "1", "DC_ALIGN": "1"}), ("flat-wide", {"DC_NO_NARROW": "1"})):
+            os.environ.update(env)
+            try:
+                outs[name] = _ddim(models["fp16"], 25, noise, xfp, xfo, length)
+            finally:
+                for k in env:
+                    del os.environ[k]
+        alone = [_ddim(models["fp16"], 25, noise[b:b + 1], xfp[b:b + 1], xfo[b:b + 1], length[b:b + 1]) for b in range(B)]
+    finally:
+        del os.environ["DC_DISABLE_GRAPH"]
+    for name, o in outs.items():
+        e = rel_l2(o, ref)
+        print(f"layout {name}: rel-L2 vs oracle {e:.3e}, vs aligned {rel_l2(o, outs['aligned'].cpu().numpy()):.3e}")
+        assert torch.isfinite(o).all() and e <= TOL_PARITY
+    assert all(torch.equal(outs["aligned"][b:b + 1], alone[b]) for b in range(B))
+
+
 def test_film_adaptive_shares_do_not_change_results(models):
     """The persistent FiLM GEMM sizes its workgroups' shares by the per-XCD speeds measured in earlier launches (>= 64
     workgroups); which workgroup computes a tile must not matter: bit-identical to equal shares (DC_FILM_STATIC=1) and

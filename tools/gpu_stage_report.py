@@ -3,6 +3,8 @@
 the oracle's taps and prints one rel-L2 line per stage, per precision mode.
 Usage on the GPU box:  python tools/gpu_stage_report.py [B T]"""
 import os
+os.environ.setdefault("DC_NO_PAD", "1")      # this report decodes the raw device images with the flat (unpadded) token layout
+import os
 import sys
 
 import numpy as np
