@@ -983,7 +983,7 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
                                 int32_t B, int32_t T, void* stream) {
     if (!s || !s->finalized) return fail(DC_ERR_INVALID, "sampler not finalized");
     if (!d_xf_proj || !d_xf_out || B < 1 || T < 32) return fail(DC_ERR_INVALID, "bad conditioning arguments (need B >= 1, T >= 32)");
-    if (T / 32 + 2 > 128) return fail(DC_ERR_UNSUPPORTED, "T=%d: the attention combine holds at most 128 token groups per clip (T <= 4032)", T);
+    if (clip_stride(s, B, T) / 32 + 2 > 128) return fail(DC_ERR_UNSUPPORTED, "T=%d: the attention combine holds at most 128 token groups per clip (T <= 4032)", T);
     if (T > s->cfg.num_frames) return fail(DC_ERR_INVALID, "T=%d exceeds num_frames=%d rows of sequence_embedding", T, s->cfg.num_frames);
     HIP_TRY(hipSetDevice(s->cfg.device));
     int rc;
