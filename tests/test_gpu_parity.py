@@ -75,6 +75,25 @@ def test_forward_straddling_groups(models):
     assert err <= TOL_X3
 
 
+@pytest.mark.parametrize("B,T", [(1, 257), (2, 288), (3, 1000), (2, 1799), (9, 1800), (33, 300)])
+def test_forward_padded_clip_strides(models, B, T):
+    """Clip strides at the edges of the padding policy (dc_api.hip clip_stride): 257 -> 288 (+12 %, small batch only), 288 and
+    1800-multiples untouched or padded by < 2 %, a batch just past the narrow-workgroup limit (9 x 1800: 135 narrow units) and
+    one that fills the chip with short clips; ragged lengths down to one frame; per-clip timesteps.  Forward vs the oracle."""
+    p = oracle_params()
+    xfp, xfo = xf_pair(B, T, first=7)
+    x = torch.from_numpy(batch_noise(B, T, first=7))
+    t = torch.tensor([(131 * b + 5) % 1000 for b in range(B)])
+    length = [T if b % 3 == 0 else (1 if b % 3 == 1 else max(1, T - 33 * b - 1)) for b in range(B)]
+    with torch.no_grad():
+        ref = O.denoiser_forward(p, x, t, length, xfp, xfo)
+    out = models["fp16"](x.cuda(), t, length=torch.tensor(length), xf_proj=xfp.cuda(), xf_out=xfo.cuda())
+    torch.cuda.synchronize()
+    err = rel_l2(out, ref)
+    print(f"padded stride B={B} T={T}: rel-L2 {err:.3e}")
+    assert torch.isfinite(out).all() and err <= TOL_PARITY
+
+
 @pytest.mark.parametrize("prec,tol", [("fp16", TOL_PARITY), ("mixed", TOL_PARITY), ("bf16x3", TOL_X3), ("bf16", TOL_BF16)])
 def test_ddim50_config1_golden(models, prec, tol):
     """G5 = BASELINE config 1: single 60 s clip, DDIM-50, with the idxs=[0,24] intermediates."""
