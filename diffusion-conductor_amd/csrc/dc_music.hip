@@ -471,6 +471,136 @@ __global__ __launch_bounds__(512, 1) void k_me_stem(const float* __restrict__ me
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// conv2 (16 -> 32 with the 1x1-convolution residual, then 32 -> 32 with the identity residual, at 5400 x 64) as ONE kernel, built
+// like k_me_stem: a persistent 8-wave workgroup per CU keeps the 32-channel intermediate of an 8 x 32-pixel tile (grown by one
+// pixel) in LDS, so its 1.4 GB per 32 clips are neither written nor read back.
+//   fill: the input tile grown by 2 (12 x 36 pixels, both planes) by LDS-DMA, reflect padding by index          -> TA
+//   B:    conv2.0 + residual at the reflected positions of the 1-pixel-grown tile (10 x 34), taps from TA        -> TB
+//   C:    conv2.1 + identity residual on the tile, taps from TB; the next tile's fill is in flight meanwhile     -> HBM
+// v_mfma_f32_32x32x16_bf16 (32 output channels = the tile's rows), weights of both layers in LDS (56 KiB).
+// ---------------------------------------------------------------------------------------------------------
+template <int ROWS, int TX>
+__global__ __launch_bounds__(512, 1) void k_me_mid(const bf16x8* __restrict__ in_hi, const bf16x8* __restrict__ in_lo,
+                                                   __bf16* __restrict__ out_hi, __bf16* __restrict__ out_lo,
+                                                   const bf16x8* __restrict__ w0 /* conv2.0: 9 hi, 9 lo, residual hi, lo */,
+                                                   const float* __restrict__ bias0_ft, const float* __restrict__ rbias0_ft,
+                                                   const bf16x8* __restrict__ w1 /* conv2.1: 18 hi, 18 lo */,
+                                                   const float* __restrict__ bias1_ft, int H, int W, int ntiles) {
+    static_assert(TX == 32 && ROWS == 8, "phase C: one tile row per wave");
+    constexpr int RAH = ROWS + 4, RAW = TX + 4, NA = RAH * RAW;           // input region (16 channels: halves kh)
+    constexpr int RBH = ROWS + 2, RBW = TX + 2, NB = RBH * RBW;           // conv2.0 region (32 channels: chunks kc, halves kh)
+    constexpr int NBP = (NB + 15) / 16 * 16;
+    constexpr int NPA = 4 * NA;                                            // 16-byte pieces of TA: [plane][kh][NA]
+    constexpr int NDMA = (NPA + 63) / 64;
+    static_assert(NA % 16 == 0, "plane stride of TA");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    bf16x8* wl0 = reinterpret_cast<bf16x8*>(lds);                          // 20 fragments
+    bf16x8* wl1 = wl0 + 20 * 64;                                           // 36 fragments
+    bf16x8* TA = wl1 + 36 * 64;                                            // pieces [plane][kh][NA]
+    bf16x8* TB = TA + NDMA * 64;                                           // pieces [plane][kc][kh][NBP]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = lane & 31, kh = lane >> 5;
+    for (int f = wave; f < 20; f += 8) wl0[f * 64 + lane] = w0[f * 64 + lane];
+    for (int f = wave; f < 36; f += 8) wl1[f * 64 + lane] = w1[f * 64 + lane];      // (in registers instead: 4.36 vs 4.25 ms per 32 clips)
+    f32x16 bias0, rbias0, bias1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        bias0[r] = bias0_ft[kh * 16 + r];
+        rbias0[r] = rbias0_ft[kh * 16 + r];
+        bias1[r] = bias1_ft[kh * 16 + r];
+    }
+    const int txn = W / TX, tyn = (H + ROWS - 1) / ROWS;
+    auto fill = [&](int t) {
+        const int tx = t % txn, ty = (t / txn) % tyn, b = t / (txn * tyn);
+        for (int j = wave; j < NDMA; j += 8) {
+            const int p = 64 * j + lane;
+            if (p < NPA) {
+                const int idx = p % NA, sel = p / NA;                      // sel = plane * 2 + kh
+                const int yy = reflect(ty * ROWS - 2 + idx / RAW, H), xx = reflect(tx * TX - 2 + idx % RAW, W);
+                const bf16x8* src = ((sel >> 1) ? in_lo : in_hi) + (((size_t)b * H + yy) * W + xx) * 2 + (sel & 1);
+                me_dma16(src, reinterpret_cast<const char*>(TA + 64 * j));
+            }
+        }
+    };
+    auto local = [](int i, int o0, int g, int G, int size, int lim) {      // as in k_me_stem
+        const int r = reflect(o0 - g + i, size) - (o0 - G);
+        return min(max(r, 1), lim - 2);
+    };
+    if ((int)blockIdx.x < ntiles) fill(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = t % txn, ty = (t / txn) % tyn, b = t / (txn * tyn);
+        const int x0 = tx * TX, y0 = ty * ROWS;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                // TA has landed; everyone has left the previous tile's phase C (TB)
+        // ---- B: conv2.0 (+ 1x1 residual) at the reflected positions of the 1-pixel-grown tile
+        for (int f0 = wave * 32; f0 < NB; f0 += 256) {
+            const int f = f0 + n, fr = min(f, NB - 1);
+            const int row = fr / RBW, px = fr % RBW;
+            const int ly = local(row, y0, 1, 2, H, RAH), lx = local(px, x0, 1, 2, W, RAW);
+            const bf16x8* ctr = TA + kh * NA + ly * RAW + lx;
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int o = (tap / 3 - 1) * RAW + tap % 3 - 1;
+                acc = mma3(wl0[tap * 64 + lane], wl0[(9 + tap) * 64 + lane], ctr[o], ctr[2 * NA + o], acc);
+            }
+            const f32x16 res = mma3(wl0[18 * 64 + lane], wl0[19 * 64 + lane], ctr[0], ctr[2 * NA], zero16());
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {           // output channels 8 q + 4 kh .. + 3: chunk q >> 1, half q & 1, byte offset 8 kh
+                bf16x4 oh, ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fmaxf(acc[4 * q + e] + bias0[4 * q + e], 0.f) + res[4 * q + e] + rbias0[4 * q + e];
+                    const __bf16 h = (__bf16)v;
+                    oh[e] = h;
+                    ol[e] = (__bf16)(v - (float)h);
+                }
+                if (f < NB) {
+                    bf16x8* dst = TB + ((q >> 1) * 2 + (q & 1)) * NBP + f;
+                    reinterpret_cast<bf16x4*>(dst)[kh] = oh;
+                    reinterpret_cast<bf16x4*>(dst + 4 * NBP)[kh] = ol;
+                }
+            }
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < ntiles) fill(t + gridDim.x);       // TA is free: the next tile's input lands during phase C
+        // ---- C: conv2.1 + identity residual: wave = tile row
+        {
+            const int row = wave;
+            const bf16x8* org = TB + kh * NBP + row * RBW + n;      // piece of (kc 0, this half, halo row `row`, halo column n)
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    const int ks = tap * 2 + kc, o = kc * 2 * NBP + (tap / 3) * RBW + tap % 3;
+                    acc = mma3(wl1[ks * 64 + lane], wl1[(18 + ks) * 64 + lane], org[o], org[4 * NBP + o], acc);
+                }
+            const int y = y0 + row;
+            if (y < H) {
+                const size_t pix = ((size_t)b * H + y) * W + x0 + n;
+                const bf16x8* ctr = TB + (row + 1) * RBW + n + 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x4 xh = reinterpret_cast<const bf16x4*>(ctr + ((q >> 1) * 2 + (q & 1)) * NBP)[kh];
+                    const bf16x4 xl = reinterpret_cast<const bf16x4*>(ctr + (4 + (q >> 1) * 2 + (q & 1)) * NBP)[kh];
+                    bf16x4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = fmaxf(acc[4 * q + e] + bias1[4 * q + e], 0.f) + (float)xh[e] + (float)xl[e];
+                        const __bf16 h = (__bf16)v;
+                        oh[e] = h;
+                        ol[e] = (__bf16)(v - (float)h);
+                    }
+                    *reinterpret_cast<bf16x4*>(out_hi + pix * 32 + 8 * q + 4 * kh) = oh;
+                    *reinterpret_cast<bf16x4*>(out_lo + pix * 32 + 8 * q + 4 * kh) = ol;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // max_pool2d on the plane pair; padding never wins (torch pads with -inf).  One thread per (pixel, 8 channels).
 // hi + lo is exact in fp32 (<= 17 significant bits), so the maximum re-splits into the very planes it came from.
 // ---------------------------------------------------------------------------------------------------------
@@ -931,6 +1061,21 @@ hipError_t launch_stem(hipStream_t st, const dc_music* m, const float* mel, bf16
                                                             m->stem_b, m->stem_wa, H, W, (int)ntiles);
     return hipGetLastError();
 }
+// conv2.0 -> conv2.1 fused (W a multiple of 32); DC_ME_NO_MID=1 keeps the two separate launches
+hipError_t launch_mid(hipStream_t st, const dc_music* m, const bf16x8* ih, const bf16x8* il, bf16x8* oh, bf16x8* ol, int Bc, int H, int W) {
+    constexpr int ROWS = 8, TX = 32;
+    constexpr int NPA = 4 * (ROWS + 4) * (TX + 4), NDMA = (NPA + 63) / 64, NBP = ((ROWS + 2) * (TX + 2) + 15) / 16 * 16;
+    constexpr int SHM = 56 * 1024 + NDMA * 1024 + 8 * NBP * 16;
+    static unsigned long long optin = 0;
+    MeDev d;
+    if (hipError_t e = me_device(d)) return e;
+    if (hipError_t e = me_optin((const void*)k_me_mid<ROWS, TX>, SHM, optin, d.dev)) return e;
+    const long long ntiles = (long long)Bc * ((H + ROWS - 1) / ROWS) * (W / TX);
+    const unsigned grid = (unsigned)std::min<long long>(ntiles, d.ncu);
+    k_me_mid<ROWS, TX><<<dim3(grid), dim3(512), SHM, st>>>(ih, il, reinterpret_cast<__bf16*>(oh), reinterpret_cast<__bf16*>(ol), m->conv[3].w,
+                                                           m->conv[3].bias, m->conv[3].rbias, m->conv[4].w, m->conv[4].bias, H, W, (int)ntiles);
+    return hipGetLastError();
+}
 template <int KH, int KW, int SH, int SW, int PH, int PW>
 hipError_t launch_pool(hipStream_t st, const bf16x8* ih, const bf16x8* il, bf16x8* oh, bf16x8* ol, int Bc, int H, int W, int C,
                        int Ho, int Wo) {
@@ -983,8 +1128,14 @@ hipError_t dc_music_encode(dc_music* m, const float* d_mel, int B, int Tm, float
             ME_TRY((launch_conv_t<16, 16, 1, 8, 2>(st, m->conv[2], bh, bl, ah, al, Bc, Tm, 128)));
         }
         ME_TRY((launch_pool<5, 5, 1, 2, 2, 2>(st, ah, al, bh, bl, Bc, Tm, 128, 16, Tm, 64)));
-        ME_TRY((launch_conv_t<16, 32, 2, 8, 2>(st, m->conv[3], bh, bl, ah, al, Bc, Tm, 64)));
-        ME_TRY((launch_conv_t<32, 32, 1, 8, 1>(st, m->conv[4], ah, al, bh, bl, Bc, Tm, 64)));
+        if (!getenv("DC_ME_NO_MID")) {
+            ME_TRY(launch_mid(st, m, bh, bl, ah, al, Bc, Tm, 64));
+            std::swap(ah, bh);      // (the two-launch form leaves conv2.1's output in b)
+            std::swap(al, bl);
+        } else {
+            ME_TRY((launch_conv_t<16, 32, 2, 8, 2>(st, m->conv[3], bh, bl, ah, al, Bc, Tm, 64)));
+            ME_TRY((launch_conv_t<32, 32, 1, 8, 1>(st, m->conv[4], ah, al, bh, bl, Bc, Tm, 64)));
+        }
         ME_TRY((launch_pool<5, 5, 3, 2, 2, 2>(st, bh, bl, ah, al, Bc, Tm, 64, 32, T, 32)));
         ME_TRY((launch_conv_t<32, 32, 1, 8, 1>(st, m->conv[5], ah, al, bh, bl, Bc, T, 32)));
         ME_TRY((launch_conv_t<32, 32, 1, 8, 1>(st, m->conv[6], bh, bl, ah, al, Bc, T, 32)));

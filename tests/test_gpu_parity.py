@@ -323,12 +323,13 @@ def test_encode_music_golden(models):
 def test_encode_music_batched_vs_oracle(models):
     """Clips are encoded in chunks (32 at full length; DC_ME_CHUNK=4 makes a batch of 9 cross two chunk edges).  30-s clips
     (Tm = 2700 -> T = 900) and an odd frame count (271 = 33 x 8 + 7: partial row tiles of the LDS-tiled convolutions, the
-    stride-3 pool's floor) against the oracle; the fused conv1 kernel and the three separate launches (DC_ME_NO_STEM=1) both."""
+    stride-3 pool's floor) against the oracle; the fused conv1 / conv2 kernels and their separate launches (DC_ME_NO_STEM=1,
+    DC_ME_NO_MID=1) both."""
     from oracle import ddim_oracle as O
     m = models["fp16"]
     p = oracle_params()
-    for B, Tm, env in ((9, 5400, {"DC_ME_CHUNK": "4"}), (3, 2700, {}), (2, 271, {}), (2, 271, {"DC_ME_NO_STEM": "1"}),
-                       (2, 2700, {"DC_ME_NO_STEM": "1"})):
+    for B, Tm, env in ((9, 5400, {"DC_ME_CHUNK": "4"}), (3, 2700, {}), (2, 271, {}), (2, 271, {"DC_ME_NO_STEM": "1", "DC_ME_NO_MID": "1"}),
+                       (2, 2700, {"DC_ME_NO_STEM": "1"}), (2, 2700, {"DC_ME_NO_MID": "1"})):
         mel = torch.from_numpy(batch_mel(B, Tm))
         os.environ.update(env)
         try:
