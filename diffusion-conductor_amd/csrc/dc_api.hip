@@ -687,7 +687,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         return DC_OK;
     }
     // workgroup-level records (no combine launches) whenever a workgroup's 256 tokens cannot touch more than two clips
-    static const bool no_wgr = getenv("DC_NO_WGREC") != nullptr;
+    const bool no_wgr = getenv("DC_NO_WGREC") != nullptr;          // (read per call: the tests toggle it)
     const bool wgr = !ss && T >= 256 && !no_wgr && s->dbg_first < 0;
     // Narrow workgroups (4 waves = 128-token units, one wave per SIMD) while every unit still gets a CU of its own: the layer
     // kernel is bound by instruction issue, so a wave alone on its SIMD runs a layer in about half the time (DESIGN.md

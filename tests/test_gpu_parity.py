@@ -188,8 +188,8 @@ def test_narrow_workgroups_agree_with_wide_ones(models):
 def test_clip_layouts_agree_and_small_batches_are_batch_invariant(models):
     """Where the workgroup-record kernels run, a clip's stride in the token space is padded to whole 32-frame groups (T = 900 -> 928
     for a small batch) and small batches run clip-aligned 4-wave workgroups: no group and no workgroup spans two clips.  The
-    layouts (padded + aligned, padded + flat units, unpadded; DC_ALIGN=1 with 8-wave workgroups) differ only by which unit
-    maxima the keys are exponentiated against: all within the parity bound, 2e-4 apart.  With aligned units a clip never
+    layouts (padded + aligned, padded + flat units, unpadded; DC_ALIGN=1 with 8-wave workgroups; per-group records + combine
+    launches on the padded stride) differ only by which unit maxima the keys are exponentiated against: all within the parity bound, 2e-4 apart.  With aligned units a clip never
     shares a workgroup, so its result does not depend on the batch around it: bit-identical to sampling it alone."""
     B, T = 3, 900
     xfp, xfo = xf_pair(B, T, first=50)
@@ -201,7 +201,8 @@ def test_clip_layouts_agree_and_small_batches_are_batch_invariant(models):
     os.environ["DC_DISABLE_GRAPH"] = "1"          # eager launches: the switches are read when a launch is enqueued
     try:
         for name, env in (("aligned", {}), ("flat", {"DC_NO_ALIGN": "1"}), ("unpadded", {"DC_NO_PAD": "1"}),
-                          ("aligned-wide", {"DC_NO_NARROW": "1", "DC_ALIGN": "1"}), ("flat-wide", {"DC_NO_NARROW": "1"})):
+                          ("aligned-wide", {"DC_NO_NARROW": "1", "DC_ALIGN": "1"}), ("flat-wide", {"DC_NO_NARROW": "1"}),
+                          ("per-group records", {"DC_NO_WGREC": "1"})):
             os.environ.update(env)
             try:
                 outs[name] = _ddim(models["fp16"], 25, noise, xfp, xfo, length)
