@@ -46,7 +46,9 @@ if ef[7] > ef[0]:
              "barrier", "record written"]
     print("k_embed_front workgroup 100, wave 0 (us): " + "   ".join(f"{n} {(ef[i + 1] - ef[i]) / 100.0:.2f}" for i, n in enumerate(names))
           + f"   total {(ef[7] - ef[0]) / 100.0:.2f}")
-wg = nat.debug_read("stamps", np.uint64, 8 * 32 + 8 + 1024).astype(np.int64)[264:].reshape(2, 256, 2)[:, :225]
+Tp = nat.clip_stride()
+nwg = (B * Tp + 255) // 256
+wg = nat.debug_read("stamps", np.uint64, 8 * 32 + 8 + 1024).astype(np.int64)[264:].reshape(2, 256, 2)[:, :nwg]
 if wg[0, :, 1].max() > 0:
     t0 = wg[0, :, 0].min()
     q = lambda a: " ".join(f"{v / 100.0:7.2f}" for v in np.percentile(a, [0, 10, 50, 90, 100]))
@@ -57,10 +59,9 @@ if wg[0, :, 1].max() > 0:
           f"  first begin to first begin: {(wg[1, :, 0].min() - wg[0, :, 0].min()) / 100.0:.2f} us")
 if wg[0, :, 1].max() > 0:
     # which workgroups are the slow ones?  logical index (wg_index: contiguous runs per XCD) and whether the 256-token unit spans two clips
-    nwg = 225
     q_, r_ = nwg >> 3, nwg & 7
     logical = np.array([(b & 7) * q_ + min(b & 7, r_) + (b >> 3) for b in range(nwg)])
-    strad = np.array([(w * 256) // T != min(w * 256 + 255, B * T - 1) // T for w in logical])
+    strad = np.array([(w * 256) // Tp != min(w * 256 + 255, B * Tp - 1) // Tp for w in logical])
     life = (wg[0, :, 1] - wg[0, :, 0]) / 100.0
     print(f"  layer 3 lifetime: straddling units ({strad.sum()}) mean {life[strad].mean():.2f} max {life[strad].max():.2f};"
           f"  others mean {life[~strad].mean():.2f} max {life[~strad].max():.2f}")
