@@ -668,12 +668,26 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     // adaptive work shares of the persistent FiLM GEMM (dc_kernels.hip, film_shares); DC_FILM_STATIC=1 keeps equal shares
     const bool film_static = getenv("DC_FILM_STATIC") != nullptr;           // (read per call: the tests toggle it)
     const bool adapt = !film_static && s->num_cu <= 1024;
+    // k_embed_front rides in the FiLM GEMM's launch (wide flat units, non-split formats, no test hooks; DC_NO_FUSE_EMBED=1 and the
+    // per-kernel profile pass keep the two launches): one kernel boundary less per step, -1.3 % per loop at bs=32
+    DcEmbedArgs ea{};
+    bool fuse_embed = false;
+    {
+        const bool wgr_ = !ss && T >= 256 && !getenv("DC_NO_WGREC") && s->dbg_first < 0 && !s->cfg.no_eff;
+        const bool can_align_ = wgr_ && T % 32 == 0 && !getenv("DC_NO_ALIGN");
+        const int nwgn_ = can_align_ ? B * ((T + 127) / 128) : (G + 3) / 4;
+        const bool narrow_ = wgr_ && nwgn_ <= s->num_cu && T <= 3840 && s->dbg_layers < 0 && s->dbg_stage == 0 && !getenv("DC_NO_NARROW") &&
+                             !getenv("DC_STAMPS");
+        fuse_embed = wgr_ && !narrow_ && !getenv("DC_ALIGN") && fuse_silu && ff == fs && s->dbg_layers < 0 && s->dbg_stage == 0 &&
+                     (G + 7) / 8 <= s->num_cu && !getenv("DC_STAMPS") && !s->prof.on && !getenv("DC_NO_FUSE_EMBED");
+        if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, s->Tx, (G + 7) / 8};
+    }
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
                                        s->NT / 16, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
                                        want_stamps_film ? s->d_stamps + 252 : nullptr,
                                        adapt ? s->d_film_rate + 1024 * s->film_rate_parity : nullptr,
                                        adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr, iter_base,
-                                       s->h_model.film_w16, s->h_model.film_b16));
+                                       s->h_model.film_w16, s->h_model.film_b16, fuse_embed ? &ea : nullptr));
     s->film_rate_parity ^= 1;
     const int nl_run = (s->dbg_layers >= 0 && s->dbg_layers < L) ? s->dbg_layers : L;
     if (s->cfg.no_eff) {
@@ -703,7 +717,9 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const bool aligned = can_align && (narrow || getenv("DC_ALIGN") != nullptr);
     const int upc = aligned ? (narrow ? upc_narrow : upc_wide) : 0;
     const int Tx = s->Tx;
-    if (s->dbg_first >= 0)
+    if (fuse_embed) {
+        // (embedded by the FiLM launch)
+    } else if (s->dbg_first >= 0)
         LAUNCH(K_EMBED, dc_launch_front_from_h(st, fs, ss, s->d_model, s->d_h, s->d_recs, s->d_length, M, T, G, B, s->dbg_first));
     else
         LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,

@@ -77,3 +77,12 @@ struct DcModel {
     int num_frames;
     int max_timesteps;
 };
+
+// k_embed_front's arguments when it rides in the FiLM GEMM's launch (the first `ne` workgroups embed one 256-token unit each, flat units)
+struct DcEmbedArgs {
+    const DcModel* dm;
+    const float* x;
+    float *hbuf, *recs;
+    const int* length;
+    int M, Tx, ne;
+};

@@ -524,12 +524,12 @@ DEV void film_shares(int& u0, int& u1, long long nunit, const float* __restrict_
 // 16-row block as pi = (0..3, 8..11, 4..7, 12..15), which is where the 32 x 32 layout expects them.
 // ------------------------------------------------------------------------------------
 template <class T16>
-__global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict__ W, const float* __restrict__ bias16,
-                                                       f16x16* __restrict__ E, int G, int NT, int round0, int nround,
-                                                       const float* __restrict__ pp, const float* __restrict__ temb,
-                                                       const int* __restrict__ t_clip, int T, int B,
-                                                       unsigned long long* __restrict__ clk, const float* __restrict__ rate_in,
-                                                       float* __restrict__ rate_out, const int* __restrict__ iter_base) {
+DEV void film_gemm3_body(const v8<T16>* __restrict__ W, const float* __restrict__ bias16,
+                         f16x16* __restrict__ E, int G, int NT, int round0, int nround,
+                         const float* __restrict__ pp, const float* __restrict__ temb,
+                         const int* __restrict__ t_clip, int T, int B,
+                         unsigned long long* __restrict__ clk, const float* __restrict__ rate_in,
+                         float* __restrict__ rate_out, const int* __restrict__ iter_base, unsigned long long t_begin) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using OP = v8<T16>;
 #ifndef DC_FILM3_PF
@@ -537,7 +537,6 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
 #endif
     constexpr int PF = DC_FILM3_PF;        // weight ring depth in 32-deep k-steps
     constexpr int KS = DC_E / 32;          // 16 k-steps
-    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     if (clk && blockIdx.x == 5 && threadIdx.x == 0) {
         clk[0] = __builtin_amdgcn_s_memtime();
         clk[1] = __builtin_amdgcn_s_memrealtime();
@@ -707,6 +706,16 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
         rate_out[blockIdx.x] = now > 0.f ? (old > 0.f ? 0.5f * old + 0.5f * now : now) : old;
     }
 }
+template <class T16>
+__global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict__ W, const float* __restrict__ bias16,
+                                                       f16x16* __restrict__ E, int G, int NT, int round0, int nround,
+                                                       const float* __restrict__ pp, const float* __restrict__ temb,
+                                                       const int* __restrict__ t_clip, int T, int B,
+                                                       unsigned long long* __restrict__ clk, const float* __restrict__ rate_in,
+                                                       float* __restrict__ rate_out, const int* __restrict__ iter_base) {
+    film_gemm3_body<T16>(W, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base,
+                         __builtin_amdgcn_s_memrealtime());
+}
 
 // ------------------------------------------------------------------------------------
 // step prologue: h = joint_embed(x) + sequence_embedding[:T] (transformer.py:488-490),
@@ -719,11 +728,12 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
 // NARROW (WGR, non-split): 4-wave workgroups = 128-token units, one wave per SIMD - for batches small enough that every
 // unit gets a CU of its own (see k_layer).
 template <class T16, bool SPLIT, bool WGR, bool FROMH = false, bool NARROW = false>
-__global__ __launch_bounds__((SPLIT || NARROW) ? 256 : 512, (SPLIT || NARROW) ? 1 : 2)
-void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /*[M][P]*/, float* __restrict__ hbuf,
-                   float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G, int B,
-                   unsigned long long* __restrict__ clk /* diagnostic: 100-MHz stamps of one wave, or nullptr */, int l0, int Tx /* frames per
-                   clip of x (<= the clip stride T) */, int upc /* workgroups per clip (clip-aligned units, WgMap) or 0 */) {
+DEV void embed_front_body(const DcModel* __restrict__ dm, const float* __restrict__ x /*[M][P]*/, float* __restrict__ hbuf,
+                          float* __restrict__ recs, const int* __restrict__ length, int M, int T, int G, int B,
+                          unsigned long long* __restrict__ clk /* diagnostic: 100-MHz stamps of one wave, or nullptr */, int l0,
+                          int Tx /* frames per clip of x (<= the clip stride T) */,
+                          int upc /* workgroups per clip (clip-aligned units, WgMap) or 0 */,
+                          int wg_fixed /* >= 0: this workgroup's unit (the caller's grid is not the unit grid) */) {
     static_assert(!(FROMH && WGR), "the h-injection hook exists for the per-group-record form only");
     static_assert(!NARROW || (WGR && !SPLIT), "narrow workgroups exist for the workgroup-record form of the non-split formats");
     constexpr int NW = (SPLIT || NARROW) ? 4 : 8;
@@ -735,7 +745,7 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
     stamp(0);
     using W = v8<T16>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wg = WGR ? wg_index() : (int)blockIdx.x;
+    const int wg = wg_fixed >= 0 ? wg_fixed : (WGR ? wg_index() : (int)blockIdx.x);
     const WgMap wm = wg_map(wg, wave, NW, G, M, T, B, WGR ? upc : 0);
     const int g = wm.g;
     const bool active = wm.active;
@@ -879,6 +889,32 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x /
         wg_write_record<NW>(recs, mx, pst, xp, ss, wave, lane, ub0, wm.nact, wm.Mu, wm.Tu, wg);
         stamp(7);
     }
+}
+template <class T16, bool SPLIT, bool WGR, bool FROMH = false, bool NARROW = false>
+__global__ __launch_bounds__((SPLIT || NARROW) ? 256 : 512, (SPLIT || NARROW) ? 1 : 2)
+void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x, float* __restrict__ hbuf, float* __restrict__ recs,
+                   const int* __restrict__ length, int M, int T, int G, int B, unsigned long long* __restrict__ clk, int l0, int Tx, int upc) {
+    embed_front_body<T16, SPLIT, WGR, FROMH, NARROW>(dm, x, hbuf, recs, length, M, T, G, B, clk, l0, Tx, upc, -1);
+}
+// The step's two kernels that depend on nothing but x and the conditioning, as ONE launch (default where the layers run wide flat
+// units; DC_NO_FUSE_EMBED=1 keeps them apart): the first `ne` workgroups
+// embed their unit (k_embed_front's body), then all sweep their share of the FiLM GEMM - one kernel boundary less per step.  The
+// GEMM's work shares follow the measured per-XCD speeds, which include the embedding time.
+template <class T16>
+__global__ __launch_bounds__(512, 2) void k_film_embed(const v8<T16>* __restrict__ W, const float* __restrict__ bias16,
+                                                       f16x16* __restrict__ E, int G, int NT, int round0, int nround,
+                                                       const float* __restrict__ pp, const float* __restrict__ temb,
+                                                       const int* __restrict__ t_clip, int T, int B,
+                                                       unsigned long long* __restrict__ clk, const float* __restrict__ rate_in,
+                                                       float* __restrict__ rate_out, const int* __restrict__ iter_base, const DcEmbedArgs ea) {
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    if ((int)blockIdx.x < ea.ne) {
+        embed_front_body<T16, false, true, false, false>(ea.dm, ea.x, ea.hbuf, ea.recs, ea.length, ea.M, T, G, B, nullptr, 0, ea.Tx, 0,
+                                                         (int)blockIdx.x);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();            // the embedding's LDS use is over before the slab fill
+    }
+    film_gemm3_body<T16>(W, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base, t_begin);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1863,7 +1899,7 @@ static void launch_film_t(hipStream_t st, const void* W, const float* bias_ft,
 template <class T16>
 static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* bias16, void* E, int G, int NT, int round0, int nround,
                                  const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk,
-                                 const float* rate_in, float* rate_out, const int* iter_base) {
+                                 const float* rate_in, float* rate_out, const int* iter_base, const DcEmbedArgs* ea) {
     const size_t shm = 4 * DC_KS_E * 1024 + 64;        // slab + the pair counter
     static unsigned long long optin_done = 0;
     if (hipError_t e = lds_optin((const void*)k_film_gemm3<T16>, (int)shm, optin_done)) return e;
@@ -1877,18 +1913,26 @@ static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* b
     int nwg = (int)(nunit < ncu ? nunit : ncu);
     if (nwg < nblk) nwg = nblk < ncu ? nblk : ncu;
     if (nwg < 1) nwg = 1;
+    if (ea && ea->x && nwg >= ea->ne) {          // fused with k_embed_front (its LDS image is smaller than the slab)
+        static unsigned long long optin2 = 0;
+        if (hipError_t e = lds_optin((const void*)k_film_embed<T16>, (int)shm, optin2)) return e;
+        k_film_embed<T16><<<dim3(nwg), dim3(512), shm, st>>>((const v8<T16>*)W16, bias16, (f16x16*)E, G, NT, round0, nround, pp, temb, t_clip, T, B,
+                                                             clk, rate_in, rate_out, iter_base, *ea);
+        return hipGetLastError();
+    }
     k_film_gemm3<T16><<<dim3(nwg), dim3(512), shm, st>>>((const v8<T16>*)W16, bias16, (f16x16*)E, G, NT, round0, nround,
                                                                            pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base);
     return hipGetLastError();
 }
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
                                int nround, const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk,
-                               const float* rate_in, float* rate_out, const int* iter_base, const void* W16, const float* bias16) {
+                               const float* rate_in, float* rate_out, const int* iter_base, const void* W16, const float* bias16,
+                               const DcEmbedArgs* embed) {
     // non-split formats with the fp32 emb image at hand: the S-stationary 16x16x32 kernel builds its operand itself; the split
     // formats (and the test hooks, which read the 16-bit operand image back) use the plain tiled kernel on S_hi / S_lo
     if (!split && pp && W16)
-        return fmt == 1 ? launch_film3_t<_Float16>(st, W16, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base)
-                        : launch_film3_t<__bf16>(st, W16, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base);
+        return fmt == 1 ? launch_film3_t<_Float16>(st, W16, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base, embed)
+                        : launch_film3_t<__bf16>(st, W16, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base, embed);
     if (round0 != 0) return hipSuccess;        // the plain kernel computes all rounds in its first launch
     DISPATCH(fmt, split, (launch_film_t<T16, SP>(st, W, bias_ft, s_hi, s_lo, E, G, NT)));
     return LAUNCH_CHECK();

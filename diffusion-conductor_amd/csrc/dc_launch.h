@@ -24,7 +24,8 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
                                unsigned long long* clk /* diagnostic clock stamps or nullptr */,
                                const float* rate_in, float* rate_out /* per-workgroup speeds of the previous / this launch (num_cu floats) or nullptr */,
                                const int* iter_base /* captured loop: t_clip = &t_of_iter[step], indexed by *iter_base; else nullptr */,
-                               const void* W16, const float* bias16 /* operands of the 16x16x32-MFMA form (used with pp, non-split) */);
+                               const void* W16, const float* bias16 /* operands of the 16x16x32-MFMA form (used with pp, non-split) */,
+                               const DcEmbedArgs* embed = nullptr /* S-stationary form only: fuse k_embed_front into this launch */);
 // pp != nullptr (non-split formats): the FiLM GEMM builds its operand SiLU(temb[t_clip] + pp) itself and s_hi is not read
 // wgr: workgroup-level partial records, combined by the consuming layer kernel itself (non-split formats and T >= 256 only;
 // no dc_launch_attn_combine between the layers then)

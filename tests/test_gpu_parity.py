@@ -219,6 +219,22 @@ def test_clip_layouts_agree_and_small_batches_are_batch_invariant(models):
     assert all(torch.equal(outs["aligned"][b:b + 1], alone[b]) for b in range(B))
 
 
+def test_embedding_fused_into_the_film_launch_is_bit_identical(models):
+    """With the chip full (wide flat units: 18 x 1800 frames and up) k_embed_front rides in the FiLM GEMM's launch; DC_NO_FUSE_EMBED=1
+    keeps the two launches.  Same arithmetic per workgroup either way: bit-identical."""
+    B, T = 18, 1800
+    xfp, xfo = xf_pair(B, T, first=3)
+    noise = torch.from_numpy(batch_noise(B, T, first=3))
+    a = _ddim(models["fp16"], 25, noise, xfp, xfo, [T] * B)
+    os.environ["DC_NO_FUSE_EMBED"] = "1"
+    os.environ["DC_DISABLE_GRAPH"] = "1"          # eager launches: the switch is read when a launch is enqueued
+    try:
+        b = _ddim(models["fp16"], 25, noise, xfp, xfo, [T] * B)
+    finally:
+        del os.environ["DC_NO_FUSE_EMBED"], os.environ["DC_DISABLE_GRAPH"]
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_film_adaptive_shares_do_not_change_results(models):
     """The persistent FiLM GEMM sizes its workgroups' shares by the per-XCD speeds measured in earlier launches (>= 64
     workgroups); which workgroup computes a tile must not matter: bit-identical to equal shares (DC_FILM_STATIC=1) and
