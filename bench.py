@@ -107,7 +107,7 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bs", type=int, default=32, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=1800)
     ap.add_argument("--ddim", type=int, default=50)
