@@ -83,6 +83,10 @@ def lib():
     if not os.path.exists(path):
         raise DcError(f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(there is no CPU fallback for the sampler)")
+    # PyTorch-ROCm ships its own libamdhip64: it must be the copy this process binds (the tensors, streams and the library's
+    # kernels have to live in ONE HIP runtime).  Loaded after ours, it becomes a second runtime and the library's own one
+    # (/opt/rocm's) sees no device - so torch goes first, also when a caller only wants build() + version().
+    import torch  # noqa: F401
     L = C.CDLL(path)
     L.dc_last_error.restype = C.c_char_p
     L.dc_version.restype = C.c_char_p
