@@ -668,20 +668,32 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     // adaptive work shares of the persistent FiLM GEMM (dc_kernels.hip, film_shares); DC_FILM_STATIC=1 keeps equal shares
     const bool film_static = getenv("DC_FILM_STATIC") != nullptr;           // (read per call: the tests toggle it)
     const bool adapt = !film_static && s->num_cu <= 1024;
+    // ---- form of the layer launches (linear attention) --------------------------------------------------------------------
+    // workgroup-level records (no combine launches) whenever a workgroup's 256 tokens cannot touch more than two clips
+    const bool no_wgr = getenv("DC_NO_WGREC") != nullptr;          // (read per call: the tests toggle it)
+    const bool wgr = !ss && T >= 256 && !no_wgr && s->dbg_first < 0 && !s->cfg.no_eff;
+    static const bool want_stamps = getenv("DC_STAMPS") != nullptr;
+    // Narrow workgroups (4 waves = 128-token units, one wave per SIMD) while every unit still gets a CU of its own: the layer
+    // kernel is bound by instruction issue, so a wave alone on its SIMD runs a layer in about half the time (DESIGN.md
+    // section 4).  T <= 3840: the narrow combine holds 32 units per clip.  DC_NO_NARROW=1 keeps the 8-wave form (read per call).
+    // Clip-aligned units (WgMap in dc_dev.h; needs a clip stride of whole groups): upc workgroups per clip, no workgroup spans two
+    // clips.  Default for the narrow (small-batch) form; with the chip full (bs=32 x 1800: 256 workgroups instead of 228 flat
+    // units) it measured 1.2 % slower than flat units - DC_ALIGN=1 forces it there.
+    const bool can_align = wgr && T % 32 == 0 && !getenv("DC_NO_ALIGN");
+    const int upc_wide = (T + 255) / 256, upc_narrow = (T + 127) / 128;
+    const int nwg_narrow = can_align ? B * upc_narrow : (G + 3) / 4;
+    const bool narrow = wgr && nwg_narrow <= s->num_cu && T <= 3840 && s->dbg_layers < 0 && s->dbg_stage == 0 &&
+                        !getenv("DC_NO_NARROW") && !want_stamps;
+    const bool aligned = can_align && (narrow || getenv("DC_ALIGN") != nullptr);
+    const int upc = aligned ? (narrow ? upc_narrow : upc_wide) : 0;
+    const int nwg = aligned ? B * upc : (narrow ? (G + 3) / 4 : (G + 7) / 8);
+    const int Tx = s->Tx;
     // k_embed_front rides in the FiLM GEMM's launch (wide flat units, non-split formats, no test hooks; DC_NO_FUSE_EMBED=1 and the
     // per-kernel profile pass keep the two launches): one kernel boundary less per step, -1.3 % per loop at bs=32
+    const bool fuse_embed = wgr && !narrow && !aligned && fuse_silu && ff == fs && s->dbg_layers < 0 && s->dbg_stage == 0 &&
+                            nwg <= s->num_cu && !want_stamps && !s->prof.on && !getenv("DC_NO_FUSE_EMBED");
     DcEmbedArgs ea{};
-    bool fuse_embed = false;
-    {
-        const bool wgr_ = !ss && T >= 256 && !getenv("DC_NO_WGREC") && s->dbg_first < 0 && !s->cfg.no_eff;
-        const bool can_align_ = wgr_ && T % 32 == 0 && !getenv("DC_NO_ALIGN");
-        const int nwgn_ = can_align_ ? B * ((T + 127) / 128) : (G + 3) / 4;
-        const bool narrow_ = wgr_ && nwgn_ <= s->num_cu && T <= 3840 && s->dbg_layers < 0 && s->dbg_stage == 0 && !getenv("DC_NO_NARROW") &&
-                             !getenv("DC_STAMPS");
-        fuse_embed = wgr_ && !narrow_ && !getenv("DC_ALIGN") && fuse_silu && ff == fs && s->dbg_layers < 0 && s->dbg_stage == 0 &&
-                     (G + 7) / 8 <= s->num_cu && !getenv("DC_STAMPS") && !s->prof.on && !getenv("DC_NO_FUSE_EMBED");
-        if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, s->Tx, (G + 7) / 8};
-    }
+    if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg};
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
                                        s->NT / 16, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
                                        want_stamps_film ? s->d_stamps + 252 : nullptr,
@@ -700,23 +712,6 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         }
         return DC_OK;
     }
-    // workgroup-level records (no combine launches) whenever a workgroup's 256 tokens cannot touch more than two clips
-    const bool no_wgr = getenv("DC_NO_WGREC") != nullptr;          // (read per call: the tests toggle it)
-    const bool wgr = !ss && T >= 256 && !no_wgr && s->dbg_first < 0;
-    // Narrow workgroups (4 waves = 128-token units, one wave per SIMD) while every unit still gets a CU of its own: the layer
-    // kernel is bound by instruction issue, so a wave alone on its SIMD runs a layer in about half the time (DESIGN.md
-    // section 4).  T <= 3840: the narrow combine holds 32 units per clip.  DC_NO_NARROW=1 keeps the 8-wave form (read per call).
-    // Clip-aligned units (WgMap in dc_dev.h; needs a clip stride of whole groups): upc workgroups per clip, no workgroup spans two
-    // clips.  Default for the narrow (small-batch) form; with the chip full (bs=32 x 1800: 256 workgroups instead of 228 flat
-    // units) it measured 1.2 % slower than flat units - DC_ALIGN=1 forces it there.
-    const bool can_align = wgr && T % 32 == 0 && !getenv("DC_NO_ALIGN");
-    const int upc_wide = (T + 255) / 256, upc_narrow = (T + 127) / 128;
-    const int nwg_narrow = can_align ? B * upc_narrow : (G + 3) / 4;
-    const bool narrow = wgr && nwg_narrow <= s->num_cu && T <= 3840 && s->dbg_layers < 0 && s->dbg_stage == 0 &&
-                        !getenv("DC_NO_NARROW") && !getenv("DC_STAMPS");
-    const bool aligned = can_align && (narrow || getenv("DC_ALIGN") != nullptr);
-    const int upc = aligned ? (narrow ? upc_narrow : upc_wide) : 0;
-    const int Tx = s->Tx;
     if (fuse_embed) {
         // (embedded by the FiLM launch)
     } else if (s->dbg_first >= 0)
@@ -724,8 +719,6 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     else
         LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
                                               want_stamps_film ? s->d_stamps + 256 : nullptr, narrow, Tx, upc));
-    static const bool want_stamps = getenv("DC_STAMPS") != nullptr;
-    const int nwg = aligned ? B * upc : (narrow ? (G + 3) / 4 : (G + 7) / 8);
     const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
     for (int l = s->dbg_first >= 0 ? s->dbg_first : 0; l < nl_run; ++l) {
         const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
