@@ -176,9 +176,14 @@ struct dc_sampler {
     std::vector<int> tab_t, tab_snap;
     std::vector<float> tab_coef, tab_coef_iter;
 
-    // graph cache: one per (B,T,steps_per_graph)
+    // graph cache: one per (B, T, steps_per_graph, launch form, update options)
     hipGraphExec_t graph = nullptr;
     int graph_B = 0, graph_T = 0, graph_K = 0;
+    unsigned long long graph_form = 0;     // form_key() of the captured launches
+    // DDIM update options of the loop being enqueued (dc_sampler_ddim_loop_ex) and the device status word
+    int upd_flags = 0;
+    const float* d_step_noise = nullptr;
+    int* d_status = nullptr;
 
     dc_music* music = nullptr;   // MusicEncoder (built when its parameters were supplied)
 
@@ -586,9 +591,11 @@ int ensure_workspace(dc_sampler* s, int B, int Tx) {
         if ((rc = dev_alloc(s, s->d_stamps, (8 * 32 + 8 + 1024 + 1024 + 256 + 8) * 8))) return rc;
         if ((rc = dev_alloc(s, s->d_film_rate, 2 * 1024 * sizeof(float)))) return rc;
         HIP_TRY(hipMemset(s->d_film_rate, 0, 2 * 1024 * sizeof(float)));      // 0 = not measured yet: equal shares
+        if ((rc = dev_alloc(s, s->d_status, 16))) return rc;
+        HIP_TRY(hipMemset(s->d_status, 0, 16));
         if ((rc = dev_alloc(s, s->d_iter, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_snap_cur, 16))) return rc;
-        if ((rc = dev_alloc(s, s->d_coef_cur, 16))) return rc;
+        if ((rc = dev_alloc(s, s->d_coef_cur, DC_COEF * 4))) return rc;
     }
     if (s->B != B || s->T != T || s->Tx != Tx) drop_graph(s);
     s->B = B;
@@ -612,8 +619,8 @@ int ensure_steps(dc_sampler* s, int S) {
         int rc;
         if ((rc = dev_alloc(s, s->d_t_of_iter, (size_t)S * 4))) return rc;
         if ((rc = dev_alloc(s, s->d_snap_of_iter, (size_t)S * 4))) return rc;
-        if ((rc = dev_alloc(s, s->d_coef_of_t, (size_t)S * 16))) return rc;
-        if ((rc = dev_alloc(s, s->d_coef_of_iter, (size_t)S * 16))) return rc;
+        if ((rc = dev_alloc(s, s->d_coef_of_t, (size_t)S * DC_COEF * 4))) return rc;
+        if ((rc = dev_alloc(s, s->d_coef_of_iter, (size_t)S * DC_COEF * 4))) return rc;
         s->cap_steps = (size_t)S;
     }
     return DC_OK;
@@ -641,6 +648,18 @@ struct Timed {   // RAII-less helper: wraps a launch with events when profiling
         }                                                             \
     } while (0)
 
+// Everything a captured graph bakes in besides (B, T, K): the environment switches that pick the launch form (read per call, so
+// that one process can A/B them: a change re-captures) and the update options of the loop.
+unsigned long long form_key(const dc_sampler* s) {
+    static const char* sw[] = {"DC_NO_WGREC", "DC_NO_NARROW", "DC_NO_ALIGN", "DC_ALIGN", "DC_NO_FUSE_EMBED", "DC_FILM_STATIC",
+                               "DC_BEGIN_STEP", "DC_NO_PAD"};
+    unsigned long long k = 0;
+    for (size_t i = 0; i < sizeof sw / sizeof *sw; ++i) k |= (getenv(sw[i]) ? 1ull : 0ull) << i;
+    k |= (unsigned long long)(s->upd_flags & 0xff) << 8;
+    k ^= (unsigned long long)(size_t)s->d_step_noise * 0x9e3779b97f4a7c15ull & ~0xffffull;     // the noise pointer is a kernel argument
+    return k;
+}
+
 // One denoiser evaluation (+ DDIM update when loop_mode) enqueued on st.
 // graph_step >= 0: step number inside a graph being captured.  On the default path (fused SiLU fill, per-layer launches) the
 // step's kernels then look the timestep / DDIM scalars up themselves - this step's slot of the per-iteration tables, offset by
@@ -656,7 +675,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const bool folded = loop_mode && graph_step >= 0 && fuse_silu && !s->cfg.no_eff && !getenv("DC_BEGIN_STEP") && s->dbg_stage == 0;
     const int* iter_base = folded ? s->d_iter : nullptr;
     const int* t_src = folded ? s->d_t_of_iter + graph_step : s->d_t_clip;
-    const float* coef_src = folded ? s->d_coef_of_iter + 4 * (size_t)graph_step : s->d_coef_cur;
+    const float* coef_src = folded ? s->d_coef_of_iter + DC_COEF * (size_t)graph_step : s->d_coef_cur;
     const int* snap_src = folded ? s->d_snap_of_iter + graph_step : s->d_snap_cur;
     if (graph_step >= 0) s->graph_folded = folded;
     if (loop_mode && !folded)
@@ -694,12 +713,13 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
                             nwg <= s->num_cu && !want_stamps && !s->prof.on && !getenv("DC_NO_FUSE_EMBED");
     DcEmbedArgs ea{};
     if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg};
+    const DcUpdate upd{loop_mode ? s->d_step_noise : nullptr, s->d_status, loop_mode ? s->upd_flags : 0, folded ? graph_step : -1};
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
                                        s->NT / 16, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
                                        want_stamps_film ? s->d_stamps + 252 : nullptr,
                                        adapt ? s->d_film_rate + 1024 * s->film_rate_parity : nullptr,
                                        adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr, iter_base,
-                                       s->h_model.film_w16, s->h_model.film_b16, fuse_embed ? &ea : nullptr));
+                                       s->h_model.film_w16, s->h_model.film_b16, fuse_embed ? &ea : nullptr, s->d_status));
     s->film_rate_parity ^= 1;
     const int nl_run = (s->dbg_layers >= 0 && s->dbg_layers < L) ? s->dbg_layers : L;
     if (s->cfg.no_eff) {
@@ -708,7 +728,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
             LAUNCH(K_LAYER, dc_launch_layer_full(st, fs, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_kv_sa[l & 1], s->d_kv_sa[(l + 1) & 1],
                                                  s->d_kv_ca, s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur,
                                                  s->d_snap_cur, s->d_snaps, M, T, B, s->KT,
-                                                 (l == nl_run - 1) ? (s->dbg_stage ? s->dbg_stage : (nl_run < L ? 3 : 0)) : 0));
+                                                 (l == nl_run - 1) ? (s->dbg_stage ? s->dbg_stage : (nl_run < L ? 3 : 0)) : 0, upd));
         }
         return DC_OK;
     }
@@ -726,7 +746,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src,
                                         s->d_snaps, M, T, G, B, dbg, ((l == 3 || l == 4) && want_stamps) ? s->d_stamps : nullptr, rec_stride,
-                                        iter_base, narrow, Tx, upc));
+                                        iter_base, narrow, Tx, upc, upd));
     }
     return DC_OK;
 }
@@ -749,8 +769,10 @@ int steps_per_graph(int S) {
     return 1;
 }
 
+// h_coef: [S][DC_COEF] per-timestep scalars (dc_common.h); flags: DC_UPD_*; d_step_noise: [S][B][Tx][P] or nullptr
 int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const float* h_coef,
-                const int32_t* h_snap_iters, int n_snap, float* d_snaps_user, hipStream_t user, bool profile) {
+                const int32_t* h_snap_iters, int n_snap, float* d_snaps_user, hipStream_t user, bool profile,
+                int flags = 0, const float* d_step_noise = nullptr) {
     if (!s || !s->finalized) return fail(DC_ERR_INVALID, "sampler not finalized");
     if (!s->cond_set) return fail(DC_ERR_INVALID, "dc_sampler_set_conditioning must be called first");
     if (S < 1 || S > s->cfg.max_timesteps) return fail(DC_ERR_INVALID, "num_steps %d outside [1, max_timesteps=%d]", S, s->cfg.max_timesteps);
@@ -773,7 +795,9 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
         snap_of_iter[h_snap_iters[k]] = k;
     }
     const bool same_tables = s->tables_S == S && s->tab_snap == snap_of_iter &&
-                             memcmp(s->tab_coef.data(), h_coef, (size_t)S * 16) == 0;
+                             memcmp(s->tab_coef.data(), h_coef, (size_t)S * DC_COEF * 4) == 0;
+    s->upd_flags = flags;
+    s->d_step_noise = d_step_noise;
     if ((rc = sync_in(s, user))) return rc;
     hipStream_t st = s->stream;
     if (!same_tables) {
@@ -782,13 +806,13 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
         s->tab_t.resize(S);
         for (int i = 0; i < S; ++i) s->tab_t[i] = S - 1 - i;            // indices = range(num_timesteps)[::-1] (gaussian_diffusion.py:943)
         s->tab_snap = snap_of_iter;
-        s->tab_coef.assign(h_coef, h_coef + (size_t)S * 4);
-        s->tab_coef_iter.resize((size_t)S * 4);
-        for (int i = 0; i < S; ++i) memcpy(&s->tab_coef_iter[4 * (size_t)i], h_coef + 4 * (size_t)s->tab_t[i], 16);
+        s->tab_coef.assign(h_coef, h_coef + (size_t)S * DC_COEF);
+        s->tab_coef_iter.resize((size_t)S * DC_COEF);
+        for (int i = 0; i < S; ++i) memcpy(&s->tab_coef_iter[DC_COEF * (size_t)i], h_coef + DC_COEF * (size_t)s->tab_t[i], DC_COEF * 4);
         HIP_TRY(hipMemcpyAsync(s->d_t_of_iter, s->tab_t.data(), S * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(s->d_snap_of_iter, s->tab_snap.data(), S * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(s->d_coef_of_t, s->tab_coef.data(), (size_t)S * 16, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(s->d_coef_of_iter, s->tab_coef_iter.data(), (size_t)S * 16, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->d_coef_of_t, s->tab_coef.data(), (size_t)S * DC_COEF * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->d_coef_of_iter, s->tab_coef_iter.data(), (size_t)S * DC_COEF * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));          // pageable sources: the copies have left the host vectors
         s->tables_S = S;
     }
@@ -805,7 +829,8 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
         s->prof.on = false;
     } else {
         const int K = steps_per_graph(S);
-        if (!s->graph || s->graph_B != s->B || s->graph_T != s->T || s->graph_K != K) {
+        const unsigned long long fk = form_key(s);
+        if (!s->graph || s->graph_B != s->B || s->graph_T != s->T || s->graph_K != K || s->graph_form != fk) {
             drop_graph(s);
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -831,6 +856,7 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
             s->graph_B = s->B;
             s->graph_T = s->T;
             s->graph_K = K;
+            s->graph_form = fk;
         }
         for (int i = 0; i < S / K; ++i) HIP_TRY(hipGraphLaunch(s->graph, st));
     }
@@ -846,6 +872,9 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
 // C ABI
 // ======================================================================================
 extern "C" {
+
+static_assert(DC_UPDATE_CLIP_DENOISED == DC_UPD_CLIP && DC_UPDATE_EPSILON == DC_UPD_EPS && DC_STATUS_F16_SATURATED == DC_STATUS_F16_SAT,
+              "include/dc_ddim.h and dc_common.h disagree");
 
 const char* dc_last_error(void) { return g_err.c_str(); }
 const char* dc_version(void) { return "dc_ddim 0.1 (gfx950)"; }
@@ -876,6 +905,23 @@ int dc_ddim_coefficients(int32_t n, const double* ac, float* coef) {
         coef[4 * t + 1] = (float)std::sqrt(1.0 / ac[t] - 1.0);
         coef[4 * t + 2] = sqrtf(a_prev);
         coef[4 * t + 3] = sqrtf(1.0f - a_prev);
+    }
+    return DC_OK;
+}
+
+int dc_ddim_coefficients_ex(int32_t n, const double* ac, float eta, float* coef8) {
+    if (n < 1 || !ac || !coef8 || !(eta >= 0.f)) return fail(DC_ERR_INVALID, "bad coefficient arguments");
+    // fp32 arithmetic on the fp32-rounded table entries, in the order ddim_sample evaluates them (gaussian_diffusion.py:812-826)
+    for (int t = 0; t < n; ++t) {
+        const float a = (float)ac[t], a_prev = t == 0 ? 1.0f : (float)ac[t - 1];
+        const float sigma = eta * sqrtf((1.0f - a_prev) / (1.0f - a)) * sqrtf(1.0f - a / a_prev);
+        float* c = coef8 + (size_t)DC_COEF * t;
+        c[0] = (float)std::sqrt(1.0 / ac[t]);
+        c[1] = (float)std::sqrt(1.0 / ac[t] - 1.0);
+        c[2] = sqrtf(a_prev);
+        c[3] = sqrtf(1.0f - a_prev - sigma * sigma);
+        c[4] = sigma;
+        c[5] = c[6] = c[7] = 0.f;
     }
     return DC_OK;
 }
@@ -930,7 +976,7 @@ void dc_sampler_destroy(dc_sampler* s) {
     void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
                     s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t, s->d_coef_of_iter,
-                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate};
+                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status};
     for (void* p : ptrs)
         if (p) hipFree(p);
     dc_music_destroy(s->music);
@@ -1133,11 +1179,47 @@ int dc_sampler_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timeste
     return sync_out(s, user);
 }
 
+namespace {
+// the eta = 0 table [S][4] of dc_ddim_coefficients in the internal [S][DC_COEF] form (sigma = 0)
+std::vector<float> widen_coef(const float* h_coef, int S) {
+    std::vector<float> c8((size_t)(S > 0 ? S : 0) * DC_COEF, 0.f);
+    if (h_coef)
+        for (int t = 0; t < S; ++t) memcpy(&c8[(size_t)DC_COEF * t], h_coef + 4 * (size_t)t, 16);
+    return c8;
+}
+}  // namespace
+
 int dc_sampler_ddim_loop(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps, const float* h_coef,
                          const int32_t* h_snap_iters, int32_t n_snap, float* d_snaps, void* stream) {
     if (s) HIP_TRY(hipSetDevice(s->cfg.device));
     if (n_snap < 0 || (n_snap > 0 && (!h_snap_iters || !d_snaps))) return fail(DC_ERR_INVALID, "bad snapshot arguments");
-    return loop_common(s, d_noise, d_out, num_steps, h_coef, h_snap_iters, n_snap, d_snaps, (hipStream_t)stream, false);
+    const std::vector<float> c8 = widen_coef(h_coef, num_steps);
+    return loop_common(s, d_noise, d_out, num_steps, h_coef ? c8.data() : nullptr, h_snap_iters, n_snap, d_snaps, (hipStream_t)stream, false);
+}
+
+int dc_sampler_ddim_loop_ex(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps, const float* h_coef8,
+                            int32_t flags, const float* d_step_noise, const int32_t* h_snap_iters, int32_t n_snap, float* d_snaps,
+                            void* stream) {
+    if (s) HIP_TRY(hipSetDevice(s->cfg.device));
+    if (n_snap < 0 || (n_snap > 0 && (!h_snap_iters || !d_snaps))) return fail(DC_ERR_INVALID, "bad snapshot arguments");
+    if (flags & ~(DC_UPD_CLIP | DC_UPD_EPS)) return fail(DC_ERR_INVALID, "unknown update flags 0x%x", flags);
+    if (h_coef8 && !d_step_noise)
+        for (int t = 0; t < num_steps; ++t)
+            if (h_coef8[(size_t)DC_COEF * t + 4] != 0.f)
+                return fail(DC_ERR_INVALID, "sigma[%d] != 0 (eta > 0) needs the per-iteration noise tensor d_step_noise [S][B][T][P]", t);
+    return loop_common(s, d_noise, d_out, num_steps, h_coef8, h_snap_iters, n_snap, d_snaps, (hipStream_t)stream, false, flags,
+                       d_step_noise);
+}
+
+int dc_sampler_status(dc_sampler* s, int32_t* h_status, int32_t clear) {
+    if (!s || !h_status) return fail(DC_ERR_INVALID, "null argument");
+    *h_status = 0;
+    if (!s->d_status) return DC_OK;                      // nothing has run yet
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(h_status, s->d_status, 4, hipMemcpyDeviceToHost));
+    if (clear) HIP_TRY(hipMemset(s->d_status, 0, 4));
+    return DC_OK;
 }
 
 int dc_sampler_profile_loop(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps, const float* h_coef,
@@ -1146,7 +1228,8 @@ int dc_sampler_profile_loop(dc_sampler* s, const float* d_noise, float* d_out, i
     HIP_TRY(hipSetDevice(s->cfg.device));
     s->prof.ev.clear();
     s->prof.ids.clear();
-    int rc = loop_common(s, d_noise, d_out, num_steps, h_coef, nullptr, 0, nullptr, (hipStream_t)stream, true);
+    const std::vector<float> c8 = widen_coef(h_coef, num_steps);
+    int rc = loop_common(s, d_noise, d_out, num_steps, h_coef ? c8.data() : nullptr, nullptr, 0, nullptr, (hipStream_t)stream, true);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     for (int i = 0; i < n; ++i) {

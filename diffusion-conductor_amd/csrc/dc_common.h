@@ -78,6 +78,20 @@ struct DcModel {
     int max_timesteps;
 };
 
+// Options of the DDIM update fused into the last layer kernel (gaussian_diffusion.py:503-521, 812-830).  The per-step scalars
+// come as 8 floats per timestep: sqrt(1/abar), sqrt(1/abar - 1), sqrt(abar_prev), sqrt(1 - abar_prev - sigma^2), sigma, 0, 0, 0.
+#define DC_COEF 8
+#define DC_UPD_CLIP 1        // clip_denoised: pred_xstart.clamp(-1, 1)  (:506-507)
+#define DC_UPD_EPS 2         // ModelMeanType.EPSILON: pred_xstart = sqrt(1/abar) x_t - sqrt(1/abar - 1) model_out  (:516-521, 539-544)
+#define DC_STATUS_NONFINITE 1    // a predicted x0 was inf / nan
+#define DC_STATUS_F16_SAT 2      // a FiLM modulation value exceeded the fp16 range when stored
+struct DcUpdate {
+    const float* z;      // eta > 0: per-iteration noise [S][B][Tx][P] (the reference's th.randn_like(x) draws, :822), else nullptr
+    int* status;         // device status word (DC_STATUS_* bits are OR-ed in), or nullptr
+    int flags;           // DC_UPD_*
+    int step;            // captured loop: step number inside the graph (iteration = step + *iter_base); eager: -1 (iteration = snap_cur[1])
+};
+
 // k_embed_front's arguments when it rides in the FiLM GEMM's launch (the first `ne` workgroups embed one 256-token unit each, flat units)
 struct DcEmbedArgs {
     const DcModel* dm;

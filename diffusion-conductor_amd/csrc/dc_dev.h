@@ -234,6 +234,11 @@ DEV float max3(float a, float b, float c) {       // (the compiler forms v_max3_
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+DEV float absmax3(float a, float b, float c) {    // max(|a|, |b|, |c|)
+    float d;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 DEV float max8(const f32x16& q, int o) {
     return max3(max3(q[o], q[o + 1], q[o + 2]), max3(q[o + 3], q[o + 4], q[o + 5]), fmaxf(q[o + 6], q[o + 7]));
 }

@@ -28,10 +28,11 @@ __global__ void k_begin_step(int* __restrict__ iter, const int* __restrict__ t_o
     const int it = *iter;
     const int t = t_of_iter[it];
     for (int b = threadIdx.x; b < B; b += blockDim.x) t_clip[b] = t;
-    if (threadIdx.x < 4) coef_cur[threadIdx.x] = coef_of_t[t * 4 + threadIdx.x];
+    if (threadIdx.x < DC_COEF) coef_cur[threadIdx.x] = coef_of_t[t * DC_COEF + threadIdx.x];
     __syncthreads();
     if (threadIdx.x == 0) {
-        *snap_cur = snap_of_iter ? snap_of_iter[it] : -1;
+        snap_cur[0] = snap_of_iter ? snap_of_iter[it] : -1;
+        snap_cur[1] = it;                  // the iteration the step kernels are in (indexes the per-iteration noise, eta > 0)
         *iter = it + 1;
     }
 }
@@ -406,7 +407,7 @@ __global__ void k_silu_emb(const float* __restrict__ pp /*frag-major fp32*/, con
 template <class T16, bool SPLIT>
 __global__ __launch_bounds__(256) void k_film_gemm(const v8<T16>* __restrict__ W, const float* __restrict__ bias_ft,
                                                    const v8<T16>* __restrict__ S_hi, const v8<T16>* __restrict__ S_lo,
-                                                   f16x16* __restrict__ E, int G, int NT) {
+                                                   f16x16* __restrict__ E, int G, int NT, int* __restrict__ status) {
     using OP = v8<T16>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ot0 = (blockIdx.x * 2 + (wave >> 1)) * 4;   // interleaved order: (s_j, h_j, s_j+1, h_j+1)
@@ -445,6 +446,16 @@ __global__ __launch_bounds__(256) void k_film_gemm(const v8<T16>* __restrict__ W
             }
     }
     const int blk = ot0 >> 3, pair0 = (ot0 & 7) >> 1;       // this wave holds feature tiles pair0, pair0+1 of block blk
+    {   // fp16 storage range check (DC_STATUS_F16_SAT): a modulation beyond +-65504 would be stored as inf
+        float am = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(acc[i][j][r]));
+        if (status && am > 65504.f) atomicOr(status, DC_STATUS_F16_SAT);
+    }
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -529,7 +540,8 @@ DEV void film_gemm3_body(const v8<T16>* __restrict__ W, const float* __restrict_
                          const float* __restrict__ pp, const float* __restrict__ temb,
                          const int* __restrict__ t_clip, int T, int B,
                          unsigned long long* __restrict__ clk, const float* __restrict__ rate_in,
-                         float* __restrict__ rate_out, const int* __restrict__ iter_base, unsigned long long t_begin) {
+                         float* __restrict__ rate_out, const int* __restrict__ iter_base, unsigned long long t_begin,
+                         int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using OP = v8<T16>;
 #ifndef DC_FILM3_PF
@@ -666,6 +678,22 @@ DEV void film_gemm3_body(const v8<T16>* __restrict__ W, const float* __restrict_
         }
         // epilogue: fp16, token halves swapped into place, store in the 32 x 32 tile order
         const int blk = p >> 2, t = p & 3;
+#ifndef DC_NO_SAT_CHECK
+        {   // fp16 storage range check (DC_STATUS_F16_SAT): |value| > 65504 would be stored as inf.  43 v_max3_f32 per 512 MFMAs.
+            float am = 0.f;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 x = acc[ti][fb][g][0], y = acc[ti][fb][g][1];
+                        am = absmax3(absmax3(absmax3(am, x[0], x[1]), x[2], x[3]), y[0], y[1]);
+                        am = absmax3(am, y[2], y[3]);
+                    }
+            if (status && am > 65504.f) atomicOr(status, DC_STATUS_F16_SAT);
+        }
+#endif
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g0 + g >= G) continue;
@@ -712,9 +740,10 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
                                                        const float* __restrict__ pp, const float* __restrict__ temb,
                                                        const int* __restrict__ t_clip, int T, int B,
                                                        unsigned long long* __restrict__ clk, const float* __restrict__ rate_in,
-                                                       float* __restrict__ rate_out, const int* __restrict__ iter_base) {
+                                                       float* __restrict__ rate_out, const int* __restrict__ iter_base,
+                                                       int* __restrict__ status) {
     film_gemm3_body<T16>(W, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base,
-                         __builtin_amdgcn_s_memrealtime());
+                         __builtin_amdgcn_s_memrealtime(), status);
 }
 
 // ------------------------------------------------------------------------------------
@@ -906,7 +935,8 @@ __global__ __launch_bounds__(512, 2) void k_film_embed(const v8<T16>* __restrict
                                                        const float* __restrict__ pp, const float* __restrict__ temb,
                                                        const int* __restrict__ t_clip, int T, int B,
                                                        unsigned long long* __restrict__ clk, const float* __restrict__ rate_in,
-                                                       float* __restrict__ rate_out, const int* __restrict__ iter_base, const DcEmbedArgs ea) {
+                                                       float* __restrict__ rate_out, const int* __restrict__ iter_base, const DcEmbedArgs ea,
+                                                       int* __restrict__ status) {
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     if ((int)blockIdx.x < ea.ne) {
         embed_front_body<T16, false, true, false, false>(ea.dm, ea.x, ea.hbuf, ea.recs, ea.length, ea.M, T, G, B, nullptr, 0, ea.Tx, 0,
@@ -914,7 +944,26 @@ __global__ __launch_bounds__(512, 2) void k_film_embed(const v8<T16>* __restrict
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();            // the embedding's LDS use is over before the slab fill
     }
-    film_gemm3_body<T16>(W, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base, t_begin);
+    film_gemm3_body<T16>(W, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base, t_begin, status);
+}
+
+// ------------------------------------------------------------------------------------
+// The DDIM update of one element (gaussian_diffusion.py:503-521 p_mean_variance's pred_xstart, :812-830 ddim_sample), fp32 with
+// the reference's own fp32 scalars c[0..4] (DC_COEF):  mo = the denoiser's output, xt = x_t, z = this iteration's noise draw.
+//   pred = mo  |  sqrt(1/abar) x_t - sqrt(1/abar - 1) mo  (EPSILON);   clamp(-1, 1) when clip_denoised;
+//   eps  = (sqrt(1/abar) x_t - pred) / sqrt(1/abar - 1);   x_{t-1} = sqrt(abar_prev) pred + sqrt(1 - abar_prev - sigma^2) eps + sigma z
+// (sigma is 0 at t = 0 - abar_prev = 1 there - which is the reference's nonzero_mask.)  Returns x_{t-1}; `bad` collects non-finite pred.
+// ------------------------------------------------------------------------------------
+DEV float ddim_update(float mo, float xt, const float* __restrict__ c, int flags, bool noisy, float z, bool& bad) {
+    const float sr = c[0], srm1 = c[1], cx0 = c[2], ceps = c[3];
+    float pred = mo;
+    if (flags & DC_UPD_EPS) pred = sr * xt - srm1 * mo;
+    bad = bad || !(fabsf(pred) <= 3.0e38f);
+    if (flags & DC_UPD_CLIP) pred = fminf(fmaxf(pred, -1.f), 1.f);
+    const float eps = (sr * xt - pred) / srm1;
+    float xn = pred * cx0 + ceps * eps;
+    if (noisy) xn += c[4] * z;
+    return xn;
 }
 
 // ------------------------------------------------------------------------------------
@@ -943,7 +992,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
              float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur, const int* __restrict__ snap_cur,
              float* __restrict__ snaps, int M, int T, int G, int B, int dbg,
              unsigned long long* __restrict__ stamps, size_t rec_stride, const int* __restrict__ iter_base,
-             int Tx /* frames per clip of xin / xout / snaps (<= the clip stride T) */, int upc /* workgroups per clip (WgMap) or 0 */) {
+             int Tx /* frames per clip of xin / xout / snaps (<= the clip stride T) */, int upc /* workgroups per clip (WgMap) or 0 */,
+             const DcUpdate upd) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     static_assert(!NARROW || (WGR && !SPLIT && !DBG), "narrow workgroups: workgroup-record form, non-split formats, no test hooks");
     constexpr int NW = (SPLIT || NARROW) ? 4 : 8;
@@ -1341,30 +1391,36 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if (xn >= Tx) return;                                           // padding frame
     const size_t xrow = (size_t)xb * Tx + xn;                       // row of xin / xout / snaps
     if (out_mode == 0) {
+        bool bad = false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = tile_row(r, cx.hh);
-            if (f < P) xout[xrow * P + f] = x0[0][r];
+            if (f < P) {
+                xout[xrow * P + f] = x0[0][r];
+                bad = bad || !(fabsf(x0[0][r]) <= 3.0e38f);
+            }
         }
+        if (bad && upd.status) atomicOr(upd.status, DC_STATUS_NONFINITE);
     } else {
         // graph-captured loop: coef_cur / snap_cur point at this step's slot of the per-iteration tables and *iter_base is
         // the iteration at which the graph replay began; otherwise they are the scalars k_begin_step prepared
         const int ib = iter_base ? *iter_base : 0;
-        coef_cur += 4 * ib;
-        const float sr = coef_cur[0], srm1 = coef_cur[1], cx0 = coef_cur[2], ceps = coef_cur[3];
+        coef_cur += DC_COEF * ib;
         const int snap = snap_cur[ib];
+        const bool noisy = upd.z != nullptr;
+        const float* zrow = noisy ? upd.z + (size_t)(iter_base ? upd.step + ib : snap_cur[1]) * B * Tx * P : nullptr;
+        bool bad = false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = tile_row(r, cx.hh);
             if (f < P) {
                 const size_t o = xrow * P + f;
-                const float xt = xin[o];
-                const float eps = (sr * xt - x0[0][r]) / srm1;
-                const float xnew = x0[0][r] * cx0 + ceps * eps;
+                const float xnew = ddim_update(x0[0][r], xin[o], coef_cur, upd.flags, noisy, noisy ? zrow[o] : 0.f, bad);
                 xout[o] = xnew;
                 if (snap >= 0) snaps[(size_t)snap * B * Tx * P + o] = xnew;
             }
         }
+        if (bad && upd.status) atomicOr(upd.status, DC_STATUS_NONFINITE);
     }
     return;
   }
@@ -1625,7 +1681,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
                                                        const int* __restrict__ length, const float* __restrict__ xin,
                                                        float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur,
                                                        const int* __restrict__ snap_cur, float* __restrict__ snaps, int M, int T,
-                                                       int B, int KT, int WPC, int stop_after) {
+                                                       int B, int KT, int WPC, int stop_after, const DcUpdate upd) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using W = v8<T16>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1717,28 +1773,32 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
     }
     if (!cx.lane_ok) return;
     const int P = dm->input_feats;
+    bool bad = false;
     if (out_mode == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = tile_row(r, cx.hh);
-            if (f < P) xout[(size_t)cx.tok * P + f] = x0[0][r];
+            if (f < P) {
+                xout[(size_t)cx.tok * P + f] = x0[0][r];
+                bad = bad || !(fabsf(x0[0][r]) <= 3.0e38f);
+            }
         }
     } else {
-        const float sr = coef_cur[0], srm1 = coef_cur[1], cx0 = coef_cur[2], ceps = coef_cur[3];
-        const int snap = *snap_cur;
+        const int snap = snap_cur[0];
+        const bool noisy = upd.z != nullptr;
+        const float* zrow = noisy ? upd.z + (size_t)snap_cur[1] * M * P : nullptr;        // (k_begin_step runs every step on this path)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = tile_row(r, cx.hh);
             if (f < P) {
                 const size_t o = (size_t)cx.tok * P + f;
-                const float xt = xin[o];
-                const float eps = (sr * xt - x0[0][r]) / srm1;
-                const float xn = x0[0][r] * cx0 + ceps * eps;
+                const float xn = ddim_update(x0[0][r], xin[o], coef_cur, upd.flags, noisy, noisy ? zrow[o] : 0.f, bad);
                 xout[o] = xn;
                 if (snap >= 0) snaps[(size_t)snap * M * P + o] = xn;
             }
         }
     }
+    if (bad && upd.status) atomicOr(upd.status, DC_STATUS_NONFINITE);
 }
 
 // Cross-attention keys/values of every layer as key tiles (one-time per batch): the linear-attention pre-pass's
@@ -1891,15 +1951,15 @@ hipError_t dc_launch_silu_emb(hipStream_t st, int fmt, bool split, const float* 
 
 template <class T16, bool SP>
 static void launch_film_t(hipStream_t st, const void* W, const float* bias_ft,
-                          const void* s_hi, const void* s_lo, void* E, int G, int NT) {
+                          const void* s_hi, const void* s_lo, void* E, int G, int NT, int* status) {
     k_film_gemm<T16, SP><<<dim3(NT / 8, (G + 3) / 4), dim3(256), 0, st>>>((const v8<T16>*)W, bias_ft,
                                                                          (const v8<T16>*)s_hi, (const v8<T16>*)s_lo,
-                                                                         (f16x16*)E, G, NT);
+                                                                         (f16x16*)E, G, NT, status);
 }
 template <class T16>
 static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* bias16, void* E, int G, int NT, int round0, int nround,
                                  const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk,
-                                 const float* rate_in, float* rate_out, const int* iter_base, const DcEmbedArgs* ea) {
+                                 const float* rate_in, float* rate_out, const int* iter_base, const DcEmbedArgs* ea, int* status) {
     const size_t shm = 4 * DC_KS_E * 1024 + 64;        // slab + the pair counter
     static unsigned long long optin_done = 0;
     if (hipError_t e = lds_optin((const void*)k_film_gemm3<T16>, (int)shm, optin_done)) return e;
@@ -1917,24 +1977,26 @@ static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* b
         static unsigned long long optin2 = 0;
         if (hipError_t e = lds_optin((const void*)k_film_embed<T16>, (int)shm, optin2)) return e;
         k_film_embed<T16><<<dim3(nwg), dim3(512), shm, st>>>((const v8<T16>*)W16, bias16, (f16x16*)E, G, NT, round0, nround, pp, temb, t_clip, T, B,
-                                                             clk, rate_in, rate_out, iter_base, *ea);
+                                                             clk, rate_in, rate_out, iter_base, *ea, status);
         return hipGetLastError();
     }
+    if (ea && ea->x) return hipErrorInvalidValue;      // the caller skipped k_embed_front relying on the fused launch: never drop it silently
     k_film_gemm3<T16><<<dim3(nwg), dim3(512), shm, st>>>((const v8<T16>*)W16, bias16, (f16x16*)E, G, NT, round0, nround,
-                                                                           pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base);
+                                                                           pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base, status);
     return hipGetLastError();
 }
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
                                int nround, const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk,
                                const float* rate_in, float* rate_out, const int* iter_base, const void* W16, const float* bias16,
-                               const DcEmbedArgs* embed) {
+                               const DcEmbedArgs* embed, int* status) {
     // non-split formats with the fp32 emb image at hand: the S-stationary 16x16x32 kernel builds its operand itself; the split
     // formats (and the test hooks, which read the 16-bit operand image back) use the plain tiled kernel on S_hi / S_lo
     if (!split && pp && W16)
-        return fmt == 1 ? launch_film3_t<_Float16>(st, W16, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base, embed)
-                        : launch_film3_t<__bf16>(st, W16, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base, embed);
+        return fmt == 1 ? launch_film3_t<_Float16>(st, W16, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base, embed, status)
+                        : launch_film3_t<__bf16>(st, W16, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base, embed, status);
+    if (embed && embed->x) return hipErrorInvalidValue;      // only the S-stationary form can carry the embedding
     if (round0 != 0) return hipSuccess;        // the plain kernel computes all rounds in its first launch
-    DISPATCH(fmt, split, (launch_film_t<T16, SP>(st, W, bias_ft, s_hi, s_lo, E, G, NT)));
+    DISPATCH(fmt, split, (launch_film_t<T16, SP>(st, W, bias_ft, s_hi, s_lo, E, G, NT, status)));
     return LAUNCH_CHECK();
 }
 
@@ -1985,7 +2047,7 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                                  int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride,
-                                 const int* iter_base, int Tx, int upc) {
+                                 const int* iter_base, int Tx, int upc, const DcUpdate& upd) {
     constexpr int NW = (SP || NARROW) ? 4 : 8;
     // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
     const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
@@ -1993,7 +2055,7 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
     if (hipError_t e = lds_optin((const void*)k_layer<T16, SP, DBG, STAMP, WGR, NARROW>, (int)shm, optin_done)) return e;
     k_layer<T16, SP, DBG, STAMP, WGR, NARROW><<<dim3((WGR && upc) ? B * upc : (G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(
         dm, l, hbuf, (const f16x16*)E, NT, (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
-        snaps, M, T, G, B, dbg, stamps, rec_stride, iter_base, Tx, WGR ? upc : 0);
+        snaps, M, T, G, B, dbg, stamps, rec_stride, iter_base, Tx, WGR ? upc : 0, upd);
     return hipGetLastError();
 }
 
@@ -2001,10 +2063,10 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride, const int* iter_base,
-                           bool narrow, int Tx, int upc) {
+                           bool narrow, int Tx, int upc, const DcUpdate& upd) {
     hipError_t e = hipSuccess;
 #define LAYER_ARGS st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps, \
-                   rec_stride, iter_base, Tx, upc
+                   rec_stride, iter_base, Tx, upc, upd
     if (wgr && !split && narrow && dbg == 0 && stamps == nullptr)      // narrow workgroups: production build only
         return fmt == 1 ? launch_layer_t<_Float16, false, false, false, true, true>(LAYER_ARGS)
                         : launch_layer_t<__bf16, false, false, false, true, true>(LAYER_ARGS);
@@ -2033,7 +2095,7 @@ template <class T16>
 static hipError_t launch_full_t(hipStream_t st, int which, const DcModel* dm, int l, const float* x, float* hbuf, const void* E,
                                 int NT, const void* kv_cur, void* kv_next, const void* kv_ca, const int* length,
                                 const float* xin, float* xout, int out_mode, const float* coef_cur, const int* snap_cur,
-                                float* snaps, int M, int T, int B, int KT, int stop_after) {
+                                float* snaps, int M, int T, int B, int KT, int stop_after, const DcUpdate& upd) {
     const int WPC = (KT + 7) / 8;
     static unsigned long long optin_done = 0;   // key-tile double buffer (32 KiB) + per-wave query fragments (64 KiB) > 64 KiB of dynamic LDS
     if (hipError_t e = lds_optin((const void*)k_layer_full<T16>, 32768 + 8 * 8192, optin_done)) return e;
@@ -2043,24 +2105,24 @@ static hipError_t launch_full_t(hipStream_t st, int which, const DcModel* dm, in
         k_layer_full<T16><<<dim3(B * WPC), dim3(512), 32768 + 8 * 8192, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const v8<T16>*)kv_cur,
                                                                    (v8<T16>*)kv_next, (const v8<T16>*)kv_ca, length, xin, xout,
                                                                    out_mode, coef_cur, snap_cur, snaps, M, T, B, KT, WPC,
-                                                                   stop_after);
+                                                                   stop_after, upd);
     return hipGetLastError();
 }
 hipError_t dc_launch_embed_front_full(hipStream_t st, int fmt, const DcModel* dm, const float* x, float* hbuf, void* kv_next,
                                       int M, int T, int B, int KT) {
     return fmt == 1 ? launch_full_t<_Float16>(st, 0, dm, 0, x, hbuf, nullptr, 0, nullptr, kv_next, nullptr, nullptr, nullptr, nullptr,
-                                              0, nullptr, nullptr, nullptr, M, T, B, KT, 0)
+                                              0, nullptr, nullptr, nullptr, M, T, B, KT, 0, DcUpdate{})
                     : launch_full_t<__bf16>(st, 0, dm, 0, x, hbuf, nullptr, 0, nullptr, kv_next, nullptr, nullptr, nullptr, nullptr, 0,
-                                            nullptr, nullptr, nullptr, M, T, B, KT, 0);
+                                            nullptr, nullptr, nullptr, M, T, B, KT, 0, DcUpdate{});
 }
 hipError_t dc_launch_layer_full(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                 const void* kv_cur, void* kv_next, const void* kv_ca, const int* length, const float* xin,
                                 float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps, int M,
-                                int T, int B, int KT, int stop_after) {
+                                int T, int B, int KT, int stop_after, const DcUpdate& upd) {
     return fmt == 1 ? launch_full_t<_Float16>(st, 1, dm, l, nullptr, hbuf, E, NT, kv_cur, kv_next, kv_ca, length, xin, xout, out_mode,
-                                              coef_cur, snap_cur, snaps, M, T, B, KT, stop_after)
+                                              coef_cur, snap_cur, snaps, M, T, B, KT, stop_after, upd)
                     : launch_full_t<__bf16>(st, 1, dm, l, nullptr, hbuf, E, NT, kv_cur, kv_next, kv_ca, length, xin, xout, out_mode,
-                                            coef_cur, snap_cur, snaps, M, T, B, KT, stop_after);
+                                            coef_cur, snap_cur, snaps, M, T, B, KT, stop_after, upd);
 }
 hipError_t dc_launch_ca_kv(hipStream_t st, int fmt, const DcModel* dm, const void* nh_hi, const void* nh_lo, void* kv_ca,
                            int M, int T, int G, int B, int KT, int L) {

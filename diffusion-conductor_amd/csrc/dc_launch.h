@@ -25,7 +25,9 @@ hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* 
                                const float* rate_in, float* rate_out /* per-workgroup speeds of the previous / this launch (num_cu floats) or nullptr */,
                                const int* iter_base /* captured loop: t_clip = &t_of_iter[step], indexed by *iter_base; else nullptr */,
                                const void* W16, const float* bias16 /* operands of the 16x16x32-MFMA form (used with pp, non-split) */,
-                               const DcEmbedArgs* embed = nullptr /* S-stationary form only: fuse k_embed_front into this launch */);
+                               const DcEmbedArgs* embed = nullptr /* S-stationary form only: fuse k_embed_front into this launch;
+                                                                     an error if the launch cannot carry it */,
+                               int* status = nullptr /* device status word: DC_STATUS_F16_SAT is OR-ed in when a tile leaves the fp16 range */);
 // pp != nullptr (non-split formats): the FiLM GEMM builds its operand SiLU(temb[t_clip] + pp) itself and s_hi is not read
 // wgr: workgroup-level partial records, combined by the consuming layer kernel itself (non-split formats and T >= 256 only;
 // no dc_launch_attn_combine between the layers then)
@@ -45,7 +47,8 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            const int* iter_base /* captured loop: coef_cur / snap_cur = this step's slots of the per-iteration tables,
                                                    indexed by *iter_base; else nullptr (scalars prepared by k_begin_step) */,
                            bool narrow /* wgr, non-split, dbg == 0: 4-wave workgroups; recs / rec_stride then count 128-token units */,
-                           int Tx /* frames per clip of xin / xout / snaps */, int upc /* as dc_launch_embed_front */);
+                           int Tx /* frames per clip of xin / xout / snaps */, int upc /* as dc_launch_embed_front */,
+                           const DcUpdate& upd /* options of the fused DDIM update + the status word (dc_common.h) */);
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);
 // rec_stride: floats between the two alternating unit-record buffers (0 = single buffer, non-wgr)
 
@@ -57,7 +60,7 @@ hipError_t dc_launch_embed_front_full(hipStream_t st, int fmt, const DcModel* dm
 hipError_t dc_launch_layer_full(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                 const void* kv_cur, void* kv_next, const void* kv_ca, const int* length, const float* xin,
                                 float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps, int M,
-                                int T, int B, int KT, int stop_after);
+                                int T, int B, int KT, int stop_after, const DcUpdate& upd);
 
 // Savitzky-Golay smoothing along time of [B][T][P] fp32 (coef: hat matrix [win][win]); y != x
 hipError_t dc_launch_savgol(hipStream_t st, const float* x, float* y, const float* coef, int B, int T, int P, int win);

@@ -51,7 +51,14 @@ class MotionTransformer(nn.Module):
         self.num_layers, self.num_heads, self.input_feats = num_layers, num_heads, input_feats
         self.time_embed_dim = latent_dim * 4
         self.device = device
+        # precision: "fp16" (default) | "mixed" | "bf16x3" | "bf16" | "auto".  "auto" starts in fp16 and, the first time a
+        # sampling loop reports a non-finite x0 (fp16 operands overflow beyond +-65504), rebuilds the sampler in "mixed"
+        # (bf16-range operands) and re-runs that loop; the switch is sticky for this module (numerics_fallback).
+        if precision not in ("fp16", "mixed", "bf16x3", "bf16", "auto"):
+            raise ValueError(f"unknown precision {precision!r}")
         self.precision = precision
+        self.active_precision = "fp16" if precision == "auto" else precision
+        self.check_numerics = True          # one dc_sampler_status per sampling loop (a stream synchronisation)
         self.max_timesteps = max_timesteps
         _build_tree(self, param_shapes(self.cfg))
         if music_model_path is not None:
@@ -80,13 +87,28 @@ class MotionTransformer(nn.Module):
         if self._native is None or self._native.device != idx:
             if self._native is not None:
                 self._native.close()
-            self._native = NativeSampler(self.cfg, self.precision, self.max_timesteps, idx)
+            self._native = NativeSampler(self.cfg, self.active_precision, self.max_timesteps, idx)
             self._native_dirty = True
         if self._native_dirty:
             self._native.load_state_dict(self.state_dict())
             self._native_dirty = False
             self._cond_key = None
         return self._native
+
+    def numerics_fallback(self, status):
+        """Called by the sampler when dc_sampler_status reported `status` after a loop.  Returns True when the module has
+        switched to a mode that can hold the values (the caller re-runs the loop on the fresh sampler), False when there is
+        none: only precision="auto" switches, only from fp16, and only for a non-finite x0 - a FiLM value outside the fp16
+        storage range is outside every mode."""
+        from . import native
+        if self.precision != "auto" or self.active_precision != "fp16" or (status & native.STATUS_F16_SATURATED):
+            return False
+        if self._native is not None:
+            self._native.close()
+        self._native = None
+        self._cond_key = None
+        self.active_precision = "mixed"
+        return True
 
     # ---- reference surface ----------------------------------------------------------------
     def generate_src_mask(self, T, length):

@@ -23,7 +23,11 @@ EXPORTS = [
     "dc_sampler_set_conditioning", "dc_sampler_encode_music", "dc_sampler_denoise", "dc_sampler_ddim_loop", "dc_sampler_profile_loop",
     "dc_kernel_name", "dc_kernel_count", "dc_sampler_workspace_bytes", "dc_sampler_clip_stride", "dc_sampler_debug_denoise",
     "dc_sampler_debug_read", "dc_sampler_debug_layer", "dc_savgol_coefficients", "dc_savgol_filter",
+    "dc_ddim_coefficients_ex", "dc_sampler_ddim_loop_ex", "dc_sampler_status",
 ]
+
+UPDATE_CLIP_DENOISED, UPDATE_EPSILON = 1, 2          # flags of dc_sampler_ddim_loop_ex
+STATUS_NONFINITE, STATUS_F16_SATURATED = 1, 2        # bits of dc_sampler_status
 
 
 class DcConfig(C.Structure):
@@ -113,6 +117,10 @@ def lib():
     L.dc_savgol_coefficients.argtypes = [C.c_int32, C.c_int32, fp]
     L.dc_savgol_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.dc_sampler_ddim_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, fp, ip, C.c_int32, C.c_void_p, C.c_void_p]
+    L.dc_ddim_coefficients_ex.argtypes = [C.c_int32, dp, C.c_float, fp]
+    L.dc_sampler_ddim_loop_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, fp, C.c_int32, C.c_void_p, ip, C.c_int32,
+                                          C.c_void_p, C.c_void_p]
+    L.dc_sampler_status.argtypes = [C.c_void_p, ip, C.c_int32]
     L.dc_sampler_debug_denoise.argtypes = [C.c_void_p, C.c_void_p, ip, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.dc_sampler_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
     L.dc_sampler_debug_layer.argtypes = [C.c_void_p, fp, ip, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
@@ -147,10 +155,16 @@ def linear_beta_schedule(num_steps: int) -> dict:
     return dict(zip(keys, arrs))
 
 
-def ddim_coefficients(alphas_cumprod: np.ndarray) -> np.ndarray:
+def ddim_coefficients(alphas_cumprod: np.ndarray, eta=None) -> np.ndarray:
+    """eta None: dc_ddim_coefficients, [S, 4] (eta = 0).  eta a float: dc_ddim_coefficients_ex, [S, 8] with sigma folded in."""
     ac = np.ascontiguousarray(alphas_cumprod, np.float64)
-    out = np.empty((ac.shape[0], 4), np.float32)
-    _check(lib().dc_ddim_coefficients(ac.shape[0], ac.ctypes.data_as(C.POINTER(C.c_double)), _fptr(out)))
+    dp = ac.ctypes.data_as(C.POINTER(C.c_double))
+    if eta is None:
+        out = np.empty((ac.shape[0], 4), np.float32)
+        _check(lib().dc_ddim_coefficients(ac.shape[0], dp, _fptr(out)))
+    else:
+        out = np.empty((ac.shape[0], 8), np.float32)
+        _check(lib().dc_ddim_coefficients_ex(ac.shape[0], dp, C.c_float(float(eta)), _fptr(out)))
     return out
 
 
@@ -172,6 +186,17 @@ def savgol_filter(poses, window: int = 19, order: int = 5):
     _check(lib().dc_savgol_filter(x.data_ptr(), out.data_ptr(), B, T, P, int(window), int(order),
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return out
+
+
+def describe_status(st: int, precision: str) -> str:
+    msg = []
+    if st & STATUS_NONFINITE:
+        msg.append(f"the denoiser produced a non-finite x0 in precision '{precision}' (fp16 operands overflow beyond +-65504): "
+                   "use precision='mixed' (bf16-range operands) or precision='auto'")
+    if st & STATUS_F16_SATURATED:
+        msg.append("a FiLM modulation value left the fp16 range in which every precision mode stores it: this checkpoint is "
+                   "outside what the library supports")
+    return "; ".join(msg) or "ok"
 
 
 def algorithmic_work(n_tokens: int) -> dict:
@@ -285,7 +310,9 @@ class NativeSampler:
         _check(lib().dc_sampler_denoise(self._h, x.data_ptr(), _iptr(ta), out.data_ptr(), self._stream()))
         return out
 
-    def ddim_loop(self, noise, coef, snap_iters=()):
+    def ddim_loop(self, noise, coef, snap_iters=(), flags=0, step_noise=None):
+        """coef [S, 4] (dc_sampler_ddim_loop: START_X, no clipping, eta = 0) or [S, 8] (dc_sampler_ddim_loop_ex with `flags` =
+        UPDATE_* and, when any sigma != 0, step_noise [S, B, T, P] on the device)."""
         import torch
         assert noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous()
         assert tuple(noise.shape) == (self.B, self.T, self.cfg.input_feats)
@@ -294,10 +321,26 @@ class NativeSampler:
         out = torch.empty_like(noise)
         si = np.ascontiguousarray(np.asarray(list(snap_iters), np.int32))
         snaps = torch.empty((len(si),) + tuple(noise.shape), dtype=torch.float32, device=noise.device) if len(si) else None
-        _check(lib().dc_sampler_ddim_loop(self._h, noise.data_ptr(), out.data_ptr(), S, _fptr(coef),
-                                          _iptr(si) if len(si) else None, len(si),
-                                          snaps.data_ptr() if snaps is not None else None, self._stream()))
+        sip, snp = (_iptr(si) if len(si) else None), (snaps.data_ptr() if snaps is not None else None)
+        if coef.shape[1] == 4:
+            assert flags == 0 and step_noise is None, "clip / epsilon / eta > 0 need the [S, 8] table of ddim_coefficients(.., eta)"
+            _check(lib().dc_sampler_ddim_loop(self._h, noise.data_ptr(), out.data_ptr(), S, _fptr(coef), sip, len(si), snp, self._stream()))
+        else:
+            assert coef.shape[1] == 8
+            zp = None
+            if step_noise is not None:
+                assert step_noise.is_cuda and step_noise.dtype == torch.float32 and step_noise.is_contiguous()
+                assert tuple(step_noise.shape) == (S,) + tuple(noise.shape)
+                zp = step_noise.data_ptr()
+            _check(lib().dc_sampler_ddim_loop_ex(self._h, noise.data_ptr(), out.data_ptr(), S, _fptr(coef), int(flags), zp, sip,
+                                                 len(si), snp, self._stream()))
         return out, snaps
+
+    def status(self, clear=True):
+        """dc_sampler_status: waits for the sampler's work; OR of STATUS_NONFINITE / STATUS_F16_SATURATED."""
+        v = C.c_int32(0)
+        _check(lib().dc_sampler_status(self._h, C.byref(v), int(bool(clear))))
+        return int(v.value)
 
     def profile_loop(self, noise, coef):
         import torch

@@ -5,11 +5,14 @@ the enums (:275-308), the constructor tables (:328-379) and the DDIM entry point
 ``ddim_sample`` (:783-831), ``ddim_sample_loop`` (:871-915) and
 ``ddim_sample_loop_progressive`` (:917-965), with the reference's argument names.
 
-Fast path: when ``model`` is this package's MotionTransformer, ``model_mean_type`` is START_X,
-``eta == 0`` and no clipping / denoised_fn / cond_fn is requested - exactly how
-DDPMTrainer.generate_music_motion calls it - the whole loop runs inside libdc_ddim.so as a
-replayed hipGraph.  Any other combination runs the same update rule step by step with the
-model call still going through the native denoiser.
+Fast path: when ``model`` is this package's MotionTransformer and no host callback
+(``denoised_fn`` / ``cond_fn``) is given, the whole loop runs inside libdc_ddim.so as a replayed
+hipGraph - for ``model_mean_type`` START_X (how DDPMTrainer.generate_music_motion calls it) or
+EPSILON, with or without ``clip_denoised`` (the reference's default is True) and for any ``eta``
+(the per-iteration noise the reference draws with ``th.randn_like`` is drawn up front, or taken
+from the extension keyword ``step_noise=`` so that runs can be reproduced).  A host callback, or
+the progressive generator, runs the same update rule step by step with the model call still
+going through the native denoiser.
 
 Training-time members (losses, VLB terms, ancestral p_sample, schedule samplers) are out of
 scope for this path and are not provided.
@@ -138,8 +141,8 @@ class GaussianDiffusion:
 
     # ---- DDIM ---------------------------------------------------------------------------
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
-                    eta=0.0):
-        """gaussian_diffusion.py:783-831."""
+                    eta=0.0, noise=None):
+        """gaussian_diffusion.py:783-831.  `noise` (extension): the draw to use in place of th.randn_like(x)."""
         if cond_fn is not None:
             raise NotImplementedError("cond_fn (classifier guidance) is not on the Diffusion-Conductor path")
         pred_xstart = self._pred_xstart(model, x, t, clip_denoised, denoised_fn, model_kwargs)
@@ -150,27 +153,56 @@ class GaussianDiffusion:
         mean_pred = pred_xstart * th.sqrt(alpha_bar_prev) + th.sqrt(1 - alpha_bar_prev - sigma ** 2) * eps
         sample = mean_pred
         if eta != 0.0:
-            noise = th.randn_like(x)
+            noise = th.randn_like(x) if noise is None else noise.to(x)
             nonzero_mask = (t != 0).float().view(-1, *([1] * (len(x.shape) - 1)))
             sample = mean_pred + nonzero_mask * sigma * noise
         return {"sample": sample, "pred_xstart": pred_xstart}
 
-    def _fast_path_ok(self, model, clip_denoised, denoised_fn, cond_fn, eta):
-        return (isinstance(model, MotionTransformer) and self.model_mean_type == ModelMeanType.START_X
+    def _fast_path_ok(self, model, denoised_fn, cond_fn):
+        return (isinstance(model, MotionTransformer)
+                and self.model_mean_type in (ModelMeanType.START_X, ModelMeanType.EPSILON)
                 and self.model_var_type in (ModelVarType.FIXED_SMALL, ModelVarType.FIXED_LARGE)
-                and not clip_denoised and denoised_fn is None and cond_fn is None and eta == 0.0
-                and not self.rescale_timesteps)
+                and denoised_fn is None and cond_fn is None and not self.rescale_timesteps)
 
-    def native_coefficients(self):
+    def native_coefficients(self, eta=None):
+        """eta None: the [S, 4] table of dc_ddim_coefficients (eta = 0); a float: the [S, 8] table of dc_ddim_coefficients_ex."""
+        key = None if eta is None else float(eta)
         if self._native_coef is None:
-            self._native_coef = native.ddim_coefficients(self.alphas_cumprod)
-        return self._native_coef
+            self._native_coef = {}
+        if key not in self._native_coef:
+            self._native_coef[key] = native.ddim_coefficients(self.alphas_cumprod, key)
+        return self._native_coef[key]
+
+    def _native_loop(self, model, img, mk, clip_denoised, eta, snap, step_noise):
+        """The captured loop on `model`'s sampler; returns (out, snaps).  Numeric health is checked once per call
+        (`model.check_numerics`): a non-finite x0 under precision="auto" falls back to the bf16-range mode in a fresh sampler."""
+        flags = (native.UPDATE_CLIP_DENOISED if clip_denoised else 0) | \
+            (native.UPDATE_EPSILON if self.model_mean_type == ModelMeanType.EPSILON else 0)
+        z = None
+        if eta != 0.0:
+            shape = (self.num_timesteps,) + tuple(img.shape)
+            z = th.randn(*shape, device=img.device) if step_noise is None else step_noise
+            z = z.to(device=img.device, dtype=th.float32).contiguous()
+            assert tuple(z.shape) == shape, f"step_noise must be {shape}"
+        plain = flags == 0 and eta == 0.0
+        coef = self.native_coefficients(None if plain else eta)
+        while True:
+            nat = model.set_conditioning(mk["xf_proj"], mk["xf_out"], mk.get("length"))
+            out, snaps = nat.ddim_loop(img, coef, snap, flags, z)
+            if not getattr(model, "check_numerics", True):
+                return out, snaps
+            st = nat.status()
+            if st == 0:
+                return out, snaps
+            if not model.numerics_fallback(st):
+                raise FloatingPointError(native.describe_status(st, model.active_precision))
 
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
-                         model_kwargs=None, device=None, progress=False, eta=0.0, idxs=[]):
+                         model_kwargs=None, device=None, progress=False, eta=0.0, idxs=[], step_noise=None):
         """gaussian_diffusion.py:871-915.  Returns the final sample, or when `idxs` is non-empty a
-        dict {iteration: sample} for the listed iterations plus {num_timesteps: final}."""
-        if self._fast_path_ok(model, clip_denoised, denoised_fn, cond_fn, eta):
+        dict {iteration: sample} for the listed iterations plus {num_timesteps: final}.
+        `step_noise` (extension, eta > 0): [S, B, T, P], the draw for iteration i in place of th.randn_like."""
+        if self._fast_path_ok(model, denoised_fn, cond_fn):
             if device is None:
                 device = next(model.parameters()).device
             assert isinstance(shape, (tuple, list))
@@ -180,9 +212,8 @@ class GaussianDiffusion:
             if mk.get("xf_proj") is None or mk.get("xf_out") is None:
                 mk = dict(mk)
                 mk["xf_proj"], mk["xf_out"] = model.encode_music(mk["text"], device)
-            nat = model.set_conditioning(mk["xf_proj"], mk["xf_out"], mk.get("length"))
             snap = sorted(int(i) for i in set(idxs) if 0 <= int(i) < self.num_timesteps)
-            out, snaps = nat.ddim_loop(img, self.native_coefficients(), snap)
+            out, snaps = self._native_loop(model, img, mk, bool(clip_denoised), float(eta), snap, step_noise)
             if len(idxs) == 0:
                 return out
             result = {it: snaps[k] for k, it in enumerate(snap)}
@@ -192,7 +223,7 @@ class GaussianDiffusion:
         for sample in self.ddim_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
                                                         denoised_fn=denoised_fn, cond_fn=cond_fn,
                                                         model_kwargs=model_kwargs, device=device,
-                                                        progress=progress, eta=eta):
+                                                        progress=progress, eta=eta, step_noise=step_noise):
             final = sample
             if i in idxs:
                 result[i] = sample["sample"]
@@ -206,7 +237,8 @@ class GaussianDiffusion:
     sample = ddim_sample_loop
 
     def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
-                                     cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0):
+                                     cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0,
+                                     step_noise=None):
         """gaussian_diffusion.py:917-965: yields {"sample","pred_xstart"} after every step."""
         if device is None:
             device = next(model.parameters()).device
@@ -216,10 +248,11 @@ class GaussianDiffusion:
         if progress:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
-        for i in indices:
+        for it, i in enumerate(indices):
             t = th.full((shape[0],), i, device=device, dtype=th.long)
             with th.no_grad():
                 out = self.ddim_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
-                                       cond_fn=cond_fn, model_kwargs=model_kwargs, eta=eta)
+                                       cond_fn=cond_fn, model_kwargs=model_kwargs, eta=eta,
+                                       noise=None if step_noise is None else step_noise[it])
                 yield out
                 img = out["sample"]

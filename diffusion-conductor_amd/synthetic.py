@@ -92,3 +92,49 @@ def batch_noise(B, T=1800, P=26, seed=2, first=0):
 
 def batch_music_features(B, T=1800, C=64, seed=3, first=0):
     return np.stack([synthetic_music_features(first + b, T, C, seed) for b in range(B)])
+
+
+def stress_state_dict(cfg: DenoiserConfig = DenoiserConfig(), seed: int = 0):
+    """A "trained-like" stress variant of the synthetic checkpoint: trained denoisers are not at initialisation
+    scale, so the parity tests also run on a draw with larger modulation / output weights, spread-out
+    LayerNorm gains and a few outlier channels (tests/golden/g8_robust.npz):
+      * StylizationBlock ``emb_layers`` / ``out_layers``, ``ffn.linear2`` and ``out`` weights x 3;
+      * every LayerNorm gain log-normal with sigma = 0.5;
+      * four 10x outlier channels in ``sequence_embedding`` and in ``joint_embed``.
+    """
+    sd = synthetic_state_dict(cfg, seed)
+    for name in sd:
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "weight" and (".emb_layers.1." in name or ".out_layers.2." in name or name.endswith("ffn.linear2.weight")
+                                 or name == "out.weight"):
+            sd[name] = np.ascontiguousarray(sd[name] * 3.0, dtype=np.float32)
+        elif leaf == "weight" and len(sd[name].shape) == 1 and (".norm." in name or "text_norm" in name):
+            g = _rng(seed, "stress:" + name)
+            sd[name] = np.exp(0.5 * g.standard_normal(sd[name].shape)).astype(np.float32)
+    ch = _rng(seed, "stress:outliers").choice(cfg.latent_dim, size=8, replace=False)
+    se = sd["sequence_embedding"].copy()
+    se[:, ch[:4]] *= 10.0
+    sd["sequence_embedding"] = se
+    je = sd["joint_embed.weight"].copy()
+    je[ch[4:], :] *= 10.0
+    sd["joint_embed.weight"] = je
+    return sd
+
+
+def smooth_mel(clip: int, n_frames: int = 5400, n_bins: int = 128, seed: int = 1):
+    """A mel in [0,1] with the smoothness of a real spectrogram (white noise low-pass filtered along time and
+    frequency, then min-max normalised as tools/visualization.py:165 does) - ``synthetic_mel`` is white."""
+    a = _rng(seed, "smooth_mel", clip).standard_normal((n_frames + 64, n_bins + 16))
+    kt = np.hanning(65)
+    kf = np.hanning(17)
+    a = np.apply_along_axis(lambda v: np.convolve(v, kt / kt.sum(), mode="valid"), 0, a)
+    a = np.apply_along_axis(lambda v: np.convolve(v, kf / kf.sum(), mode="valid"), 1, a)
+    a = a[:n_frames, :n_bins]
+    a = (a - a.min()) / (a.max() - a.min())
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def batch_step_noise(S, B, T=1800, P=26, seed=4, first=0):
+    """Per-iteration DDIM noise z_i ~ N(0,1) (eta > 0), [S, B, T, P]: iteration i of clip b has its own stream."""
+    return np.stack([np.stack([_rng(seed, f"z{i}", first + b).standard_normal((T, P), dtype=np.float32) for b in range(B)])
+                     for i in range(S)])

@@ -87,6 +87,14 @@ int dc_linear_beta_schedule(int32_t num_steps, double* h_betas, double* h_alphas
  *   h_coef[t*4 + 3] = sqrtf(1 - (float)abar_{t-1})     (coefficient of eps)          */
 int dc_ddim_coefficients(int32_t num_steps, const double* h_alphas_cumprod, float* h_coef);
 
+/* The same for any eta >= 0 (models/gaussian_diffusion.py:814-826), eight floats per timestep, fp32 arithmetic on the
+ * fp32-rounded table entries in the reference's own order:
+ *   h_coef8[t*8 + 0..2] as above;  sigma = eta sqrt((1-abar_{t-1})/(1-abar_t)) sqrt(1-abar_t/abar_{t-1})
+ *   h_coef8[t*8 + 3] = sqrtf(1 - abar_{t-1} - sigma^2)   (coefficient of eps)
+ *   h_coef8[t*8 + 4] = sigma                             (coefficient of the noise draw; 0 at t = 0 = the reference's nonzero_mask)
+ *   h_coef8[t*8 + 5..7] = 0 */
+int dc_ddim_coefficients_ex(int32_t num_steps, const double* h_alphas_cumprod, float eta, float* h_coef8);
+
 /* Test hook: pack a row-major Linear weight W[n_out][k_in] (torch layout) into the
  * MFMA fragment-major bf16 image the kernels read (see DESIGN.md "weight image").
  * `chained` != 0 uses the accumulator-as-operand k order, 0 the natural k order.
@@ -150,6 +158,33 @@ int dc_sampler_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timeste
 int dc_sampler_ddim_loop(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps,
                          const float* h_coef, const int32_t* h_snap_iters, int32_t n_snap,
                          float* d_snaps, void* stream);
+
+/* The same loop with the other branches of the reference's sampler on the device (replaces the rest of p_mean_variance /
+ * ddim_sample, models/gaussian_diffusion.py:503-521, 812-830; ddim_sample_loop's own default is clip_denoised=True, :876):
+ *   h_coef8  fp32 [S,8]    per-timestep scalars from dc_ddim_coefficients_ex (eta folded in: sigma, sqrt(1-abar_prev-sigma^2))
+ *   flags                  DC_UPDATE_CLIP_DENOISED: pred_xstart.clamp(-1, 1) (:506-507);
+ *                          DC_UPDATE_EPSILON: the denoiser predicts epsilon, pred_xstart = sqrt(1/abar) x_t - sqrt(1/abar-1) out
+ *                          (ModelMeanType.EPSILON, :516-521, 539-544)
+ *   d_step_noise fp32 [S,B,T,P]  the draws the reference takes with th.randn_like(x) at iteration i = 0 .. S-1 (:822);
+ *                          required when any sigma != 0 (eta > 0), ignored (may be NULL) otherwise.  The caller draws it, as x_T.
+ * Everything else as dc_sampler_ddim_loop; flags = 0 with an eta = 0 table is that call.  denoised_fn / cond_fn are host
+ * callbacks and stay on the caller's side of the ABI (per-step dc_sampler_denoise). */
+#define DC_UPDATE_CLIP_DENOISED 1
+#define DC_UPDATE_EPSILON 2
+int dc_sampler_ddim_loop_ex(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps, const float* h_coef8,
+                            int32_t flags, const float* d_step_noise, const int32_t* h_snap_iters, int32_t n_snap,
+                            float* d_snaps, void* stream);
+
+/* Numeric health of everything enqueued so far (no reference counterpart: the reference computes in fp32).  Waits for the
+ * sampler's work, then returns the OR of
+ *   DC_STATUS_NONFINITE    a predicted x0 (the denoiser's output) was inf or nan;
+ *   DC_STATUS_F16_SATURATED  a FiLM modulation value (StylizationBlock scale / shift, transformer.py:74-78) left the fp16 range
+ *                          in which the layer kernels receive it - the fp16 / mixed modes do not hold for this checkpoint:
+ *                          use precision bf16x3 (Python: MotionTransformer(precision="auto") retries by itself).
+ * clear != 0 resets the word. */
+#define DC_STATUS_NONFINITE 1
+#define DC_STATUS_F16_SATURATED 2
+int dc_sampler_status(dc_sampler* s, int32_t* h_status, int32_t clear);
 
 /* Timing hook for bench.py: device time (ms, HIP events on the library's own stream)
  * of the last dc_sampler_ddim_loop and the summed duration + launch count of its

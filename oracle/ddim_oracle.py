@@ -330,31 +330,47 @@ def encode_music(p, mel):
 
 
 def ddim_sample_loop(p, noise, xf_proj, xf_out, length, num_steps, num_layers=8, num_heads=8,
-                     no_eff=False, eta=0.0, idxs=(), emu=FP32, progress=None):
-    """ddim_sample_loop / _progressive / ddim_sample with model_mean_type=START_X,
-    clip_denoised=False, eta as given (gaussian_diffusion.py:783-831, 871-965).
-    With eta == 0 the noise term is multiplied by zero, so no RNG is consumed here."""
-    assert eta == 0.0, "oracle covers the deterministic (eta=0) path the harness uses"
+                     no_eff=False, eta=0.0, idxs=(), emu=FP32, progress=None, clip_denoised=False,
+                     eps_model=False, step_noise=None, return_pred=False):
+    """ddim_sample_loop / _progressive / ddim_sample (gaussian_diffusion.py:783-831, 871-965) on top of
+    p_mean_variance's pred_xstart (:503-521): model_mean_type START_X (the harness, `eps_model=False`) or
+    EPSILON (`eps_model=True`: pred = sqrt(1/abar) x_t - sqrt(1/abar - 1) model_out, :539-544), then
+    `clip_denoised` (x.clamp(-1, 1), :506-507).  With eta == 0 the noise term is multiplied by zero and no
+    RNG is consumed; with eta > 0 iteration `it` adds nonzero_mask * sigma * step_noise[it] (:822-830; the
+    reference draws th.randn_like(x) there - the caller supplies the same draws to compare).
+    `return_pred`: also return the list of per-iteration pred_xstart (what the progressive generator yields)."""
+    if eta != 0.0:
+        assert step_noise is not None and len(step_noise) == num_steps, "eta > 0 needs the per-iteration noise [S,B,T,P]"
     co = torch.from_numpy(ddim_step_coefficients(ddim_tables(linear_beta_schedule(num_steps)), eta)).to(noise.dtype)
     img = noise
     B = noise.shape[0]
     result = {}
+    preds = []
     it = 0
     for i in reversed(range(num_steps)):
         t = torch.tensor([i] * B)
-        x0 = denoiser_forward(p, img, t, length, xf_proj, xf_out, num_layers, num_heads, no_eff, emu)
-        sr, srm1, c_x0, c_eps, _ = co[i]
+        out = denoiser_forward(p, img, t, length, xf_proj, xf_out, num_layers, num_heads, no_eff, emu)
+        sr, srm1, c_x0, c_eps, sigma = co[i]
+        x0 = sr * img - srm1 * out if eps_model else out
+        if clip_denoised:
+            x0 = x0.clamp(-1, 1)
         eps = (sr * img - x0) / srm1
-        img = x0 * c_x0 + c_eps * eps
+        mean = x0 * c_x0 + c_eps * eps
+        if eta != 0.0:
+            mask = 0.0 if i == 0 else 1.0
+            img = mean + mask * sigma * torch.as_tensor(step_noise[it]).to(noise.dtype)
+        else:
+            img = mean
+        preds.append(x0)
         if it in idxs:
             result[it] = img
         it += 1
         if progress is not None:
             progress(it)
     if len(idxs) == 0:
-        return img
+        return (img, preds) if return_pred else img
     result[it] = img
-    return result
+    return (result, preds) if return_pred else result
 
 
 def generate_music_motion(p, mel, dim_pose, num_steps, noise, num_layers=8, num_heads=8, no_eff=False):

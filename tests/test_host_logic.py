@@ -47,6 +47,45 @@ def test_schedule_and_coefficients_match_reference_tables():
         assert co[0, 2] == 1.0 and co[0, 3] == 0.0
 
 
+def test_coefficients_ex_match_the_oracles_fp32_scalars():
+    """dc_ddim_coefficients_ex (eta > 0): sigma and sqrt(1 - abar_prev - sigma^2) in the reference's fp32 op order
+    (gaussian_diffusion.py:814-826) - within 2 ulp of the oracle's torch evaluation; eta = 0 reproduces the 4-float table."""
+    from helpers import O
+    for S in (50, 1000):
+        tab = O.ddim_tables(O.linear_beta_schedule(S))
+        for eta in (0.0, 0.3, 1.0):
+            ref = O.ddim_step_coefficients(tab, eta)
+            co = native.ddim_coefficients(tab["alphas_cumprod"], eta)
+            assert co.shape == (S, 8) and not co[:, 5:].any()
+            assert np.allclose(co[:, :5], ref, rtol=3e-7, atol=1e-9), (S, eta, np.abs(co[:, :5] - ref).max())
+            assert co[0, 4] == 0.0                                   # t = 0: no noise (the reference's nonzero_mask)
+        assert np.array_equal(native.ddim_coefficients(tab["alphas_cumprod"], 0.0)[:, :4], native.ddim_coefficients(tab["alphas_cumprod"]))
+
+
+def test_sampler_routes_every_model_branch_to_the_native_loop():
+    """Which calls take the captured loop: START_X and EPSILON, any clip_denoised / eta; host callbacks do not."""
+    from diffusion_conductor_amd import MotionTransformer
+    from diffusion_conductor_amd.sampler import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,
+                                                 get_named_beta_schedule)
+    m = MotionTransformer(input_feats=26, num_frames=64, num_layers=1, latent_dim=128, device="cpu", precision="auto")
+    assert m.active_precision == "fp16" and m.check_numerics
+    with pytest.raises(ValueError):
+        MotionTransformer(input_feats=26, latent_dim=128, precision="fp8")
+    for mt, ok in ((ModelMeanType.START_X, True), (ModelMeanType.EPSILON, True), (ModelMeanType.PREVIOUS_X, False)):
+        gd = GaussianDiffusion(betas=get_named_beta_schedule("linear", 50), model_mean_type=mt,
+                               model_var_type=ModelVarType.FIXED_SMALL, loss_type=LossType.MSE)
+        assert gd._fast_path_ok(m, None, None) is ok
+        assert not gd._fast_path_ok(m, lambda x: x, None) and not gd._fast_path_ok(lambda *a, **k: None, None, None)
+    assert gd.native_coefficients(0.5).shape == (50, 8) and gd.native_coefficients().shape == (50, 4)
+    # numerics_fallback: only "auto" switches, once, and never for a FiLM tile outside the fp16 storage range
+    assert not m.numerics_fallback(native.STATUS_F16_SATURATED) and m.active_precision == "fp16"
+    assert m.numerics_fallback(native.STATUS_NONFINITE) and m.active_precision == "mixed"
+    assert not m.numerics_fallback(native.STATUS_NONFINITE)
+    m2 = MotionTransformer(input_feats=26, num_frames=64, num_layers=1, latent_dim=128, device="cpu", precision="fp16")
+    assert not m2.numerics_fallback(native.STATUS_NONFINITE)
+    assert "precision='mixed'" in native.describe_status(native.STATUS_NONFINITE, "fp16")
+
+
 def test_gaussian_diffusion_tables_and_enums():
     from diffusion_conductor_amd.sampler import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,
                                                  get_named_beta_schedule)

@@ -106,3 +106,57 @@ def test_precision_emulation_budget():
             err[mode] = rel_l2(O.denoiser_forward(p, *args, emu=O.Emu(mode)), g["forward"])
     print(err)
     assert err["x3"] < 1e-4 and err["mixed"] < 5e-4 and err["mixed"] < err["fp16"] < 1e-3 < err["bf16"] < 2e-2
+
+
+def _features_of(sd, B, T, first):
+    from diffusion_conductor_amd.synthetic import batch_music_features
+    xf = torch.from_numpy(batch_music_features(B, T, first=first))
+    return torch.nn.functional.linear(xf, torch.from_numpy(sd["proj.weight"]), torch.from_numpy(sd["proj.bias"])), xf
+
+
+def test_ddim50_other_checkpoints_g8():
+    """G8: the oracle on checkpoints / inputs other than seed 0 + white noise: seeds 1 and 2, the trained-like stress
+    checkpoint, and a smooth mel through encode_music (pinned by the reference run in make_golden.py g8)."""
+    from diffusion_conductor_amd.param_spec import DenoiserConfig
+    from diffusion_conductor_amd.synthetic import smooth_mel, stress_state_dict, synthetic_state_dict
+    g = golden("g8_robust.npz")
+    torch.set_num_threads(8)
+    cases = {"seed1": (synthetic_state_dict(DenoiserConfig(), seed=1), 30), "stress": (stress_state_dict(DenoiserConfig(), seed=0), 32),
+             "smooth": (synthetic_state_dict(DenoiserConfig(), seed=0), 33)}
+    for tag, (sd, first) in cases.items():
+        q = O.to_torch_params(sd)
+        with torch.no_grad():
+            if tag == "smooth":
+                xfp, xfo = O.encode_music(q, torch.from_numpy(smooth_mel(first)[None]))
+            else:
+                xfp, xfo = _features_of(sd, 1, 1800, first)
+            out = O.ddim_sample_loop(q, torch.from_numpy(batch_noise(1, 1800, first=first)), xfp, xfo, [1800], 50)
+        assert rel_l2(out, g[f"{tag}_x0"]) < 1e-5, tag
+    # the stress checkpoint is not a rescaled seed-0 run: its x0 leaves [-1, 1] by two orders of magnitude
+    assert np.abs(g["stress_x0"]).max() > 50 * np.abs(g["seed1_x0"]).max() > 0
+
+
+def test_sampler_branches_g9():
+    """G9: clip_denoised=True, eta = 0.5 and ModelMeanType.EPSILON (+ clip, eta = 0.3) of the oracle's loop against the
+    reference's ddim_sample_loop / _progressive outputs (final sample, idxs, pred_xstart of three iterations)."""
+    from diffusion_conductor_amd.param_spec import DenoiserConfig
+    from diffusion_conductor_amd.synthetic import batch_step_noise, stress_state_dict
+    g = golden("g9_sampler_branches.npz")
+    sd = stress_state_dict(DenoiserConfig(), seed=0)
+    q = O.to_torch_params(sd)
+    B, T, S = 2, 96, 50
+    xfp, xfo = _features_of(sd, B, T, 40)
+    nz = torch.from_numpy(batch_noise(B, T, first=40))
+    z = torch.from_numpy(batch_step_noise(S, B, T, first=40))
+    for tag, (clip, eta, eps) in {"clip": (True, 0.0, False), "eta": (False, 0.5, False), "eps": (True, 0.3, True)}.items():
+        with torch.no_grad():
+            res, preds = O.ddim_sample_loop(q, nz, xfp, xfo, [96, 70], S, idxs=(0, 24), clip_denoised=clip, eta=eta,
+                                            eps_model=eps, step_noise=z, return_pred=True)
+        for k in (0, 24, S):
+            assert rel_l2(res[k], g[f"{tag}_idx{k}"]) < 1e-5, (tag, k)
+        for it in (0, 24, 49):
+            assert rel_l2(preds[it], g[f"{tag}_pred{it}"]) < 1e-5, (tag, it)
+        if clip:
+            assert float(np.abs(g[f"{tag}_pred24"]).max()) <= 1.0
+    # eta changes the answer; so does the clamp (the fixtures are not one result stored three times)
+    assert rel_l2(g["eta_idx50"], g["clip_idx50"]) > 1e-2
