@@ -15,7 +15,11 @@ rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set),
 JSON line and exits with the children's worst return code.  Launched by `python -m
 torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks run directly.  Clips are
 sharded (weak scaling: 32 per GPU); the only collective is one RCCL all-gather of the final poses
-per step, inside the timed region.
+per step, inside the timed region.  With N > 1 the JSON line also carries what proves the run was N ranks on N devices:
+`multi_gpu` = {rccl_ranks (dist.get_world_size()), devices (one "pci bus id / uuid" per rank, all-gathered, asserted
+distinct), ms_per_step_by_rank (min, max), gather_block_equals_local (every rank found its own block of the all-gather bit-equal
+to its local result), sharded_equals_single_gpu (rank 0 re-sampled the LAST rank's shard alone and found it bit-equal to that
+rank's block - SURVEY.md section 8d, config 3)}.
 
 Extra objects on the JSON line:
   roofline        the kernel with the largest share of the loop (k_layer, HBM roof; or k_film_gemm, MFMA
@@ -134,7 +138,8 @@ def launch_ranks(n, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+        # DC_BENCH_WORKER: the rank program (tests/test_host_logic.py runs a stub through the real launcher); default: this file
+        procs.append(subprocess.Popen([sys.executable, os.environ.get("DC_BENCH_WORKER") or os.path.abspath(__file__), *argv], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     worst = 0
     deadline = None
@@ -152,6 +157,38 @@ def launch_ranks(n, argv):
                 p.kill()
         time.sleep(0.05)
     return worst
+
+
+def multi_gpu_evidence(dist, dev, local, rank, world, B, s_per_step, gathered, nat, noise, coef, model, args):
+    """What proves an N-rank run (module docstring).  Collectives outside the timed region; every rank takes part."""
+    import torch
+    from diffusion_conductor_amd.synthetic import batch_music_features, batch_noise
+    pr = torch.cuda.get_device_properties(local)
+    ident = f"{getattr(pr, 'pci_bus_id', '?'):02x}:{getattr(pr, 'pci_device_id', '?'):02x} {getattr(pr, 'uuid', '')} {pr.name}" \
+        if isinstance(getattr(pr, "pci_bus_id", None), int) else f"{getattr(pr, 'uuid', '')} {pr.name} #{local}"
+    idents = [None] * world
+    dist.all_gather_object(idents, ident)
+    assert len(set(idents)) == world, f"ranks share a device: {idents}"
+    t = torch.tensor([s_per_step * 1e3], device=dev, dtype=torch.float64)
+    ts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(ts, t)
+    ms = [float(x.item()) for x in ts]
+    # the gathered tensor is [world * B, T, P] in rank order: my block must be my own result, bit for bit
+    mine, _ = nat.ddim_loop(noise, coef)
+    ok = torch.tensor([int(torch.equal(gathered[rank * B:(rank + 1) * B], mine))], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    same_single = None
+    if rank == 0:        # rank 0 samples the LAST rank's shard alone (inputs regenerated from their seeds) and compares
+        r = world - 1
+        xf = torch.from_numpy(batch_music_features(B, args.frames, first=r * B)).to(dev)
+        xfp = torch.nn.functional.linear(xf, model.proj.weight, model.proj.bias).contiguous()
+        nz = torch.from_numpy(batch_noise(B, args.frames, first=r * B)).to(dev)
+        solo, _ = model.set_conditioning(xfp, xf, [args.frames] * B).ddim_loop(nz, coef)
+        same_single = bool(torch.equal(solo, gathered[r * B:(r + 1) * B]))
+    return {"rccl_ranks": int(dist.get_world_size()), "backend": dist.get_backend(), "devices": idents,
+            "ms_per_step_by_rank": {"min": round(min(ms), 3), "max": round(max(ms), 3)},
+            "gather_block_equals_local": bool(ok.item()), "sharded_equals_single_gpu": same_single,
+            "all_gather_bytes_per_rank": int(mine.numel() * 4)}
 
 
 def build_model(precision, no_eff, dev):
@@ -222,6 +259,8 @@ def main():
 
     def step():
         out, _ = nat.ddim_loop(noise, coef)
+        st = nat.status()                          # the product path's numeric health check (one stream synchronisation per loop)
+        assert st == 0, f"sampler status {st}"
         return gather_poses(out, world * B) if world > 1 else out
 
     def barrier():
@@ -238,13 +277,16 @@ def main():
     for _ in range(args.steps):
         out = step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt = dt_local = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     assert torch.isfinite(out).all()
     log(f"timed region: {dt:.3f} s for {args.steps} steps")
+    multi = None
+    if world > 1:
+        multi = multi_gpu_evidence(dist, dev, local, rank, world, B, dt_local / args.steps, out, nat, noise, coef, model, args)
 
     frames = world * B * T * args.steps
     value = frames / dt
@@ -262,6 +304,8 @@ def main():
         "mfma_roofline_frac_whole_loop": round(value / world * S * (2 * (7.56e9 + 13.27e9 * T / 1800) / 1800 if args.no_eff
                                                                       else FLOP_PER_TOKEN_STEP) / PEAK_BF16_FLOPS, 4),
     }
+    if multi is not None:
+        line["multi_gpu"] = multi
     if rank == 0:
         from diffusion_conductor_amd import native
         extras = not args.no_extras
@@ -301,9 +345,6 @@ def main():
             ms, cnt = prof[name]
             per = ms / cnt * 1e-3
             w = dict(alg[name])
-            if name == "k_layer" and cnt == S:        # persistent form: one launch = all 8 layers
-                w = {k: (v * 8 if isinstance(v, (int, float)) else v) for k, v in w.items()}
-                w["layers_per_launch"] = 8
             if w["bound"] == "mfma":
                 ach, peak, unit = w["flops"] / per / 1e12, PEAK_BF16_FLOPS / 1e12, "TFLOP/s"
             else:

@@ -184,6 +184,9 @@ struct dc_sampler {
     int upd_flags = 0;
     const float* d_step_noise = nullptr;
     int* d_status = nullptr;
+    // Savitzky-Golay smoothing applied by the loop's final write (dc_sampler_set_smoothing; window 0 = off)
+    int smooth_window = 0, smooth_order = 0;
+    float* d_smooth_coef = nullptr;
 
     dc_music* music = nullptr;   // MusicEncoder (built when its parameters were supplied)
 
@@ -860,7 +863,14 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
         }
         for (int i = 0; i < S / K; ++i) HIP_TRY(hipGraphLaunch(s->graph, st));
     }
-    HIP_TRY(hipMemcpyAsync(d_out, s->d_x, MP * 4, hipMemcpyDeviceToDevice, st));
+    // the final write x0 -> the caller's tensor: a copy, or (dc_sampler_set_smoothing) the Savitzky-Golay filter along time
+    // (tools/visualization.py:20-26,126) reading the loop's x0 and writing the caller's tensor directly - no pass of its own
+    if (s->smooth_window > 0) {
+        if (s->Tx < s->smooth_window) return fail(DC_ERR_INVALID, "smoothing window %d exceeds the %d frames of a clip", s->smooth_window, s->Tx);
+        HIP_TRY(dc_launch_savgol(st, s->d_x, d_out, s->d_smooth_coef, s->B, s->Tx, s->cfg.input_feats, s->smooth_window));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_out, s->d_x, MP * 4, hipMemcpyDeviceToDevice, st));
+    }
     if (n_snap > 0 && d_snaps_user)
         HIP_TRY(hipMemcpyAsync(d_snaps_user, s->d_snaps, (size_t)n_snap * MP * 4, hipMemcpyDeviceToDevice, st));
     return sync_out(s, user);
@@ -976,7 +986,7 @@ void dc_sampler_destroy(dc_sampler* s) {
     void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
                     s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t, s->d_coef_of_iter,
-                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status};
+                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status, s->d_smooth_coef};
     for (void* p : ptrs)
         if (p) hipFree(p);
     dc_music_destroy(s->music);
@@ -1143,6 +1153,24 @@ int dc_savgol_coefficients(int32_t window, int32_t order, float* h_coef) {
             }
             h_coef[(size_t)i * w + k] = (float)acc;
         }
+    return DC_OK;
+}
+
+int dc_sampler_set_smoothing(dc_sampler* s, int32_t window, int32_t order) {
+    if (!s) return fail(DC_ERR_INVALID, "null sampler");
+    HIP_TRY(hipSetDevice(s->cfg.device));
+    if (window == 0) {
+        s->smooth_window = 0;
+        return DC_OK;
+    }
+    std::vector<float> coef((size_t)(window > 0 ? window : 0) * (window > 0 ? window : 0));
+    int rc = dc_savgol_coefficients(window, order, coef.data());
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));          // an earlier loop may still read the old table
+    if ((rc = dev_alloc(s, s->d_smooth_coef, coef.size() * 4))) return rc;
+    HIP_TRY(hipMemcpy(s->d_smooth_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
+    s->smooth_window = window;
+    s->smooth_order = order;
     return DC_OK;
 }
 

@@ -818,7 +818,9 @@ DEV void embed_front_body(const DcModel* __restrict__ dm, const float* __restric
             constexpr int OFF_XS = 8192 + 34 * 1024;               // inside pst, behind the key image; 3.5 KiB per wave
             const int gb = (32 * g) / T, gn = 32 * g - gb * T;      // the group's first token
             const size_t row0 = (size_t)gb * Tx + gn;
-            staged = active && 32 * g + 32 <= M && gn + 32 <= Tx && (row0 * P) % 4 == 0;     // wave-uniform: 32 real
+            // (the patch holds 32 x P floats for P <= 28; x itself must be 16-byte aligned for the f32x4 loads: a caller may pass a slice)
+            staged = active && 32 * g + 32 <= M && gn + 32 <= Tx && (row0 * P) % 4 == 0 && 32 * P * 4 <= 3584 &&
+                     (reinterpret_cast<size_t>(x) & 15) == 0;                                     // wave-uniform: 32 real
             if (staged) {                                                                                       // frames of one clip, 16-B aligned
                 float* xs = reinterpret_cast<float*>(lds + OFF_XS + wave * 3584);
                 const f32x4* src = reinterpret_cast<const f32x4*>(x + row0 * P);
@@ -984,8 +986,11 @@ DEV float ddim_update(float mo, float xt, const float* __restrict__ c, int flags
 // NARROW (WGR, non-split, production build only): 4 waves per workgroup = 128-token units, ONE wave per SIMD.  The kernel is
 // bound by instruction issue, so a wave that has its SIMD to itself runs the layer in about half the time; worth it
 // whenever the batch is small enough for every unit to get its own CU (<= 32 K tokens: e.g. the reference's one clip per call).
+#ifndef DC_SPLIT_NW
+#define DC_SPLIT_NW 8      // waves per k_layer workgroup in the split modes (4: one wave per SIMD, round 1-2's form)
+#endif
 template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR, bool NARROW = false>
-__global__ __launch_bounds__((SPLIT || NARROW) ? 256 : 512, (SPLIT || NARROW) ? 1 : 2)
+__global__ __launch_bounds__((NARROW || (SPLIT && DC_SPLIT_NW == 4)) ? 256 : 512, (NARROW || (SPLIT && DC_SPLIT_NW == 4)) ? 1 : 2)
 void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
              const v8<T16>* __restrict__ a_sa /*[B][16][64]*/, const v8<T16>* __restrict__ a_ca /*[L][B][16][64]*/,
              float* __restrict__ recs, const int* __restrict__ length, const float* __restrict__ xin,
@@ -996,7 +1001,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
              const DcUpdate upd) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     static_assert(!NARROW || (WGR && !SPLIT && !DBG), "narrow workgroups: workgroup-record form, non-split formats, no test hooks");
-    constexpr int NW = (SPLIT || NARROW) ? 4 : 8;
+    constexpr int NW = NARROW ? 4 : (SPLIT ? DC_SPLIT_NW : 8);
     constexpr int WM = SPLIT ? 2 : 1;            // operand images per matrix (hi [+ lo])
     constexpr int NFW = 32 * WM;
     // diagnostic build aid: 100 MHz timestamps per stage for the waves of workgroup 3 (stamps == nullptr normally)
@@ -2048,7 +2053,7 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                                  int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride,
                                  const int* iter_base, int Tx, int upc, const DcUpdate& upd) {
-    constexpr int NW = (SP || NARROW) ? 4 : 8;
+    constexpr int NW = NARROW ? 4 : (SP ? DC_SPLIT_NW : 8);
     // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
     const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
     static unsigned long long optin_done = 0;   // > 64 KiB of dynamic LDS needs the opt-in

@@ -116,9 +116,8 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
         if k + 1 < nb:
             pf.start(k + 1)
         noise = torch.stack([clip_noise(seed, k * batch_size + i, T, dim_pose) for i in range(len(bid))])
-        pred = trainer.generate_music_motion(mel, dim_pose, noise=noise)          # [B, T, dim_pose] on the device
-        if smooth:
-            pred = smooth_motion(pred.view(len(bid), T, -1, 2), kernel=19).reshape(len(bid), T, dim_pose)
+        # [B, T, dim_pose] on the device; smoothing (tools/visualization.py:126) happens in the sampling loop's final write
+        pred = trainer.generate_music_motion(mel, dim_pose, noise=noise, smooth=19 if smooth else None)
         pred = pred.cpu().numpy()
         for i, cid in enumerate(bid):
             pm = pred[i].reshape([pred[i].shape[0], dim_pose // 2, 2])          # eval_new.py:124-125

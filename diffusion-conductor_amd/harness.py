@@ -40,17 +40,19 @@ class DDPMTrainer(object):
         self.encoder.load_state_dict(checkpoint["encoder"], strict=False)
         return checkpoint.get("ep", 0), checkpoint.get("total_it", 0)
 
-    def _sample_local(self, mel, noise, dim_pose, idxs):
+    def _sample_local(self, mel, noise, dim_pose, idxs, smooth=None):
         xf_proj, xf_out = self.encoder.encode_music(mel, self.device)
         B, T = mel.shape[0], xf_proj.shape[1]
         return self.diffusion.ddim_sample_loop(
             self.encoder, (B, T, dim_pose), noise=noise, clip_denoised=False, progress=False,
             model_kwargs={"xf_proj": xf_proj, "xf_out": xf_out,
                           "length": torch.LongTensor([T] * B)},
-            idxs=idxs)
+            idxs=idxs, smooth=smooth)
 
-    def generate_music_motion(self, music_mel, dim_pose, batch_size=1024, idxs=[], noise=None, seed=None):
-        """music_mel: np.ndarray/tensor [5400,128] (reference) or [B,5400,128] -> tensor [B,1800,dim_pose]."""
+    def generate_music_motion(self, music_mel, dim_pose, batch_size=1024, idxs=[], noise=None, seed=None, smooth=None):
+        """music_mel: np.ndarray/tensor [5400,128] (reference) or [B,5400,128] -> tensor [B,1800,dim_pose].
+        smooth: None, or the Savitzky-Golay kernel size (order 5) tools/visualization.py:126 smooths the keypoints with - applied
+        by the sampling loop's final write."""
         mel = torch.as_tensor(np.asarray(music_mel) if not torch.is_tensor(music_mel) else music_mel)
         if mel.dim() == 2:
             mel = mel.unsqueeze(0)
@@ -74,7 +76,8 @@ class DDPMTrainer(object):
             noise = torch.randn(B, T, dim_pose, generator=g)
         if noise is not None:
             noise = torch.as_tensor(noise).to(self.device, dtype=torch.float32)
+        sm = (int(smooth), 5) if smooth else None
         with torch.no_grad():
             if not grouped or len(idxs):
-                return self._sample_local(mel, noise, dim_pose, idxs)
-            return sharded_sample(lambda m, n: self._sample_local(m, n, dim_pose, []), mel, noise, out_shape=(T, dim_pose))
+                return self._sample_local(mel, noise, dim_pose, idxs, sm)
+            return sharded_sample(lambda m, n: self._sample_local(m, n, dim_pose, [], sm), mel, noise, out_shape=(T, dim_pose))

@@ -23,7 +23,7 @@ EXPORTS = [
     "dc_sampler_set_conditioning", "dc_sampler_encode_music", "dc_sampler_denoise", "dc_sampler_ddim_loop", "dc_sampler_profile_loop",
     "dc_kernel_name", "dc_kernel_count", "dc_sampler_workspace_bytes", "dc_sampler_clip_stride", "dc_sampler_debug_denoise",
     "dc_sampler_debug_read", "dc_sampler_debug_layer", "dc_savgol_coefficients", "dc_savgol_filter",
-    "dc_ddim_coefficients_ex", "dc_sampler_ddim_loop_ex", "dc_sampler_status",
+    "dc_ddim_coefficients_ex", "dc_sampler_ddim_loop_ex", "dc_sampler_status", "dc_sampler_set_smoothing",
 ]
 
 UPDATE_CLIP_DENOISED, UPDATE_EPSILON = 1, 2          # flags of dc_sampler_ddim_loop_ex
@@ -121,6 +121,7 @@ def lib():
     L.dc_sampler_ddim_loop_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, fp, C.c_int32, C.c_void_p, ip, C.c_int32,
                                           C.c_void_p, C.c_void_p]
     L.dc_sampler_status.argtypes = [C.c_void_p, ip, C.c_int32]
+    L.dc_sampler_set_smoothing.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.dc_sampler_debug_denoise.argtypes = [C.c_void_p, C.c_void_p, ip, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.dc_sampler_debug_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
     L.dc_sampler_debug_layer.argtypes = [C.c_void_p, fp, ip, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
@@ -335,6 +336,10 @@ class NativeSampler:
             _check(lib().dc_sampler_ddim_loop_ex(self._h, noise.data_ptr(), out.data_ptr(), S, _fptr(coef), int(flags), zp, sip,
                                                  len(si), snp, self._stream()))
         return out, snaps
+
+    def set_smoothing(self, window=19, order=5):
+        """dc_sampler_set_smoothing: the loops write Savitzky-Golay-smoothed poses from now on (window 0: off)."""
+        _check(lib().dc_sampler_set_smoothing(self._h, int(window), int(order)))
 
     def status(self, clear=True):
         """dc_sampler_status: waits for the sampler's work; OR of STATUS_NONFINITE / STATUS_F16_SATURATED."""

@@ -173,7 +173,7 @@ class GaussianDiffusion:
             self._native_coef[key] = native.ddim_coefficients(self.alphas_cumprod, key)
         return self._native_coef[key]
 
-    def _native_loop(self, model, img, mk, clip_denoised, eta, snap, step_noise):
+    def _native_loop(self, model, img, mk, clip_denoised, eta, snap, step_noise, smooth=None):
         """The captured loop on `model`'s sampler; returns (out, snaps).  Numeric health is checked once per call
         (`model.check_numerics`): a non-finite x0 under precision="auto" falls back to the bf16-range mode in a fresh sampler."""
         flags = (native.UPDATE_CLIP_DENOISED if clip_denoised else 0) | \
@@ -188,6 +188,7 @@ class GaussianDiffusion:
         coef = self.native_coefficients(None if plain else eta)
         while True:
             nat = model.set_conditioning(mk["xf_proj"], mk["xf_out"], mk.get("length"))
+            nat.set_smoothing(*(smooth if smooth else (0, 0)))
             out, snaps = nat.ddim_loop(img, coef, snap, flags, z)
             if not getattr(model, "check_numerics", True):
                 return out, snaps
@@ -198,10 +199,12 @@ class GaussianDiffusion:
                 raise FloatingPointError(native.describe_status(st, model.active_precision))
 
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
-                         model_kwargs=None, device=None, progress=False, eta=0.0, idxs=[], step_noise=None):
+                         model_kwargs=None, device=None, progress=False, eta=0.0, idxs=[], step_noise=None, smooth=None):
         """gaussian_diffusion.py:871-915.  Returns the final sample, or when `idxs` is non-empty a
         dict {iteration: sample} for the listed iterations plus {num_timesteps: final}.
-        `step_noise` (extension, eta > 0): [S, B, T, P], the draw for iteration i in place of th.randn_like."""
+        `step_noise` (extension, eta > 0): [S, B, T, P], the draw for iteration i in place of th.randn_like.
+        `smooth` (extension): (window, order) of the Savitzky-Golay filter tools/visualization.py:126 applies to the result,
+        folded into the loop's final write (native loop only)."""
         if self._fast_path_ok(model, denoised_fn, cond_fn):
             if device is None:
                 device = next(model.parameters()).device
@@ -213,12 +216,14 @@ class GaussianDiffusion:
                 mk = dict(mk)
                 mk["xf_proj"], mk["xf_out"] = model.encode_music(mk["text"], device)
             snap = sorted(int(i) for i in set(idxs) if 0 <= int(i) < self.num_timesteps)
-            out, snaps = self._native_loop(model, img, mk, bool(clip_denoised), float(eta), snap, step_noise)
+            out, snaps = self._native_loop(model, img, mk, bool(clip_denoised), float(eta), snap, step_noise, smooth)
             if len(idxs) == 0:
                 return out
             result = {it: snaps[k] for k, it in enumerate(snap)}
             result[self.num_timesteps] = out
             return result
+        if smooth:
+            raise NotImplementedError("smooth= is folded into the native loop's final write; with host callbacks apply evaluate.smooth_motion")
         final, i, result = None, 0, {}
         for sample in self.ddim_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
                                                         denoised_fn=denoised_fn, cond_fn=cond_fn,

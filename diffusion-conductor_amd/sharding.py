@@ -47,13 +47,15 @@ def sharded_sample(sample_fn, mel, noise=None, group=None, out_shape=None):
     it must still enter the collective, or the other ranks would wait for it forever."""
     rank, world = dist_info(group)
     B = mel.shape[0]
+    # validated on EVERY rank before anyone samples: raising on the one rank whose shard is empty would leave the others
+    # waiting in the all-gather
+    if B < world and out_shape is None and noise is None:
+        raise ValueError("sharded_sample: fewer clips than ranks needs out_shape=(T, P) or noise to size the empty shards' contribution")
     lo, hi = shard_bounds(B, rank, world)
     if hi > lo:
         local = sample_fn(mel[lo:hi], None if noise is None else noise[lo:hi])
     else:
         if out_shape is None:
-            if noise is None:
-                raise ValueError("sharded_sample: an empty shard needs out_shape=(T, P) or noise to size its contribution")
             out_shape = tuple(noise.shape[1:])
         local = torch.zeros((0,) + tuple(out_shape), dtype=torch.float32, device=mel.device)
     return gather_poses(local, B, group)

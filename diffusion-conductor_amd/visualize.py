@@ -3,8 +3,8 @@
     python -m diffusion_conductor_amd.visualize --opt_path <.../opt.txt> --music_path <mel.npy | dir of *.npy> \
         --npy_path out.npy --gpu_id 0 [--smooth] [--model latest.tar] [--seed 0]
 
-Same flags and call sequence as Diffusion_Stage/tools/visualization.py:180-223: ``get_opt`` (utils/get_opt.py:29-105:
-the ``opt.txt`` round trip with its type sniffing and forced fields) -> ``build_models`` (:169-178) -> ``DDPMTrainer`` ->
+Same flags and call sequence as Diffusion_Stage/tools/visualization.py:180-223: ``get_opt`` (this package's reader of the
+training run's ``opt.txt``; the reference's is utils/get_opt.py:29-105) -> ``build_models`` (:169-178) -> ``DDPMTrainer`` ->
 ``trainer.load(<model_dir>/latest.tar)`` -> ``eval_mode`` -> ``generate_music_motion(mel, opt.dim_pose)`` -> reshape
 ``[T,13,2]`` (:217-218) -> (``smooth_motion(kernel=19)``, :126, with ``--smooth``) -> ``np.save(npy_path)``.
 
@@ -25,83 +25,68 @@ from os.path import join as pjoin
 
 import numpy as np
 
-DIM_POS_OHOT = 15      # len(POS_enumerator), utils/word_vectorizer.py:5-21 (a field of opt the sampling path never reads)
+# opt.txt is what train.py writes (options/base_options.py:79-89): one "key: value" line per option between two banner lines.
+# A value is a bool ("True" / "False"), a signed integer, a signed decimal with digits on both sides of the point, or text -
+# anything else (a list, scientific notation) stays text, which is how the reference's reader (utils/get_opt.py:8-26, 37-48)
+# types them too.
+_LINE = re.compile(r"^\s*([^:\s][^:]*?)\s*:\s(.*?)\s*$")
+_INT = re.compile(r"^[+-]?\d+$")
+_DEC = re.compile(r"^[+-]?\d+\.\d+$")
+
+# per dataset: (joints, frames per clip).  Only the conducting-motion dataset has a sampler here.
+_DATASETS = {"ConductorMotion100": (13, 1800)}
+
+# options the sampler reads, with the value an opt.txt that lacks them implies (utils/get_opt.py:50-59)
+_SAMPLER_DEFAULTS = {"num_layers": 8, "latent_dim": 512, "diffusion_steps": 1000, "no_clip": False, "no_eff": False}
 
 
-def is_float(numStr):
-    """utils/get_opt.py:8-18: digits '.' digits, optional sign."""
-    numStr = str(numStr).strip().lstrip('-').lstrip('+')
-    return re.match(r'^[-+]?[0-9]+\.[0-9]+$', numStr) is not None
-
-
-def is_number(numStr):
-    """utils/get_opt.py:21-26."""
-    return str(numStr).strip().lstrip('-').lstrip('+').isdigit()
+def _literal(text):
+    if text in ("True", "False"):
+        return text == "True"
+    if _DEC.match(text):
+        return float(text)
+    if _INT.match(text):
+        return int(text)
+    return text
 
 
 def get_opt(opt_path, device):
-    """utils/get_opt.py:29-105: reads the ``key: value`` lines train.py wrote (options/base_options.py:79-89), sniffs
-    bool / float / int / str exactly as the reference does, then forces the inference fields."""
-    opt = Namespace()
-    opt_dict = vars(opt)
-    skip = ('-------------- End ----------------', '------------ Options -------------', '\n')
-    print('Reading', opt_path)
+    """Reads a training run's ``opt.txt`` into the options object the sampling entry point needs (the role of
+    utils/get_opt.py:29-105).  Every ``key: value`` line becomes an attribute (typed by `_literal`); on top of that the fields
+    the sampler consumes are filled in: the denoiser's size (``num_layers``, ``latent_dim``, ``no_eff``, ``no_clip``),
+    ``diffusion_steps``, the pose geometry of the dataset (``joints_num``, ``dim_pose``, ``max_motion_length``) and where the
+    checkpoint lives (``model_dir`` = <checkpoints_dir>/<dataset_name>/<name>/model, trainers load ``latest.tar`` from it);
+    inference is forced (``is_train`` / ``is_continue`` False, ``which_epoch`` "latest")."""
+    print("Reading", opt_path)
+    opt = Namespace(**_SAMPLER_DEFAULTS)
     with open(opt_path) as f:
-        for line in f:
-            if line.strip() not in skip:
-                key, value = line.strip().split(': ')
-                if value in ('True', 'False'):
-                    opt_dict[key] = value == 'True'
-                elif is_float(value):
-                    opt_dict[key] = float(value)
-                elif is_number(value):
-                    opt_dict[key] = int(value)
-                else:
-                    opt_dict[key] = str(value)
-    opt_dict['which_epoch'] = 'latest'
-    opt_dict.setdefault('num_layers', 8)
-    opt_dict.setdefault('latent_dim', 512)
-    opt_dict.setdefault('diffusion_steps', 1000)
-    opt_dict.setdefault('no_clip', False)
-    opt_dict.setdefault('no_eff', False)
+        for raw in f:
+            m = _LINE.match(raw)
+            if m is None or raw.lstrip().startswith("-"):          # banner / blank lines
+                continue
+            setattr(opt, m.group(1), _literal(m.group(2)))
+    for need in ("checkpoints_dir", "dataset_name", "name"):
+        if not hasattr(opt, need):
+            raise KeyError(f"{opt_path}: no '{need}' line")
+    if opt.dataset_name not in _DATASETS:
+        raise KeyError(f"Dataset not recognized: {opt.dataset_name!r} (this package samples {sorted(_DATASETS)})")
+    opt.joints_num, opt.max_motion_length = _DATASETS[opt.dataset_name]
+    opt.dim_pose = 2 * opt.joints_num
     opt.save_root = pjoin(opt.checkpoints_dir, opt.dataset_name, opt.name)
-    opt.model_dir = pjoin(opt.save_root, 'model')
-    opt.meta_dir = pjoin(opt.save_root, 'meta')
-    if opt.dataset_name == 'ConductorMotion100':
-        opt.data_root = '/mnt/data/zhuoran/'
-        opt.joints_num = 13
-        opt.max_motion_length = 1800
-    elif opt.dataset_name == 't2m':
-        opt.data_root = './data/HumanML3D'
-        opt.motion_dir = pjoin(opt.data_root, 'new_joint_vecs')
-        opt.text_dir = pjoin(opt.data_root, 'texts')
-        opt.joints_num = 22
-        opt.dim_pose = 263
-        opt.max_motion_length = 196
-    elif opt.dataset_name == 'kit':
-        opt.data_root = './data/KIT-ML'
-        opt.motion_dir = pjoin(opt.data_root, 'new_joint_vecs')
-        opt.text_dir = pjoin(opt.data_root, 'texts')
-        opt.joints_num = 21
-        opt.dim_pose = 251
-        opt.max_motion_length = 196
-    else:
-        raise KeyError('Dataset not recognized')
-    opt.dim_word = 300
-    opt.num_classes = 200 // opt.unit_length
-    opt.dim_pos_ohot = DIM_POS_OHOT
+    opt.model_dir = pjoin(opt.save_root, "model")
+    opt.which_epoch = "latest"
     opt.is_train = False
     opt.is_continue = False
     opt.device = device
     return opt
 
 
-def build_models(opt):
+def build_models(opt, precision="fp16"):
     """tools/visualization.py:169-178."""
     from . import MotionTransformer
     return MotionTransformer(input_feats=opt.dim_pose, num_frames=opt.max_motion_length, num_layers=opt.num_layers,
                              latent_dim=opt.latent_dim, device=opt.device, no_clip=opt.no_clip, no_eff=opt.no_eff,
-                             music_model_path=None)
+                             music_model_path=None, precision=precision)
 
 
 def load_mels(music_path):
@@ -135,39 +120,31 @@ def make_parser():
     parser.add_argument('--model', type=str, default=None, help="checkpoint; default <model_dir>/latest.tar as in the reference")
     parser.add_argument('--smooth', action='store_true', help="Savitzky-Golay smoothing (kernel 19, order 5) as vis_motion applies it")
     parser.add_argument('--seed', type=int, default=None, help="seed of x_T (reproducible sampling)")
-    parser.add_argument('--precision', type=str, default="fp16", choices=["fp16", "mixed", "bf16x3", "bf16"])
+    parser.add_argument('--precision', type=str, default="fp16", choices=["fp16", "mixed", "bf16x3", "bf16", "auto"])
     return parser
 
 
 def main(argv=None):
     import torch
     from . import DDPMTrainer
-    from .evaluate import smooth_motion
     args = make_parser().parse_args(argv)
     if args.gpu_id == -1:
         raise SystemExit("this package has no CPU path: --gpu_id must name an MI355X")
     device = torch.device('cuda:%d' % args.gpu_id)
     opt = get_opt(args.opt_path, device)
-    opt.do_denoise = True
     assert args.motion_length <= 196
-    opt.joints_num = 13
-    opt.dim_pose = 26
     torch.cuda.set_device(device)
-    encoder = build_models(opt)
-    encoder.precision = args.precision
-    encoder = encoder.to(device)
+    encoder = build_models(opt, precision=args.precision).to(device)
     trainer = DDPMTrainer(opt, encoder)
     trainer.load(args.model if args.model else pjoin(opt.model_dir, 'latest.tar'))
     trainer.eval_mode()
     trainer.to(opt.device)
     with torch.no_grad():
         mel, names = load_mels(args.music_path)
-        pred_motions = trainer.generate_music_motion(mel, opt.dim_pose, seed=args.seed)      # [B, T, 26] on the device
+        # [B, T, 26] on the device; --smooth: smooth_motion(kernel=19) (:126) happens in the loop's final write
+        pred_motions = trainer.generate_music_motion(mel, opt.dim_pose, seed=args.seed, smooth=19 if args.smooth else None)
         B, T = pred_motions.shape[0], pred_motions.shape[1]
-        motion = pred_motions.view(B, T, 13, 2)
-        if args.smooth:
-            motion = smooth_motion(motion, kernel=19)
-        motion = motion.cpu().numpy()
+        motion = pred_motions.view(B, T, 13, 2).cpu().numpy()
     out = motion[0] if mel.ndim == 2 else motion
     print(" #%d frames x %d clip(s): %s" % (T, B, ", ".join(names)))
     if args.npy_path:

@@ -218,6 +218,10 @@ int dc_sampler_debug_layer(dc_sampler* s, const float* h_h, const int32_t* h_tim
  * the FIR taps, rows 0..window/2-1 and window/2+1.. the edge frames).  dc_savgol_filter: d_in, d_out fp32 [B, T, P] device
  * pointers (distinct), T >= window. */
 int dc_savgol_coefficients(int32_t window, int32_t order, float* h_coef);
+/* The same filter as part of the sampling loop: after this call dc_sampler_ddim_loop / _ex write
+ * the SMOOTHED x0 to d_out - the filter reads the loop's final x0 and writes the caller's tensor in place of the plain copy, so
+ * smoothing costs no pass of its own.  window = 0 switches it off again; snapshots (`idxs`) stay unsmoothed. */
+int dc_sampler_set_smoothing(dc_sampler* s, int32_t window, int32_t order);
 int dc_savgol_filter(const float* d_in, float* d_out, int32_t B, int32_t T, int32_t P, int32_t window, int32_t order,
                      void* stream);
 

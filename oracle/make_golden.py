@@ -339,13 +339,15 @@ def main():
 
     def make_g9():
         # ---- G9: the sampler's other branches (gaussian_diffusion.py:503-521, 812-830, 876) at B=2, T=96, ragged, DDIM-50,
-        # on the stress checkpoint (its x0 predictions leave [-1, 1], so the clamp is active): clip_denoised=True (the
-        # default of ddim_sample_loop), eta=0.5, and ModelMeanType.EPSILON with clip + eta=0.3.  th.randn_like inside
+        # on the seed-0 checkpoint (40 % of its x0 predictions leave [-1, 1], so the clamp is active): clip_denoised=True
+        # (the default of ddim_sample_loop), eta=0.5, and ModelMeanType.EPSILON with clip + eta=0.3.  th.randn_like inside
         # ddim_sample is patched to hand out the seeded per-iteration noise, so the oracle / the HIP path can be fed the
-        # same draws.
-        from diffusion_conductor_amd.synthetic import batch_step_noise, stress_state_dict
-        sd = stress_state_dict(DenoiserConfig(), seed=0)
-        q = O.to_torch_params(sd)
+        # same draws.  (Not the stress checkpoint: its predictions are ~300x outside [-1, 1], and a clamp at 1 turns a 3e-4
+        # relative error of such a prediction into a 3e-2 absolute one on every element that crosses zero - any 11-bit
+        # arithmetic, the oracle's own fp16 emulation included, reads 3e-3 there.)
+        from diffusion_conductor_amd.synthetic import batch_step_noise
+        sd = sd_np
+        q = p
         m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cpu",
                               music_model_path=None, no_clip=True)
         m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)

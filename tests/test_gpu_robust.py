@@ -70,7 +70,7 @@ def test_ddim50_other_checkpoints_g8(case, prec):
 
 
 def _g9_setup():
-    sd = stress_state_dict(DenoiserConfig(), seed=0)
+    sd = synthetic_state_dict(DenoiserConfig(), seed=0)
     B, T, S = 2, 96, 50
     xfp, xfo = _features(sd, B, T, 40)
     return sd, B, T, S, [96, 70], xfp.cuda(), xfo.cuda(), torch.from_numpy(batch_noise(B, T, first=40)).cuda(), \
@@ -181,3 +181,28 @@ def test_nonfinite_flag_and_auto_fallback():
     print(f"auto fallback: active precision {ma.active_precision}, rel-L2 vs oracle {err:.3e}")
     assert ma.active_precision == "mixed" and torch.isfinite(out).all() and err <= TOL
     assert ma._native.status() & native.STATUS_NONFINITE == 0
+
+
+def test_smoothing_in_the_loops_final_write():
+    """dc_sampler_set_smoothing: the loop's final write applies the Savitzky-Golay filter (tools/visualization.py:20-26, 126)
+    in place of the plain copy - the same numbers as filtering the unsmoothed result afterwards (bit for bit: one kernel on the
+    same x0), scipy within 1e-5; snapshots stay unsmoothed; window 0 switches it off."""
+    from scipy.signal import savgol_filter
+    from diffusion_conductor_amd import native
+    sd, B, T, S, length, xfp, xfo, noise, z = _g9_setup()
+    m = _model(sd, "fp16")
+    gd = make_diffusion(S)
+    kw = dict(noise=noise, clip_denoised=False, progress=False, idxs=[10],
+              model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.LongTensor(length)})
+    plain = gd.ddim_sample_loop(m, (B, T, 26), **kw)
+    sm = gd.ddim_sample_loop(m, (B, T, 26), smooth=(19, 5), **kw)
+    again = gd.ddim_sample_loop(m, (B, T, 26), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(sm[10], plain[10]) and torch.equal(again[S], plain[S])
+    assert torch.equal(sm[S], native.savgol_filter(plain[S], 19, 5))
+    ref = savgol_filter(plain[S].cpu().numpy().astype(np.float64), 19, 5, axis=1)
+    err = rel_l2(sm[S], ref)
+    print(f"in-loop smoothing vs scipy: rel-L2 {err:.3e}")
+    assert err <= 1e-5 and rel_l2(sm[S], plain[S]) > 1e-3
+    with pytest.raises(native.DcError, match="window"):
+        m._native.set_smoothing(18, 5)

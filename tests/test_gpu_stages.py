@@ -183,7 +183,11 @@ print("NCCL_OK")
 
 
 def test_rccl_world_size_one_gather():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    with socket.socket() as sk:                 # a free port: concurrent runs on one box must not collide
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _NCCL_SCRIPT.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "NCCL_OK" in r.stdout

@@ -298,30 +298,31 @@ def test_production_layer_kernel_has_no_register_spills():
     assert all(spills[k] == 0 for k in prod), {k: spills[k] for k in prod}
 
 
-# ---- tools/visualization.py-shaped entry point: the opt.txt round trip (utils/get_opt.py:29-105) ---------------------------
-def test_get_opt_parses_like_the_reference(tmp_path):
-    from diffusion_conductor_amd.visualize import get_opt, is_float, is_number, make_parser
+# ---- tools/visualization.py-shaped entry point: reading a training run's opt.txt ------------------------------------------
+def test_get_opt_reads_a_training_runs_opt_txt(tmp_path):
+    from diffusion_conductor_amd.visualize import get_opt, make_parser
     p = tmp_path / "opt.txt"
     p.write_text("------------ Options -------------\n"
                  "batch_size: 32\ncheckpoints_dir: ./checkpoints\ndataset_name: ConductorMotion100\ndiffusion_steps: 50\n"
                  "gpu_id: [0]\nis_train: True\nlatent_dim: 128\nlr: 0.0002\nname: train\nno_clip: True\nnum_epochs: 500\n"
-                 "unit_length: 4\nweird: 1e-4\nneg: -3\nnegf: -0.5\n"
+                 "unit_length: 4\nweird: 1e-4\nneg: -3\nnegf: -0.5\nplus: +7\nnote: a value: with a colon\n"
                  "-------------- End ----------------\n")
     opt = get_opt(str(p), "cuda:0")
     assert opt.batch_size == 32 and isinstance(opt.batch_size, int)
     assert opt.lr == 0.0002 and isinstance(opt.lr, float)
-    assert opt.no_clip is True and opt.no_eff is False          # no_eff absent -> default (get_opt.py:58-59)
-    assert opt.gpu_id == "[0]" and opt.weird == "1e-4"          # neither int nor digits.digits: stays a string, as in the reference
-    assert opt.neg == -3 and opt.negf == -0.5
+    assert opt.no_clip is True and opt.no_eff is False          # no_eff absent -> the default an old opt.txt implies
+    assert opt.gpu_id == "[0]" and opt.weird == "1e-4"          # neither an integer nor digits.digits: stays text
+    assert opt.neg == -3 and opt.negf == -0.5 and opt.plus == 7 and opt.note == "a value: with a colon"
     assert opt.num_layers == 8 and opt.latent_dim == 128 and opt.diffusion_steps == 50
     assert opt.which_epoch == "latest" and opt.is_train is False and opt.is_continue is False
-    assert opt.max_motion_length == 1800 and opt.joints_num == 13
-    assert opt.model_dir == os.path.join("./checkpoints", "ConductorMotion100", "train", "model")
-    assert opt.num_classes == 50 and opt.dim_word == 300 and opt.dim_pos_ohot == 15 and opt.device == "cuda:0"
-    assert is_float("-0.5") and not is_float("1e-4") and not is_float("5") and is_number("+7") and not is_number("7.0")
-    (tmp_path / "bad.txt").write_text("dataset_name: nope\ncheckpoints_dir: x\nname: y\nunit_length: 4\n")
-    with pytest.raises(KeyError):
+    assert opt.max_motion_length == 1800 and opt.joints_num == 13 and opt.dim_pose == 26
+    assert opt.model_dir == os.path.join("./checkpoints", "ConductorMotion100", "train", "model") and opt.device == "cuda:0"
+    (tmp_path / "bad.txt").write_text("dataset_name: t2m\ncheckpoints_dir: x\nname: y\nunit_length: 4\n")
+    with pytest.raises(KeyError, match="Dataset not recognized"):
         get_opt(str(tmp_path / "bad.txt"), "cpu")
+    (tmp_path / "short.txt").write_text("dataset_name: ConductorMotion100\nname: y\n")
+    with pytest.raises(KeyError, match="checkpoints_dir"):
+        get_opt(str(tmp_path / "short.txt"), "cpu")
     a = make_parser().parse_args(["--opt_path", "o", "--music_path", "m.npy"])
     assert a.npy_path == "" and a.motion_length == 60 and a.result_path == "test_sample.gif"      # the reference's defaults
 
@@ -343,15 +344,48 @@ def test_bench_parent_spawns_one_process_per_gpu():
     code.  In this CPU container every rank stops at the `needs MI355X` assert - after having received its RANK."""
     import subprocess
     import sys
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       env=env, capture_output=True, text=True, timeout=600)
     import torch
     if torch.cuda.is_available():
         pytest.skip("CPU-container test (on a GPU box both ranks would share cuda:0 / need cuda:1)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DC_BENCH_WORKER")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert r.stderr.count("AssertionError: bench.py needs MI355X GPUs") == 2, r.stderr[-2000:]
     assert "WORLD_SIZE=" not in r.stderr                      # the ranks saw WORLD_SIZE == --gpus
+
+
+def test_bench_parent_launches_eight_ranks(tmp_path):
+    """The launcher at N = 8 (the driver's scaling run), with a stub in place of the rank program: eight processes, ranks 0..7,
+    one rendezvous (127.0.0.1, one port, HSA_ENABLE_IPC_MODE_LEGACY=0), the arguments forwarded, rank 0's JSON line on the
+    parent's stdout and the worst child code as the parent's own."""
+    import json
+    import subprocess
+    import sys
+    stub = tmp_path / "rank_stub.py"
+    stub.write_text(
+        "import json, os, sys\n"
+        "r = int(os.environ['RANK'])\n"
+        "rec = {k: os.environ.get(k) for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',"
+        " 'HSA_ENABLE_IPC_MODE_LEGACY')}\n"
+        "rec['argv'] = sys.argv[1:]\n"
+        "open(os.path.join(os.environ['STUB_OUT'], f'rank{r}.json'), 'w').write(json.dumps(rec))\n"
+        "if r == 0: print(json.dumps({'metric': 'stub', 'n_gpus': int(os.environ['WORLD_SIZE'])}), flush=True)\n"
+        "sys.exit(int(os.environ.get('STUB_FAIL_RANK', '-1')) == r and 7 or 0)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DC_BENCH_WORKER=str(stub), STUB_OUT=str(tmp_path))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == {"metric": "stub", "n_gpus": 8}
+    recs = [json.loads((tmp_path / f"rank{i}.json").read_text()) for i in range(8)]
+    assert [int(x["RANK"]) for x in recs] == list(range(8)) == [int(x["LOCAL_RANK"]) for x in recs]
+    assert {x["WORLD_SIZE"] for x in recs} == {"8"} == {x["LOCAL_WORLD_SIZE"] for x in recs}
+    assert {x["MASTER_ADDR"] for x in recs} == {"127.0.0.1"} and len({x["MASTER_PORT"] for x in recs}) == 1
+    assert {x["HSA_ENABLE_IPC_MODE_LEGACY"] for x in recs} == {"0"}
+    assert all(x["argv"] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] for x in recs)
+    r = subprocess.run(cmd, env=dict(env, STUB_FAIL_RANK="5"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7                                   # a failing rank is the parent's exit code
 
 
 def test_prefetcher_hands_loader_errors_to_the_consumer(tmp_path):

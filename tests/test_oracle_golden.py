@@ -140,9 +140,9 @@ def test_sampler_branches_g9():
     """G9: clip_denoised=True, eta = 0.5 and ModelMeanType.EPSILON (+ clip, eta = 0.3) of the oracle's loop against the
     reference's ddim_sample_loop / _progressive outputs (final sample, idxs, pred_xstart of three iterations)."""
     from diffusion_conductor_amd.param_spec import DenoiserConfig
-    from diffusion_conductor_amd.synthetic import batch_step_noise, stress_state_dict
+    from diffusion_conductor_amd.synthetic import batch_step_noise, synthetic_state_dict
     g = golden("g9_sampler_branches.npz")
-    sd = stress_state_dict(DenoiserConfig(), seed=0)
+    sd = synthetic_state_dict(DenoiserConfig(), seed=0)
     q = O.to_torch_params(sd)
     B, T, S = 2, 96, 50
     xfp, xfo = _features_of(sd, B, T, 40)
