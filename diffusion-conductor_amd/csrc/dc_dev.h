@@ -163,9 +163,10 @@ DEV void mmb_oc_pair(f32x16& acca, f32x16& accb, const v8<T16>* __restrict__ wa,
         }
 }
 
-// all four output tiles of one 128 x 128 image at once: four independent chains (non-split)
-template <int OC, int KT, class T16>
-DEV void mmb_oc_quad(f32x16& a, f32x16& b, f32x16& c, f32x16& d, const v8<T16>* __restrict__ w, const XFrag<T16, false> (&x)[KT], int lane) {
+// all four output tiles of one 128 x 128 image at once: four independent chains (split: three products per fragment)
+template <int OC, int KT, class T16, bool SPLIT = false>
+DEV void mmb_oc_quad(f32x16& a, f32x16& b, f32x16& c, f32x16& d, const v8<T16>* __restrict__ w, const XFrag<T16, SPLIT> (&x)[KT], int lane) {
+    constexpr int NF = OC * KT * 2;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -176,6 +177,18 @@ DEV void mmb_oc_quad(f32x16& a, f32x16& b, f32x16& c, f32x16& d, const v8<T16>* 
             b = mfma(x[kt].hi[s], fb, b);
             c = mfma(x[kt].hi[s], fc, c);
             d = mfma(x[kt].hi[s], fd, d);
+            if constexpr (SPLIT) {
+                a = mfma(x[kt].lo[s], fa, a);
+                b = mfma(x[kt].lo[s], fb, b);
+                c = mfma(x[kt].lo[s], fc, c);
+                d = mfma(x[kt].lo[s], fd, d);
+                const v8<T16> la = w[(NF + (kt * OC + 0) * 2 + s) * 64 + lane], lb = w[(NF + (kt * OC + 1) * 2 + s) * 64 + lane];
+                const v8<T16> lc = w[(NF + (kt * OC + 2) * 2 + s) * 64 + lane], ld = w[(NF + (kt * OC + 3) * 2 + s) * 64 + lane];
+                a = mfma(x[kt].hi[s], la, a);
+                b = mfma(x[kt].hi[s], lb, b);
+                c = mfma(x[kt].hi[s], lc, c);
+                d = mfma(x[kt].hi[s], ld, d);
+            }
         }
 }
 
@@ -184,7 +197,23 @@ DEV f32x16 ld_ft(const float* __restrict__ p, int tile, int hh) {
     return *reinterpret_cast<const f32x16*>(p + (tile * 2 + hh) * 16);
 }
 
+#ifndef DC_SCALAR_F32
 typedef float f32x2 __attribute__((ext_vector_type(2)));   // operand of the packed-fp32 VALU ops (v_pk_add/mul/fma_f32)
+DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+// A/B build (tools/ab.sh build S -DDC_SCALAR_F32 -fno-slp-vectorize): the same arithmetic as scalar v_add / v_mul / v_fma_f32 -
+// MI355X_MICROARCH.md prices packed fp32 beside MFMAs as an anti-lever; measured on this kernel in DESIGN.md section 4
+struct f32x2 {
+    float x, y;
+};
+DEV f32x2 operator+(f32x2 a, f32x2 b) { return {a.x + b.x, a.y + b.y}; }
+DEV f32x2 operator-(f32x2 a, f32x2 b) { return {a.x - b.x, a.y - b.y}; }
+DEV f32x2 operator*(f32x2 a, f32x2 b) { return {a.x * b.x, a.y * b.y}; }
+DEV f32x2 operator+(f32x2 a, float b) { return {a.x + b, a.y + b}; }
+DEV f32x2 operator*(f32x2 a, float b) { return {a.x * b, a.y * b}; }
+DEV f32x2& operator+=(f32x2& a, f32x2 b) { a.x += b.x; a.y += b.y; return a; }
+DEV f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#endif
 typedef __attribute__((ext_vector_type(8))) uint32_t u32x8;
 // nn.LayerNorm(128) over the feature axis of an FT activation (transformer.py:79,104,147)
 template <int NT>
@@ -197,7 +226,7 @@ DEV void ln_stats(const f32x16 (&x)[NT], float& mean, float& rstd) {
         for (int r = 0; r < 8; ++r) {
             const f32x2 v = {x[t][2 * r], x[t][2 * r + 1]};
             s2 += v;
-            q2 = __builtin_elementwise_fma(v, v, q2);
+            q2 = fma2(v, v, q2);
         }
     const float s = xhalf_sum(s2.x + s2.y);
     const float q = xhalf_sum(q2.x + q2.y);
@@ -217,7 +246,7 @@ DEV void ln_frags(XFrag<T16, SPLIT> (&nf)[4], const f32x16 (&x)[4]) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const f32x2 v = {x[kt][2 * r], x[kt][2 * r + 1]};
-            const f32x2 w = __builtin_elementwise_fma(v, (f32x2){rstd, rstd}, (f32x2){shift, shift});
+            const f32x2 w = fma2(v, (f32x2){rstd, rstd}, (f32x2){shift, shift});
             n[2 * r] = w.x;
             n[2 * r + 1] = w.y;
         }
@@ -321,19 +350,19 @@ DEV float gelu_erf(float x) {
 DEV f32x2 gelu_erf_pair(float x0, float x1) {
     const f32x2 x = {x0, x1};
     const f32x2 ax = {fabsf(x0), fabsf(x1)};
-    const f32x2 den = __builtin_elementwise_fma(ax, (f32x2){0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f},
+    const f32x2 den = fma2(ax, (f32x2){0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f},
                                                 (f32x2){1.f, 1.f});
     const f32x2 t = {fast_rcp(den.x), fast_rcp(den.y)};
-    f32x2 poly = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
-    poly = __builtin_elementwise_fma(poly, t, (f32x2){1.421413741f, 1.421413741f});
-    poly = __builtin_elementwise_fma(poly, t, (f32x2){-0.284496736f, -0.284496736f});
-    poly = __builtin_elementwise_fma(poly, t, (f32x2){0.254829592f, 0.254829592f});
+    f32x2 poly = fma2(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
+    poly = fma2(poly, t, (f32x2){1.421413741f, 1.421413741f});
+    poly = fma2(poly, t, (f32x2){-0.284496736f, -0.284496736f});
+    poly = fma2(poly, t, (f32x2){0.254829592f, 0.254829592f});
     const f32x2 xx = x * x * (-0.5f * 1.4426950408889634f);
     const f32x2 ex = {exp2f_fast(xx.x), exp2f_fast(xx.y)};
     const f32x2 pe = poly * t * ex;                                    // 1 - erf(a)
     const f32x2 half_ax = ax * 0.5f;
     // x/2 + |x|/2 (1 - pe)
-    return __builtin_elementwise_fma(half_ax, (f32x2){1.f, 1.f} - pe, x * 0.5f);
+    return fma2(half_ax, (f32x2){1.f, 1.f} - pe, x * 0.5f);
 }
 
 // XCD-aware workgroup index: blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so logical workgroup
@@ -644,7 +673,7 @@ DEV float wg_colmax(const float* mx, int oc, int sl, int c) {
     return m == -INFINITY ? 0.f : m;
 }
 // one 32-feature tile against a GIVEN column maximum: column sums of exp2(K-m) and the kept head blocks of exp2(K-m)^T V
-template <class T16>
+template <class T16, bool SPLIT = false>
 DEV void partial_tile(const f32x16& K, const f32x16& V, const RowRange& rr, float m, const GroupCtx& cx, float& ssum, f32x8& keep) {
     f32x16 Ee, Vm;
     float s = 0.f;
@@ -662,12 +691,18 @@ DEV void partial_tile(const f32x16& K, const f32x16& V, const RowRange& rr, floa
         }
     }
     ssum = xhalf_sum(s);
-    XFrag<T16, false> ef, vf;
-    make_frag<T16, false>(Ee, ef);
-    make_frag<T16, false>(Vm, vf);
+    XFrag<T16, SPLIT> ef, vf;
+    make_frag<T16, SPLIT>(Ee, ef);
+    make_frag<T16, SPLIT>(Vm, vf);
     f32x16 P = splat(0.f);
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) P = mfma(ef.hi[s2], vf.hi[s2], P);
+    for (int s2 = 0; s2 < 2; ++s2) {
+        P = mfma(ef.hi[s2], vf.hi[s2], P);
+        if constexpr (SPLIT) {
+            P = mfma(ef.lo[s2], vf.hi[s2], P);
+            P = mfma(ef.hi[s2], vf.lo[s2], P);
+        }
+    }
     keep = keep_head_block(P, cx.c);
 }
 
@@ -714,8 +749,9 @@ DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8*
 }
 // The workgroup's own combine (512 threads): attention operand fragments A[d][l] of clips ub0, ub0+1 from the unit
 // records of the previous kernel -> af [2 clips][8 frags][64 lanes] in LDS (the 8 hi fragments k_attn_combine makes).
+// SPLIT (clip-aligned units only: the workgroup has ONE clip): af [8 hi frags | 8 lo frags][64 lanes] of clip ub0.
 // scratch (LDS): w [2][NU][128] floats, z [2][128] floats.  Summation order is fixed.
-template <class T16>
+template <class T16, bool SPLIT = false>
 DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scratch, int ub0, int B, int M, int T, int tid, int wg,
                          unsigned long long* st = nullptr) {
 #define CSTAMP(k) do { if (st && (tid & 63) == 0) st[(tid >> 6) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -813,19 +849,31 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
         for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], pv[j], acc[j]);
     }
     CSTAMP(25);
-    v8<T16> out, zero;
+    v8<T16> out, outl, zero;
     {
         float z8[8];
         wrow(zsc + ci * 128, z8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            out[j] = (T16)(z8[j] > 0.f ? acc[j] * fast_rcp(z8[j]) : 0.f);
+            // (split: an exact division - the reciprocal approximation's 1 ulp would be the largest error of the mode)
+            const float a = z8[j] > 0.f ? (SPLIT ? acc[j] / z8[j] : acc[j] * fast_rcp(z8[j])) : 0.f;
+            out[j] = (T16)a;
+            outl[j] = (T16)(a - (float)out[j]);
             zero[j] = (T16)0.f;
         }
     }
     const int s = c >> 4;
-    af[(ci * 8 + oc * 2 + s) * 64 + ln] = out;
-    af[(ci * 8 + oc * 2 + (s ^ 1)) * 64 + ln] = zero;
+    if constexpr (SPLIT) {
+        if (ci == 0) {
+            af[(oc * 2 + s) * 64 + ln] = out;
+            af[(oc * 2 + (s ^ 1)) * 64 + ln] = zero;
+            af[(8 + oc * 2 + s) * 64 + ln] = outl;
+            af[(8 + oc * 2 + (s ^ 1)) * 64 + ln] = zero;
+        }
+    } else {
+        af[(ci * 8 + oc * 2 + s) * 64 + ln] = out;
+        af[(ci * 8 + oc * 2 + (s ^ 1)) * 64 + ln] = zero;
+    }
 }
 
 
@@ -1013,7 +1061,7 @@ struct RowStats {
         for (int r = 0; r < 8; ++r) {
             const f32x2 v = {x[2 * r], x[2 * r + 1]};
             s += v;
-            q = __builtin_elementwise_fma(v, v, q);
+            q = fma2(v, v, q);
         }
     }
     // LayerNorm(128) of a StylizationBlock input, in the log2(e) scaling of styl_tile: log2(e) nhat = x*rstd + shift

@@ -678,8 +678,10 @@ DEV void film_gemm3_body(const v8<T16>* __restrict__ W, const float* __restrict_
         }
         // epilogue: fp16, token halves swapped into place, store in the 32 x 32 tile order
         const int blk = p >> 2, t = p & 3;
-#ifndef DC_NO_SAT_CHECK
-        {   // fp16 storage range check (DC_STATUS_F16_SAT): |value| > 65504 would be stored as inf.  43 v_max3_f32 per 512 MFMAs.
+#ifdef DC_FILM_SAT_CHECK
+        // (off in the production build: measured at 12 us per launch = 4 % of this kernel, 1.6 % of the loop, same box; a saturated
+        // tile reaches x0 as inf / nan, DC_STATUS_NONFINITE, and dc_sampler_status then scans the tiles: k_scan_f16_nonfinite)
+        {   // fp16 storage range check (DC_STATUS_F16_SAT): |value| > 65504 would be stored as inf.  64 v_max3_f32 per 512 MFMAs.
             float am = 0.f;
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti)
@@ -765,7 +767,7 @@ DEV void embed_front_body(const DcModel* __restrict__ dm, const float* __restric
                           int wg_fixed /* >= 0: this workgroup's unit (the caller's grid is not the unit grid) */) {
     static_assert(!(FROMH && WGR), "the h-injection hook exists for the per-group-record form only");
     static_assert(!NARROW || (WGR && !SPLIT), "narrow workgroups exist for the workgroup-record form of the non-split formats");
-    constexpr int NW = (SPLIT || NARROW) ? 4 : 8;
+    constexpr int NW = (NARROW || (SPLIT && !WGR)) ? 4 : 8;
     constexpr int WM = SPLIT ? 2 : 1;
     const bool stamping = clk && blockIdx.x == 100 && threadIdx.x == 0;
     auto stamp = [&](int i) {
@@ -785,13 +787,19 @@ DEV void embed_front_body(const DcModel* __restrict__ dm, const float* __restric
     const int n = live ? xn : 0;
     const size_t xrow = (size_t)xb * Tx + n;                                     // row of x
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int OFF_IMG_K = 8192, OFF_IMG_V = 8192 + 65536 + 8192 + 9 * 4 * 32 * 4;
+    // LDS (workgroup records): mx 8 KiB | pst (64 KiB; the key image lies here) | xp 8 KiB (non-split) | ss 4.5 KiB | value image.
+    // Split formats: the images are 65 KiB (hi + lo fragments + constants), pst overlays the key image once it is consumed, and no
+    // wave spans two clips (clip-aligned units), so there is no xp.
+    constexpr int NIMG = 32 * WM + 1;
+    constexpr int PST_SZ = SPLIT ? NIMG * 1024 : 65536, XP_SZ = SPLIT ? 0 : 8192;
+    constexpr int OFF_SS = 8192 + PST_SZ + XP_SZ;
+    constexpr int OFF_IMG_K = 8192, OFF_IMG_V = OFF_SS + 9 * 4 * 32 * 4;
     if constexpr (WGR) {
-        // layer 0's key / value images (32 fragments + 1 KiB of bias each) go to LDS by LDS-DMA while the embedding is
+        // layer 0's key / value images (32 fragments (x 2: hi, lo) + 1 KiB of bias each) go to LDS by LDS-DMA while the embedding is
         // computed; the key image lies in the pst region, which is first written after the barrier that ends its use
         const W* gk = reinterpret_cast<const W*>(dm->layer[0].img_sa_k);
         const W* gv = reinterpret_cast<const W*>(dm->layer[0].img_sa_v);
-        for (int f = wave; f < 33; f += NW) {
+        for (int f = wave; f < NIMG; f += NW) {
             lds_dma16(gk + f * 64 + lane, lds + OFF_IMG_K + f * 1024);
             lds_dma16(gv + f * 64 + lane, lds + OFF_IMG_V + f * 1024);
         }
@@ -811,7 +819,7 @@ DEV void embed_front_body(const DcModel* __restrict__ dm, const float* __restric
         XFrag<T16, true> xf[1];
         f32x16 xv;
         bool staged = false;
-        if constexpr (WGR) {
+        if constexpr (WGR && !SPLIT) {
             // A group's 32 x P floats are contiguous: fetch them with 16-byte loads (<= 4 per lane) and turn them through a
             // wave-private LDS patch.  (Per-element loads touch 32+ cache lines per instruction; the 8 waves' 128 such
             // instructions queue in the CU's address unit for ~4 us.)  The last, partial group keeps the element loads.
@@ -872,16 +880,16 @@ DEV void embed_front_body(const DcModel* __restrict__ dm, const float* __restric
     if constexpr (!WGR) {
         front_stage<T16, SPLIT>(nf, wk, wv, reinterpret_cast<const float*>(wk + 32 * WM * 64),
                                 reinterpret_cast<const float*>(wv + 32 * WM * 64), cx, M, T, length, recs, active);
-    } else {     // workgroup-level record (see wg_* helpers); LDS: mx 8 KiB | pst 64 KiB | xp 8 KiB | ss 4.5 KiB | value image 33 KiB
+    } else {     // workgroup-level record (see wg_* helpers); LDS map above
         float* mx = reinterpret_cast<float*>(lds);
         f32x8* pst = reinterpret_cast<f32x8*>(lds + 8192);
-        f32x8* xp = reinterpret_cast<f32x8*>(lds + 8192 + 65536);
-        float* ss = reinterpret_cast<float*>(lds + 8192 + 65536 + 8192);
+        f32x8* xp = reinterpret_cast<f32x8*>(lds + 8192 + PST_SZ);
+        float* ss = reinterpret_cast<float*>(lds + OFF_SS);
         const int ub0 = wm.ub0;
         const W* lk = reinterpret_cast<const W*>(lds + OFF_IMG_K);
         const W* lv = reinterpret_cast<const W*>(lds + OFF_IMG_V);
-        const float* bk = reinterpret_cast<const float*>(lk + 32 * 64);
-        const float* bv = reinterpret_cast<const float*>(lv + 32 * 64);
+        const float* bk = reinterpret_cast<const float*>(lk + 32 * WM * 64);
+        const float* bv = reinterpret_cast<const float*>(lv + 32 * WM * 64);
         const RowRange vr[2] = {valid_rows_clip(cx, ub0, B, M, T, length, active), valid_rows_clip(cx, ub0 + 1, B, M, T, length, active)};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's image pieces have landed
         __syncthreads();
@@ -890,7 +898,7 @@ DEV void embed_front_body(const DcModel* __restrict__ dm, const float* __restric
 #pragma unroll
         for (int oc = 0; oc < 4; ++oc) {
             K[oc] = splat(bk[32 * oc + cx.c]);
-            mmb_oc<4, 4, T16, false>(K[oc], lk, oc, nf, lane);
+            mmb_oc<4, 4, T16, SPLIT>(K[oc], lk, oc, nf, lane);
         }
         wg_put_maxes<NW>(K, cx, vr, mx, wave);
         __syncthreads();
@@ -901,14 +909,14 @@ DEV void embed_front_body(const DcModel* __restrict__ dm, const float* __restric
 #pragma unroll
         for (int oc = 0; oc < 4; ++oc) {
             f32x16 V = splat(bv[32 * oc + cx.c]);
-            mmb_oc<4, 4, T16, false>(V, lv, oc, nf, lane);
+            mmb_oc<4, 4, T16, SPLIT>(V, lv, oc, nf, lane);
             float ssum;
             f32x8 keep;
-            partial_tile<T16>(K[oc], V, vr_own, wg_colmax<NW>(mx, oc, s0, cx.c), cx, ssum, keep);
+            partial_tile<T16, SPLIT>(K[oc], V, vr_own, wg_colmax<NW>(mx, oc, s0, cx.c), cx, ssum, keep);
             pst[(wave * 4 + oc) * 64 + lane] = keep;
             if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssum;
-            if (active && cx.straddle) {
-                partial_tile<T16>(K[oc], V, vr[1], wg_colmax<NW>(mx, oc, 1, cx.c), cx, ssum, keep);
+            if (!SPLIT && active && cx.straddle) {
+                partial_tile<T16, SPLIT>(K[oc], V, vr[1], wg_colmax<NW>(mx, oc, 1, cx.c), cx, ssum, keep);
                 xp[oc * 64 + lane] = keep;
                 if (cx.hh == 0) ss[(NW * 4 + oc) * 32 + cx.c] = ssum;
             }
@@ -922,7 +930,7 @@ DEV void embed_front_body(const DcModel* __restrict__ dm, const float* __restric
     }
 }
 template <class T16, bool SPLIT, bool WGR, bool FROMH = false, bool NARROW = false>
-__global__ __launch_bounds__((SPLIT || NARROW) ? 256 : 512, (SPLIT || NARROW) ? 1 : 2)
+__global__ __launch_bounds__((NARROW || (SPLIT && !WGR)) ? 256 : 512, (NARROW || (SPLIT && !WGR)) ? 1 : 2)
 void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x, float* __restrict__ hbuf, float* __restrict__ recs,
                    const int* __restrict__ length, int M, int T, int G, int B, unsigned long long* __restrict__ clk, int l0, int Tx, int upc) {
     embed_front_body<T16, SPLIT, WGR, FROMH, NARROW>(dm, x, hbuf, recs, length, M, T, G, B, clk, l0, Tx, upc, -1);
@@ -1017,9 +1025,11 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             stamps[264 + ((l - 3) * 256 + blockIdx.x) * 2 + (e)] = __builtin_amdgcn_s_memrealtime();       \
     } while (0)
     constexpr int WSZ = (NFW + 1) * 1024;
-    constexpr int OFF_AF = 2 * WSZ;              // non-split: attention frags of the workgroup's <= 2 clips (16 KiB)
+    constexpr int OFF_AF = 2 * WSZ;              // attention frags: non-split 8 hi frags of each of the workgroup's <= 2 clips; split (clip-aligned
+                                                 // units, one clip per workgroup) its 8 hi + 8 lo frags (16 KiB either way)
     constexpr int OFF_ER = OFF_AF + 16384;       // non-split: per-wave FiLM tile rings (8 KiB each)
-    constexpr int OFF_SS = OFF_ER + 8 * 8192;    // non-split: column sums of the workgroup record (4.5 KiB)
+    constexpr int OFF_SS = SPLIT ? OFF_AF + 16384 : OFF_ER + 8 * 8192;    // column sums of the workgroup record (4.5 KiB)
+    static_assert(!(SPLIT && WGR) || NW == 8, "split workgroup records: 8-wave workgroups");
     using W = v8<T16>;
     const int nl = dm->num_layers;
     f32x16 h[4];
@@ -1046,9 +1056,13 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const int ub0 = wm.ub0;
     char* ring = lds + OFF_ER + wave * 8192;
     auto stage_attn = [&](const W* a) {          // frags of clips ub0, ub0+1 -> AF region
-        const int c1i = min(ub0 + 1, B - 1);
-        stage_frags<NW>(a + (size_t)ub0 * 16 * 64, lds + OFF_AF, 8, wave, lane);
-        stage_frags<NW>(a + (size_t)c1i * 16 * 64, lds + OFF_AF + 8192, 8, wave, lane);
+        if constexpr (SPLIT) {                   // (workgroup records, clip-aligned: hi + lo frags of the one clip)
+            stage_frags<NW>(a + (size_t)ub0 * 16 * 64, lds + OFF_AF, 16, wave, lane);
+        } else {
+            const int c1i = min(ub0 + 1, B - 1);
+            stage_frags<NW>(a + (size_t)ub0 * 16 * 64, lds + OFF_AF, 8, wave, lane);
+            stage_frags<NW>(a + (size_t)c1i * 16 * 64, lds + OFF_AF + 8192, 8, wave, lane);
+        }
     };
     const W* af = reinterpret_cast<const W*>(lds + OFF_AF);
     const DcLayer& L = dm->layer[l];
@@ -1065,8 +1079,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if constexpr (NARROW)
         wg_combine_attn_narrow<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, wm.Mu, wm.Tu, tid_, wg);
     else if constexpr (WGR)      // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
-        wg_combine_attn<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, wm.Mu, wm.Tu, tid_, wg,
-                             (STAMP && stamps && blockIdx.x == 3 && l == 3) ? stamps : nullptr);
+        wg_combine_attn<T16, SPLIT>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, wm.Mu, wm.Tu, tid_, wg,
+                                    (STAMP && stamps && blockIdx.x == 3 && l == 3) ? stamps : nullptr);
     else if (wg_lds)
         stage_attn(a_sa);
     DC_STAMP(14);
@@ -1091,8 +1105,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const int skip_blocks = DBG ? (dbg >> 16) & 3 : 0;
     if (DBG && skip_blocks >= 1) {
     } else if (wg_lds)     // two instantiations so that each keeps its address space (a generic pointer means flat loads)
-        query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (size_t)(cx.b0 - ub0) * 8 * 64,
-                                 af + (size_t)(cx.b1 - ub0) * 8 * 64, cx);
+        query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (SPLIT ? 0 : (size_t)(cx.b0 - ub0) * 8 * 64),
+                                 af + (SPLIT ? 0 : (size_t)(cx.b1 - ub0) * 8 * 64), cx);
     else
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, a_sa + (size_t)cx.b0 * 16 * 64,
                                  a_sa + (size_t)cx.b1 * 16 * 64, cx);
@@ -1125,8 +1139,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if constexpr (use_ring) epre_load<DBG>(ep, Eg + 8 * 128, lane);
     if (DBG && skip_blocks >= 2) {
     } else if (wg_lds)
-        query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (size_t)(cx.b0 - ub0) * 8 * 64,
-                                 af + (size_t)(cx.b1 - ub0) * 8 * 64, cx);
+        query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (SPLIT ? 0 : (size_t)(cx.b0 - ub0) * 8 * 64),
+                                 af + (SPLIT ? 0 : (size_t)(cx.b1 - ub0) * 8 * 64), cx);
     else
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, acl + (size_t)cx.b0 * 16 * 64,
                                  acl + (size_t)cx.b1 * 16 * 64, cx);
@@ -1228,20 +1242,22 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             // operand fragments (32 registers); the maxima go to LDS.  One barrier (maxima visible, values landed).  Then
             // values, exp(K-m_w)^T V, and the rescale exp2(m_w - M) to the workgroup maximum applied to the fp32 blocks,
             // staged per wave in the idle FiLM rings; barrier; summed in wave order and written by wg_write_record.
+            // split formats (no FiLM rings; clip-aligned units, so no wave spans two clips and xp stays unused): the staged blocks go
+            // to buf0 once its key image is consumed (behind the barrier below), the rescale factors to the upper half of AF
             float* mx = reinterpret_cast<float*>(lds + OFF_AF);
-            f32x8* pst = reinterpret_cast<f32x8*>(lds + OFF_ER);
+            f32x8* pst = reinterpret_cast<f32x8*>(SPLIT ? buf0 : lds + OFF_ER);
             f32x8* xp = reinterpret_cast<f32x8*>(lds + OFF_AF + 8192);
             float* ss = reinterpret_cast<float*>(lds + OFF_SS);
-            float* scw = reinterpret_cast<float*>(buf0) + wave * 2 * 4 * 32;   // this wave's rescale factors [2 slots][4 oc][32 cols];
-                                                                              // buf0's key image is consumed before the barrier below
+            float* scw = reinterpret_cast<float*>(SPLIT ? lds + OFF_AF + 8192 : buf0) + wave * 2 * 4 * 32;   // this wave's rescale factors
+                                                   // [2 slots][4 oc][32 cols]; (buf0's key image is consumed before the barrier below)
             const RowRange vr0 = valid_rows_clip(cx, ub0, B, M, T, length, active);
             const RowRange vr1 = valid_rows_clip(cx, ub0 + 1, B, M, T, length, active);
             const int s0 = cx.b0 - ub0;
             const RowRange vr_own = s0 ? vr1 : vr0;
-            const bool strad = active && cx.straddle;
-            XFrag<T16, false> efA[4], efB[4];
+            const bool strad = !SPLIT && active && cx.straddle;
+            XFrag<T16, SPLIT> efA[4], efB[SPLIT ? 1 : 4];
             float ssA[4], ssB[4], mA[4], mB[4];
-            auto keys_of = [&](const f32x16& K, const RowRange& rr, XFrag<T16, false>& ef, float& ssum, float& mcol) {
+            auto keys_of = [&](const f32x16& K, const RowRange& rr, XFrag<T16, SPLIT>& ef, float& ssum, float& mcol) {
                 float m = -INFINITY;
                 const bool full = __builtin_amdgcn_readfirstlane(rr.span) == 32u;
                 if (full) {
@@ -1265,17 +1281,18 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                     }
                 }
                 ssum = xhalf_sum(sacc);
-                make_frag<T16, false>(Ee, ef);
+                make_frag<T16, SPLIT>(Ee, ef);
             };
             {
                 f32x16 Kp[4] = {splat(c0[cx.c]), splat(c0[32 + cx.c]), splat(c0[64 + cx.c]), splat(c0[96 + cx.c])};
-                mmb_oc_quad<4, 4, T16>(Kp[0], Kp[1], Kp[2], Kp[3], w0, nf, lane);
+                mmb_oc_quad<4, 4, T16, SPLIT>(Kp[0], Kp[1], Kp[2], Kp[3], w0, nf, lane);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int oc = q;
                     keys_of(Kp[q], vr_own, efA[oc], ssA[oc], mA[oc]);
                     mB[oc] = -INFINITY;
-                    if (strad) keys_of(Kp[q], vr1, efB[oc], ssB[oc], mB[oc]);
+                    if constexpr (!SPLIT)
+                        if (strad) keys_of(Kp[q], vr1, efB[oc], ssB[oc], mB[oc]);
                     if (cx.hh == 0) {
                         mx[((oc * 2 + s0) * 32 + cx.c) * NW + wave] = mA[oc];
                         mx[((oc * 2 + (s0 ^ 1)) * 32 + cx.c) * NW + wave] = s0 ? -INFINITY : mB[oc];
@@ -1298,7 +1315,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 const float fa = mA[oc] == -INFINITY ? 0.f : exp2f_fast(mA[oc] - wg_colmax<NW>(mx, oc, s0, cx.c));
                 ssA[oc] *= fa;
                 if (cx.hh == 0) scw[(0 * 4 + oc) * 32 + cx.c] = fa;
-                if (strad) {
+                if (!SPLIT && strad) {
                     const float fb = mB[oc] == -INFINITY ? 0.f : exp2f_fast(mB[oc] - wg_colmax<NW>(mx, oc, 1, cx.c));
                     ssB[oc] *= fb;
                     if (cx.hh == 0) scw[(1 * 4 + oc) * 32 + cx.c] = fb;
@@ -1306,7 +1323,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int rowq = 16 * (cx.c >> 4) + 4 * cx.hh;            // kept value j <-> column (row of P) rowq + (j&3) + 8(j>>2)
-            auto block_of = [&](const XFrag<T16, false>& ef, const f32x16& V, const RowRange& rr, const float* sc) {
+            auto block_of = [&](const XFrag<T16, SPLIT>& ef, const f32x16& V, const RowRange& rr, const float* sc) {
                 f32x16 Vm;
                 if (__builtin_amdgcn_readfirstlane(rr.span) == 32u) {
                     Vm = V;
@@ -1314,11 +1331,17 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
 #pragma unroll
                     for (int r = 0; r < 16; ++r) Vm[r] = row_ok(rr, r) ? V[r] : 0.f;
                 }
-                XFrag<T16, false> vf;
-                make_frag<T16, false>(Vm, vf);
+                XFrag<T16, SPLIT> vf;
+                make_frag<T16, SPLIT>(Vm, vf);
                 f32x16 P = splat(0.f);
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) P = mfma(ef.hi[s2], vf.hi[s2], P);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    P = mfma(ef.hi[s2], vf.hi[s2], P);
+                    if constexpr (SPLIT) {
+                        P = mfma(ef.lo[s2], vf.hi[s2], P);
+                        P = mfma(ef.hi[s2], vf.lo[s2], P);
+                    }
+                }
                 f32x8 keep = keep_head_block(P, cx.c);
                 const f32x4 f0 = *reinterpret_cast<const f32x4*>(sc + rowq), f1 = *reinterpret_cast<const f32x4*>(sc + rowq + 8);
 #pragma unroll
@@ -1330,16 +1353,17 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             };
             {
                 f32x16 Vp[4] = {splat(c1[cx.c]), splat(c1[32 + cx.c]), splat(c1[64 + cx.c]), splat(c1[96 + cx.c])};
-                mmb_oc_quad<4, 4, T16>(Vp[0], Vp[1], Vp[2], Vp[3], w1, nf, lane);
+                mmb_oc_quad<4, 4, T16, SPLIT>(Vp[0], Vp[1], Vp[2], Vp[3], w1, nf, lane);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int oc = q;
                     pst[(wave * 4 + oc) * 64 + lane] = block_of(efA[oc], Vp[q], vr_own, scw + (0 * 4 + oc) * 32);
                     if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssA[oc];
-                    if (strad) {
-                        xp[oc * 64 + lane] = block_of(efB[oc], Vp[q], vr1, scw + (1 * 4 + oc) * 32);
-                        if (cx.hh == 0) ss[(NW * 4 + oc) * 32 + cx.c] = ssB[oc];
-                    }
+                    if constexpr (!SPLIT)
+                        if (strad) {
+                            xp[oc * 64 + lane] = block_of(efB[oc], Vp[q], vr1, scw + (1 * 4 + oc) * 32);
+                            if (cx.hh == 0) ss[(NW * 4 + oc) * 32 + cx.c] = ssB[oc];
+                        }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1896,6 +1920,21 @@ static int cu_count() {     // of the current device
     return n[dev];
 }
 
+// Diagnosis pass behind a DC_STATUS_NONFINITE report: do the FiLM tiles (fp16) hold an inf / nan?  n8 = number of 16-byte pieces.
+__global__ __launch_bounds__(256) void k_scan_f16_nonfinite(const u32x8* __restrict__ e, size_t n32, int* __restrict__ status) {
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n32; i += (size_t)gridDim.x * 256) {
+        const u32x8 v = e[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc |= ((v[k] & 0x7c007c00u) + 0x04000400u) & 0x80008000u;      // a half's exponent all ones
+    }
+    if (acc) atomicOr(status, DC_STATUS_F16_SAT);
+}
+hipError_t dc_launch_scan_f16(hipStream_t st, const void* e, size_t bytes, int* status) {
+    k_scan_f16_nonfinite<<<dim3(2048), dim3(256), 0, st>>>(reinterpret_cast<const u32x8*>(e), bytes / 32, status);
+    return hipGetLastError();
+}
+
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k) {
     k_advance_iter<<<1, 1, 0, st>>>(iter, k);
     return hipGetLastError();
@@ -2022,8 +2061,8 @@ hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcM
 template <class T16, bool SP, bool WGR, bool NARROW = false>
 static hipError_t launch_embed_t(hipStream_t st, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
                                  int M, int T, int G, int B, unsigned long long* clk, int Tx, int upc) {
-    constexpr int NW = (SP || NARROW) ? 4 : 8;
-    const size_t shm = WGR ? 8192 + 65536 + 8192 + 9 * 4 * 32 * 4 + 33 * 1024 : 0;
+    constexpr int NW = (NARROW || (SP && !WGR)) ? 4 : 8;
+    const size_t shm = !WGR ? 0 : SP ? 8192 + 65 * 1024 + 9 * 4 * 32 * 4 + 65 * 1024 : 8192 + 65536 + 8192 + 9 * 4 * 32 * 4 + 33 * 1024;
     if (WGR) {
         static unsigned long long optin_done = 0;
         if (hipError_t e = lds_optin((const void*)k_embed_front<T16, SP, WGR, false, NARROW>, (int)shm, optin_done)) return e;
@@ -2043,6 +2082,11 @@ hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, 
                      : launch_embed_t<__bf16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc);
         return e;
     }
+    if (wgr) {            // split formats: workgroup records on clip-aligned units only (one clip per workgroup)
+        if (upc <= 0) return hipErrorInvalidValue;
+        return fmt == 1 ? launch_embed_t<_Float16, true, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc)
+                        : launch_embed_t<__bf16, true, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc);
+    }
     DISPATCH(fmt, split, (e = launch_embed_t<T16, SP, false>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc)));
     return e;
 }
@@ -2055,7 +2099,7 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
                                  const int* iter_base, int Tx, int upc, const DcUpdate& upd) {
     constexpr int NW = NARROW ? 4 : (SP ? DC_SPLIT_NW : 8);
     // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
-    const size_t shm = SP ? 2 * 65 * 1024 : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
+    const size_t shm = SP ? 2 * 65 * 1024 + (WGR ? 16384 + 6144 : 0) : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
     static unsigned long long optin_done = 0;   // > 64 KiB of dynamic LDS needs the opt-in
     if (hipError_t e = lds_optin((const void*)k_layer<T16, SP, DBG, STAMP, WGR, NARROW>, (int)shm, optin_done)) return e;
     k_layer<T16, SP, DBG, STAMP, WGR, NARROW><<<dim3((WGR && upc) ? B * upc : (G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(
@@ -2083,6 +2127,10 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
         else
             e = fmt == 1 ? launch_layer_t<_Float16, false, false, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, false, false, true>(LAYER_ARGS);
         return e;
+    }
+    if (wgr) {            // split formats: workgroup records + in-kernel combine on clip-aligned units (production build only)
+        if (upc <= 0 || dbg != 0 || stamps != nullptr) return hipErrorInvalidValue;
+        return fmt == 1 ? launch_layer_t<_Float16, true, false, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, true, false, false, true>(LAYER_ARGS);
     }
     if (dbg != 0) {
         DISPATCH(fmt, split, (e = launch_layer_t<T16, SP, true, false, false>(LAYER_ARGS)));

@@ -50,6 +50,8 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            int Tx /* frames per clip of xin / xout / snaps */, int upc /* as dc_launch_embed_front */,
                            const DcUpdate& upd /* options of the fused DDIM update + the status word (dc_common.h) */);
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);
+// diagnosis: OR DC_STATUS_F16_SAT into *status when the fp16 buffer e holds an inf / nan
+hipError_t dc_launch_scan_f16(hipStream_t st, const void* e, size_t bytes, int* status);
 // rec_stride: floats between the two alternating unit-record buffers (0 = single buffer, non-wgr)
 
 // ---- no_eff variant (full T x T attention); non-split formats only.  KT = key tiles per clip array.

@@ -178,9 +178,11 @@ int dc_sampler_ddim_loop_ex(dc_sampler* s, const float* d_noise, float* d_out, i
 /* Numeric health of everything enqueued so far (no reference counterpart: the reference computes in fp32).  Waits for the
  * sampler's work, then returns the OR of
  *   DC_STATUS_NONFINITE    a predicted x0 (the denoiser's output) was inf or nan;
- *   DC_STATUS_F16_SATURATED  a FiLM modulation value (StylizationBlock scale / shift, transformer.py:74-78) left the fp16 range
- *                          in which the layer kernels receive it - the fp16 / mixed modes do not hold for this checkpoint:
- *                          use precision bf16x3 (Python: MotionTransformer(precision="auto") retries by itself).
+ *   DC_STATUS_F16_SATURATED  (reported together with NONFINITE, from a scan of the last step's tiles) a FiLM modulation value
+ *                          (StylizationBlock scale / shift, transformer.py:74-78) left the fp16 range in which every precision
+ *                          mode stores it: the checkpoint is outside what the library supports.  Without this bit a
+ *                          non-finite x0 in the fp16 mode means an fp16 OPERAND overflowed: use precision "mixed" (bf16-range
+ *                          operands; Python: MotionTransformer(precision="auto") switches and re-runs by itself).
  * clear != 0 resets the word. */
 #define DC_STATUS_NONFINITE 1
 #define DC_STATUS_F16_SATURATED 2

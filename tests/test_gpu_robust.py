@@ -211,3 +211,22 @@ def test_smoothing_in_the_loops_final_write():
     assert err <= 1e-5 and rel_l2(sm[S], plain[S]) > 1e-3
     with pytest.raises(native.DcError, match="window"):
         m._native.set_smoothing(18, 5)
+
+
+def test_film_tile_saturation_is_diagnosed():
+    """FiLM modulation values beyond the fp16 storage range (emb_layers x 1e6): x0 turns non-finite, dc_sampler_status scans the
+    tiles and adds the F16_SATURATED bit, and precision="auto" does NOT retry (no mode stores those tiles wider) - it raises."""
+    from diffusion_conductor_amd import native
+    sd = dict(synthetic_state_dict(DenoiserConfig(), seed=0))
+    for k in list(sd):
+        if ".emb_layers.1.weight" in k:
+            sd[k] = (sd[k] * 1.0e6).astype(np.float32)
+    B, T, S = 2, 96, 25
+    xfp, xfo = _features(sd, B, T, 50)
+    noise = torch.from_numpy(batch_noise(B, T, first=50)).cuda()
+    m = _model(sd, "auto")
+    with pytest.raises(FloatingPointError, match="every precision mode stores"):
+        make_diffusion(S).ddim_sample_loop(m, (B, T, 26), noise=noise, clip_denoised=False, progress=False,
+                                           model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor([96, 70])})
+    assert m.active_precision == "fp16"
+    assert m._native.status() == 0
