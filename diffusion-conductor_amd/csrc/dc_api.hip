@@ -697,7 +697,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     // (split formats: on clip-aligned units only - the doubled weight images leave LDS for ONE clip's attention fragments - and in
     // the production build only: the test hooks keep the per-group form)
     const bool wgr = T >= 256 && !no_wgr && s->dbg_first < 0 && !s->cfg.no_eff &&
-                     (!ss || (T % 32 == 0 && s->dbg_layers < 0 && s->dbg_stage == 0 && !getenv("DC_STAMPS") && !getenv("DC_NO_ALIGN")));
+                     (!ss || (T % 32 == 0 && s->dbg_layers < 0 && s->dbg_stage == 0 && !getenv("DC_NO_ALIGN")));
     static const bool want_stamps = getenv("DC_STAMPS") != nullptr;
     // Narrow workgroups (4 waves = 128-token units, one wave per SIMD) while every unit still gets a CU of its own: the layer
     // kernel is bound by instruction issue, so a wave alone on its SIMD runs a layer in about half the time (DESIGN.md

@@ -2129,7 +2129,9 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
         return e;
     }
     if (wgr) {            // split formats: workgroup records + in-kernel combine on clip-aligned units (production build only)
-        if (upc <= 0 || dbg != 0 || stamps != nullptr) return hipErrorInvalidValue;
+        if (upc <= 0 || dbg != 0) return hipErrorInvalidValue;
+        if (stamps != nullptr)
+            return fmt == 1 ? launch_layer_t<_Float16, true, false, true, true>(LAYER_ARGS) : launch_layer_t<__bf16, true, false, true, true>(LAYER_ARGS);
         return fmt == 1 ? launch_layer_t<_Float16, true, false, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, true, false, false, true>(LAYER_ARGS);
     }
     if (dbg != 0) {

@@ -6,7 +6,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from helpers import make_model, make_diffusion, xf_pair, batch_noise
 B, T = 32, 1800
-m = make_model("fp16")
+m = make_model(os.environ.get("DC_STAMP_PREC", "fp16"))
 xfp, xfo = xf_pair(B, T); noise = torch.from_numpy(batch_noise(B, T)).cuda()
 nat = m.set_conditioning(xfp.cuda(), xfo.cuda(), [T] * B)
 gd = make_diffusion(50)
