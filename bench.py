@@ -315,20 +315,26 @@ def main():
             from diffusion_conductor_amd.synthetic import batch_mel
             mel_h = torch.from_numpy(batch_mel(B, 3 * T)).pin_memory()
             e2e = {}
-            for rep in range(2):                      # first repetition warms the encoder's activation planes
+            for rep in range(3):                      # first repetition warms the encoder's activation planes
                 torch.cuda.synchronize()
                 t = [time.perf_counter()]
-                mel = mel_h.to(dev, non_blocking=True)
-                torch.cuda.synchronize(); t.append(time.perf_counter())
-                exp, ex = model.encode_music(mel, dev)
+                # encode_music on the pinned host batch: the copy runs in chunks beside the encoder (denoiser.py)
+                exp, ex = model.encode_music(mel_h, dev)
                 torch.cuda.synchronize(); t.append(time.perf_counter())
                 nat2 = model.set_conditioning(exp, ex, [T] * B)
                 torch.cuda.synchronize(); t.append(time.perf_counter())
                 o2, _ = nat2.ddim_loop(noise, coef)
                 o2h = o2.cpu(); t.append(time.perf_counter())
                 e2e = {"ms": round(1e3 * (t[-1] - t[0]), 2), "frames_per_s": round(B * T / (t[-1] - t[0]), 1),
-                       "h2d_mel_ms": round(1e3 * (t[1] - t[0]), 2), "encode_music_ms": round(1e3 * (t[2] - t[1]), 2),
-                       "set_conditioning_ms": round(1e3 * (t[3] - t[2]), 2), "loop_and_d2h_ms": round(1e3 * (t[4] - t[3]), 2)}
+                       "h2d_mel_and_encode_music_ms": round(1e3 * (t[1] - t[0]), 2),
+                       "set_conditioning_ms": round(1e3 * (t[2] - t[1]), 2), "loop_and_d2h_ms": round(1e3 * (t[3] - t[2]), 2)}
+            # the two overlapped stages on their own (separate, synchronised): what the pipelining hides
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            mel = mel_h.to(dev, non_blocking=True)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            model.encode_music(mel, dev)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            e2e.update({"h2d_mel_alone_ms": round(1e3 * (t1 - t0), 2), "encode_music_alone_ms": round(1e3 * (t2 - t1), 2)})
             line["end_to_end"] = e2e
             log(f"end to end: {e2e}")
             nat = model.set_conditioning(xfp, xf, [T] * B)      # back to the benchmark's conditioning for the profile pass

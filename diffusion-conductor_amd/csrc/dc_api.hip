@@ -716,10 +716,12 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const int Tx = s->Tx;
     // k_embed_front rides in the FiLM GEMM's launch (wide flat units, non-split formats, no test hooks; DC_NO_FUSE_EMBED=1 and the
     // per-kernel profile pass keep the two launches): one kernel boundary less per step, -1.3 % per loop at bs=32
-    const bool fuse_embed = wgr && !narrow && !aligned && fuse_silu && ff == fs && s->dbg_layers < 0 && s->dbg_stage == 0 &&
-                            nwg <= s->num_cu && !want_stamps && !s->prof.on && !getenv("DC_NO_FUSE_EMBED");
+    // (flat units in the non-split formats; the "mixed" mode - f16 GEMM, split-bf16 embedding - on its clip-aligned units)
+    const bool mixed_form = ss && !sf && ff == 1 && fs == 0;
+    const bool fuse_embed = wgr && !narrow && (ss ? (aligned && mixed_form) : (!aligned && ff == fs)) && fuse_silu && s->dbg_layers < 0 &&
+                            s->dbg_stage == 0 && nwg <= s->num_cu && !want_stamps && !s->prof.on && !getenv("DC_NO_FUSE_EMBED");
     DcEmbedArgs ea{};
-    if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg};
+    if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, ss ? upc : 0, ss ? 1 : 0};
     const DcUpdate upd{loop_mode ? s->d_step_noise : nullptr, s->d_status, loop_mode ? s->upd_flags : 0, folded ? graph_step : -1};
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
                                        s->NT / 16, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,

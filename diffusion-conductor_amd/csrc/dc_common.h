@@ -99,4 +99,6 @@ struct DcEmbedArgs {
     float *hbuf, *recs;
     const int* length;
     int M, Tx, ne;
+    int upc;         // 0: flat 256-token units (non-split formats); > 0: clip-aligned units, `upc` workgroups per clip (split formats)
+    int split_bf16;  // the embedding runs in the split-bf16 format of the "mixed" mode (FiLM GEMM f16, 128-wide GEMMs bf16x3)
 };

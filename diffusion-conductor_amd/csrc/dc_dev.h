@@ -1154,11 +1154,12 @@ DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shif
             z[2 * k] = zz.x;
             z[2 * k + 1] = zz.y;
         }
-    } else {
+    } else {             // fp32 y (split formats): the FiLM tiles still enter through mixed-precision FMAs (no v_cvt_f32_f16)
+        const u32x8 gw = __builtin_bit_cast(u32x8, gp), hw = __builtin_bit_cast(u32x8, hp);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float n0 = fmaf((float)y[2 * k], rstd, shift), n1 = fmaf((float)y[2 * k + 1], rstd, shift);
-            const f32x2 zz = silu_l2_pair(fmaf(n0, (float)gp[2 * k], n0 + (float)hp[2 * k]), fmaf(n1, (float)gp[2 * k + 1], n1 + (float)hp[2 * k + 1]));
+            const f32x2 zz = silu_l2_pair(add_mix_h<0>(hw[k], fma_mix_h<0>(gw[k], n0, n0)), add_mix_h<1>(hw[k], fma_mix_h<1>(gw[k], n1, n1)));
             z[2 * k] = zz.x;
             z[2 * k + 1] = zz.y;
         }

@@ -939,7 +939,9 @@ void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x, 
 // units; DC_NO_FUSE_EMBED=1 keeps them apart): the first `ne` workgroups
 // embed their unit (k_embed_front's body), then all sweep their share of the FiLM GEMM - one kernel boundary less per step.  The
 // GEMM's work shares follow the measured per-XCD speeds, which include the embedding time.
-template <class T16>
+// TS / SP: operand type and split flag of the embedding (the "mixed" mode embeds in split bf16 beside an f16 FiLM GEMM; its
+// units are clip-aligned: ea.upc workgroups per clip).
+template <class T16, class TS = T16, bool SP = false>
 __global__ __launch_bounds__(512, 2) void k_film_embed(const v8<T16>* __restrict__ W, const float* __restrict__ bias16,
                                                        f16x16* __restrict__ E, int G, int NT, int round0, int nround,
                                                        const float* __restrict__ pp, const float* __restrict__ temb,
@@ -949,8 +951,8 @@ __global__ __launch_bounds__(512, 2) void k_film_embed(const v8<T16>* __restrict
                                                        int* __restrict__ status) {
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     if ((int)blockIdx.x < ea.ne) {
-        embed_front_body<T16, false, true, false, false>(ea.dm, ea.x, ea.hbuf, ea.recs, ea.length, ea.M, T, G, B, nullptr, 0, ea.Tx, 0,
-                                                         (int)blockIdx.x);
+        embed_front_body<TS, SP, true, false, false>(ea.dm, ea.x, ea.hbuf, ea.recs, ea.length, ea.M, T, G, B, nullptr, 0, ea.Tx, ea.upc,
+                                                     (int)blockIdx.x);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();            // the embedding's LDS use is over before the slab fill
     }
@@ -2018,6 +2020,15 @@ static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* b
     if (nwg < nblk) nwg = nblk < ncu ? nblk : ncu;
     if (nwg < 1) nwg = 1;
     if (ea && ea->x && nwg >= ea->ne) {          // fused with k_embed_front (its LDS image is smaller than the slab)
+        if (ea->split_bf16) {                    // "mixed": split-bf16 embedding (two 65-KiB images: more LDS than the slab) beside the f16 GEMM
+            if (!std::is_same<T16, _Float16>::value || ea->upc <= 0) return hipErrorInvalidValue;
+            const size_t shm2 = 8192 + 65 * 1024 + 9 * 4 * 32 * 4 + 65 * 1024;
+            static unsigned long long optin3 = 0;
+            if (hipError_t e = lds_optin((const void*)k_film_embed<T16, __bf16, true>, (int)shm2, optin3)) return e;
+            k_film_embed<T16, __bf16, true><<<dim3(nwg), dim3(512), shm2, st>>>((const v8<T16>*)W16, bias16, (f16x16*)E, G, NT, round0, nround, pp, temb,
+                                                                                t_clip, T, B, clk, rate_in, rate_out, iter_base, *ea, status);
+            return hipGetLastError();
+        }
         static unsigned long long optin2 = 0;
         if (hipError_t e = lds_optin((const void*)k_film_embed<T16>, (int)shm, optin2)) return e;
         k_film_embed<T16><<<dim3(nwg), dim3(512), shm, st>>>((const v8<T16>*)W16, bias16, (f16x16*)E, G, NT, round0, nround, pp, temb, t_clip, T, B,

@@ -289,14 +289,20 @@ class NativeSampler:
         _check(lib().dc_sampler_set_conditioning(self._h, xf_proj.data_ptr(), xf_out.data_ptr(), lp, B, T, self._stream()))
         self.B, self.T = B, T
 
-    def encode_music(self, mel):
-        """mel fp32 [B, Tm, 128] on the device -> (xf_proj, xf_out), each [B, (Tm-1)//3+1, 64]."""
+    def encode_music(self, mel, out=None):
+        """mel fp32 [B, Tm, 128] on the device -> (xf_proj, xf_out), each [B, (Tm-1)//3+1, 64] (`out`: the pair to fill, e.g.
+        batch slices of larger tensors)."""
         import torch
         assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous() and mel.dim() == 3
         B, Tm, nm = mel.shape
         T = (Tm - 1) // 3 + 1
-        xf_proj = torch.empty((B, T, 64), dtype=torch.float32, device=mel.device)
-        xf_out = torch.empty_like(xf_proj)
+        if out is None:
+            xf_proj = torch.empty((B, T, 64), dtype=torch.float32, device=mel.device)
+            xf_out = torch.empty_like(xf_proj)
+        else:
+            xf_proj, xf_out = out
+            for t in out:
+                assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (B, T, 64)
         _check(lib().dc_sampler_encode_music(self._h, mel.data_ptr(), B, Tm, nm, xf_proj.data_ptr(), xf_out.data_ptr(),
                                              self._stream()))
         return xf_proj, xf_out

@@ -230,3 +230,20 @@ def test_film_tile_saturation_is_diagnosed():
                                            model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor([96, 70])})
     assert m.active_precision == "fp16"
     assert m._native.status() == 0
+
+
+def test_encode_music_from_a_pinned_host_batch_is_pipelined_and_identical():
+    """A pinned host batch is copied in chunks beside the encoder (denoiser._encode_music_pipelined): same numbers as the
+    encode of the batch already on the device, bit for bit (per-clip kernels see the same inputs)."""
+    from helpers import batch_mel
+    sd = synthetic_state_dict(DenoiserConfig(), seed=0)
+    m = _model(sd, "fp16")
+    mel = torch.from_numpy(batch_mel(19, 540))                  # 2 full chunks of 8 + a ragged one
+    xp_d, x_d = m.encode_music(mel.cuda(), "cuda:0")
+    xp_h, x_h = m.encode_music(mel.pin_memory(), "cuda:0")
+    torch.cuda.synchronize()
+    assert tuple(x_h.shape) == (19, 180, 64) and torch.equal(xp_h, xp_d) and torch.equal(x_h, x_d)
+    p = O.to_torch_params(sd)
+    with torch.no_grad():
+        rxp, rx = O.encode_music(p, mel[16:19])
+    assert rel_l2(x_h[16:19], rx) <= 1e-4 and rel_l2(xp_h[16:19], rxp) <= 1e-4
