@@ -35,6 +35,7 @@ Extra objects on the JSON line:
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -46,7 +47,9 @@ PEAK_BF16_FLOPS = 2.5e15            # dense bf16 MFMA, MI355X
 FLOP_PER_TOKEN_STEP = 2 * 4250112   # algorithmic, hoisted (SURVEY.md section 8d / BASELINE.md section 4)
 FILM_FLOP_PER_TOKEN = 2 * 512 * 6144
 PEAK_HBM_BYTES = 8.0e12             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+# HBM bytes per launch from the committed PMC passes of this command (tools/collect_profiles.sh + tools/make_traffic.py): newest round
+TRAFFIC_FILE = max((os.path.join("profiles", f) for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_traffic\.json", f)),
+                   default=os.path.join("profiles", "r02_traffic.json"))
 
 
 def cpu_baseline(runs=3):

@@ -1087,6 +1087,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         stage_attn(a_sa);
     DC_STAMP(14);
     constexpr bool use_ring = !SPLIT;             // FiLM tiles through the per-wave LDS ring (else: registers)
+#ifdef DC_PROLOGUE_WAIT_ALL
     if constexpr (use_ring) {
         ering_issue(Eg, 0, ring, lane);
         ering_issue(Eg, 1, ring + 4096, lane);
@@ -1094,6 +1095,23 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DC_STAMP(15);
     stage_sync();
+#else
+    // The first two FiLM ring tiles are this wave's 8 youngest vector-memory operations and are first read in stage 2, behind
+    // stage 1's closing vmcnt(0): the prologue waits for everything BUT them (vmcnt counts in issue order) - at kernel start
+    // every workgroup pulls its 128 KiB of residual stream at once, and the ring tiles (a third of that burst's bytes) no
+    // longer sit between the workgroup and its first barrier.
+    if constexpr (use_ring) {
+        ering_issue(Eg, 0, ring, lane);
+        ering_issue(Eg, 1, ring + 4096, lane);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    DC_STAMP(15);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     DC_STAMP(1);
 
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
