@@ -247,3 +247,35 @@ def test_encode_music_from_a_pinned_host_batch_is_pipelined_and_identical():
     with torch.no_grad():
         rxp, rx = O.encode_music(p, mel[16:19])
     assert rel_l2(x_h[16:19], rx) <= 1e-4 and rel_l2(xp_h[16:19], rxp) <= 1e-4
+
+
+@pytest.mark.parametrize("B,T", [(1, 257), (3, 1000), (2, 1799), (9, 1800), (33, 300), (5, 77)])
+def test_mixed_mode_clip_aligned_units_edge_shapes(B, T):
+    """The split-bf16 layer path on workgroup records runs clip-aligned 8-wave units on a padded clip stride (T >= 256; below that
+    the per-group form): strides that need padding, ragged lengths down to one frame, more clips than the fused embedding launch
+    carries (33 x 300 -> 66 units), per-clip timesteps.  One forward and a DDIM-6 loop with an intermediate, vs the oracle."""
+    sd = synthetic_state_dict(DenoiserConfig(), seed=0)
+    p = O.to_torch_params(sd)
+    m = _model(sd, "mixed")
+    xfp, xfo = _features(sd, B, T, 7)
+    x = torch.from_numpy(batch_noise(B, T, first=7))
+    t = torch.tensor([(131 * b + 5) % 1000 for b in range(B)])
+    length = [T if b % 3 == 0 else (1 if b % 3 == 1 else max(1, T - 33 * b - 1)) for b in range(B)]
+    with torch.no_grad():
+        ref = O.denoiser_forward(p, x, t, length, xfp, xfo)
+    out = m(x.cuda(), t, length=torch.tensor(length), xf_proj=xfp.cuda(), xf_out=xfo.cuda())
+    torch.cuda.synchronize()
+    e_fwd = rel_l2(out, ref)
+    S = 25
+    with torch.no_grad():
+        rl = O.ddim_sample_loop(p, x, xfp, xfo, length, S, idxs=(3,))
+    gd = make_diffusion(S)
+    res = gd.ddim_sample_loop(m, (B, T, 26), noise=x.cuda(), clip_denoised=False, progress=False, idxs=[3],
+                              model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor(length)})
+    torch.cuda.synchronize()
+    e3, eS = rel_l2(res[3], rl[3]), rel_l2(res[S], rl[S])
+    print(f"mixed B={B} T={T} (clip stride {m._native.clip_stride()}): forward {e_fwd:.2e}  ddim-{S} idx3 {e3:.2e} final {eS:.2e}")
+    assert torch.isfinite(res[S]).all() and max(e_fwd, e3, eS) <= 2e-4
+    again = gd.ddim_sample_loop(m, (B, T, 26), noise=x.cuda(), clip_denoised=False, progress=False, idxs=[3],
+                                model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor(length)})
+    assert torch.equal(again[S], res[S]) and torch.equal(again[3], res[3])
