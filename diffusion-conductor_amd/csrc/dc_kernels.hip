@@ -1250,8 +1250,22 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         // youngest operations (the 16 dwordx4 stores of h) are outstanding means "the image has landed" while the
         // stores keep draining behind the K/V projections.
         __builtin_amdgcn_sched_barrier(0);
+#ifdef DC_DIAG_NO_HSTORE
+        const bool st_h = false;          // diagnostic build (timing only, results invalid): what the residual-stream stores cost the tail
+#else
         const bool st_h = active;
-        if (st_h) store_h(h, hbuf, g, lane);
+#endif
+        // Wide non-split workgroups stagger the stores: the 128 KiB of a workgroup take the CU's store path ~1 us, and issued by
+        // all eight waves at once they cost the second wave of each SIMD ~2.5 us of queueing in front of its LayerNorm - on the
+        // path to the barrier below (stage stamps).  Waves 4-7 therefore keep h in registers through the key pass and store it
+        // in front of the wait (their stores are then still the wave's 16 youngest operations).
+#ifdef DC_NO_STORE_STAGGER
+        constexpr bool stagger = false;
+#else
+        constexpr bool stagger = WGR && !SPLIT && !NARROW && !DBG;
+#endif
+        const bool late_store = stagger && wave >= NW / 2;
+        if (st_h && !late_store) store_h(h, hbuf, g, lane);
         __builtin_amdgcn_sched_barrier(0);
         XFrag<T16, SPLIT> nf[4];
         ln_frags<T16, SPLIT>(nf, h);
@@ -1321,6 +1335,11 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 __builtin_amdgcn_sched_barrier(0);
             }
             DC_STAMP(20);
+            if (st_h && late_store) {
+                __builtin_amdgcn_sched_barrier(0);
+                store_h(h, hbuf, g, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (st_h)
                 asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else

@@ -98,3 +98,26 @@ def test_fewer_clips_than_ranks(tmp_path):
     out = str(tmp_path / "small.npy")
     mp.spawn(_worker_small, args=(2, _free_port(), out), nprocs=2, join=True)
     assert np.load(out).shape == (1, 8, 26)
+
+
+def _worker_unsized(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from diffusion_conductor_amd.sharding import sharded_sample
+    msg = "no error"
+    try:
+        sharded_sample(lambda m, n: torch.zeros(m.shape[0], 8, 26), torch.zeros(1, 3, 1), None)      # B=1 < world, nothing sizes the empty shard
+    except ValueError as e:
+        msg = str(e)
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write(msg)
+    dist.barrier()                                            # reachable: NO rank is stuck in the all-gather
+    dist.destroy_process_group()
+
+
+def test_unsized_empty_shard_raises_on_every_rank(tmp_path):
+    """Fewer clips than ranks with neither out_shape nor noise: the argument error is raised on EVERY rank before anyone samples -
+    raised only on the rank with the empty shard it would leave the others waiting in the collective (round 2's advisor finding)."""
+    mp.spawn(_worker_unsized, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert "fewer clips than ranks" in (tmp_path / f"rank{r}.txt").read_text()
