@@ -238,7 +238,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path for the sampler)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    selftest_multi = world == 1 and bool(os.environ.get("DC_BENCH_SELFTEST_MULTI"))     # exercise the N > 1 evidence code on one GPU
+    if selftest_multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+    if world > 1 or selftest_multi:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from diffusion_conductor_amd.sampler import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,
@@ -288,7 +292,7 @@ def main():
     assert torch.isfinite(out).all()
     log(f"timed region: {dt:.3f} s for {args.steps} steps")
     multi = None
-    if world > 1:
+    if world > 1 or selftest_multi:
         multi = multi_gpu_evidence(dist, dev, local, rank, world, B, dt_local / args.steps, out, nat, noise, coef, model, args)
 
     frames = world * B * T * args.steps
@@ -395,7 +399,7 @@ def main():
                                      "rel_l2": float(f"{rel_l2(o2[:1], cpu_x0):.3e}") if cpu_x0 is not None else None}
                 log(f"bf16 mode: {line['bf16_mode']}")
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or selftest_multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -184,6 +184,7 @@ struct dc_sampler {
     int upd_flags = 0;
     const float* d_step_noise = nullptr;
     int* d_status = nullptr;
+    unsigned* d_unit_flags = nullptr;      // persistent layer launch: per-unit progress flags (reset by every step's embedding)
     // Savitzky-Golay smoothing applied by the loop's final write (dc_sampler_set_smoothing; window 0 = off)
     int smooth_window = 0, smooth_order = 0;
     float* d_smooth_coef = nullptr;
@@ -597,6 +598,8 @@ int ensure_workspace(dc_sampler* s, int B, int Tx) {
         HIP_TRY(hipMemset(s->d_film_rate, 0, 2 * 1024 * sizeof(float)));      // 0 = not measured yet: equal shares
         if ((rc = dev_alloc(s, s->d_status, 16))) return rc;
         HIP_TRY(hipMemset(s->d_status, 0, 16));
+        if ((rc = dev_alloc(s, s->d_unit_flags, 4096 * sizeof(unsigned)))) return rc;
+        HIP_TRY(hipMemset(s->d_unit_flags, 0, 4096 * sizeof(unsigned)));
         if ((rc = dev_alloc(s, s->d_iter, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_snap_cur, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_coef_cur, DC_COEF * 4))) return rc;
@@ -656,7 +659,7 @@ struct Timed {   // RAII-less helper: wraps a launch with events when profiling
 // that one process can A/B them: a change re-captures) and the update options of the loop.
 unsigned long long form_key(const dc_sampler* s) {
     static const char* sw[] = {"DC_NO_WGREC", "DC_NO_NARROW", "DC_NO_ALIGN", "DC_ALIGN", "DC_NO_FUSE_EMBED", "DC_FILM_STATIC",
-                               "DC_BEGIN_STEP", "DC_NO_PAD"};
+                               "DC_BEGIN_STEP", "DC_NO_PAD", "DC_NO_PERSIST"};
     unsigned long long k = 0;
     for (size_t i = 0; i < sizeof sw / sizeof *sw; ++i) k |= (getenv(sw[i]) ? 1ull : 0ull) << i;
     k |= (unsigned long long)(s->upd_flags & 0xff) << 8;
@@ -720,9 +723,15 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const bool mixed_form = ss && !sf && ff == 1 && fs == 0;
     const bool fuse_embed = wgr && !narrow && (ss ? (aligned && mixed_form) : (!aligned && ff == fs)) && fuse_silu && s->dbg_layers < 0 &&
                             s->dbg_stage == 0 && nwg <= s->num_cu && !want_stamps && !s->prof.on && !getenv("DC_NO_FUSE_EMBED");
+    // Persistent layer launch (k_layer PERS): all layers of the step in ONE kernel when every wide workgroup has a CU of its own and
+    // the model has the depth the kernel is compiled for; DC_NO_PERSIST=1 keeps the per-layer launches (read per call).  The
+    // per-kernel profile pass keeps the per-layer launches too (its numbers are per layer).
+    const bool persistent = wgr && !narrow && !ss && nwg <= s->num_cu && nwg <= 4096 && L == DC_PERS_LAYERS && s->dbg_layers < 0 &&
+                            s->dbg_stage == 0 && s->dbg_first < 0 && !s->prof.on && !getenv("DC_NO_PERSIST");
+    unsigned* unit_flags = persistent ? s->d_unit_flags : nullptr;
     DcEmbedArgs ea{};
-    if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, ss ? upc : 0, ss ? 1 : 0};
-    const DcUpdate upd{loop_mode ? s->d_step_noise : nullptr, s->d_status, loop_mode ? s->upd_flags : 0, folded ? graph_step : -1};
+    if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, ss ? upc : 0, ss ? 1 : 0, unit_flags};
+    const DcUpdate upd{loop_mode ? s->d_step_noise : nullptr, s->d_status, loop_mode ? s->upd_flags : 0, folded ? graph_step : -1, unit_flags};
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
                                        s->NT / 16, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
                                        want_stamps_film ? s->d_stamps + 252 : nullptr,
@@ -747,8 +756,14 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         LAUNCH(K_EMBED, dc_launch_front_from_h(st, fs, ss, s->d_model, s->d_h, s->d_recs, s->d_length, M, T, G, B, s->dbg_first));
     else
         LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
-                                              want_stamps_film ? s->d_stamps + 256 : nullptr, narrow, Tx, upc));
+                                              want_stamps_film ? s->d_stamps + 256 : nullptr, narrow, Tx, upc, unit_flags));
     const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
+    if (persistent) {
+        LAUNCH(K_LAYER, dc_launch_layers_persistent(st, fs, s->d_model, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs, s->d_length,
+                                                    x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src, s->d_snaps, M, T, G, B, rec_stride,
+                                                    iter_base, Tx, upc, upd, want_stamps ? s->d_stamps : nullptr));
+        return DC_OK;
+    }
     for (int l = s->dbg_first >= 0 ? s->dbg_first : 0; l < nl_run; ++l) {
         const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
@@ -992,7 +1007,7 @@ void dc_sampler_destroy(dc_sampler* s) {
     void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
                     s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t, s->d_coef_of_iter,
-                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status, s->d_smooth_coef};
+                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status, s->d_smooth_coef, s->d_unit_flags};
     for (void* p : ptrs)
         if (p) hipFree(p);
     dc_music_destroy(s->music);

@@ -279,3 +279,30 @@ def test_mixed_mode_clip_aligned_units_edge_shapes(B, T):
     again = gd.ddim_sample_loop(m, (B, T, 26), noise=x.cuda(), clip_denoised=False, progress=False, idxs=[3],
                                 model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor(length)})
     assert torch.equal(again[S], res[S]) and torch.equal(again[3], res[3])
+
+
+@pytest.mark.parametrize("B,T,S", [(32, 1800, 50), (20, 1000, 25), (9, 1800, 25), (33, 300, 25)])
+def test_persistent_layer_launch_equals_per_layer_launches(B, T, S):
+    """Round 3: with every wide workgroup on a CU of its own, the eight layers of a step run as ONE launch (k_layer PERS: residual
+    stream in registers, unit records exchanged inside the launch with sc1 stores / loads behind per-unit progress flags).  Same
+    arithmetic in the same order: bit-identical to the per-layer launches (DC_NO_PERSIST=1), re-runs identical, status clean;
+    ragged lengths; 33 x 300 exceeds the CU count only in the narrow form and runs wide-persistent too."""
+    import os
+    sd = synthetic_state_dict(DenoiserConfig(), seed=0)
+    m = _model(sd, "fp16")
+    xfp, xfo = _features(sd, B, T, 3)
+    noise = torch.from_numpy(batch_noise(B, T, first=3)).cuda()
+    length = [T if b % 3 else max(1, T - 37 * b) for b in range(B)]
+    nat = m.set_conditioning(xfp.cuda(), xfo.cuda(), length)
+    coef = make_diffusion(S).native_coefficients()
+    a, _ = nat.ddim_loop(noise, coef, (3,))
+    st = nat.status()
+    os.environ["DC_NO_PERSIST"] = "1"
+    try:
+        b, _ = nat.ddim_loop(noise, coef, (3,))
+    finally:
+        del os.environ["DC_NO_PERSIST"]
+    c, _ = nat.ddim_loop(noise, coef, (3,))
+    torch.cuda.synchronize()
+    assert st == 0 and torch.isfinite(a).all()
+    assert torch.equal(a, b) and torch.equal(a, c)

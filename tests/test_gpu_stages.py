@@ -193,6 +193,24 @@ def test_rccl_world_size_one_gather():
     assert r.returncode == 0 and "NCCL_OK" in r.stdout
 
 
+def test_bench_multi_gpu_evidence_fields_on_one_rank():
+    """bench.py's N > 1 evidence code (rccl_ranks, device identities, per-rank times, gather block == local == single-GPU re-run)
+    runs on a one-rank RCCL group (DC_BENCH_SELFTEST_MULTI=1): no 8-GPU box is needed to know it does not fall over there."""
+    import json
+    env = dict(os.environ, DC_BENCH_SELFTEST_MULTI="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bs", "2", "--frames", "300", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    print(r.stderr[-1500:])
+    assert r.returncode == 0
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    m = line["multi_gpu"]
+    assert m["rccl_ranks"] == 1 and m["backend"] == "nccl" and len(m["devices"]) == 1 and len(m["devices"][0]) > 4
+    assert m["gather_block_equals_local"] is True and m["sharded_equals_single_gpu"] is True
+    assert m["ms_per_step_by_rank"]["min"] > 0 and m["all_gather_bytes_per_rank"] == 2 * 300 * 26 * 4
+
+
 # ---- tools/visualization.py-shaped entry point ---------------------------------------------------------------------------
 def test_visualize_entry_point_end_to_end(tmp_path):
     """opt.txt -> get_opt -> build_models -> DDPMTrainer.load(latest.tar) -> generate_music_motion -> smooth -> np.save, against
