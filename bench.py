@@ -242,7 +242,13 @@ def main():
     if selftest_multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
+    result_out = sys.stdout
     if world > 1 or selftest_multi:
+        # RCCL prints a version banner through C stdio on fd 1 (it lands BEHIND the result line when stdout is a pipe): keep fd 1 for
+        # the ONE JSON line only - everything else that writes to "stdout" from here on goes to stderr
+        sys.stdout.flush()
+        result_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from diffusion_conductor_amd.sampler import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,
@@ -398,7 +404,7 @@ def main():
                 line["bf16_mode"] = {"precision": "mixed", "ms_per_step": round(1e3 * t2, 3), "frames_per_s": round(B * T / t2, 1),
                                      "rel_l2": float(f"{rel_l2(o2[:1], cpu_x0):.3e}") if cpu_x0 is not None else None}
                 log(f"bf16 mode: {line['bf16_mode']}")
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=result_out, flush=True)
     if world > 1 or selftest_multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -659,7 +659,7 @@ struct Timed {   // RAII-less helper: wraps a launch with events when profiling
 // that one process can A/B them: a change re-captures) and the update options of the loop.
 unsigned long long form_key(const dc_sampler* s) {
     static const char* sw[] = {"DC_NO_WGREC", "DC_NO_NARROW", "DC_NO_ALIGN", "DC_ALIGN", "DC_NO_FUSE_EMBED", "DC_FILM_STATIC",
-                               "DC_BEGIN_STEP", "DC_NO_PAD", "DC_NO_PERSIST"};
+                               "DC_BEGIN_STEP", "DC_NO_PAD", "DC_PERSIST"};
     unsigned long long k = 0;
     for (size_t i = 0; i < sizeof sw / sizeof *sw; ++i) k |= (getenv(sw[i]) ? 1ull : 0ull) << i;
     k |= (unsigned long long)(s->upd_flags & 0xff) << 8;
@@ -710,10 +710,19 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     // units) it measured 1.2 % slower than flat units - DC_ALIGN=1 forces it there.
     const bool can_align = wgr && T % 32 == 0 && !getenv("DC_NO_ALIGN");
     const int upc_wide = (T + 255) / 256, upc_narrow = (T + 127) / 128;
+    const bool aligned_env = can_align && getenv("DC_ALIGN") != nullptr;
     const int nwg_narrow = can_align ? B * upc_narrow : (G + 3) / 4;
     const bool narrow = wgr && !ss && nwg_narrow <= s->num_cu && T <= 3840 && s->dbg_layers < 0 && s->dbg_stage == 0 &&
                         !getenv("DC_NO_NARROW") && !want_stamps;
-    const bool aligned = can_align && (narrow || ss || getenv("DC_ALIGN") != nullptr);
+    // Persistent layer launch (k_layer PERS, opt-in with DC_PERSIST=1, read per call): all layers of the step in ONE kernel when
+    // every wide workgroup has a CU of its own and the model has the depth the kernel is compiled for; the unit records are
+    // exchanged inside the launch behind per-unit progress flags.  Same units, same arithmetic, same order as the per-layer
+    // launches: bit-identical results.  Measured -0.6 ... -1.7 % per loop at bs=32 (profiles/r03_ab_pers_nt.txt), and it needs
+    // all its workgroups co-resident (a GPU shared with another process can break that: DC_STATUS_SYNC_TIMEOUT) - hence not the
+    // default.  The per-kernel profile pass keeps the per-layer launches (its numbers are per layer).
+    const bool persistent = wgr && !narrow && !ss && getenv("DC_PERSIST") && (long long)(aligned_env ? B * upc_wide : (G + 7) / 8) <= s->num_cu &&
+                            2 * upc_wide + 2 <= 64 /* one lane per awaited unit */ && L == DC_PERS_LAYERS && s->dbg_layers < 0 && s->dbg_stage == 0 && s->dbg_first < 0 && !s->prof.on;
+    const bool aligned = can_align && (narrow || ss || aligned_env);
     const int upc = aligned ? (narrow ? upc_narrow : upc_wide) : 0;
     const int nwg = aligned ? B * upc : (narrow ? (G + 3) / 4 : (G + 7) / 8);
     const int Tx = s->Tx;
@@ -721,16 +730,11 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     // per-kernel profile pass keep the two launches): one kernel boundary less per step, -1.3 % per loop at bs=32
     // (flat units in the non-split formats; the "mixed" mode - f16 GEMM, split-bf16 embedding - on its clip-aligned units)
     const bool mixed_form = ss && !sf && ff == 1 && fs == 0;
-    const bool fuse_embed = wgr && !narrow && (ss ? (aligned && mixed_form) : (!aligned && ff == fs)) && fuse_silu && s->dbg_layers < 0 &&
+    const bool fuse_embed = wgr && !narrow && (ss ? (aligned && mixed_form) : ff == fs) && fuse_silu && s->dbg_layers < 0 &&
                             s->dbg_stage == 0 && nwg <= s->num_cu && !want_stamps && !s->prof.on && !getenv("DC_NO_FUSE_EMBED");
-    // Persistent layer launch (k_layer PERS): all layers of the step in ONE kernel when every wide workgroup has a CU of its own and
-    // the model has the depth the kernel is compiled for; DC_NO_PERSIST=1 keeps the per-layer launches (read per call).  The
-    // per-kernel profile pass keeps the per-layer launches too (its numbers are per layer).
-    const bool persistent = wgr && !narrow && !ss && nwg <= s->num_cu && nwg <= 4096 && L == DC_PERS_LAYERS && s->dbg_layers < 0 &&
-                            s->dbg_stage == 0 && s->dbg_first < 0 && !s->prof.on && !getenv("DC_NO_PERSIST");
     unsigned* unit_flags = persistent ? s->d_unit_flags : nullptr;
     DcEmbedArgs ea{};
-    if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, ss ? upc : 0, ss ? 1 : 0, unit_flags};
+    if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, aligned ? upc : 0, ss ? 1 : 0, unit_flags};
     const DcUpdate upd{loop_mode ? s->d_step_noise : nullptr, s->d_status, loop_mode ? s->upd_flags : 0, folded ? graph_step : -1, unit_flags};
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
                                        s->NT / 16, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,

@@ -1323,11 +1323,11 @@ DEV void epre_load(EPre& e, const f16x8* __restrict__ Eg, int lane) {
     for (int i = 0; i < 2; ++i) {
         const f16x8* pg = Eg + (2 + i) * 128 + lane;
         const f16x8* ph = Eg + (4 + 2 + i) * 128 + lane;
-        if constexpr (SAFE) {
-            e.glo[i] = pg[0];
-            e.ghi[i] = pg[64];
-            e.hlo[i] = ph[0];
-            e.hhi[i] = ph[64];
+        if constexpr (SAFE) {                      // (non-temporal like the no-wait form: the tiles are read exactly once)
+            e.glo[i] = __builtin_nontemporal_load(pg);
+            e.ghi[i] = __builtin_nontemporal_load(pg + 64);
+            e.hlo[i] = __builtin_nontemporal_load(ph);
+            e.hhi[i] = __builtin_nontemporal_load(ph + 64);
         } else {
             e.glo[i] = ld16_nowait(pg);
             e.ghi[i] = ld16_nowait(pg + 64);
@@ -1335,6 +1335,14 @@ DEV void epre_load(EPre& e, const f16x8* __restrict__ Eg, int lane) {
             e.hhi[i] = ld16_nowait(ph + 64);
         }
     }
+}
+// Tracked (SAFE) prefetch without its price: the compiler guards the FIRST use of a load it knows about with a vmcnt wait, and
+// placed in the middle of the consuming stage that wait would also cover the LDS-DMAs issued just before it.  A use at the very
+// start of the consuming stage - behind the previous stage's closing vmcnt(0), before any new vector-memory operation - puts the
+// compiler's wait where the queue is empty.
+DEV void epre_landed(EPre& e) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(e.glo[i]), "+v"(e.ghi[i]), "+v"(e.hlo[i]), "+v"(e.hhi[i]));
 }
 DEV f16x16 join16(const f16x8& lo8, const f16x8& hi8) {
     f16x16 v;

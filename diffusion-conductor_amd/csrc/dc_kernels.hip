@@ -999,6 +999,15 @@ DEV float ddim_update(float mo, float xt, const float* __restrict__ c, int flags
 // NARROW (WGR, non-split, production build only): 4 waves per workgroup = 128-token units, ONE wave per SIMD.  The kernel is
 // bound by instruction issue, so a wave that has its SIMD to itself runs the layer in about half the time; worth it
 // whenever the batch is small enough for every unit to get its own CU (<= 32 K tokens: e.g. the reference's one clip per call).
+#ifndef DC_PERS_PAIRS
+#define DC_PERS_PAIRS 0          // persistent form: the record tail's projections two feature tiles at a time (0: four, as the per-layer form)
+#endif
+#ifndef DC_PERS_FLAT
+#define DC_PERS_FLAT 1           // persistent form on any units (a workgroup of flat units may span two clips: the tail keeps its two-clip paths)
+#endif
+#ifndef DC_PERS_SAFE_EPRE
+#define DC_PERS_SAFE_EPRE 1      // persistent form: compiler-tracked FiLM-tile prefetch (0: the untracked no-wait form of the per-layer kernel)
+#endif
 #ifndef DC_SPLIT_NW
 #define DC_SPLIT_NW 8      // waves per k_layer workgroup in the split modes (4: one wave per SIMD, round 1-2's form)
 #endif
@@ -1051,7 +1060,11 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         load_h(h, hbuf, g0, threadIdx.x & 63);      // in flight across the first prologue
     }
   constexpr int NLP = PERS ? DC_PERS_LAYERS : 1;
+#ifdef DC_PERS_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
   for (int li = 0; li < NLP; ++li, ++l) {
     const int tid_ = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), lane = tid_ & 63;
@@ -1139,7 +1152,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
     stage_frags<NW>(L.img_sa_o, buf1, NFW + 1, wave, lane);
     EPre ep;
-    if constexpr (use_ring) epre_load<DBG || PERS>(ep, Eg, lane);          // (PERS: the loop-carried residual stream makes the compiler
+    if constexpr (use_ring) epre_load<DBG || (PERS && DC_PERS_SAFE_EPRE)>(ep, Eg, lane);          // (PERS: the loop-carried residual stream makes the compiler
                                                                           // spill; an untracked load's target must never be spilled)
     ytile<SPLIT> y[4];
     float y_rstd, y_shift;
@@ -1156,6 +1169,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(2);
     stage_sync();
     DC_STAMP(3);
+    if constexpr (PERS && DC_PERS_SAFE_EPRE) epre_landed(ep);
     // ---- stage 2: SA stylization [buf1]; prefetch CA query -> buf0 (+ cross-attention frags)
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
@@ -1179,7 +1193,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(5);
     // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
     stage_frags<NW>(L.img_ca_o, buf1, NFW + 1, wave, lane);
-    if constexpr (use_ring) epre_load<DBG || PERS>(ep, Eg + 8 * 128, lane);
+    if constexpr (use_ring) epre_load<DBG || (PERS && DC_PERS_SAFE_EPRE)>(ep, Eg + 8 * 128, lane);
     if (DBG && skip_blocks >= 2) {
     } else if (wg_lds)
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (SPLIT ? 0 : (size_t)(cx.b0 - ub0) * 8 * 64),
@@ -1189,6 +1203,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                                  acl + (size_t)cx.b1 * 16 * 64, cx);
     DC_STAMP(6);
     stage_sync();
+    if constexpr (PERS && DC_PERS_SAFE_EPRE) epre_landed(ep);
     // ---- stage 4: CA stylization [buf1]; prefetch FFN W1|W2 (+ b1|b2) -> buf0
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
@@ -1212,7 +1227,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(8);
     // ---- stage 5: FFN [buf0]; prefetch FFN out-proj -> buf1
     stage_frags<NW>(L.img_ffn_o, buf1, NFW + 1, wave, lane);
-    if constexpr (use_ring) epre_load<DBG || PERS>(ep, Eg + 16 * 128, lane);
+    if constexpr (use_ring) epre_load<DBG || (PERS && DC_PERS_SAFE_EPRE)>(ep, Eg + 16 * 128, lane);
     {
         f32x16 u[2];
         {
@@ -1246,6 +1261,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     }
     DC_STAMP(9);
     stage_sync();
+    if constexpr (PERS && DC_PERS_SAFE_EPRE) epre_landed(ep);
     // ---- stage 6: FFN stylization [buf1]; prefetch next layer's key projection (or the output projection) -> buf0
     {
         auto next_w = [&]() {
@@ -1311,8 +1327,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             const RowRange vr1 = valid_rows_clip(cx, ub0 + 1, B, M, T, length, active);
             const int s0 = cx.b0 - ub0;
             const RowRange vr_own = s0 ? vr1 : vr0;
-            const bool strad = !SPLIT && active && cx.straddle;
-            XFrag<T16, SPLIT> efA[4], efB[SPLIT ? 1 : 4];
+            const bool strad = !SPLIT && !(PERS && !DC_PERS_FLAT) && active && cx.straddle;      // (split and persistent forms: clip-aligned units)
+            XFrag<T16, SPLIT> efA[4], efB[(SPLIT || (PERS && !DC_PERS_FLAT)) ? 1 : 4];
             float ssA[4], ssB[4], mA[4], mB[4];
             auto keys_of = [&](const f32x16& K, const RowRange& rr, XFrag<T16, SPLIT>& ef, float& ssum, float& mcol) {
                 float m = -INFINITY;
@@ -1340,7 +1356,26 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 ssum = xhalf_sum(sacc);
                 make_frag<T16, SPLIT>(Ee, ef);
             };
-            {
+            if constexpr (PERS && DC_PERS_PAIRS) {
+                // (the residual stream stays in registers through this tail: two feature tiles at a time instead of four - 32 accumulator
+                // registers less at the peak; every tile's chain of MFMAs is the same, so are the results)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    f32x16 Ka = splat(c0[64 * hf + cx.c]), Kb = splat(c0[64 * hf + 32 + cx.c]);
+                    mmb_oc_pair<4, 4, T16>(Ka, Kb, w0, 2 * hf, w0, 2 * hf + 1, nf, lane);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int oc = 2 * hf + q;
+                        keys_of(q ? Kb : Ka, vr_own, efA[oc], ssA[oc], mA[oc]);
+                        mB[oc] = -INFINITY;
+                        if (cx.hh == 0) {
+                            mx[((oc * 2 + s0) * 32 + cx.c) * NW + wave] = mA[oc];
+                            mx[((oc * 2 + (s0 ^ 1)) * 32 + cx.c) * NW + wave] = -INFINITY;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
                 f32x16 Kp[4] = {splat(c0[cx.c]), splat(c0[32 + cx.c]), splat(c0[64 + cx.c]), splat(c0[96 + cx.c])};
                 mmb_oc_quad<4, 4, T16, SPLIT>(Kp[0], Kp[1], Kp[2], Kp[3], w0, nf, lane);
 #pragma unroll
@@ -1413,7 +1448,20 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 }
                 return keep;
             };
-            {
+            if constexpr (PERS && DC_PERS_PAIRS) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    f32x16 Va = splat(c1[64 * hf + cx.c]), Vb = splat(c1[64 * hf + 32 + cx.c]);
+                    mmb_oc_pair<4, 4, T16>(Va, Vb, w1, 2 * hf, w1, 2 * hf + 1, nf, lane);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int oc = 2 * hf + q;
+                        pst[(wave * 4 + oc) * 64 + lane] = block_of(efA[oc], q ? Vb : Va, vr_own, scw + (0 * 4 + oc) * 32);
+                        if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssA[oc];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
                 f32x16 Vp[4] = {splat(c1[cx.c]), splat(c1[32 + cx.c]), splat(c1[64 + cx.c]), splat(c1[96 + cx.c])};
                 mmb_oc_quad<4, 4, T16, SPLIT>(Vp[0], Vp[1], Vp[2], Vp[3], w1, nf, lane);
 #pragma unroll

@@ -196,7 +196,7 @@ def describe_status(st: int, precision: str) -> str:
                    "use precision='mixed' (bf16-range operands) or precision='auto'")
     if st & 4:
         msg.append("a workgroup of the persistent layer launch timed out waiting for its neighbours (GPU shared with another process?): "
-                   "results invalid - set DC_NO_PERSIST=1")
+                   "results invalid - unset DC_PERSIST")
     if st & STATUS_F16_SATURATED:
         msg.append("a FiLM modulation value left the fp16 range in which every precision mode stores it: this checkpoint is "
                    "outside what the library supports")

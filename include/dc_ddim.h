@@ -186,8 +186,8 @@ int dc_sampler_ddim_loop_ex(dc_sampler* s, const float* d_noise, float* d_out, i
  * clear != 0 resets the word. */
 #define DC_STATUS_NONFINITE 1
 #define DC_STATUS_F16_SATURATED 2
-#define DC_STATUS_SYNC_TIMEOUT 4   /* a workgroup of the persistent layer launch gave up waiting for its clip's other units (they were not
-                                      co-resident: another process on the GPU?) - the results are invalid; DC_NO_PERSIST=1 avoids the form */
+#define DC_STATUS_SYNC_TIMEOUT 4   /* a workgroup of the persistent layer launch (opt-in: DC_PERSIST=1) gave up waiting for its clip's other
+                                      units (not co-resident: another process on the GPU?) - the results are invalid */
 int dc_sampler_status(dc_sampler* s, int32_t* h_status, int32_t clear);
 
 /* Timing hook for bench.py: device time (ms, HIP events on the library's own stream)

@@ -281,12 +281,14 @@ def test_mixed_mode_clip_aligned_units_edge_shapes(B, T):
     assert torch.equal(again[S], res[S]) and torch.equal(again[3], res[3])
 
 
-@pytest.mark.parametrize("B,T,S", [(32, 1800, 50), (20, 1000, 25), (9, 1800, 25), (33, 300, 25)])
-def test_persistent_layer_launch_equals_per_layer_launches(B, T, S):
-    """Round 3: with every wide workgroup on a CU of its own, the eight layers of a step run as ONE launch (k_layer PERS: residual
-    stream in registers, unit records exchanged inside the launch with sc1 stores / loads behind per-unit progress flags).  Same
-    arithmetic in the same order: bit-identical to the per-layer launches (DC_NO_PERSIST=1), re-runs identical, status clean;
-    ragged lengths; 33 x 300 exceeds the CU count only in the narrow form and runs wide-persistent too."""
+@pytest.mark.parametrize("B,T,S,align", [(32, 1800, 50, False), (32, 1800, 25, True), (20, 1024, 25, False), (9, 1800, 25, False),
+                                         (33, 300, 25, False), (40, 1600, 25, False)])
+def test_persistent_layer_launch_equals_per_layer_launches(B, T, S, align):
+    """Round 3, opt-in (DC_PERSIST=1): with every wide workgroup on a CU of its own, the eight layers of a step run as ONE launch
+    (k_layer PERS: residual stream in registers, unit records exchanged inside the launch with sc1 stores / loads behind per-unit
+    progress flags).  Same units, same arithmetic, same order: bit-identical to the per-layer launches, re-runs identical, status
+    clean; ragged lengths; flat and clip-aligned units; shapes that are not eligible (narrow form, more units than CUs) simply keep
+    the per-layer launches."""
     import os
     sd = synthetic_state_dict(DenoiserConfig(), seed=0)
     m = _model(sd, "fp16")
@@ -295,14 +297,19 @@ def test_persistent_layer_launch_equals_per_layer_launches(B, T, S):
     length = [T if b % 3 else max(1, T - 37 * b) for b in range(B)]
     nat = m.set_conditioning(xfp.cuda(), xfo.cuda(), length)
     coef = make_diffusion(S).native_coefficients()
-    a, _ = nat.ddim_loop(noise, coef, (3,))
-    st = nat.status()
-    os.environ["DC_NO_PERSIST"] = "1"
+    if align:
+        os.environ["DC_ALIGN"] = "1"
     try:
         b, _ = nat.ddim_loop(noise, coef, (3,))
+        os.environ["DC_PERSIST"] = "1"
+        try:
+            a, _ = nat.ddim_loop(noise, coef, (3,))
+            st = nat.status()
+            c, _ = nat.ddim_loop(noise, coef, (3,))
+        finally:
+            del os.environ["DC_PERSIST"]
     finally:
-        del os.environ["DC_NO_PERSIST"]
-    c, _ = nat.ddim_loop(noise, coef, (3,))
+        os.environ.pop("DC_ALIGN", None)
     torch.cuda.synchronize()
     assert st == 0 and torch.isfinite(a).all()
     assert torch.equal(a, b) and torch.equal(a, c)

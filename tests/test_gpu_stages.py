@@ -204,7 +204,9 @@ def test_bench_multi_gpu_evidence_fields_on_one_rank():
                         "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
     print(r.stderr[-1500:])
     assert r.returncode == 0
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 1, out                     # exactly ONE line on stdout (RCCL's version banner goes to stderr)
+    line = json.loads(out[0])
     m = line["multi_gpu"]
     assert m["rccl_ranks"] == 1 and m["backend"] == "nccl" and len(m["devices"]) == 1 and len(m["devices"][0]) > 4
     assert m["gather_block_equals_local"] is True and m["sharded_equals_single_gpu"] is True
