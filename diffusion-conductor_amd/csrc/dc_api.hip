@@ -366,9 +366,9 @@ int build_model(dc_sampler* s) {
     };
     const double LOG2E = 1.4426950408889634;
     // softmax inputs: the linear-attention kernels use exp2 on log2(e)-scaled queries/keys; the full-attention
-    // (no_eff) kernels keep keys unscaled and fold the 1/sqrt(head_dim) = 1/4 into the queries (exact)
+    // (no_eff) kernels keep keys unscaled and fold log2(e) / sqrt(head_dim) into the queries (scores arrive as exp2 exponents)
     const bool full = c.no_eff != 0;
-    const double QS = full ? 0.25 : LOG2E, KS = full ? 1.0 : LOG2E;
+    const double QS = full ? 0.25 * LOG2E : LOG2E, KS = full ? 1.0 : LOG2E;
     // FiLM: all 3L blocks stacked along the output axis -> one [3L*256][512] GEMM operand; inside a block the
     // 32-row tiles are interleaved (scale0, shift0, scale1, shift1, ...) so one wave holds matching pairs
     const int NT = 3 * L * DC_FILM_TILES_PER_BLOCK;

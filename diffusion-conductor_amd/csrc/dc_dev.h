@@ -37,6 +37,24 @@ DEV float xhalf_max(float v) {
 DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 DEV float exp2f_fast(float x) { return __builtin_amdgcn_exp2f(x); }     // v_exp_f32
 
+// acc + the sum of the 8 elements of an operand fragment register group (v_dot2c_f32_f16 / _bf16 against ones)
+DEV float sum8(f16x8 a, float acc) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 one = {(_Float16)1.f, (_Float16)1.f};
+    acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 0, 1), one, acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 2, 3), one, acc, false);
+    acc = __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 4, 5), one, acc, false);
+    return __builtin_amdgcn_fdot2(__builtin_shufflevector(a, a, 6, 7), one, acc, false);
+}
+DEV float sum8(bf16x8 a, float acc) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    const b2 one = {(__bf16)1.f, (__bf16)1.f};
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 0, 1), one, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 2, 3), one, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 4, 5), one, acc, false);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 6, 7), one, acc, false);
+}
+
 // row (feature in FT, token in TF) held by register r of lane-half hh
 DEV int tile_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 

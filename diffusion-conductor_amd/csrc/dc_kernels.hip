@@ -1588,6 +1588,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
 // query row, transformer.py:224) - reproduced including its fp32 rounding; values are never masked; the 1/sqrt(16)
 // is folded into the query projection on the host (exact).
 // ====================================================================================
+#define DC_FULL_ZOFF (32768 + 8 * 8192)          // LDS: key-tile double buffer | per-wave query fragments | 8 KiB of zeros
+#define DC_FULL_LDS (DC_FULL_ZOFF + 8192)
 struct ClipCtx {
     int b, g_lo, nkt, g, c, hh, tok, n;
     bool active, lane_ok;
@@ -1681,6 +1683,9 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
         ls[i] = 0.f;
     }
     const float qshift = q_pad ? -100000.f : 0.f;
+    // the -1e5 of a padded QUERY row only matters to waves that hold such a row (wave-uniform)
+    const bool wpad = any_pad && __builtin_amdgcn_ballot_w64(q_pad) != 0;
+    constexpr float INV_LOG2E = 0.6931471805599453f;
     auto issue = [&](int kt) {       // 16 fragments of key tile kt -> buffer kt & 1, two per wave
         const v8<T16>* src = kv + (size_t)kt * 16 * 64;
         char* dst = lds + (kt & 1) * 16384;
@@ -1689,7 +1694,12 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                 // nobody still reads the buffers (previous attention of this kernel)
+    // 8 KiB of zeros: what the lanes of the OTHER head of a pair read in place of their value rows (all of them the same address
+    // per fragment: a broadcast), so both heads of a pair accumulate into one FT tile without a select per operand register
+    reinterpret_cast<f32x4*>(lds + DC_FULL_ZOFF)[threadIdx.x] = f32x4{0.f, 0.f, 0.f, 0.f};
     issue(0);
+    const bool head0_lane = ((lane & 31) >> 4) == 0;
+    const char* zb = lds + DC_FULL_ZOFF - 8192;          // + the value fragments' offsets inside a key tile (8192 ..)
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) {
             issue(kt + 1);
@@ -1699,12 +1709,15 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
         }
         __syncthreads();
         if (active) {
-            const v8<T16>* fr = reinterpret_cast<const v8<T16>*>(lds + (kt & 1) * 16384);
+            const char* frc = lds + (kt & 1) * 16384;
+            const v8<T16>* fr = reinterpret_cast<const v8<T16>*>(frc);
+            const char* vb[2] = {head0_lane ? frc + lane * 16 : zb, head0_lane ? zb : frc + lane * 16};
             const int k0 = tok0 + 32 * kt;                    // flat token of the tile's row 0
             const bool edge = k0 < key_lo || k0 + 32 > key_hi;
+            // Scores arrive in log2 units (log2(e)/4 is folded into the query projection): exp2(S - running maximum).  (Starting
+            // the MFMA from -maximum instead costs 16 v_mov for the accumulator tuple: the same issue slots as the subtraction.)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const v8<T16> vf0 = fr[(8 + 2 * t) * 64 + lane], vf1 = fr[(8 + 2 * t + 1) * 64 + lane];
 #pragma unroll
                 for (int sh = 0; sh < 2; ++sh) {
                     const int hd = 2 * t + sh;
@@ -1716,9 +1729,9 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
                             if (key < key_lo || key >= key_hi) S[r] = -1e30f;
                         }
                     }
-                    if (any_pad) {
+                    if (wpad) {      // transformer.py:224 in its own units: fl(score + (-1e5)) on the padded query rows
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) S[r] += qshift;
+                        for (int r = 0; r < 16; ++r) S[r] = fmaf(S[r], INV_LOG2E, qshift) * LOG2E;
                     }
                     float mt = S[0];
 #pragma unroll
@@ -1727,31 +1740,22 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
                     // the running maximum rarely moves after the first key tiles: rescale only when some lane's did (wave-uniform)
                     if (__builtin_amdgcn_ballot_w64(mt > mx[hd]) != 0) {
                         const float mn = fmaxf(mx[hd], mt);
-                        const float alpha = exp2f_fast((mx[hd] - mn) * LOG2E);
+                        const float alpha = exp2f_fast(mx[hd] - mn);
                         mx[hd] = mn;
                         ls[hd] *= alpha;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) Y[t][8 * sh + r] *= alpha;
                     }
-                    const float ml = mx[hd] * LOG2E;
-                    float sum = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        S[r] = exp2f_fast(fmaf(S[r], LOG2E, -ml));
-                        sum += S[r];
-                    }
-                    ls[hd] += sum;
+                    for (int r = 0; r < 16; ++r) S[r] -= mx[hd];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) S[r] = exp2f_fast(S[r]);
                     XFrag<T16, false> pf;
                     make_frag<T16, false>(S, pf);
-                    // value rows (features) of the other head of the pair contribute nothing
-                    const bool mine = ((lane & 31) >> 4) == sh;
-                    v8<T16> a0 = vf0, a1 = vf1;
-                    if (!mine) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) a0[e] = a1[e] = (T16)0.f;
-                    }
-                    Y[t] = mfma(a0, pf.hi[0], Y[t]);
-                    Y[t] = mfma(a1, pf.hi[1], Y[t]);
+                    // the normaliser sums the ROUNDED weights, i.e. exactly what the value product uses (v_dot2c_f32_*)
+                    ls[hd] = sum8(pf.hi[1], sum8(pf.hi[0], ls[hd]));
+                    Y[t] = mfma(*reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t) * 1024), pf.hi[0], Y[t]);
+                    Y[t] = mfma(*reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t + 1) * 1024), pf.hi[1], Y[t]);
                     __builtin_amdgcn_sched_barrier(0);      // one head at a time: bounds the fragment-read lookahead
                 }
             }
@@ -2295,11 +2299,11 @@ static hipError_t launch_full_t(hipStream_t st, int which, const DcModel* dm, in
                                 float* snaps, int M, int T, int B, int KT, int stop_after, const DcUpdate& upd) {
     const int WPC = (KT + 7) / 8;
     static unsigned long long optin_done = 0;   // key-tile double buffer (32 KiB) + per-wave query fragments (64 KiB) > 64 KiB of dynamic LDS
-    if (hipError_t e = lds_optin((const void*)k_layer_full<T16>, 32768 + 8 * 8192, optin_done)) return e;
+    if (hipError_t e = lds_optin((const void*)k_layer_full<T16>, DC_FULL_LDS, optin_done)) return e;
     if (which == 0)
         k_embed_front_full<T16><<<dim3(B * WPC), dim3(512), 0, st>>>(dm, x, hbuf, (v8<T16>*)kv_next, M, T, KT, WPC);
     else
-        k_layer_full<T16><<<dim3(B * WPC), dim3(512), 32768 + 8 * 8192, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const v8<T16>*)kv_cur,
+        k_layer_full<T16><<<dim3(B * WPC), dim3(512), DC_FULL_LDS, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const v8<T16>*)kv_cur,
                                                                    (v8<T16>*)kv_next, (const v8<T16>*)kv_ca, length, xin, xout,
                                                                    out_mode, coef_cur, snap_cur, snaps, M, T, B, KT, WPC,
                                                                    stop_after, upd);
