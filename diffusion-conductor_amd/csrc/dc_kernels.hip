@@ -1716,16 +1716,24 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
             const bool edge = k0 < key_lo || k0 + 32 > key_hi;
             // Scores arrive in log2 units (log2(e)/4 is folded into the query projection): exp2(S - running maximum).  (Starting
             // the MFMA from -maximum instead costs 16 v_mov for the accumulator tuple: the same issue slots as the subtraction.)
+            // one head ahead: the next head's score MFMA is in the pipe while this head's exponentials issue
+            f32x16 Snext = mfma(fr[lane], qs[lane], splat(0.f));
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
 #pragma unroll
                 for (int sh = 0; sh < 2; ++sh) {
                     const int hd = 2 * t + sh;
-                    f32x16 S = mfma(fr[hd * 64 + lane], qs[hd * 64 + lane], splat(0.f));
+                    f32x16 S = Snext;
+                    if (hd < 7) {
+                        Snext = mfma(fr[(hd + 1) * 64 + lane], qs[(hd + 1) * 64 + lane], splat(0.f));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if (edge) {
+                        int kb = k0 + 4 * hh;
+                        asm volatile("" : "+v"(kb));          // keeps the 15 key indices of this rare path out of the common one
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int key = k0 + tile_row(r, hh);
+                            const int key = kb + (r & 3) + 8 * (r >> 2);
                             if (key < key_lo || key >= key_hi) S[r] = -1e30f;
                         }
                     }
@@ -1733,27 +1741,35 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
 #pragma unroll
                         for (int r = 0; r < 16; ++r) S[r] = fmaf(S[r], INV_LOG2E, qshift) * LOG2E;
                     }
-                    float mt = S[0];
+                    // The reference point of the exponentials only has to keep them in range, so it is not the exact running
+                    // maximum: tile 0 fixes it, and afterwards it moves only when a tile's weights sum to more than 64 in some
+                    // lane (then a score exceeds it by up to 6 bits - the weights stay below 2^6 * 16, far inside f16/bf16) - the
+                    // test is one compare on the sum the normaliser needs anyway instead of a 16-way maximum per head and tile.
+                    XFrag<T16, false> pf;
+                    float tsum;
+                    auto weights = [&]() {
+                        f32x16 Pw;
 #pragma unroll
-                    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, S[r]);
-                    mt = xhalf_max(mt);
-                    // the running maximum rarely moves after the first key tiles: rescale only when some lane's did (wave-uniform)
-                    if (__builtin_amdgcn_ballot_w64(mt > mx[hd]) != 0) {
+                        for (int r = 0; r < 16; ++r) Pw[r] = exp2f_fast(S[r] - mx[hd]);
+                        make_frag<T16, false>(Pw, pf);
+                        // the normaliser sums the ROUNDED weights, i.e. exactly what the value product uses (v_dot2c_f32_*)
+                        tsum = sum8(pf.hi[1], sum8(pf.hi[0], 0.f));
+                    };
+                    if (kt > 0) weights();
+                    if (kt == 0 || __builtin_amdgcn_ballot_w64(!(tsum <= 64.f)) != 0) {      // (wave-uniform; NaN/inf land here too)
+                        float mt = S[0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, S[r]);
+                        mt = xhalf_max(mt);
                         const float mn = fmaxf(mx[hd], mt);
                         const float alpha = exp2f_fast(mx[hd] - mn);
                         mx[hd] = mn;
                         ls[hd] *= alpha;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) Y[t][8 * sh + r] *= alpha;
+                        weights();
                     }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) S[r] -= mx[hd];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) S[r] = exp2f_fast(S[r]);
-                    XFrag<T16, false> pf;
-                    make_frag<T16, false>(S, pf);
-                    // the normaliser sums the ROUNDED weights, i.e. exactly what the value product uses (v_dot2c_f32_*)
-                    ls[hd] = sum8(pf.hi[1], sum8(pf.hi[0], ls[hd]));
+                    ls[hd] += tsum;
                     Y[t] = mfma(*reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t) * 1024), pf.hi[0], Y[t]);
                     Y[t] = mfma(*reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t + 1) * 1024), pf.hi[1], Y[t]);
                     __builtin_amdgcn_sched_barrier(0);      // one head at a time: bounds the fragment-read lookahead
