@@ -1700,6 +1700,23 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
     issue(0);
     const bool head0_lane = ((lane & 31) >> 4) == 0;
     const char* zb = lds + DC_FULL_ZOFF - 8192;          // + the value fragments' offsets inside a key tile (8192 ..)
+    // The reference point m of a head's exponentials rides in the score MFMA itself: a second k-step whose key operand is the
+    // constant (1, 0, ..) and whose query operand is (-m, 0, ..) makes the accumulators S - m, so the common case has no
+    // subtraction per score (16 v_sub per head and tile against one MFMA + one v_mov).  m is kept as a T16 value for that
+    // (any per-query constant cancels in the softmax).  Waves with padded query rows take the unfolded form: the reference's
+    // -1e5 is added to the raw score there.
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const bool fold = !wpad;
+    const unsigned short one16 = __builtin_bit_cast(unsigned short, (T16)1.f);
+    const v8<T16> kone = __builtin_bit_cast(v8<T16>, u32x4{lane < 32 ? (unsigned)one16 : 0u, 0u, 0u, 0u});
+    unsigned negm[8];                                      // (-m as T16 in k-slot 0 of lanes 0-31 | zero), per head
+#pragma unroll
+    for (int i = 0; i < 8; ++i) negm[i] = 0u;
+    auto scores = [&](const v8<T16>* fr, int hd) {
+        f32x16 S0 = mfma(fr[hd * 64 + lane], qs[hd * 64 + lane], splat(0.f));
+        if (fold) S0 = mfma(kone, __builtin_bit_cast(v8<T16>, u32x4{negm[hd], 0u, 0u, 0u}), S0);
+        return S0;
+    };
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) {
             issue(kt + 1);
@@ -1714,10 +1731,9 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
             const char* vb[2] = {head0_lane ? frc + lane * 16 : zb, head0_lane ? zb : frc + lane * 16};
             const int k0 = tok0 + 32 * kt;                    // flat token of the tile's row 0
             const bool edge = k0 < key_lo || k0 + 32 > key_hi;
-            // Scores arrive in log2 units (log2(e)/4 is folded into the query projection): exp2(S - running maximum).  (Starting
-            // the MFMA from -maximum instead costs 16 v_mov for the accumulator tuple: the same issue slots as the subtraction.)
-            // one head ahead: the next head's score MFMA is in the pipe while this head's exponentials issue
-            f32x16 Snext = mfma(fr[lane], qs[lane], splat(0.f));
+            // Scores arrive in log2 units (log2(e)/4 is folded into the query projection).
+            // One head ahead: the next head's score MFMAs are in the pipe while this head's exponentials issue.
+            f32x16 Snext = scores(fr, 0);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -1725,7 +1741,7 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
                     const int hd = 2 * t + sh;
                     f32x16 S = Snext;
                     if (hd < 7) {
-                        Snext = mfma(fr[(hd + 1) * 64 + lane], qs[(hd + 1) * 64 + lane], splat(0.f));
+                        Snext = scores(fr, hd + 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (edge) {
@@ -1741,33 +1757,49 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
 #pragma unroll
                         for (int r = 0; r < 16; ++r) S[r] = fmaf(S[r], INV_LOG2E, qshift) * LOG2E;
                     }
-                    // The reference point of the exponentials only has to keep them in range, so it is not the exact running
-                    // maximum: tile 0 fixes it, and afterwards it moves only when a tile's weights sum to more than 64 in some
-                    // lane (then a score exceeds it by up to 6 bits - the weights stay below 2^6 * 16, far inside f16/bf16) - the
-                    // test is one compare on the sum the normaliser needs anyway instead of a 16-way maximum per head and tile.
+                    // m only has to keep the exponentials in range, so it is not the exact running maximum: tile 0 fixes it, and
+                    // afterwards it moves only when a tile's weights sum to more than 64 in some lane (then a score exceeds it by
+                    // up to 6 bits - the weights stay below 2^6 * 16, far inside f16/bf16) - one compare on the sum the normaliser
+                    // needs anyway instead of a 16-way maximum per head and tile.
                     XFrag<T16, false> pf;
                     float tsum;
-                    auto weights = [&]() {
+                    auto weights = [&](float off) {      // exp2(S - off) as operand fragments + their sum
                         f32x16 Pw;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) Pw[r] = exp2f_fast(S[r] - mx[hd]);
+                        for (int r = 0; r < 16; ++r) Pw[r] = exp2f_fast(S[r] - off);
                         make_frag<T16, false>(Pw, pf);
                         // the normaliser sums the ROUNDED weights, i.e. exactly what the value product uses (v_dot2c_f32_*)
                         tsum = sum8(pf.hi[1], sum8(pf.hi[0], 0.f));
                     };
-                    if (kt > 0) weights();
+                    if (kt > 0) {
+                        if (fold) {
+                            f32x16 Pw;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) Pw[r] = exp2f_fast(S[r]);
+                            make_frag<T16, false>(Pw, pf);
+                            tsum = sum8(pf.hi[1], sum8(pf.hi[0], 0.f));
+                        } else {
+                            weights(mx[hd]);
+                        }
+                    }
                     if (kt == 0 || __builtin_amdgcn_ballot_w64(!(tsum <= 64.f)) != 0) {      // (wave-uniform; NaN/inf land here too)
+                        const float base = (fold && kt > 0) ? mx[hd] : 0.f;                 // what S already has taken off
                         float mt = S[0];
 #pragma unroll
                         for (int r = 1; r < 16; ++r) mt = fmaxf(mt, S[r]);
-                        mt = xhalf_max(mt);
-                        const float mn = fmaxf(mx[hd], mt);
+                        mt = xhalf_max(mt) + base;
+                        float mn = fmaxf(mx[hd], mt);
+                        if (fold) {
+                            const T16 m16 = (T16)mn;
+                            mn = (float)m16;
+                            negm[hd] = lane < 32 ? (unsigned)__builtin_bit_cast(unsigned short, (T16)(-mn)) : 0u;
+                        }
                         const float alpha = exp2f_fast(mx[hd] - mn);
                         mx[hd] = mn;
                         ls[hd] *= alpha;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) Y[t][8 * sh + r] *= alpha;
-                        weights();
+                        weights(mn - base);
                     }
                     ls[hd] += tsum;
                     Y[t] = mfma(*reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t) * 1024), pf.hi[0], Y[t]);
