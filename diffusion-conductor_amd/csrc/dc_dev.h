@@ -1297,6 +1297,15 @@ DEV void styl_accumulate(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd,
     __builtin_amdgcn_sched_barrier(0);
 }
 
+DEV f16x16 join16(const f16x8& lo8, const f16x8& hi8) {
+    f16x16 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v[i] = lo8[i];
+        v[8 + i] = hi8[i];
+    }
+    return v;
+}
 // Per-wave FiLM tile ring in LDS: two 4-KiB slots, each holding one k-tile's (G'-1, H') tile pair.
 // FiLM tiles are read exactly once: non-temporal, so that 88 MB per layer do not flush the weights, attention fragments and
 // records the workgroups of an XCD share through L2 (same-box A/B: -4 % k_layer, -3.5 % loop)
@@ -1361,15 +1370,6 @@ DEV void epre_load(EPre& e, const f16x8* __restrict__ Eg, int lane) {
 DEV void epre_landed(EPre& e) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(e.glo[i]), "+v"(e.ghi[i]), "+v"(e.hlo[i]), "+v"(e.hhi[i]));
-}
-DEV f16x16 join16(const f16x8& lo8, const f16x8& hi8) {
-    f16x16 v;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        v[i] = lo8[i];
-        v[8 + i] = hi8[i];
-    }
-    return v;
 }
 template <class T16, bool SPLIT, class F>
 DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd, float shift, const EPre& ep,

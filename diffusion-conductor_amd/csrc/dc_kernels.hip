@@ -1588,6 +1588,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
 // query row, transformer.py:224) - reproduced including its fp32 rounding; values are never masked; the 1/sqrt(16)
 // is folded into the query projection on the host (exact).
 // ====================================================================================
+#ifndef DC_FULL_SUM_ADDS
+#define DC_FULL_SUM_ADDS 1       // normaliser as 16 f32 adds of the unrounded weights (0: 8 v_dot2c on the operand fragments, +3.8 % per loop)
+#endif
 #define DC_FULL_ZOFF (32768 + 8 * 8192)          // LDS: key-tile double buffer | per-wave query fragments | 8 KiB of zeros
 #define DC_FULL_LDS (DC_FULL_ZOFF + 8192)
 struct ClipCtx {
@@ -1717,6 +1720,9 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
         if (fold) S0 = mfma(kone, __builtin_bit_cast(v8<T16>, u32x4{negm[hd], 0u, 0u, 0u}), S0);
         return S0;
     };
+#ifdef DC_DIAG_FULL_NKT               // diagnostic builds (results invalid): the key loop cut short, to split a layer's time
+    nkt = min(nkt, DC_DIAG_FULL_NKT);
+#endif
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) {
             issue(kt + 1);
@@ -1777,7 +1783,13 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
 #pragma unroll
                             for (int r = 0; r < 16; ++r) Pw[r] = exp2f_fast(S[r]);
                             make_frag<T16, false>(Pw, pf);
+#if DC_FULL_SUM_ADDS
+                            tsum = 0.f;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) tsum += Pw[r];
+#else
                             tsum = sum8(pf.hi[1], sum8(pf.hi[0], 0.f));
+#endif
                         } else {
                             weights(mx[hd]);
                         }
@@ -1898,7 +1910,8 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
     full_attend<T16>(y, y_rstd, y_shift, h, reinterpret_cast<const W*>(L.img_sa_q), kv_cur + (size_t)cx.b * KT * 16 * 64, cx.nkt,
                      cx.g_lo * 32, key_lo, key_hi, q_pad, any_pad, lds, cx.active, wave, lane, cx.hh);
     load_h(h, hbuf, cx.g, lane);           // not kept live across the key loop
-    styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg, consts(L.img_sa_o), reinterpret_cast<const W*>(L.img_sa_o), lane, cx.hh);
+    styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg, consts(L.img_sa_o), reinterpret_cast<const W*>(L.img_sa_o), lane,
+                                cx.hh);
     if (stop_after == 1) { store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok); return; }
     // ---- cross-attention (no mask, transformer.py:244-264)
     store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok);
