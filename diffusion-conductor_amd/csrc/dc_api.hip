@@ -747,10 +747,12 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     if (s->cfg.no_eff) {
         LAUNCH(K_EMBED, dc_launch_embed_front_full(st, fs, s->d_model, x_src, s->d_h, s->d_kv_sa[0], M, T, B, s->KT));
         for (int l = 0; l < nl_run; ++l) {
+            DcUpdate u = upd;              // (stage stamps of layer 3, tools/stage_stamps_full.py + a -DDC_FULL_STAMPS build: the unused flag pointer carries the buffer)
+            u.unit_flags = (want_stamps && l == 3) ? reinterpret_cast<unsigned*>(s->d_stamps) : nullptr;
             LAUNCH(K_LAYER, dc_launch_layer_full(st, fs, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_kv_sa[l & 1], s->d_kv_sa[(l + 1) & 1],
                                                  s->d_kv_ca, s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur,
                                                  s->d_snap_cur, s->d_snaps, M, T, B, s->KT,
-                                                 (l == nl_run - 1) ? (s->dbg_stage ? s->dbg_stage : (nl_run < L ? 3 : 0)) : 0, upd));
+                                                 (l == nl_run - 1) ? (s->dbg_stage ? s->dbg_stage : (nl_run < L ? 3 : 0)) : 0, u));
         }
         return DC_OK;
     }

@@ -1654,7 +1654,8 @@ DEV void front_full(const XFrag<T16, false> (&nf)[4], const v8<T16>* __restrict_
 template <class T16>
 DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const f32x16 (&h)[4],
                      const v8<T16>* __restrict__ wq, const v8<T16>* __restrict__ kv, int nkt, int tok0, int key_lo,
-                     int key_hi, bool q_pad, bool any_pad, char* lds, bool active, int wave, int lane, int hh) {
+                     int key_hi, bool q_pad, bool any_pad, char* lds, bool active, int wave, int lane, int hh,
+                     unsigned long long* stamps = nullptr /* diagnostic builds: two slots of this wave */) {
     constexpr float LOG2E = 1.4426950408889634f;
     XFrag<T16, false> qf[4];
     {
@@ -1695,6 +1696,7 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
         lds_dma16(src + (size_t)wave * 64 + lane, dst + wave * 1024);
         lds_dma16(src + (size_t)(8 + wave) * 64 + lane, dst + (8 + wave) * 1024);
     };
+    if (stamps && lane == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();       // query projection done
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                 // nobody still reads the buffers (previous attention of this kernel)
     // 8 KiB of zeros: what the lanes of the OTHER head of a pair read in place of their value rows (all of them the same address
@@ -1739,49 +1741,51 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
             const bool edge = k0 < key_lo || k0 + 32 > key_hi;
             // Scores arrive in log2 units (log2(e)/4 is folded into the query projection).
             // One head ahead: the next head's score MFMAs are in the pipe while this head's exponentials issue.
-            f32x16 Snext = scores(fr, 0);
+            // COMMON (compile time): not the first tile, no clip edge in it, no padded query row in the wave - two copies of the
+            // head loop instead of three wave-uniform branches per head.
+            auto tile_body = [&](auto common_tag) {
+                constexpr bool COMMON = decltype(common_tag)::value;
+                f32x16 Snext = scores(fr, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < 4; ++t) {
 #pragma unroll
-                for (int sh = 0; sh < 2; ++sh) {
-                    const int hd = 2 * t + sh;
-                    f32x16 S = Snext;
-                    if (hd < 7) {
-                        Snext = scores(fr, hd + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (edge) {
-                        int kb = k0 + 4 * hh;
-                        asm volatile("" : "+v"(kb));          // keeps the 15 key indices of this rare path out of the common one
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int key = kb + (r & 3) + 8 * (r >> 2);
-                            if (key < key_lo || key >= key_hi) S[r] = -1e30f;
+                    for (int sh = 0; sh < 2; ++sh) {
+                        const int hd = 2 * t + sh;
+                        f32x16 S = Snext;
+                        if (hd < 7) {
+                            Snext = scores(fr, hd + 1);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                    }
-                    if (wpad) {      // transformer.py:224 in its own units: fl(score + (-1e5)) on the padded query rows
+                        if constexpr (!COMMON) {
+                            if (edge) {
+                                int kb = k0 + 4 * hh;
+                                asm volatile("" : "+v"(kb));          // keeps the 15 key indices of this rare path out of the common one
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) S[r] = fmaf(S[r], INV_LOG2E, qshift) * LOG2E;
-                    }
-                    // m only has to keep the exponentials in range, so it is not the exact running maximum: tile 0 fixes it, and
-                    // afterwards it moves only when a tile's weights sum to more than 64 in some lane (then a score exceeds it by
-                    // up to 6 bits - the weights stay below 2^6 * 16, far inside f16/bf16) - one compare on the sum the normaliser
-                    // needs anyway instead of a 16-way maximum per head and tile.
-                    XFrag<T16, false> pf;
-                    float tsum;
-                    auto weights = [&](float off) {      // exp2(S - off) as operand fragments + their sum
-                        f32x16 Pw;
+                                for (int r = 0; r < 16; ++r) {
+                                    const int key = kb + (r & 3) + 8 * (r >> 2);
+                                    if (key < key_lo || key >= key_hi) S[r] = -1e30f;
+                                }
+                            }
+                            if (wpad) {      // transformer.py:224 in its own units: fl(score + (-1e5)) on the padded query rows
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) Pw[r] = exp2f_fast(S[r] - off);
-                        make_frag<T16, false>(Pw, pf);
-                        // the normaliser sums the ROUNDED weights, i.e. exactly what the value product uses (v_dot2c_f32_*)
-                        tsum = sum8(pf.hi[1], sum8(pf.hi[0], 0.f));
-                    };
-                    if (kt > 0) {
-                        if (fold) {
-                            f32x16 Pw;
+                                for (int r = 0; r < 16; ++r) S[r] = fmaf(S[r], INV_LOG2E, qshift) * LOG2E;
+                            }
+                        }
+                        // m only has to keep the exponentials in range, so it is not the exact running maximum: tile 0 fixes it,
+                        // and afterwards it moves only when a tile's weights sum to more than 64 in some lane (then a score exceeds
+                        // it by up to 6 bits - the weights stay below 2^6 * 16, far inside f16/bf16) - one compare on the sum the
+                        // normaliser needs anyway instead of a 16-way maximum per head and tile.
+                        XFrag<T16, false> pf;
+                        float tsum;
+                        auto weights = [&](float off, bool sub) {      // exp2(S - off) as operand fragments + their sum (f32 adds:
+                            f32x16 Pw;                                  // v_dot2c on the fragments costs more issue than it saves)
+                            if (sub) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) Pw[r] = exp2f_fast(S[r]);
+                                for (int r = 0; r < 16; ++r) Pw[r] = exp2f_fast(S[r] - off);
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) Pw[r] = exp2f_fast(S[r]);
+                            }
                             make_frag<T16, false>(Pw, pf);
 #if DC_FULL_SUM_ADDS
                             tsum = 0.f;
@@ -1790,38 +1794,45 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
 #else
                             tsum = sum8(pf.hi[1], sum8(pf.hi[0], 0.f));
 #endif
-                        } else {
-                            weights(mx[hd]);
-                        }
-                    }
-                    if (kt == 0 || __builtin_amdgcn_ballot_w64(!(tsum <= 64.f)) != 0) {      // (wave-uniform; NaN/inf land here too)
-                        const float base = (fold && kt > 0) ? mx[hd] : 0.f;                 // what S already has taken off
-                        float mt = S[0];
+                        };
+                        if constexpr (COMMON)
+                            weights(0.f, false);
+                        else if (kt > 0)
+                            weights(mx[hd], !fold);
+                        if ((!COMMON && kt == 0) || __builtin_amdgcn_ballot_w64(!(tsum <= 64.f)) != 0) {      // (wave-uniform; NaN/inf land here too)
+                            const float base = (fold && kt > 0) ? mx[hd] : 0.f;             // what S already has taken off
+                            float mt = S[0];
 #pragma unroll
-                        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, S[r]);
-                        mt = xhalf_max(mt) + base;
-                        float mn = fmaxf(mx[hd], mt);
-                        if (fold) {
-                            const T16 m16 = (T16)mn;
-                            mn = (float)m16;
-                            negm[hd] = lane < 32 ? (unsigned)__builtin_bit_cast(unsigned short, (T16)(-mn)) : 0u;
-                        }
-                        const float alpha = exp2f_fast(mx[hd] - mn);
-                        mx[hd] = mn;
-                        ls[hd] *= alpha;
+                            for (int r = 1; r < 16; ++r) mt = fmaxf(mt, S[r]);
+                            mt = xhalf_max(mt) + base;
+                            float mn = fmaxf(mx[hd], mt);
+                            if (fold) {
+                                const T16 m16 = (T16)mn;
+                                mn = (float)m16;
+                                negm[hd] = lane < 32 ? (unsigned)__builtin_bit_cast(unsigned short, (T16)(-mn)) : 0u;
+                            }
+                            const float alpha = exp2f_fast(mx[hd] - mn);
+                            mx[hd] = mn;
+                            ls[hd] *= alpha;
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) Y[t][8 * sh + r] *= alpha;
-                        weights(mn - base);
+                            for (int r = 0; r < 8; ++r) Y[t][8 * sh + r] *= alpha;
+                            weights(mn - base, true);
+                        }
+                        ls[hd] += tsum;
+                        Y[t] = mfma(*reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t) * 1024), pf.hi[0], Y[t]);
+                        Y[t] = mfma(*reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t + 1) * 1024), pf.hi[1], Y[t]);
+                        __builtin_amdgcn_sched_barrier(0);      // one head at a time: bounds the fragment-read lookahead
                     }
-                    ls[hd] += tsum;
-                    Y[t] = mfma(*reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t) * 1024), pf.hi[0], Y[t]);
-                    Y[t] = mfma(*reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t + 1) * 1024), pf.hi[1], Y[t]);
-                    __builtin_amdgcn_sched_barrier(0);      // one head at a time: bounds the fragment-read lookahead
                 }
-            }
+            };
+            if (kt > 0 && !edge && fold)
+                tile_body(std::true_type{});
+            else
+                tile_body(std::false_type{});
         }
         __syncthreads();             // the buffer just read is the next-but-one tile's target
     }
+    if (stamps && lane == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();       // key loop done
     RowStats st;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -1881,6 +1892,17 @@ __global__ __launch_bounds__(512, 2) void k_embed_front_full(const DcModel* __re
                     kv_next + ((size_t)cx.b * KT + (cx.g - cx.g_lo)) * 16 * 64, lane, cx.c, cx.hh);
 }
 
+#ifdef DC_FULL_STAMPS          // diagnostic build: s_memrealtime of workgroup 3's waves at the block boundaries of k_layer_full
+#define FSTAMP(i)                                                                                                       \
+    do {                                                                                                                \
+        if (upd.unit_flags && blockIdx.x == 3 && (threadIdx.x & 63) == 0)                                               \
+            reinterpret_cast<unsigned long long*>(upd.unit_flags)[(threadIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define FSTAMP_PTR(i) ((upd.unit_flags && blockIdx.x == 3) ? reinterpret_cast<unsigned long long*>(upd.unit_flags) + (threadIdx.x >> 6) * 32 + (i) : nullptr)
+#else
+#define FSTAMP(i) do {} while (0)
+#define FSTAMP_PTR(i) nullptr
+#endif
 template <class T16>
 __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf,
                                                        const f16x16* __restrict__ E, int NT, const v8<T16>* __restrict__ kv_cur,
@@ -1906,22 +1928,27 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
     ytile<false> y[4];
     float y_rstd, y_shift;
     // ---- self-attention
+    FSTAMP(0);
     load_h(h, hbuf, cx.g, lane);
     full_attend<T16>(y, y_rstd, y_shift, h, reinterpret_cast<const W*>(L.img_sa_q), kv_cur + (size_t)cx.b * KT * 16 * 64, cx.nkt,
-                     cx.g_lo * 32, key_lo, key_hi, q_pad, any_pad, lds, cx.active, wave, lane, cx.hh);
+                     cx.g_lo * 32, key_lo, key_hi, q_pad, any_pad, lds, cx.active, wave, lane, cx.hh, FSTAMP_PTR(8));
+    FSTAMP(1);
     load_h(h, hbuf, cx.g, lane);           // not kept live across the key loop
     styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg, consts(L.img_sa_o), reinterpret_cast<const W*>(L.img_sa_o), lane,
                                 cx.hh);
     if (stop_after == 1) { store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok); return; }
     // ---- cross-attention (no mask, transformer.py:244-264)
+    FSTAMP(2);
     store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok);
     full_attend<T16>(y, y_rstd, y_shift, h, reinterpret_cast<const W*>(L.img_ca_q), kv_ca + ((size_t)l * B + cx.b) * KT * 16 * 64,
-                     cx.nkt, cx.g_lo * 32, key_lo, key_hi, false, false, lds, cx.active, wave, lane, cx.hh);
+                     cx.nkt, cx.g_lo * 32, key_lo, key_hi, false, false, lds, cx.active, wave, lane, cx.hh, FSTAMP_PTR(10));
+    FSTAMP(3);
     load_h(h, hbuf, cx.g, lane);
     styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg + 8 * 128, consts(L.img_ca_o), reinterpret_cast<const W*>(L.img_ca_o), lane,
                                 cx.hh);
     if (stop_after == 2) { store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok); return; }
     // ---- FFN
+    FSTAMP(4);
     {
         const W* w1 = reinterpret_cast<const W*>(L.img_ffn_w1);
         const W* w2 = reinterpret_cast<const W*>(L.img_ffn_w2);
@@ -1956,8 +1983,10 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
         }
         st.finish(y_rstd, y_shift);
     }
+    FSTAMP(5);
     styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg + 16 * 128, consts(L.img_ffn_o), reinterpret_cast<const W*>(L.img_ffn_o), lane,
                                 cx.hh);
+    FSTAMP(6);
     if (!cx.active) return;
     if (!last || stop_after == 3) {
         store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok);
@@ -1967,6 +1996,7 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
         const DcLayer& Ln = dm->layer[l + 1];
         front_full<T16>(nf, reinterpret_cast<const W*>(Ln.img_sa_k), reinterpret_cast<const W*>(Ln.img_sa_v),
                         kv_next + ((size_t)cx.b * KT + (cx.g - cx.g_lo)) * 16 * 64, lane, cx.c, cx.hh);
+        FSTAMP(7);
         return;
     }
     // ---- output projection (always split) + DDIM update (gaussian_diffusion.py:812-830 collapsed)
