@@ -444,6 +444,57 @@ def test_no_eff_long_clip_vs_oracle(model_no_eff):
     assert err <= 5e-3
 
 
+def test_no_eff_stress_checkpoint_ragged_long_clips_vs_oracle():
+    """Round 3's key loop keeps the reference point of the exponentials inside the score MFMA, moves it lazily (only when a
+    tile's weights sum past 64) and takes the general path on the first tile, clip edges and waves with padded query rows.
+    The trained-like stress checkpoint (x3 weights, outlier channels: scores several times larger, reference points that do
+    move) on 29-tile clips with ragged lengths exercises all of them; one forward per clip against the oracle."""
+    from helpers import DenoiserConfig
+    from diffusion_conductor_amd import MotionTransformer
+    from diffusion_conductor_amd.synthetic import batch_music_features, stress_state_dict
+    sd = stress_state_dict(DenoiserConfig(), seed=0)
+    m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cuda", no_clip=True,
+                          precision="fp16", no_eff=True)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda").eval()
+    p = O.to_torch_params(sd, torch.float32)
+    B, T = 3, 900
+    xf = torch.from_numpy(batch_music_features(B, T, first=40))
+    xfp = torch.nn.functional.linear(xf, p["proj.weight"], p["proj.bias"])
+    x = torch.from_numpy(batch_noise(B, T, first=40))
+    t = torch.tensor([49, 7, 0])
+    length = [900, 611, 35]
+    with torch.no_grad():
+        ref = O.denoiser_forward(p, x, t, length, xfp, xf, no_eff=True)
+    out = m(x.cuda(), t, length=torch.tensor(length), xf_proj=xfp.cuda(), xf_out=xf.cuda())
+    again = m(x.cuda(), t, length=torch.tensor(length), xf_proj=xfp.cuda(), xf_out=xf.cuda())
+    torch.cuda.synchronize()
+    err = rel_l2(out, ref)
+    per_clip = [rel_l2(out[b:b + 1], ref[b:b + 1]) for b in range(B)]
+    print(f"no_eff stress checkpoint T=900 ragged: rel-L2 {err:.3e} per clip {['%.2e' % e for e in per_clip]}")
+    assert torch.isfinite(out).all() and torch.equal(out, again)
+    assert err <= 5e-3 and max(per_clip) <= 1e-2
+
+
+def test_no_eff_bf16_mode_vs_oracle():
+    """The bf16 build of the full-attention kernels (same code, v_mfma_*_bf16 and the bf16 reference-point slot): loosely
+    bounded like every plain-bf16 result (8 mantissa bits), ragged lengths and a clip edge inside a key tile."""
+    m = make_model("bf16", no_eff=True)
+    B, T = 3, 200
+    p = oracle_params()
+    xfp, xfo = xf_pair(B, T, first=50)
+    x = torch.from_numpy(batch_noise(B, T, first=50))
+    t = torch.tensor([3, 30, 49])
+    length = [200, 117, 200]
+    with torch.no_grad():
+        ref = O.denoiser_forward(p, x, t, length, xfp, xfo, no_eff=True)
+    out = m(x.cuda(), t, length=torch.tensor(length), xf_proj=xfp.cuda(), xf_out=xfo.cuda())
+    torch.cuda.synchronize()
+    err = rel_l2(out, ref)
+    print(f"no_eff bf16 mode rel-L2 {err:.3e}")
+    assert torch.isfinite(out).all() and err <= TOL_BF16
+
+
 # ---- SURVEY section 8f: post-processing and the batched evaluation driver ------------------------------------------
 def test_savgol_smoothing_matches_scipy():
     """smooth_motion (tools/visualization.py:20-26, kernel 19, order 5) on the GPU vs scipy.signal.savgol_filter."""
