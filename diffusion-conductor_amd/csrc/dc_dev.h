@@ -55,6 +55,15 @@ DEV float sum8(bf16x8 a, float acc) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 6, 7), one, acc, false);
 }
 
+// the sum of the 16 elements of two operand fragment register groups by a packed-f16 tree (7 v_pk_add_f16 + the last pair in f32)
+DEV float sum16_pk(f16x8 a, f16x8 b) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const f16x8 s8 = a + b;                                                       // 4 v_pk_add_f16
+    const f16x4 s4 = __builtin_shufflevector(s8, s8, 0, 1, 2, 3) + __builtin_shufflevector(s8, s8, 4, 5, 6, 7);
+    const h2 s2 = __builtin_shufflevector(s4, s4, 0, 1) + __builtin_shufflevector(s4, s4, 2, 3);
+    return (float)s2[0] + (float)s2[1];
+}
+
 // row (feature in FT, token in TF) held by register r of lane-half hh
 DEV int tile_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 

@@ -1589,7 +1589,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
 // is folded into the query projection on the host (exact).
 // ====================================================================================
 #ifndef DC_FULL_SUM_ADDS
-#define DC_FULL_SUM_ADDS 1       // normaliser as 16 f32 adds of the unrounded weights (0: 8 v_dot2c on the operand fragments, +3.8 % per loop)
+#define DC_FULL_SUM_ADDS 2       // a tile's normaliser term: 2 = packed-f16 tree over the operand fragments (7 v_pk_add_f16, f16 mode; -3 % per
+                                 // loop, goldens +1e-5), 1 = 16 f32 adds of the unrounded weights, 0 = 8 v_dot2c on the fragments (+3.8 %)
 #endif
 #define DC_FULL_ZOFF (32768 + 8 * 8192)          // LDS: key-tile double buffer | per-wave query fragments | 8 KiB of zeros
 #define DC_FULL_LDS (DC_FULL_ZOFF + 8192)
@@ -1787,7 +1788,15 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
                                 for (int r = 0; r < 16; ++r) Pw[r] = exp2f_fast(S[r]);
                             }
                             make_frag<T16, false>(Pw, pf);
-#if DC_FULL_SUM_ADDS
+#if DC_FULL_SUM_ADDS == 2
+                            if constexpr (std::is_same<T16, _Float16>::value)
+                                tsum = sum16_pk(pf.hi[0], pf.hi[1]);
+                            else {
+                                tsum = 0.f;
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) tsum += Pw[r];
+                            }
+#elif DC_FULL_SUM_ADDS
                             tsum = 0.f;
 #pragma unroll
                             for (int r = 0; r < 16; ++r) tsum += Pw[r];
