@@ -116,6 +116,30 @@ def test_sampler_branches_graph_path_g9(tag, prec):
 
 
 @pytest.mark.parametrize("tag", ["clip", "eta", "eps"])
+def test_sampler_branches_no_eff_vs_oracle(tag):
+    """The same three branches through the full-attention kernels (k_layer_full carries the same fused update): against the
+    oracle's loop on the same draws (the oracle is pinned to the reference on these branches by G9 and on no_eff by G3 / G6b)."""
+    from diffusion_conductor_amd import MotionTransformer
+    from helpers import O
+    sd, B, T, S, length, xfp, xfo, noise, z = _g9_setup()
+    clip, eta, mt = _BRANCH[tag]
+    m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cuda", no_clip=True,
+                          precision="fp16", no_eff=True)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda").eval()
+    gd = _diffusion(S, mt)
+    res = gd.ddim_sample_loop(m, (B, T, 26), noise=noise, clip_denoised=clip, progress=False, eta=eta,
+                              model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.LongTensor(length)}, step_noise=z)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.ddim_sample_loop(O.to_torch_params(sd, torch.float32), noise.cpu(), xfp.cpu(), xfo.cpu(), length, S, no_eff=True,
+                                 eta=eta, clip_denoised=clip, eps_model=(mt == "EPSILON"), step_noise=z.cpu())
+    err = rel_l2(res, ref)
+    print(f"no_eff sampler branch [{tag}] rel-L2 vs oracle {err:.3e}")
+    assert torch.isfinite(res).all() and err <= TOL
+
+
+@pytest.mark.parametrize("tag", ["clip", "eta", "eps"])
 def test_sampler_branches_progressive_path_g9(tag):
     """The generator form (one native denoiser call per step, the update on the host side of the ABI) yields the same samples
     and the reference's pred_xstart."""
