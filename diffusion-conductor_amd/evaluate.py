@@ -110,6 +110,7 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
     pf = _Prefetcher(root, ids, batch_size, mel_shape)
     pf.start(0)
     per_clip, total_loss = {}, 0.0
+    out_h = None
     t0 = time.perf_counter()
     for k in range(nb):
         bid, mel, gts = pf.take()
@@ -118,7 +119,12 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
         noise = torch.stack([clip_noise(seed, k * batch_size + i, T, dim_pose) for i in range(len(bid))])
         # [B, T, dim_pose] on the device; smoothing (tools/visualization.py:126) happens in the sampling loop's final write
         pred = trainer.generate_music_motion(mel, dim_pose, noise=noise, smooth=19 if smooth else None)
-        pred = pred.cpu().numpy()
+        if out_h is None or out_h.shape[0] < pred.shape[0] or out_h.shape[1:] != pred.shape[1:]:
+            out_h = torch.empty(tuple(pred.shape), dtype=pred.dtype, pin_memory=pred.is_cuda)     # pageable D2H costs ~3x the copy
+        out_h[:pred.shape[0]].copy_(pred, non_blocking=True)
+        if pred.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        pred = out_h[:pred.shape[0]].numpy()
         for i, cid in enumerate(bid):
             pm = pred[i].reshape([pred[i].shape[0], dim_pose // 2, 2])          # eval_new.py:124-125
             cur = mse_loss(gts[i], pm)
