@@ -273,7 +273,7 @@ def test_encode_music_from_a_pinned_host_batch_is_pipelined_and_identical():
     assert rel_l2(x_h[16:19], rx) <= 1e-4 and rel_l2(xp_h[16:19], rxp) <= 1e-4
 
 
-@pytest.mark.parametrize("B,T", [(1, 257), (3, 1000), (2, 1799), (9, 1800), (33, 300), (5, 77)])
+@pytest.mark.parametrize("B,T", [(1, 257), (3, 1000), (2, 1799), (4, 1800), (33, 300), (5, 77)])
 def test_mixed_mode_clip_aligned_units_edge_shapes(B, T):
     """The split-bf16 layer path on workgroup records runs clip-aligned 8-wave units on a padded clip stride (T >= 256; below that
     the per-group form): strides that need padding, ragged lengths down to one frame, more clips than the fused embedding launch
