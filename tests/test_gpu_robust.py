@@ -262,7 +262,7 @@ def test_encode_music_from_a_pinned_host_batch_is_pipelined_and_identical():
     from helpers import batch_mel
     sd = synthetic_state_dict(DenoiserConfig(), seed=0)
     m = _model(sd, "fp16")
-    mel = torch.from_numpy(batch_mel(19, 540))                  # 2 full chunks of 8 + a ragged one
+    mel = torch.from_numpy(batch_mel(19, 540))                  # a first chunk of 8 clips + the other 11
     xp_d, x_d = m.encode_music(mel.cuda(), "cuda:0")
     xp_h, x_h = m.encode_music(mel.pin_memory(), "cuda:0")
     torch.cuda.synchronize()
