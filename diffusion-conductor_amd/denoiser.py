@@ -153,10 +153,10 @@ class MotionTransformer(nn.Module):
         sizes = [int(v) for v in sched.split(",")] if sched else [self.h2d_chunk, max(1, B - self.h2d_chunk)]
         with torch.cuda.stream(cs):
             lo = 0
-            for n in sizes:
+            for i, n in enumerate(sizes):
                 if lo >= B:
                     break
-                hi = min(lo + max(1, n), B) if n is not sizes[-1] else B
+                hi = min(lo + max(1, n), B) if i + 1 < len(sizes) else B
                 mel[lo:hi].copy_(mel_host[lo:hi], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(cs)
