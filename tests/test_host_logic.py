@@ -404,3 +404,15 @@ def test_prefetcher_hands_loader_errors_to_the_consumer(tmp_path):
     pf.start(1)                                               # clip 002 has the wrong mel shape
     with pytest.raises(ValueError, match="002/mel.npy"):
         pf.take()
+
+
+def test_pinned_host_encode_chunk_boundaries():
+    """denoiser._h2d_bounds: a first chunk, then the rest; explicit schedules; every clip exactly once, in order."""
+    from diffusion_conductor_amd.denoiser import MotionTransformer
+    f = MotionTransformer._h2d_bounds
+    assert f(32, [8, 24]) == [(0, 8), (8, 32)] and f(16, [8, 8]) == [(0, 8), (8, 16)] and f(5, [8, 1]) == [(0, 5)]
+    assert f(9, [8, 1]) == [(0, 8), (8, 9)] and f(19, [4, 12, 16]) == [(0, 4), (4, 16), (16, 19)]
+    assert f(40, [8, 8, 8]) == [(0, 8), (8, 16), (16, 40)] and f(1, [8, 1]) == [(0, 1)]
+    for B in range(1, 70):
+        r = f(B, [8, max(1, B - 8)])
+        assert r[0][0] == 0 and r[-1][1] == B and all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(lo < hi for lo, hi in r)
