@@ -113,8 +113,8 @@ struct Arena {
     }
 };
 
-enum KernelId { K_BEGIN = 0, K_SILU, K_FILM, K_EMBED, K_COMBINE, K_LAYER, K_COUNT };
-const char* kKernelNames[K_COUNT] = {"k_begin_step", "k_silu_emb", "k_film_gemm", "k_embed_front", "k_attn_combine", "k_layer"};
+enum KernelId { K_BEGIN = 0, K_SILU, K_FILM, K_EMBED, K_COMBINE, K_LAYER, K_NOISE, K_COUNT };
+const char* kKernelNames[K_COUNT] = {"k_begin_step", "k_silu_emb", "k_film_gemm", "k_embed_front", "k_attn_combine", "k_layer", "k_step_noise"};
 
 struct Prof {
     bool on = false;
@@ -181,12 +181,16 @@ struct dc_sampler {
     int graph_B = 0, graph_T = 0, graph_K = 0;
     unsigned long long graph_form = 0;     // form_key() of the captured launches
     // DDIM update options of the loop being enqueued (dc_sampler_ddim_loop_ex) and the device status word
-    int upd_flags = 0;
-    const float* d_step_noise = nullptr;
+    int upd_flags = 0;              // DC_UPD_* of the loop being enqueued (incl. the internal NOISY / ZSTEP bits)
+    const float** d_zslot = nullptr;    // device slot holding the base address of the per-iteration noise (DcUpdate::zslot)
+    float* d_zstep = nullptr;       // library-generated draws of one iteration [B][Tx][P] (dc_sampler_set_step_noise_seed)
+    size_t cap_zstep = 0;
+    unsigned long long noise_seed = 0;
+    bool noise_seed_set = false;
     int* d_status = nullptr;
     unsigned* d_unit_flags = nullptr;      // persistent layer launch: per-unit progress flags (reset by every step's embedding)
     // Savitzky-Golay smoothing applied by the loop's final write (dc_sampler_set_smoothing; window 0 = off)
-    int smooth_window = 0, smooth_order = 0;
+    int smooth_window = 0, smooth_order = 0, smooth_table_window = 0;     // (table_window: the hat matrix d_smooth_coef holds)
     float* d_smooth_coef = nullptr;
 
     dc_music* music = nullptr;   // MusicEncoder (built when its parameters were supplied)
@@ -600,6 +604,8 @@ int ensure_workspace(dc_sampler* s, int B, int Tx) {
         HIP_TRY(hipMemset(s->d_status, 0, 16));
         if ((rc = dev_alloc(s, s->d_unit_flags, 4096 * sizeof(unsigned)))) return rc;
         HIP_TRY(hipMemset(s->d_unit_flags, 0, 4096 * sizeof(unsigned)));
+        if ((rc = dev_alloc(s, s->d_zslot, 16))) return rc;
+        HIP_TRY(hipMemset(s->d_zslot, 0, 16));
         if ((rc = dev_alloc(s, s->d_iter, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_snap_cur, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_coef_cur, DC_COEF * 4))) return rc;
@@ -662,8 +668,7 @@ unsigned long long form_key(const dc_sampler* s) {
                                "DC_BEGIN_STEP", "DC_NO_PAD", "DC_PERSIST"};
     unsigned long long k = 0;
     for (size_t i = 0; i < sizeof sw / sizeof *sw; ++i) k |= (getenv(sw[i]) ? 1ull : 0ull) << i;
-    k |= (unsigned long long)(s->upd_flags & 0xff) << 8;
-    k ^= (unsigned long long)(size_t)s->d_step_noise * 0x9e3779b97f4a7c15ull & ~0xffffull;     // the noise pointer is a kernel argument
+    k |= (unsigned long long)(s->upd_flags & 0xff) << 16;     // (the noise tensor's address is not baked in: the kernels read it from d_zslot)
     return k;
 }
 
@@ -688,6 +693,9 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     if (loop_mode && !folded)
         LAUNCH(K_BEGIN, dc_launch_begin_step(st, s->d_iter, s->d_t_of_iter, s->d_coef_of_t, s->d_snap_of_iter,
                                              s->d_t_clip, s->d_coef_cur, s->d_snap_cur, B));
+    if (loop_mode && (s->upd_flags & DC_UPD_ZSTEP))       // this iteration's draws (eta > 0, library-generated): consumed by the last layer's epilogue
+        LAUNCH(K_NOISE, dc_launch_step_noise(st, s->d_zstep, (size_t)B * s->Tx * s->cfg.input_feats, s->noise_seed, iter_base, folded ? graph_step : 0,
+                                             folded ? nullptr : s->d_snap_cur));
     if (!fuse_silu)
         LAUNCH(K_SILU, dc_launch_silu_emb(st, ff, sf, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, G, T, B));
     static const bool want_stamps_film = getenv("DC_STAMPS") != nullptr;       // clock stamps land in stamp slots 28..31 of wave 7
@@ -735,7 +743,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     unsigned* unit_flags = persistent ? s->d_unit_flags : nullptr;
     DcEmbedArgs ea{};
     if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, aligned ? upc : 0, ss ? 1 : 0, unit_flags};
-    const DcUpdate upd{loop_mode ? s->d_step_noise : nullptr, s->d_status, loop_mode ? s->upd_flags : 0, folded ? graph_step : -1, unit_flags};
+    const DcUpdate upd{s->d_zslot, s->d_status, loop_mode ? s->upd_flags : 0, folded ? graph_step : -1, unit_flags};
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
                                        s->NT / 16, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
                                        want_stamps_film ? s->d_stamps + 252 : nullptr,
@@ -807,6 +815,8 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     if (!s->cond_set) return fail(DC_ERR_INVALID, "dc_sampler_set_conditioning must be called first");
     if (S < 1 || S > s->cfg.max_timesteps) return fail(DC_ERR_INVALID, "num_steps %d outside [1, max_timesteps=%d]", S, s->cfg.max_timesteps);
     if (!d_noise || !d_out || !h_coef) return fail(DC_ERR_INVALID, "null pointer argument");
+    if (s->smooth_window > 0 && s->Tx < s->smooth_window)       // (before anything is enqueued: a failed call leaves no work and no half-ordered streams)
+        return fail(DC_ERR_INVALID, "smoothing window %d exceeds the %d frames of a clip", s->smooth_window, s->Tx);
     int rc;
     if ((rc = ensure_steps(s, S))) return rc;
     const size_t MP = (size_t)s->B * s->Tx * s->cfg.input_feats;          // x, snapshots: the caller's layout
@@ -826,10 +836,28 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     }
     const bool same_tables = s->tables_S == S && s->tab_snap == snap_of_iter &&
                              memcmp(s->tab_coef.data(), h_coef, (size_t)S * DC_COEF * 4) == 0;
+    // eta > 0: the caller's [S][B][Tx][P] draws, or - none given, a seed set - one iteration's draws generated at the head of every step
+    const float* zbase = nullptr;
+    if (flags & DC_UPD_NOISY) {
+        if (d_step_noise) {
+            zbase = d_step_noise;
+        } else {
+            if (MP > s->cap_zstep) {
+                s->cap_zstep = 0;
+                if ((rc = dev_alloc(s, s->d_zstep, MP * 4))) return rc;
+                s->cap_zstep = MP;
+            }
+            zbase = s->d_zstep;
+            flags |= DC_UPD_ZSTEP;
+        }
+    }
     s->upd_flags = flags;
-    s->d_step_noise = d_step_noise;
     if ((rc = sync_in(s, user))) return rc;
     hipStream_t st = s->stream;
+    // the status word reports on THIS loop: bits left by earlier work on the sampler (a dc_sampler_denoise, a loop nobody asked
+    // about) must not fail it
+    HIP_TRY(hipMemsetAsync(s->d_status, 0, 4, st));
+    HIP_TRY(dc_launch_set_ptr(st, s->d_zslot, zbase));
     if (!same_tables) {
         HIP_TRY(hipStreamSynchronize(st));          // an earlier call's copies out of the member vectors are done
         s->tables_S = 0;
@@ -893,7 +921,6 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     // the final write x0 -> the caller's tensor: a copy, or (dc_sampler_set_smoothing) the Savitzky-Golay filter along time
     // (tools/visualization.py:20-26,126) reading the loop's x0 and writing the caller's tensor directly - no pass of its own
     if (s->smooth_window > 0) {
-        if (s->Tx < s->smooth_window) return fail(DC_ERR_INVALID, "smoothing window %d exceeds the %d frames of a clip", s->smooth_window, s->Tx);
         HIP_TRY(dc_launch_savgol(st, s->d_x, d_out, s->d_smooth_coef, s->B, s->Tx, s->cfg.input_feats, s->smooth_window));
     } else {
         HIP_TRY(hipMemcpyAsync(d_out, s->d_x, MP * 4, hipMemcpyDeviceToDevice, st));
@@ -901,6 +928,14 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     if (n_snap > 0 && d_snaps_user)
         HIP_TRY(hipMemcpyAsync(d_snaps_user, s->d_snaps, (size_t)n_snap * MP * 4, hipMemcpyDeviceToDevice, st));
     return sync_out(s, user);
+}
+
+// the eta = 0 table [S][4] of dc_ddim_coefficients in the internal [S][DC_COEF] form (sigma = 0)
+std::vector<float> widen_coef(const float* h_coef, int S) {
+    std::vector<float> c8((size_t)(S > 0 ? S : 0) * DC_COEF, 0.f);
+    if (h_coef)
+        for (int t = 0; t < S; ++t) memcpy(&c8[(size_t)DC_COEF * t], h_coef + 4 * (size_t)t, 16);
+    return c8;
 }
 
 }  // namespace
@@ -1013,7 +1048,7 @@ void dc_sampler_destroy(dc_sampler* s) {
     void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
                     s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t, s->d_coef_of_iter,
-                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status, s->d_smooth_coef, s->d_unit_flags};
+                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status, s->d_smooth_coef, s->d_unit_flags, s->d_zslot, s->d_zstep};
     for (void* p : ptrs)
         if (p) hipFree(p);
     dc_music_destroy(s->music);
@@ -1190,13 +1225,17 @@ int dc_sampler_set_smoothing(dc_sampler* s, int32_t window, int32_t order) {
         s->smooth_window = 0;
         return DC_OK;
     }
+    if (window == s->smooth_table_window && order == s->smooth_order && s->d_smooth_coef) {      // the table on the device is this one
+        s->smooth_window = window;
+        return DC_OK;
+    }
     std::vector<float> coef((size_t)(window > 0 ? window : 0) * (window > 0 ? window : 0));
     int rc = dc_savgol_coefficients(window, order, coef.data());
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));          // an earlier loop may still read the old table
     if ((rc = dev_alloc(s, s->d_smooth_coef, coef.size() * 4))) return rc;
     HIP_TRY(hipMemcpy(s->d_smooth_coef, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
-    s->smooth_window = window;
+    s->smooth_window = s->smooth_table_window = window;
     s->smooth_order = order;
     return DC_OK;
 }
@@ -1234,16 +1273,6 @@ int dc_sampler_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timeste
     return sync_out(s, user);
 }
 
-namespace {
-// the eta = 0 table [S][4] of dc_ddim_coefficients in the internal [S][DC_COEF] form (sigma = 0)
-std::vector<float> widen_coef(const float* h_coef, int S) {
-    std::vector<float> c8((size_t)(S > 0 ? S : 0) * DC_COEF, 0.f);
-    if (h_coef)
-        for (int t = 0; t < S; ++t) memcpy(&c8[(size_t)DC_COEF * t], h_coef + 4 * (size_t)t, 16);
-    return c8;
-}
-}  // namespace
-
 int dc_sampler_ddim_loop(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps, const float* h_coef,
                          const int32_t* h_snap_iters, int32_t n_snap, float* d_snaps, void* stream) {
     if (s) HIP_TRY(hipSetDevice(s->cfg.device));
@@ -1258,12 +1287,28 @@ int dc_sampler_ddim_loop_ex(dc_sampler* s, const float* d_noise, float* d_out, i
     if (s) HIP_TRY(hipSetDevice(s->cfg.device));
     if (n_snap < 0 || (n_snap > 0 && (!h_snap_iters || !d_snaps))) return fail(DC_ERR_INVALID, "bad snapshot arguments");
     if (flags & ~(DC_UPD_CLIP | DC_UPD_EPS)) return fail(DC_ERR_INVALID, "unknown update flags 0x%x", flags);
-    if (h_coef8 && !d_step_noise)
-        for (int t = 0; t < num_steps; ++t)
-            if (h_coef8[(size_t)DC_COEF * t + 4] != 0.f)
-                return fail(DC_ERR_INVALID, "sigma[%d] != 0 (eta > 0) needs the per-iteration noise tensor d_step_noise [S][B][T][P]", t);
-    return loop_common(s, d_noise, d_out, num_steps, h_coef8, h_snap_iters, n_snap, d_snaps, (hipStream_t)stream, false, flags,
-                       d_step_noise);
+    bool noisy = false;
+    if (h_coef8 && num_steps > 0)
+        for (int t = 0; t < num_steps; ++t) noisy = noisy || h_coef8[(size_t)DC_COEF * t + 4] != 0.f;
+    if (noisy && !d_step_noise && !(s && s->noise_seed_set))
+        return fail(DC_ERR_INVALID, "sigma != 0 (eta > 0) needs the per-iteration noise: the tensor d_step_noise [S][B][T][P], or a seed "
+                    "(dc_sampler_set_step_noise_seed) for draws generated step by step");
+    return loop_common(s, d_noise, d_out, num_steps, h_coef8, h_snap_iters, n_snap, d_snaps, (hipStream_t)stream, false,
+                       flags | (noisy ? DC_UPD_NOISY : 0), noisy ? d_step_noise : nullptr);
+}
+
+int dc_sampler_set_step_noise_seed(dc_sampler* s, uint64_t seed) {
+    if (!s) return fail(DC_ERR_INVALID, "null sampler");
+    s->noise_seed = seed;
+    s->noise_seed_set = true;
+    return DC_OK;
+}
+
+int dc_step_noise_fill(float* d_out, int64_t n, uint64_t seed, int32_t iteration, void* stream) {
+    if (!d_out || n < 0 || iteration < 0) return fail(DC_ERR_INVALID, "bad step-noise arguments");
+    if (n == 0) return DC_OK;
+    HIP_TRY(dc_launch_step_noise((hipStream_t)stream, d_out, (size_t)n, seed, nullptr, iteration, nullptr));
+    return DC_OK;
 }
 
 int dc_sampler_status(dc_sampler* s, int32_t* h_status, int32_t clear) {
@@ -1274,11 +1319,29 @@ int dc_sampler_status(dc_sampler* s, int32_t* h_status, int32_t clear) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipMemcpy(h_status, s->d_status, 4, hipMemcpyDeviceToHost));
     if ((*h_status & DC_STATUS_NONFINITE) && s->d_E && s->G > 0) {
-        // diagnosis (failure path only): was it the fp16 storage of the FiLM tiles?  The range check is not in the GEMM's
-        // epilogue (it measured at 4 % of that kernel); the tiles of the last step are scanned here instead.
-        HIP_TRY(dc_launch_scan_f16(s->stream, s->d_E, (size_t)s->G * s->NT * 64 * 32, s->d_status));
+        // diagnosis (failure path only): was it the fp16 storage of the FiLM tiles?  The range check is not in the production GEMM's
+        // epilogue (it measured at 4 % of that kernel); the tiles are scanned here instead - the last step's as they stand, then,
+        // while nothing was found, the tiles of every other timestep of the last loop (the GEMM re-run per timestep: the modulation
+        // depends on t, and a value that saturates only early in the loop would otherwise read as an operand overflow)
+        const size_t ebytes = (size_t)s->G * s->NT * 64 * 32;
+        HIP_TRY(dc_launch_scan_f16(s->stream, s->d_E, ebytes, s->d_status));
         HIP_TRY(hipStreamSynchronize(s->stream));
         HIP_TRY(hipMemcpy(h_status, s->d_status, 4, hipMemcpyDeviceToHost));
+        if (!(*h_status & DC_STATUS_F16_SAT) && s->cond_set && s->tables_S > 1 && s->d_t_clip) {
+            std::vector<int> tc((size_t)s->B);
+            for (int i = 0; i + 1 < s->tables_S && !(*h_status & DC_STATUS_F16_SAT); ++i) {
+                std::fill(tc.begin(), tc.end(), s->tab_t[i]);
+                HIP_TRY(hipMemcpy(s->d_t_clip, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
+                if (s->split_film)
+                    HIP_TRY(dc_launch_silu_emb(s->stream, s->film_fmt, true, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, s->G, s->T, s->B));
+                HIP_TRY(dc_launch_film_gemm(s->stream, s->film_fmt, s->split_film, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E,
+                                            s->G, s->NT, 0, s->NT / 16, s->split_film ? nullptr : s->d_pp, s->h_model.temb, s->d_t_clip, s->T, s->B,
+                                            nullptr, nullptr, nullptr, nullptr, s->h_model.film_w16, s->h_model.film_b16, nullptr, s->d_status));
+                HIP_TRY(dc_launch_scan_f16(s->stream, s->d_E, ebytes, s->d_status));
+                HIP_TRY(hipStreamSynchronize(s->stream));
+                HIP_TRY(hipMemcpy(h_status, s->d_status, 4, hipMemcpyDeviceToHost));
+            }
+        }
     }
     if (clear) HIP_TRY(hipMemset(s->d_status, 0, 4));
     return DC_OK;

@@ -83,10 +83,14 @@ struct DcModel {
 #define DC_COEF 8
 #define DC_UPD_CLIP 1        // clip_denoised: pred_xstart.clamp(-1, 1)  (:506-507)
 #define DC_UPD_EPS 2         // ModelMeanType.EPSILON: pred_xstart = sqrt(1/abar) x_t - sqrt(1/abar - 1) model_out  (:516-521, 539-544)
+#define DC_UPD_NOISY 4       // (internal) eta > 0: sigma z is added; the draws are read from *zslot
+#define DC_UPD_ZSTEP 8       // (internal) *zslot holds ONE iteration's draws [B][Tx][P], refilled by k_step_noise at the head of every step
 #define DC_STATUS_NONFINITE 1    // a predicted x0 was inf / nan
 #define DC_STATUS_F16_SAT 2      // a FiLM modulation value exceeded the fp16 range when stored
 struct DcUpdate {
-    const float* z;      // eta > 0: per-iteration noise [S][B][Tx][P] (the reference's th.randn_like(x) draws, :822), else nullptr
+    const float* const* zslot;   // DC_UPD_NOISY: device slot holding the base of the per-iteration noise (the reference's th.randn_like(x)
+                         // draws, :822): the caller's [S][B][Tx][P] tensor, or (DC_UPD_ZSTEP) the library's one-iteration buffer.  A slot,
+                         // not the address itself, so that a captured graph stays valid when the caller hands in another tensor
     int* status;         // device status word (DC_STATUS_* bits are OR-ed in), or nullptr
     int flags;           // DC_UPD_*
     int step;            // captured loop: step number inside the graph (iteration = step + *iter_base); eager: -1 (iteration = snap_cur[1])

@@ -1136,7 +1136,9 @@ DEV void stage_frags(const void* __restrict__ src, char* dst, int nfrags, int wa
 DEV void stage_sync() {
     __builtin_amdgcn_sched_barrier(0);           // stages do not interleave: keeps each stage's live set separate
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#ifndef DC_DIAG_NO_STAGE_BARRIER                 // diagnostic build (timing only, results invalid): the waves of a workgroup free-run
+    __syncthreads();                             // through the stage closers - the bound on what any point-to-point hand-off can gain
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 

@@ -39,6 +39,51 @@ __global__ void k_begin_step(int* __restrict__ iter, const int* __restrict__ t_o
 
 // end of a captured graph of k steps whose kernels indexed the iteration tables themselves (iter_base): next replay starts k later
 __global__ void k_advance_iter(int* __restrict__ iter, int k) { *iter += k; }
+__global__ void k_set_ptr(const float** slot, const float* p) { *slot = p; }
+
+// ------------------------------------------------------------------------------------
+// eta > 0 without a caller-supplied noise tensor: the N(0, 1) draws of ONE iteration (the reference's th.randn_like(x),
+// gaussian_diffusion.py:822), generated at the head of the step that consumes them - a [B][Tx][P] buffer instead of the
+// [S][B][Tx][P] tensor (6 GB at S = 1000, bs = 32).  Philox4x32-10 keyed by the seed, counter = (element quad, iteration);
+// Box-Muller on the four words.  Element e of iteration it depends on (seed, it, e) only: batch layout, graph form and
+// launch geometry do not enter.
+// ------------------------------------------------------------------------------------
+DEV void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (unsigned)p1;
+    c[3] = (unsigned)p0;
+    c[0] = n0;
+    c[2] = n2;
+}
+__global__ __launch_bounds__(256) void k_step_noise(float* __restrict__ z, size_t n, unsigned long long seed, const int* __restrict__ iter_base,
+                                                    int step, const int* __restrict__ snap_cur) {
+    const unsigned it = (unsigned)(iter_base ? step + *iter_base : (snap_cur ? snap_cur[1] : step));
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; 4 * q < n; q += (size_t)gridDim.x * 256) {
+        unsigned c[4] = {(unsigned)q, (unsigned)(q >> 32), it, 0x5eedu};
+        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        float o[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)(c[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);            // (0, 1]
+            const float u2 = (float)(c[2 * h + 1] >> 8) * (1.0f / 16777216.0f);                 // [0, 1)
+            const float rad = sqrtf(-2.0f * logf(u1));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            o[2 * h] = rad * cs;
+            o[2 * h + 1] = rad * sn;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * q + i < n) z[4 * q + i] = o[i];
+    }
+}
 
 // ------------------------------------------------------------------------------------
 // timestep_embedding + time_embed MLP table (transformer.py:8-25, 410-414): one block per t
@@ -1008,6 +1053,9 @@ DEV float ddim_update(float mo, float xt, const float* __restrict__ c, int flags
 #ifndef DC_PERS_SAFE_EPRE
 #define DC_PERS_SAFE_EPRE 1      // persistent form: compiler-tracked FiLM-tile prefetch (0: the untracked no-wait form of the per-layer kernel)
 #endif
+#ifndef DC_EPRE_SAFE
+#define DC_EPRE_SAFE 0           // 1: the per-layer kernel's FiLM-tile prefetch as compiler-tracked loads + epre_landed (A/B switch)
+#endif
 #ifndef DC_SPLIT_NW
 #define DC_SPLIT_NW 8      // waves per k_layer workgroup in the split modes (4: one wave per SIMD, round 1-2's form)
 #endif
@@ -1152,7 +1200,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
     stage_frags<NW>(L.img_sa_o, buf1, NFW + 1, wave, lane);
     EPre ep;
-    if constexpr (use_ring) epre_load<DBG || (PERS && DC_PERS_SAFE_EPRE)>(ep, Eg, lane);          // (PERS: the loop-carried residual stream makes the compiler
+    if constexpr (use_ring) epre_load<DBG || DC_EPRE_SAFE || (PERS && DC_PERS_SAFE_EPRE)>(ep, Eg, lane);          // (PERS: the loop-carried residual stream makes the compiler
                                                                           // spill; an untracked load's target must never be spilled)
     ytile<SPLIT> y[4];
     float y_rstd, y_shift;
@@ -1169,7 +1217,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(2);
     stage_sync();
     DC_STAMP(3);
-    if constexpr (PERS && DC_PERS_SAFE_EPRE) epre_landed(ep);
+    if constexpr (DC_EPRE_SAFE || (PERS && DC_PERS_SAFE_EPRE)) epre_landed(ep);
     // ---- stage 2: SA stylization [buf1]; prefetch CA query -> buf0 (+ cross-attention frags)
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
@@ -1193,7 +1241,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(5);
     // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
     stage_frags<NW>(L.img_ca_o, buf1, NFW + 1, wave, lane);
-    if constexpr (use_ring) epre_load<DBG || (PERS && DC_PERS_SAFE_EPRE)>(ep, Eg + 8 * 128, lane);
+    if constexpr (use_ring) epre_load<DBG || DC_EPRE_SAFE || (PERS && DC_PERS_SAFE_EPRE)>(ep, Eg + 8 * 128, lane);
     if (DBG && skip_blocks >= 2) {
     } else if (wg_lds)
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (SPLIT ? 0 : (size_t)(cx.b0 - ub0) * 8 * 64),
@@ -1203,7 +1251,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                                  acl + (size_t)cx.b1 * 16 * 64, cx);
     DC_STAMP(6);
     stage_sync();
-    if constexpr (PERS && DC_PERS_SAFE_EPRE) epre_landed(ep);
+    if constexpr (DC_EPRE_SAFE || (PERS && DC_PERS_SAFE_EPRE)) epre_landed(ep);
     // ---- stage 4: CA stylization [buf1]; prefetch FFN W1|W2 (+ b1|b2) -> buf0
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
@@ -1227,7 +1275,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(8);
     // ---- stage 5: FFN [buf0]; prefetch FFN out-proj -> buf1
     stage_frags<NW>(L.img_ffn_o, buf1, NFW + 1, wave, lane);
-    if constexpr (use_ring) epre_load<DBG || (PERS && DC_PERS_SAFE_EPRE)>(ep, Eg + 16 * 128, lane);
+    if constexpr (use_ring) epre_load<DBG || DC_EPRE_SAFE || (PERS && DC_PERS_SAFE_EPRE)>(ep, Eg + 16 * 128, lane);
     {
         f32x16 u[2];
         {
@@ -1261,7 +1309,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     }
     DC_STAMP(9);
     stage_sync();
-    if constexpr (PERS && DC_PERS_SAFE_EPRE) epre_landed(ep);
+    if constexpr (DC_EPRE_SAFE || (PERS && DC_PERS_SAFE_EPRE)) epre_landed(ep);
     // ---- stage 6: FFN stylization [buf1]; prefetch next layer's key projection (or the output projection) -> buf0
     {
         auto next_w = [&]() {
@@ -1550,8 +1598,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         const int ib = iter_base ? *iter_base : 0;
         coef_cur += DC_COEF * ib;
         const int snap = snap_cur[ib];
-        const bool noisy = upd.z != nullptr;
-        const float* zrow = noisy ? upd.z + (size_t)(iter_base ? upd.step + ib : snap_cur[1]) * B * Tx * P : nullptr;
+        const bool noisy = (upd.flags & DC_UPD_NOISY) != 0;
+        const float* zrow = nullptr;
+        if (noisy) zrow = *upd.zslot + ((upd.flags & DC_UPD_ZSTEP) ? (size_t)0 : (size_t)(iter_base ? upd.step + ib : snap_cur[1]) * B * Tx * P);
         bool bad = false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -2032,8 +2081,9 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
         }
     } else {
         const int snap = snap_cur[0];
-        const bool noisy = upd.z != nullptr;
-        const float* zrow = noisy ? upd.z + (size_t)snap_cur[1] * M * P : nullptr;        // (k_begin_step runs every step on this path)
+        const bool noisy = (upd.flags & DC_UPD_NOISY) != 0;
+        const float* zrow = nullptr;                                                      // (k_begin_step runs every step on this path)
+        if (noisy) zrow = *upd.zslot + ((upd.flags & DC_UPD_ZSTEP) ? (size_t)0 : (size_t)snap_cur[1] * M * P);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = tile_row(r, cx.hh);
@@ -2155,6 +2205,17 @@ hipError_t dc_launch_scan_f16(hipStream_t st, const void* e, size_t bytes, int* 
 
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k) {
     k_advance_iter<<<1, 1, 0, st>>>(iter, k);
+    return hipGetLastError();
+}
+hipError_t dc_launch_set_ptr(hipStream_t st, const float** slot, const float* p) {
+    k_set_ptr<<<1, 1, 0, st>>>(slot, p);
+    return hipGetLastError();
+}
+hipError_t dc_launch_step_noise(hipStream_t st, float* z, size_t n, unsigned long long seed, const int* iter_base, int step, const int* snap_cur) {
+    const size_t quads = (n + 3) / 4;
+    const size_t nb = (quads + 255) / 256;
+    const unsigned grid = (unsigned)(nb < 4096 ? nb : 4096);
+    k_step_noise<<<dim3(grid ? grid : 1), dim3(256), 0, st>>>(z, n, seed, iter_base, step, snap_cur);
     return hipGetLastError();
 }
 hipError_t dc_launch_begin_step(hipStream_t st, int* iter, const int* t_of_iter, const float* coef_of_t,

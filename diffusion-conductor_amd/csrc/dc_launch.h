@@ -58,6 +58,9 @@ hipError_t dc_launch_layers_persistent(hipStream_t st, int fmt, const DcModel* d
                                        size_t rec_stride, const int* iter_base, int Tx, int upc, const DcUpdate& upd,
                                        unsigned long long* stamps = nullptr /* diagnostic stage stamps of layer 3 (tools/stage_stamps.py) */);
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);
+hipError_t dc_launch_set_ptr(hipStream_t st, const float** slot, const float* p);
+// N(0, 1) draws of one DDIM iteration (Philox keyed by seed; iteration = step + *iter_base, else snap_cur[1], else step) into z[0..n)
+hipError_t dc_launch_step_noise(hipStream_t st, float* z, size_t n, unsigned long long seed, const int* iter_base, int step, const int* snap_cur);
 // diagnosis: OR DC_STATUS_F16_SAT into *status when the fp16 buffer e holds an inf / nan
 hipError_t dc_launch_scan_f16(hipStream_t st, const void* e, size_t bytes, int* status);
 // rec_stride: floats between the two alternating unit-record buffers (0 = single buffer, non-wgr)

@@ -56,7 +56,12 @@ class DDPMTrainer(object):
         mel = torch.as_tensor(np.asarray(music_mel) if not torch.is_tensor(music_mel) else music_mel)
         if mel.dim() == 2:
             mel = mel.unsqueeze(0)
-        mel = mel.to(self.device, dtype=torch.float32)
+        # A pinned fp32 host batch stays on the host: encode_music copies it in chunks beside the encoder (denoiser.py,
+        # _encode_music_pipelined), and a rank of a sharded run copies only its own clips.  Everything else (pageable host
+        # memory - the driver stages it through its own pinned buffers anyway -, other dtypes, device tensors) goes to the
+        # device here, as ddpm_trainer.py:185 does.
+        if not (not mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous() and mel.is_pinned()):
+            mel = mel.to(self.device, dtype=torch.float32)
         B, T = mel.shape[0], (mel.shape[1] - 1) // 3 + 1       # frames encode_music produces (MusicEncoder pools time by 3)
         _, world = dist_info()
         grouped = torch.distributed.is_available() and torch.distributed.is_initialized()     # a world-size-1 group still gathers
@@ -80,4 +85,5 @@ class DDPMTrainer(object):
         with torch.no_grad():
             if not grouped or len(idxs):
                 return self._sample_local(mel, noise, dim_pose, idxs, sm)
-            return sharded_sample(lambda m, n: self._sample_local(m, n, dim_pose, [], sm), mel, noise, out_shape=(T, dim_pose))
+            return sharded_sample(lambda m, n: self._sample_local(m, n, dim_pose, [], sm), mel, noise, out_shape=(T, dim_pose),
+                                  device=self.device)

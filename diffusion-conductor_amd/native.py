@@ -24,6 +24,7 @@ EXPORTS = [
     "dc_kernel_name", "dc_kernel_count", "dc_sampler_workspace_bytes", "dc_sampler_clip_stride", "dc_sampler_debug_denoise",
     "dc_sampler_debug_read", "dc_sampler_debug_layer", "dc_savgol_coefficients", "dc_savgol_filter",
     "dc_ddim_coefficients_ex", "dc_sampler_ddim_loop_ex", "dc_sampler_status", "dc_sampler_set_smoothing",
+    "dc_sampler_set_step_noise_seed", "dc_step_noise_fill",
 ]
 
 UPDATE_CLIP_DENOISED, UPDATE_EPSILON = 1, 2          # flags of dc_sampler_ddim_loop_ex
@@ -54,7 +55,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     bdir = os.path.join(_HERE, "build")
     os.makedirs(bdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value"]
     objs, jobs = [], []
     for src in srcs:
         obj = os.path.join(bdir, os.path.basename(src).replace(".hip", ".o"))
@@ -120,6 +121,8 @@ def lib():
     L.dc_ddim_coefficients_ex.argtypes = [C.c_int32, dp, C.c_float, fp]
     L.dc_sampler_ddim_loop_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, fp, C.c_int32, C.c_void_p, ip, C.c_int32,
                                           C.c_void_p, C.c_void_p]
+    L.dc_sampler_set_step_noise_seed.argtypes = [C.c_void_p, C.c_uint64]
+    L.dc_step_noise_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_int32, C.c_void_p]
     L.dc_sampler_status.argtypes = [C.c_void_p, ip, C.c_int32]
     L.dc_sampler_set_smoothing.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.dc_sampler_debug_denoise.argtypes = [C.c_void_p, C.c_void_p, ip, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
@@ -186,6 +189,17 @@ def savgol_filter(poses, window: int = 19, order: int = 5):
     out = torch.empty_like(x)
     _check(lib().dc_savgol_filter(x.data_ptr(), out.data_ptr(), B, T, P, int(window), int(order),
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
+
+
+def step_noise(shape, seed: int, iteration: int, device):
+    """dc_step_noise_fill: the library's N(0, 1) draws of one DDIM iteration for `seed` as a new fp32 tensor of `shape` on `device`
+    (what a seeded eta > 0 loop adds at that iteration)."""
+    import torch
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    with torch.cuda.device(out.device):
+        _check(lib().dc_step_noise_fill(out.data_ptr(), out.numel(), C.c_uint64(int(seed) & (2 ** 64 - 1)), int(iteration),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     return out
 
 
@@ -320,9 +334,10 @@ class NativeSampler:
         _check(lib().dc_sampler_denoise(self._h, x.data_ptr(), _iptr(ta), out.data_ptr(), self._stream()))
         return out
 
-    def ddim_loop(self, noise, coef, snap_iters=(), flags=0, step_noise=None):
+    def ddim_loop(self, noise, coef, snap_iters=(), flags=0, step_noise=None, noise_seed=None):
         """coef [S, 4] (dc_sampler_ddim_loop: START_X, no clipping, eta = 0) or [S, 8] (dc_sampler_ddim_loop_ex with `flags` =
-        UPDATE_* and, when any sigma != 0, step_noise [S, B, T, P] on the device)."""
+        UPDATE_* and, when any sigma != 0, either step_noise [S, B, T, P] on the device or noise_seed: the library then generates
+        each iteration's draws at the head of its step, dc_sampler_set_step_noise_seed)."""
         import torch
         assert noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous()
         assert tuple(noise.shape) == (self.B, self.T, self.cfg.input_feats)
@@ -342,6 +357,8 @@ class NativeSampler:
                 assert step_noise.is_cuda and step_noise.dtype == torch.float32 and step_noise.is_contiguous()
                 assert tuple(step_noise.shape) == (S,) + tuple(noise.shape)
                 zp = step_noise.data_ptr()
+            elif noise_seed is not None:
+                _check(lib().dc_sampler_set_step_noise_seed(self._h, C.c_uint64(int(noise_seed) & (2 ** 64 - 1))))
             _check(lib().dc_sampler_ddim_loop_ex(self._h, noise.data_ptr(), out.data_ptr(), S, _fptr(coef), int(flags), zp, sip,
                                                  len(si), snp, self._stream()))
         return out, snaps

@@ -178,18 +178,23 @@ class GaussianDiffusion:
         (`model.check_numerics`): a non-finite x0 under precision="auto" falls back to the bf16-range mode in a fresh sampler."""
         flags = (native.UPDATE_CLIP_DENOISED if clip_denoised else 0) | \
             (native.UPDATE_EPSILON if self.model_mean_type == ModelMeanType.EPSILON else 0)
-        z = None
+        z, zseed = None, None
         if eta != 0.0:
-            shape = (self.num_timesteps,) + tuple(img.shape)
-            z = th.randn(*shape, device=img.device) if step_noise is None else step_noise
-            z = z.to(device=img.device, dtype=th.float32).contiguous()
-            assert tuple(z.shape) == shape, f"step_noise must be {shape}"
+            if step_noise is not None:
+                shape = (self.num_timesteps,) + tuple(img.shape)
+                z = step_noise.to(device=img.device, dtype=th.float32).contiguous()
+                assert tuple(z.shape) == shape, f"step_noise must be {shape}"
+            else:
+                # the reference draws th.randn_like(x) once per step (gaussian_diffusion.py:822); so does the library, at the head
+                # of each step, from a seed taken off torch's default generator (torch.manual_seed makes a run reproducible) -
+                # never the whole [S, B, T, P] tensor up front (6 GB at S = 1000, bs = 32)
+                zseed = int(th.randint(0, 2 ** 62, (1,)).item())
         plain = flags == 0 and eta == 0.0
         coef = self.native_coefficients(None if plain else eta)
         while True:
             nat = model.set_conditioning(mk["xf_proj"], mk["xf_out"], mk.get("length"))
             nat.set_smoothing(*(smooth if smooth else (0, 0)))
-            out, snaps = nat.ddim_loop(img, coef, snap, flags, z)
+            out, snaps = nat.ddim_loop(img, coef, snap, flags, z, zseed)
             if not getattr(model, "check_numerics", True):
                 return out, snaps
             st = nat.status()

@@ -40,9 +40,10 @@ def gather_poses(local: torch.Tensor, n_clips: int, group=None) -> torch.Tensor:
     return torch.cat([out[r * bmax: r * bmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)
 
 
-def sharded_sample(sample_fn, mel, noise=None, group=None, out_shape=None):
+def sharded_sample(sample_fn, mel, noise=None, group=None, out_shape=None, device=None):
     """Run `sample_fn(mel_shard, noise_shard) -> [b_local,T,P]` on this rank's clips and gather.
-    mel: [B, Tm, 128]; noise: [B, T, P] or None.  A rank whose shard is empty (fewer clips than ranks, e.g. the
+    mel: [B, Tm, 128], on the device or still on the host (each rank then copies only its own clips; `device` = where the
+    results live, default mel.device); noise: [B, T, P] or None.  A rank whose shard is empty (fewer clips than ranks, e.g. the
     last batch of a dataset) samples nothing and contributes zero rows of `out_shape` = (T, P) to the gather -
     it must still enter the collective, or the other ranks would wait for it forever."""
     rank, world = dist_info(group)
@@ -57,5 +58,5 @@ def sharded_sample(sample_fn, mel, noise=None, group=None, out_shape=None):
     else:
         if out_shape is None:
             out_shape = tuple(noise.shape[1:])
-        local = torch.zeros((0,) + tuple(out_shape), dtype=torch.float32, device=mel.device)
+        local = torch.zeros((0,) + tuple(out_shape), dtype=torch.float32, device=mel.device if device is None else device)
     return gather_poses(local, B, group)

@@ -23,6 +23,10 @@
 
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table
+ * (tests/test_host_logic.py compares `nm -D` with this header). */
+#define DC_EXPORT __attribute__((visibility("default")))
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -66,8 +70,8 @@ typedef struct dc_config {
     int32_t device;        /* HIP device ordinal                       */
 } dc_config;
 
-const char* dc_last_error(void);
-const char* dc_version(void);
+DC_EXPORT const char* dc_last_error(void);
+DC_EXPORT const char* dc_version(void);
 
 /* ------------------------------------------------------------------------------------
  * Host-only helpers (no GPU needed; usable and tested on a CPU-only box).
@@ -75,7 +79,7 @@ const char* dc_version(void);
 
 /* get_named_beta_schedule('linear', n) (models/gaussian_diffusion.py:228-245) and the
  * tables GaussianDiffusion.__init__ derives from it (:342-361), all fp64, each [n]. */
-int dc_linear_beta_schedule(int32_t num_steps, double* h_betas, double* h_alphas_cumprod,
+DC_EXPORT int dc_linear_beta_schedule(int32_t num_steps, double* h_betas, double* h_alphas_cumprod,
                             double* h_alphas_cumprod_prev, double* h_sqrt_recip_alphas_cumprod,
                             double* h_sqrt_recipm1_alphas_cumprod);
 
@@ -85,7 +89,7 @@ int dc_linear_beta_schedule(int32_t num_steps, double* h_betas, double* h_alphas
  *   h_coef[t*4 + 1] = (float)sqrt(1/abar_t - 1)        (sqrt_recipm1_alphas_cumprod)
  *   h_coef[t*4 + 2] = sqrtf((float)abar_{t-1})         (coefficient of pred_xstart)
  *   h_coef[t*4 + 3] = sqrtf(1 - (float)abar_{t-1})     (coefficient of eps)          */
-int dc_ddim_coefficients(int32_t num_steps, const double* h_alphas_cumprod, float* h_coef);
+DC_EXPORT int dc_ddim_coefficients(int32_t num_steps, const double* h_alphas_cumprod, float* h_coef);
 
 /* The same for any eta >= 0 (models/gaussian_diffusion.py:814-826), eight floats per timestep, fp32 arithmetic on the
  * fp32-rounded table entries in the reference's own order:
@@ -93,13 +97,13 @@ int dc_ddim_coefficients(int32_t num_steps, const double* h_alphas_cumprod, floa
  *   h_coef8[t*8 + 3] = sqrtf(1 - abar_{t-1} - sigma^2)   (coefficient of eps)
  *   h_coef8[t*8 + 4] = sigma                             (coefficient of the noise draw; 0 at t = 0 = the reference's nonzero_mask)
  *   h_coef8[t*8 + 5..7] = 0 */
-int dc_ddim_coefficients_ex(int32_t num_steps, const double* h_alphas_cumprod, float eta, float* h_coef8);
+DC_EXPORT int dc_ddim_coefficients_ex(int32_t num_steps, const double* h_alphas_cumprod, float eta, float* h_coef8);
 
 /* Test hook: pack a row-major Linear weight W[n_out][k_in] (torch layout) into the
  * MFMA fragment-major bf16 image the kernels read (see DESIGN.md "weight image").
  * `chained` != 0 uses the accumulator-as-operand k order, 0 the natural k order.
  * h_hi / h_lo receive ceil(n_out/32)*ceil(k_in/32)*2*64*8 uint16 (bf16 bits) each. */
-int dc_pack_weight(const float* h_w, int32_t n_out, int32_t k_in, int32_t chained,
+DC_EXPORT int dc_pack_weight(const float* h_w, int32_t n_out, int32_t k_in, int32_t chained,
                    uint16_t* h_hi, uint16_t* h_lo);
 
 /* ------------------------------------------------------------------------------------
@@ -108,19 +112,19 @@ int dc_pack_weight(const float* h_w, int32_t n_out, int32_t k_in, int32_t chaine
 
 /* Replaces constructing MotionTransformer (models/transformer.py:360-445) +
  * GaussianDiffusion (models/gaussian_diffusion.py:328-379) for sampling. */
-int dc_sampler_create(const dc_config* cfg, dc_sampler** out);
-void dc_sampler_destroy(dc_sampler* s);
+DC_EXPORT int dc_sampler_create(const dc_config* cfg, dc_sampler** out);
+DC_EXPORT void dc_sampler_destroy(dc_sampler* s);
 
 /* Replaces nn.Module.load_state_dict for the entries of state['encoder']
  * (trainers/ddpm_trainer.py:303-319): call once per float tensor with the reference's
  * own key (e.g. "temporal_decoder_blocks.3.sa_block.query.weight") and its contiguous
  * fp32 data, then dc_sampler_finalize_params.  Unknown keys -> DC_ERR_PARAM. */
-int dc_sampler_set_param(dc_sampler* s, const char* name, const float* h_data, int64_t numel);
+DC_EXPORT int dc_sampler_set_param(dc_sampler* s, const char* name, const float* h_data, int64_t numel);
 
 /* Packs all parameters into the device weight image and builds the
  * timestep_embedding + time_embed table (models/transformer.py:8-25, 410-414, 482).
  * Missing entries -> DC_ERR_PARAM.  Synchronous. */
-int dc_sampler_finalize_params(dc_sampler* s);
+DC_EXPORT int dc_sampler_finalize_params(dc_sampler* s);
 
 /* Step-invariant part of MotionTransformer.forward (models/transformer.py:479-482 and
  * the K/V/attention half of LinearTemporalCrossAttention.forward :149-155): applies
@@ -129,7 +133,7 @@ int dc_sampler_finalize_params(dc_sampler* s);
  * h_length: int32 [B] (model_kwargs['length']), NULL = all T.
  * Must be called before dc_sampler_denoise / dc_sampler_ddim_loop; (re)allocates the
  * workspace for (B, T). */
-int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const float* d_xf_out,
+DC_EXPORT int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const float* d_xf_out,
                                 const int32_t* h_length, int32_t B, int32_t T, void* stream);
 
 /* MotionTransformer.encode_music in eval mode (models/transformer.py:447-459) with the MusicEncoder conv stack
@@ -137,12 +141,12 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
  * trainers/ddpm_trainer.py:186-189) -> d_xf_out = music_encoder(mel) and d_xf_proj = proj(d_xf_out), both fp32
  * [B, (Tm-1)/3+1, 64], caller-allocated.  Needs the `music_encoder.*` and `proj.*` state_dict entries
  * (optional as a group in dc_sampler_set_param; DC_ERR_PARAM here when they were not supplied). */
-int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t B, int32_t Tm, int32_t n_mels,
+DC_EXPORT int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t B, int32_t Tm, int32_t n_mels,
                             float* d_xf_proj, float* d_xf_out, void* stream);
 
 /* One MotionTransformer.forward (models/transformer.py:469-497) on the conditioning set
  * above: d_x fp32 [B, T, input_feats], h_timesteps int32 [B] -> d_out fp32 [B, T, input_feats]. */
-int dc_sampler_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timesteps,
+DC_EXPORT int dc_sampler_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timesteps,
                        float* d_out, void* stream);
 
 /* GaussianDiffusion.ddim_sample_loop (models/gaussian_diffusion.py:871-965) with
@@ -155,7 +159,7 @@ int dc_sampler_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timeste
  *   h_snap_iters int32[n_snap], d_snaps fp32 [n_snap,B,T,P]: `idxs` - the sample after
  *                          iteration i (0 = after the first step) is also stored; may be NULL/0.
  * The step sequence is captured once into a hipGraph per (B,T,S) and replayed. */
-int dc_sampler_ddim_loop(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps,
+DC_EXPORT int dc_sampler_ddim_loop(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps,
                          const float* h_coef, const int32_t* h_snap_iters, int32_t n_snap,
                          float* d_snaps, void* stream);
 
@@ -165,55 +169,70 @@ int dc_sampler_ddim_loop(dc_sampler* s, const float* d_noise, float* d_out, int3
  *   flags                  DC_UPDATE_CLIP_DENOISED: pred_xstart.clamp(-1, 1) (:506-507);
  *                          DC_UPDATE_EPSILON: the denoiser predicts epsilon, pred_xstart = sqrt(1/abar) x_t - sqrt(1/abar-1) out
  *                          (ModelMeanType.EPSILON, :516-521, 539-544)
- *   d_step_noise fp32 [S,B,T,P]  the draws the reference takes with th.randn_like(x) at iteration i = 0 .. S-1 (:822);
- *                          required when any sigma != 0 (eta > 0), ignored (may be NULL) otherwise.  The caller draws it, as x_T.
+ *   d_step_noise fp32 [S,B,T,P]  the draws the reference takes with th.randn_like(x) at iteration i = 0 .. S-1 (:822); used when
+ *                          any sigma != 0 (eta > 0), ignored (may be NULL) otherwise.  NULL with sigma != 0: the library generates
+ *                          the draws step by step (dc_sampler_set_step_noise_seed must have been called).  The tensor's address is
+ *                          read through a device slot: another tensor on the next call does not re-capture the hipGraph.
  * Everything else as dc_sampler_ddim_loop; flags = 0 with an eta = 0 table is that call.  denoised_fn / cond_fn are host
  * callbacks and stay on the caller's side of the ABI (per-step dc_sampler_denoise). */
 #define DC_UPDATE_CLIP_DENOISED 1
 #define DC_UPDATE_EPSILON 2
-int dc_sampler_ddim_loop_ex(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps, const float* h_coef8,
+DC_EXPORT int dc_sampler_ddim_loop_ex(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps, const float* h_coef8,
                             int32_t flags, const float* d_step_noise, const int32_t* h_snap_iters, int32_t n_snap,
                             float* d_snaps, void* stream);
 
-/* Numeric health of everything enqueued so far (no reference counterpart: the reference computes in fp32).  Waits for the
- * sampler's work, then returns the OR of
+/* eta > 0 without a noise tensor.  After this call a dc_sampler_ddim_loop_ex with sigma != 0 and d_step_noise == NULL
+ * generates the draws of each iteration itself at the head of the step that consumes them (one [B,T,P] buffer instead of the
+ * [S,B,T,P] tensor: 6 GB at S = 1000, bs = 32): Philox4x32-10 keyed by `seed`, counter = (element, iteration), Box-Muller.
+ * Draw (seed, iteration, element) does not depend on the batch layout or launch form.  The reference draws with
+ * th.randn_like on its own device generator (:822), which no other implementation can reproduce - parity tests pass the
+ * draws explicitly (d_step_noise); dc_step_noise_fill writes the library's draws of one iteration into a caller buffer
+ * (n = B*T*P elements), so a [S,B,T,P] tensor that reproduces a seeded run can be assembled. */
+DC_EXPORT int dc_sampler_set_step_noise_seed(dc_sampler* s, uint64_t seed);
+DC_EXPORT int dc_step_noise_fill(float* d_out, int64_t n, uint64_t seed, int32_t iteration, void* stream);
+
+/* Numeric health of the sampler's LAST sampling loop (the word is reset when a loop starts), plus whatever a
+ * dc_sampler_denoise since then added (no reference counterpart: the reference computes in fp32).  Waits for the sampler's
+ * work, then returns the OR of
  *   DC_STATUS_NONFINITE    a predicted x0 (the denoiser's output) was inf or nan;
- *   DC_STATUS_F16_SATURATED  (reported together with NONFINITE, from a scan of the last step's tiles) a FiLM modulation value
- *                          (StylizationBlock scale / shift, transformer.py:74-78) left the fp16 range in which every precision
- *                          mode stores it: the checkpoint is outside what the library supports.  Without this bit a
- *                          non-finite x0 in the fp16 mode means an fp16 OPERAND overflowed: use precision "mixed" (bf16-range
- *                          operands; Python: MotionTransformer(precision="auto") switches and re-runs by itself).
+ *   DC_STATUS_F16_SATURATED  a FiLM modulation value (StylizationBlock scale / shift, transformer.py:74-78) left the fp16 range
+ *                          in which every precision mode stores it: the checkpoint is outside what the library supports.
+ *                          Sources: the range check in the epilogue of the split-path FiLM GEMM (bf16x3 / bf16 modes: the bit
+ *                          can then appear without NONFINITE), and - in every mode, behind a NONFINITE report - a scan of the
+ *                          FiLM tiles of every timestep of the last loop (the GEMM is re-run per timestep on this failure path).
+ *                          NONFINITE without this bit in the fp16 mode means an fp16 OPERAND overflowed: use precision "mixed"
+ *                          (bf16-range operands; Python: MotionTransformer(precision="auto") switches and re-runs by itself).
  * clear != 0 resets the word. */
 #define DC_STATUS_NONFINITE 1
 #define DC_STATUS_F16_SATURATED 2
 #define DC_STATUS_SYNC_TIMEOUT 4   /* a workgroup of the persistent layer launch (opt-in: DC_PERSIST=1) gave up waiting for its clip's other
                                       units (not co-resident: another process on the GPU?) - the results are invalid */
-int dc_sampler_status(dc_sampler* s, int32_t* h_status, int32_t clear);
+DC_EXPORT int dc_sampler_status(dc_sampler* s, int32_t* h_status, int32_t clear);
 
 /* Timing hook for bench.py: device time (ms, HIP events on the library's own stream)
  * of the last dc_sampler_ddim_loop and the summed duration + launch count of its
  * dominant kernel are not observable from outside a graph, so the library can run the
  * same loop eagerly with per-kernel events.  Fills h_ms[kernel_id] with the total ms
  * and h_count[kernel_id] with launches for each kernel id < n (see dc_kernel_name). */
-int dc_sampler_profile_loop(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps,
+DC_EXPORT int dc_sampler_profile_loop(dc_sampler* s, const float* d_noise, float* d_out, int32_t num_steps,
                             const float* h_coef, float* h_ms, int32_t* h_count, int32_t n, void* stream);
-const char* dc_kernel_name(int32_t kernel_id);
-int32_t dc_kernel_count(void);
+DC_EXPORT const char* dc_kernel_name(int32_t kernel_id);
+DC_EXPORT int32_t dc_kernel_count(void);
 
 /* Test hooks (tests/ only).  dc_sampler_debug_denoise runs dc_sampler_denoise but stops after
  * `n_layers` decoder layers, the last one cut after stage 1 = self-attention, 2 = cross-attention,
  * 3 = FFN (0 = whole layer), leaving the residual stream in the internal buffer "h".
  * dc_sampler_debug_read copies an internal device buffer to the host (synchronous); names:
  * "h" "pp" "s_hi" "s_lo" "E" "recs" "a_sa" "a_ca" "temb" (layouts: DESIGN.md). */
-int dc_sampler_debug_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timesteps, float* d_out,
+DC_EXPORT int dc_sampler_debug_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timesteps, float* d_out,
                              int32_t n_layers, int32_t stage, void* stream);
-int dc_sampler_debug_read(dc_sampler* s, const char* what, void* h_out, int64_t nbytes);
+DC_EXPORT int dc_sampler_debug_read(dc_sampler* s, const char* what, void* h_out, int64_t nbytes);
 /* Test hook: decoder layer `layer` alone on a GIVEN residual stream - h_h is host fp32 [B*T][128] row-major, the `h` a
  * LinearTemporalDiffusionTransformerDecoderLayer.forward receives (models/transformer.py:192-196); emb comes from
  * h_timesteps and the conditioning set before.  Blocks first_stage .. last_stage of the layer run (1 = sa_block,
  * 2 = ca_block, 3 = ffn; 1..3 = the whole layer); the result is left in the internal buffer "h" (dc_sampler_debug_read).
  * Lets the block-level known answers of tests/golden/g3_blocks.npz gate the kernels directly. */
-int dc_sampler_debug_layer(dc_sampler* s, const float* h_h, const int32_t* h_timesteps, int32_t layer, int32_t first_stage,
+DC_EXPORT int dc_sampler_debug_layer(dc_sampler* s, const float* h_h, const int32_t* h_timesteps, int32_t layer, int32_t first_stage,
                            int32_t last_stage, void* stream);
 
 /* Post-processing of the sampled poses as tools/visualization.py applies it (smooth_motion :20-26, called with kernel=19,
@@ -221,19 +240,19 @@ int dc_sampler_debug_layer(dc_sampler* s, const float* h_h, const int32_t* h_tim
  * dc_savgol_coefficients: host only; h_coef receives the [window][window] hat matrix of the polynomial fit (row window/2 =
  * the FIR taps, rows 0..window/2-1 and window/2+1.. the edge frames).  dc_savgol_filter: d_in, d_out fp32 [B, T, P] device
  * pointers (distinct), T >= window. */
-int dc_savgol_coefficients(int32_t window, int32_t order, float* h_coef);
+DC_EXPORT int dc_savgol_coefficients(int32_t window, int32_t order, float* h_coef);
 /* The same filter as part of the sampling loop: after this call dc_sampler_ddim_loop / _ex write
  * the SMOOTHED x0 to d_out - the filter reads the loop's final x0 and writes the caller's tensor in place of the plain copy, so
  * smoothing costs no pass of its own.  window = 0 switches it off again; snapshots (`idxs`) stay unsmoothed. */
-int dc_sampler_set_smoothing(dc_sampler* s, int32_t window, int32_t order);
-int dc_savgol_filter(const float* d_in, float* d_out, int32_t B, int32_t T, int32_t P, int32_t window, int32_t order,
+DC_EXPORT int dc_sampler_set_smoothing(dc_sampler* s, int32_t window, int32_t order);
+DC_EXPORT int dc_savgol_filter(const float* d_in, float* d_out, int32_t B, int32_t T, int32_t P, int32_t window, int32_t order,
                      void* stream);
 
 /* Introspection used by tests: bytes of device workspace currently held; frames per clip of the sampler's internal token space
  * (the T of dc_sampler_set_conditioning, padded to whole 32-frame groups where the clip-aligned kernels run): the layout of the
  * buffers dc_sampler_debug_read returns. */
-int64_t dc_sampler_workspace_bytes(const dc_sampler* s);
-int32_t dc_sampler_clip_stride(const dc_sampler* s);
+DC_EXPORT int64_t dc_sampler_workspace_bytes(const dc_sampler* s);
+DC_EXPORT int32_t dc_sampler_clip_stride(const dc_sampler* s);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by IMPORTING THE REFERENCE (build container only).
 
-Run:  python oracle/make_golden.py [g1 .. g9]   (needs /root/reference; everything: ~7 min on 8 cores;
+Run:  python oracle/make_golden.py [g1 .. g10]   (needs /root/reference; everything: ~7 min on 8 cores;
                                                  with section names only those fixtures are regenerated)
 
 What it does
@@ -400,8 +400,44 @@ def main():
         run("eps", True, 0.3, "EPSILON")
         np.savez_compressed(os.path.join(OUT, "g9_sampler_branches.npz"), **g9)
 
+    def make_g10():
+        # ---- G10: no_eff (full T x T attention, transformer.py:198-287) DDIM-50 x0 at PRODUCTION length - G6b only has 3 key
+        # tiles per clip; at T=1800 a query sees 57 key tiles, at T=900 29: the lengths at which an online softmax's running
+        # reference point actually moves.  (a) seed-0 checkpoint, B=1, T=1800; (b) the "trained-like" stress checkpoint,
+        # B=2, T=900, ragged lengths.
+        from diffusion_conductor_amd.synthetic import stress_state_dict
+        g10 = {}
+        xfp_, xf_ = features(1, 1800, first=50)
+        nz = torch.from_numpy(batch_noise(1, 1800, first=50))
+        t0 = time.time()
+        ref = ref_ddim(model_no_eff(), 50, nz, xfp_, xf_, [1800])
+        log["g10_ref_t1800_seconds"] = time.time() - t0
+        with torch.no_grad():
+            mine = O.ddim_sample_loop(p, nz, xfp_, xf_, [1800], 50, no_eff=True)
+        log["g10_no_eff_t1800"] = rel_l2(mine.numpy(), ref.numpy())
+        assert log["g10_no_eff_t1800"] < 1e-5, log["g10_no_eff_t1800"]
+        g10["t1800_x0"] = ref.numpy()
+
+        sd = stress_state_dict(DenoiserConfig(), seed=0)
+        q = O.to_torch_params(sd)
+        m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cpu",
+                              music_model_path=None, no_clip=True, no_eff=True)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        m.eval()
+        length = [900, 613]
+        xfp2, xf2 = features(2, 900, first=52, params=q)
+        nz2 = torch.from_numpy(batch_noise(2, 900, first=52))
+        ref2 = ref_ddim(m, 50, nz2, xfp2, xf2, length)
+        with torch.no_grad():
+            mine2 = O.ddim_sample_loop(q, nz2, xfp2, xf2, length, 50, no_eff=True)
+        log["g10_no_eff_stress_t900"] = rel_l2(mine2.numpy(), ref2.numpy())
+        assert log["g10_no_eff_stress_t900"] < 1e-5, log["g10_no_eff_stress_t900"]
+        g10["stress_t900_x0"] = ref2.numpy()
+        g10["stress_t900_length"] = np.asarray(length, np.int64)
+        np.savez_compressed(os.path.join(OUT, "g10_no_eff_long.npz"), **g10)
+
     for name, fn in (("g1", make_g1), ("g2", make_g2), ("g3", make_g3), ("g4", make_g4), ("g5", make_g5), ("g6", make_g6),
-                     ("g6b", make_g6b), ("g7", make_g7), ("g8", make_g8), ("g9", make_g9)):
+                     ("g6b", make_g6b), ("g7", make_g7), ("g8", make_g8), ("g9", make_g9), ("g10", make_g10)):
         if want(name):
             t0 = time.time()
             fn()

@@ -307,6 +307,31 @@ def test_bs32_full_size_properties(models):
     assert err <= TOL_PARITY
 
 
+def test_bs32_interior_clips_vs_oracle(models):
+    """The headline configuration (bs=32 x 1800, DDIM-50) runs FLAT 256-token units: a unit that contains a clip edge exponentiates
+    both clips' keys against one shared maximum before the f16 rounding, so a clip's result depends on its neighbours (DESIGN
+    section 5).  Clip 0 starts on a unit edge and is the least affected clip of the batch; clips 13, 17 and 31 have both ends
+    (31: its head) inside units shared with a neighbour.  Each is compared with the CPU oracle's DDIM-50 of that clip ALONE
+    (gaussian_diffusion.py:871-915, transformer.py:96-196), in the default f16 mode and in the bf16-MFMA mode ("mixed", which
+    always runs clip-aligned units)."""
+    B, T = 32, 1800
+    clips = (13, 17, 31)
+    xfp, xfo = xf_pair(B, T)
+    noise = torch.from_numpy(batch_noise(B, T))
+    p = oracle_params()
+    refs = {}
+    with torch.no_grad():
+        for c in clips:
+            refs[c] = O.ddim_sample_loop(p, noise[c:c + 1], xfp[c:c + 1], xfo[c:c + 1], [T], 50)
+    worst = {}
+    for mode in ("fp16", "mixed"):
+        a = _ddim(models[mode], 50, noise, xfp, xfo, [T] * B)
+        errs = {c: rel_l2(a[c:c + 1], refs[c]) for c in clips}
+        worst[mode] = max(errs.values())
+        print(f"bs32 interior clips vs oracle ({mode}): " + "  ".join(f"clip {c}: {e:.3e}" for c, e in errs.items()))
+    assert worst["fp16"] <= TOL_PARITY and worst["mixed"] <= TOL_PARITY, worst
+
+
 def test_harness_generate_music_motion_golden(models):
     """G7: DDPMTrainer.generate_music_motion end to end (encode_music + DDIM-50) on the reference's
     own call pattern: np mel [5400,128] in, tensor [1,1800,26] out."""
@@ -409,6 +434,36 @@ def test_no_eff_ddim50_golden(model_no_eff):
     err = rel_l2(out, golden("g6b_no_eff.npz")["x0"])
     print(f"ddim50 no_eff rel-L2 {err:.3e}")
     assert err <= TOL_PARITY
+
+
+def test_no_eff_ddim50_long_goldens_g10(model_no_eff):
+    """G10: the imported reference's no_eff DDIM-50 x0 at production length - (a) B=1, T=1800 (57 key tiles per query: the
+    lengths at which the key loop's lazily moved reference point actually moves and 1 800 f16 weights are summed), seed-0
+    checkpoint; (b) B=2, T=900, lengths [900, 613] on the trained-like stress checkpoint."""
+    from helpers import DenoiserConfig
+    from diffusion_conductor_amd import MotionTransformer
+    from diffusion_conductor_amd.synthetic import batch_music_features, stress_state_dict
+    g = golden("g10_no_eff_long.npz")
+    xfp, xfo = xf_pair(1, 1800, first=50)
+    noise = torch.from_numpy(batch_noise(1, 1800, first=50))
+    out = _ddim(model_no_eff, 50, noise, xfp, xfo, [1800])
+    e1 = rel_l2(out, g["t1800_x0"])
+    print(f"no_eff DDIM-50 B=1 T=1800 vs reference: rel-L2 {e1:.3e}")
+    sd = stress_state_dict(DenoiserConfig(), seed=0)
+    m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cuda", no_clip=True,
+                          precision="fp16", no_eff=True)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda").eval()
+    q = O.to_torch_params(sd, torch.float32)
+    xf2 = torch.from_numpy(batch_music_features(2, 900, first=52))
+    xfp2 = torch.nn.functional.linear(xf2, q["proj.weight"], q["proj.bias"])
+    noise2 = torch.from_numpy(batch_noise(2, 900, first=52))
+    length = [int(v) for v in g["stress_t900_length"]]
+    out2 = _ddim(m, 50, noise2, xfp2, xf2, length)
+    e2 = rel_l2(out2, g["stress_t900_x0"])
+    print(f"no_eff DDIM-50 B=2 T=900 ragged, stress checkpoint, vs reference: rel-L2 {e2:.3e}")
+    assert torch.isfinite(out).all() and torch.isfinite(out2).all()
+    assert e1 <= TOL_PARITY and e2 <= TOL_PARITY, (e1, e2)
 
 
 def test_no_eff_straddling_clips_vs_oracle(model_no_eff):

@@ -212,6 +212,93 @@ def test_nonfinite_flag_and_auto_fallback():
     assert ma._native.status() & native.STATUS_NONFINITE == 0
 
 
+def test_status_word_reports_on_the_loop_that_was_asked_about():
+    """The device status word is reset when a loop starts: a non-finite bit left behind by work nobody checked (a loop with
+    check_numerics off, a forward()) must not fail - or switch the precision of - the next, healthy loop on the same sampler."""
+    from diffusion_conductor_amd import native
+    good = synthetic_state_dict(DenoiserConfig(), seed=0)
+    bad = dict(good)
+    for l in range(8):
+        k = f"temporal_decoder_blocks.{l}.ffn.linear1.weight"
+        bad[k] = (bad[k] * 3.0e5).astype(np.float32)
+    B, T, S = 2, 96, 25
+    xfp, xfo = _features(good, B, T, 50)
+    noise = torch.from_numpy(batch_noise(B, T, first=50)).cuda()
+    kw = dict(noise=noise, clip_denoised=False, progress=False,
+              model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor([96, 70])})
+    gd = make_diffusion(S)
+    m = _model(bad, "auto")
+    m.check_numerics = False
+    out = gd.ddim_sample_loop(m, (B, T, 26), **kw)                    # leaves DC_STATUS_NONFINITE behind, unread
+    m(noise, torch.tensor([3, 3]), length=torch.LongTensor([96, 70]), xf_proj=kw["model_kwargs"]["xf_proj"], xf_out=kw["model_kwargs"]["xf_out"])
+    torch.cuda.synchronize()
+    assert not torch.isfinite(out).all()
+    nat = m._native
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in good.items()}, strict=True)    # same sampler object, healthy weights
+    m.check_numerics = True
+    out = gd.ddim_sample_loop(m, (B, T, 26), **kw)
+    torch.cuda.synchronize()
+    assert m._native is nat and m.active_precision == "fp16" and torch.isfinite(out).all()
+    assert not m.numerics_fallback(native.STATUS_NONFINITE | 4) and not m.numerics_fallback(4)     # never on SYNC_TIMEOUT
+    assert m.active_precision == "fp16"
+
+
+def test_seeded_step_noise_equals_the_explicit_tensor():
+    """eta > 0 without a noise tensor: the library draws each iteration's N(0,1) noise at the head of its step from a seed
+    (one [B,T,P] buffer, dc_sampler_set_step_noise_seed) - the same result, bit for bit, as handing it the [S,B,T,P] tensor
+    assembled from dc_step_noise_fill; the draws are standard normal, differ per iteration and per seed, and a second
+    tensor at another address replays the captured graph (the address travels through a device slot)."""
+    from diffusion_conductor_amd import native
+    sd, B, T, S, length, xfp, xfo, noise, _ = _g9_setup()
+    m = _model(sd, "fp16")
+    gd = make_diffusion(S)
+    nat = m.set_conditioning(xfp, xfo, length)
+    coef = gd.native_coefficients(0.5)
+    seeded, _ = nat.ddim_loop(noise, coef, noise_seed=1234)
+    z = torch.stack([native.step_noise((B, T, 26), 1234, i, noise.device) for i in range(S)])
+    explicit, _ = nat.ddim_loop(noise, coef, step_noise=z)
+    z2 = z.clone()
+    explicit2, _ = nat.ddim_loop(noise, coef, step_noise=z2)
+    other, _ = nat.ddim_loop(noise, coef, noise_seed=1235)
+    torch.cuda.synchronize()
+    assert nat.status() == 0
+    assert torch.equal(seeded, explicit) and torch.equal(explicit, explicit2) and not torch.equal(seeded, other)
+    zc = z.double().cpu()
+    print(f"library draws: mean {zc.mean():.4f} std {zc.std():.4f} kurtosis {((zc - zc.mean()) ** 4).mean() / zc.var() ** 2:.3f}")
+    assert abs(float(zc.mean())) < 0.01 and abs(float(zc.std()) - 1.0) < 0.01 and abs(float(((zc - zc.mean()) ** 4).mean() / zc.var() ** 2) - 3.0) < 0.1
+    assert not torch.equal(z[0], z[1]) and abs(float((zc[0] * zc[1]).mean())) < 0.02
+    # through the Python surface: torch.manual_seed makes an eta > 0 run reproducible
+    kw = dict(noise=noise, clip_denoised=False, progress=False, eta=0.5,
+              model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.LongTensor(length)})
+    torch.manual_seed(7)
+    a = gd.ddim_sample_loop(m, (B, T, 26), **kw)
+    torch.manual_seed(7)
+    b = gd.ddim_sample_loop(m, (B, T, 26), **kw)
+    c = gd.ddim_sample_loop(m, (B, T, 26), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(c).all()
+
+
+def test_smoothing_window_longer_than_the_clip_fails_before_any_work():
+    """The window check of the loop's final write runs before anything is enqueued: the call fails cleanly and the next one works."""
+    from diffusion_conductor_amd import native
+    sd = synthetic_state_dict(DenoiserConfig(), seed=0)
+    B, T, S = 1, 32, 25
+    xfp, xfo = _features(sd, B, T, 50)
+    noise = torch.from_numpy(batch_noise(B, T, first=50)).cuda()
+    m = _model(sd, "fp16")
+    gd = make_diffusion(S)
+    kw = dict(noise=noise, clip_denoised=False, progress=False,
+              model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor([32])})
+    with pytest.raises(native.DcError, match="smoothing window"):
+        gd.ddim_sample_loop(m, (B, T, 26), smooth=(51, 5), **kw)
+    a = gd.ddim_sample_loop(m, (B, T, 26), **kw)
+    b = gd.ddim_sample_loop(m, (B, T, 26), smooth=(19, 5), **kw)
+    c = gd.ddim_sample_loop(m, (B, T, 26), smooth=(19, 5), **kw)          # same (window, order): no table upload, same result
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and torch.equal(b, c) and torch.equal(b, native.savgol_filter(a, 19, 5))
+
+
 def test_smoothing_in_the_loops_final_write():
     """dc_sampler_set_smoothing: the loop's final write applies the Savitzky-Golay filter (tools/visualization.py:20-26, 126)
     in place of the plain copy - the same numbers as filtering the unsmoothed result afterwards (bit for bit: one kernel on the

@@ -23,6 +23,19 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in L.dc_version()
 
 
+def test_dynamic_symbol_table_is_exactly_the_header():
+    """The library is built with -fvisibility=hidden and the header marks its entry points DC_EXPORT: the functions the library
+    defines in its dynamic symbol table (`nm -D --defined-only`, type T) are the header's and nothing else - no helper with C
+    linkage, no C++-mangled launcher (round 3 exported `widen_coef` and 29 `_Z...` functions).  What remains beside them are
+    weak libstdc++ template instantiations (W) and the HIP kernel handles (V), neither of which is an entry point."""
+    import subprocess
+    path = os.environ.get("DC_DDIM_LIB", native.LIB_PATH)
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    defined = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] == "T"}
+    defined -= {"_init", "_fini"}
+    assert defined == set(native.EXPORTS), defined ^ set(native.EXPORTS)
+
+
 def test_schedule_and_coefficients_match_reference_tables():
     """The C-ABI schedule helper reproduces the reference's fp64 tables BIT FOR BIT (numpy's linspace / cumprod order of
     operations).  The four fp32 step scalars: sqrt_recip / sqrt_recipm1 are casts of those tables (bit-equal); the two
