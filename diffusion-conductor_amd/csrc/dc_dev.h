@@ -1317,6 +1317,47 @@ DEV f16x16 join16(const f16x8& lo8, const f16x8& hi8) {
     }
     return v;
 }
+// The same block for the split formats (no LDS left for FiLM rings: two 65-KiB weight images): the FiLM tiles of k-tile kt + 2
+// are requested as soon as those of k-tile kt have been consumed, and the out-projection's MFMAs of a k-tile follow its SiLU
+// directly - two tile pairs (32 registers) in flight instead of all operand fragments of the block (64) plus loads at the point
+// of use.  Same products in the same order per accumulator as styl_accumulate (k-tile-major): identical results.
+template <class T16, bool SPLIT>
+DEV void styl_accumulate_pf(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd, float shift, const f16x8* __restrict__ Eg,
+                            const float* bo, const v8<T16>* w, int lane, int hh) {
+    f16x8 g0[2], g1[2], h0[2], h1[2];            // [slot]: the 16-byte halves of the (G' - 1, H') tiles of k-tiles kt, kt + 1
+    auto fetch = [&](int kt, int slot) {
+        const f16x8* pg = Eg + kt * 128 + lane;
+        const f16x8* ph = Eg + (4 + kt) * 128 + lane;
+        g0[slot] = __builtin_nontemporal_load(pg);
+        g1[slot] = __builtin_nontemporal_load(pg + 64);
+        h0[slot] = __builtin_nontemporal_load(ph);
+        h1[slot] = __builtin_nontemporal_load(ph + 64);
+    };
+    fetch(0, 0);
+    fetch(1, 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const f32x16 bb = ld_ft(bo, t, hh);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {                                  // v_pk_add_f32
+            const f32x2 v = (f32x2){h[t][2 * r], h[t][2 * r + 1]} + (f32x2){bb[2 * r], bb[2 * r + 1]};
+            h[t][2 * r] = v.x;
+            h[t][2 * r + 1] = v.y;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        XFrag<T16, SPLIT> zf;
+        styl_tile<T16, SPLIT, ytile<SPLIT>>(zf, y[kt], rstd, shift, join16(g0[kt & 1], g1[kt & 1]), join16(h0[kt & 1], h1[kt & 1]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < 4) fetch(kt + 2, kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_kt<4, 4, T16, SPLIT>(h, w, kt, zf, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Per-wave FiLM tile ring in LDS: two 4-KiB slots, each holding one k-tile's (G'-1, H') tile pair.
 // FiLM tiles are read exactly once: non-temporal, so that 88 MB per layer do not flush the weights, attention fragments and
 // records the workgroups of an XCD share through L2 (same-box A/B: -4 % k_layer, -3.5 % loop)

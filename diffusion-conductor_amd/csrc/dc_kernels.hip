@@ -1056,6 +1056,9 @@ DEV float ddim_update(float mo, float xt, const float* __restrict__ c, int flags
 #ifndef DC_EPRE_SAFE
 #define DC_EPRE_SAFE 0           // 1: the per-layer kernel's FiLM-tile prefetch as compiler-tracked loads + epre_landed (A/B switch)
 #endif
+#ifndef DC_SPLIT_STYL_PF
+#define DC_SPLIT_STYL_PF 1       // split formats: stylization with the FiLM tiles prefetched two k-tiles ahead (0: all at the point of use)
+#endif
 #ifndef DC_SPLIT_NW
 #define DC_SPLIT_NW 8      // waves per k_layer workgroup in the split modes (4: one wave per SIMD, round 1-2's form)
 #endif
@@ -1222,7 +1225,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
         if (wg_lds) stage_attn(acl);
-        if (!(DBG && skip_blocks >= 1)) styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh);
+        if (!(DBG && skip_blocks >= 1)) { if constexpr (DC_SPLIT_STYL_PF && SPLIT && !DBG) styl_accumulate_pf<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh); }
     } else {
         auto next2 = [&]() {
             stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
@@ -1256,7 +1259,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
         stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
-        if (!(DBG && skip_blocks >= 2)) styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh);
+        if (!(DBG && skip_blocks >= 2)) { if constexpr (DC_SPLIT_STYL_PF && SPLIT && !DBG) styl_accumulate_pf<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh); }
     } else {
         auto next4 = [&]() {
             stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
@@ -1320,7 +1323,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         };
         if constexpr (!use_ring) {
             next_w();
-            styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, c1, w1, lane, cx.hh);
+            { if constexpr (DC_SPLIT_STYL_PF && SPLIT && !DBG) styl_accumulate_pf<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, c1, w1, lane, cx.hh); }
         } else {
             styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, next_w);
         }

@@ -165,16 +165,18 @@ def test_sampler_branches_progressive_path_g9(tag):
 
 
 def test_eta_needs_noise_and_default_draw_is_finite():
-    """eta > 0 without step_noise draws its own noise (as the reference does); the C ABI refuses sigma != 0 without a tensor."""
+    """eta > 0 without step_noise draws its own noise (as the reference does: the library generates it step by step from a seed);
+    the C ABI refuses sigma != 0 with neither a tensor nor a seed."""
     from diffusion_conductor_amd import native
     sd, B, T, S, length, xfp, xfo, noise, z = _g9_setup()
     m = _model(sd, "fp16")
     gd = _diffusion(S, "START_X")
+    nat = m.set_conditioning(xfp, xfo, length)
+    with pytest.raises(native.DcError, match="needs the per-iteration noise"):
+        nat.ddim_loop(noise, gd.native_coefficients(0.5), (), 0, None)              # fresh sampler: no seed was ever set
     out = gd.ddim_sample_loop(m, (B, T, 26), noise=noise, clip_denoised=True, progress=False, eta=1.0,
                               model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.LongTensor(length)})
     assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6          # t = 0: x0 = clamp(pred)
-    with pytest.raises(native.DcError, match="needs the per-iteration noise"):
-        m._native.ddim_loop(noise, gd.native_coefficients(0.5), (), 0, None)
 
 
 def test_nonfinite_flag_and_auto_fallback():
