@@ -188,7 +188,6 @@ struct dc_sampler {
     unsigned long long noise_seed = 0;
     bool noise_seed_set = false;
     int* d_status = nullptr;
-    unsigned* d_unit_flags = nullptr;      // persistent layer launch: per-unit progress flags (reset by every step's embedding)
     // Savitzky-Golay smoothing applied by the loop's final write (dc_sampler_set_smoothing; window 0 = off)
     int smooth_window = 0, smooth_order = 0, smooth_table_window = 0;     // (table_window: the hat matrix d_smooth_coef holds)
     float* d_smooth_coef = nullptr;
@@ -602,8 +601,6 @@ int ensure_workspace(dc_sampler* s, int B, int Tx) {
         HIP_TRY(hipMemset(s->d_film_rate, 0, 2 * 1024 * sizeof(float)));      // 0 = not measured yet: equal shares
         if ((rc = dev_alloc(s, s->d_status, 16))) return rc;
         HIP_TRY(hipMemset(s->d_status, 0, 16));
-        if ((rc = dev_alloc(s, s->d_unit_flags, 4096 * sizeof(unsigned)))) return rc;
-        HIP_TRY(hipMemset(s->d_unit_flags, 0, 4096 * sizeof(unsigned)));
         if ((rc = dev_alloc(s, s->d_zslot, 16))) return rc;
         HIP_TRY(hipMemset(s->d_zslot, 0, 16));
         if ((rc = dev_alloc(s, s->d_iter, 16))) return rc;
@@ -665,7 +662,7 @@ struct Timed {   // RAII-less helper: wraps a launch with events when profiling
 // that one process can A/B them: a change re-captures) and the update options of the loop.
 unsigned long long form_key(const dc_sampler* s) {
     static const char* sw[] = {"DC_NO_WGREC", "DC_NO_NARROW", "DC_NO_ALIGN", "DC_ALIGN", "DC_NO_FUSE_EMBED", "DC_FILM_STATIC",
-                               "DC_BEGIN_STEP", "DC_NO_PAD", "DC_PERSIST"};
+                               "DC_BEGIN_STEP", "DC_NO_PAD"};
     unsigned long long k = 0;
     for (size_t i = 0; i < sizeof sw / sizeof *sw; ++i) k |= (getenv(sw[i]) ? 1ull : 0ull) << i;
     k |= (unsigned long long)(s->upd_flags & 0xff) << 16;     // (the noise tensor's address is not baked in: the kernels read it from d_zslot)
@@ -722,14 +719,6 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const int nwg_narrow = can_align ? B * upc_narrow : (G + 3) / 4;
     const bool narrow = wgr && !ss && nwg_narrow <= s->num_cu && T <= 3840 && s->dbg_layers < 0 && s->dbg_stage == 0 &&
                         !getenv("DC_NO_NARROW") && !want_stamps;
-    // Persistent layer launch (k_layer PERS, opt-in with DC_PERSIST=1, read per call): all layers of the step in ONE kernel when
-    // every wide workgroup has a CU of its own and the model has the depth the kernel is compiled for; the unit records are
-    // exchanged inside the launch behind per-unit progress flags.  Same units, same arithmetic, same order as the per-layer
-    // launches: bit-identical results.  Measured -0.6 ... -1.7 % per loop at bs=32 (profiles/r03_ab_pers_nt.txt), and it needs
-    // all its workgroups co-resident (a GPU shared with another process can break that: DC_STATUS_SYNC_TIMEOUT) - hence not the
-    // default.  The per-kernel profile pass keeps the per-layer launches (its numbers are per layer).
-    const bool persistent = wgr && !narrow && !ss && getenv("DC_PERSIST") && (long long)(aligned_env ? B * upc_wide : (G + 7) / 8) <= s->num_cu &&
-                            2 * upc_wide + 2 <= 64 /* one lane per awaited unit */ && L == DC_PERS_LAYERS && s->dbg_layers < 0 && s->dbg_stage == 0 && s->dbg_first < 0 && !s->prof.on;
     const bool aligned = can_align && (narrow || ss || aligned_env);
     const int upc = aligned ? (narrow ? upc_narrow : upc_wide) : 0;
     const int nwg = aligned ? B * upc : (narrow ? (G + 3) / 4 : (G + 7) / 8);
@@ -740,10 +729,9 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const bool mixed_form = ss && !sf && ff == 1 && fs == 0;
     const bool fuse_embed = wgr && !narrow && (ss ? (aligned && mixed_form) : ff == fs) && fuse_silu && s->dbg_layers < 0 &&
                             s->dbg_stage == 0 && nwg <= s->num_cu && !want_stamps && !s->prof.on && !getenv("DC_NO_FUSE_EMBED");
-    unsigned* unit_flags = persistent ? s->d_unit_flags : nullptr;
     DcEmbedArgs ea{};
-    if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, aligned ? upc : 0, ss ? 1 : 0, unit_flags};
-    const DcUpdate upd{s->d_zslot, s->d_status, loop_mode ? s->upd_flags : 0, folded ? graph_step : -1, unit_flags};
+    if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, aligned ? upc : 0, ss ? 1 : 0};
+    const DcUpdate upd{s->d_zslot, s->d_status, loop_mode ? s->upd_flags : 0, folded ? graph_step : -1, nullptr};
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
                                        s->NT / 16, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
                                        want_stamps_film ? s->d_stamps + 252 : nullptr,
@@ -755,8 +743,8 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     if (s->cfg.no_eff) {
         LAUNCH(K_EMBED, dc_launch_embed_front_full(st, fs, s->d_model, x_src, s->d_h, s->d_kv_sa[0], M, T, B, s->KT));
         for (int l = 0; l < nl_run; ++l) {
-            DcUpdate u = upd;              // (stage stamps of layer 3, tools/stage_stamps_full.py + a -DDC_FULL_STAMPS build: the unused flag pointer carries the buffer)
-            u.unit_flags = (want_stamps && l == 3) ? reinterpret_cast<unsigned*>(s->d_stamps) : nullptr;
+            DcUpdate u = upd;              // (stage stamps of layer 3, tools/stage_stamps_full.py + a -DDC_FULL_STAMPS build: DcUpdate::stamps carries the buffer)
+            u.stamps = (want_stamps && l == 3) ? s->d_stamps : nullptr;
             LAUNCH(K_LAYER, dc_launch_layer_full(st, fs, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_kv_sa[l & 1], s->d_kv_sa[(l + 1) & 1],
                                                  s->d_kv_ca, s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur,
                                                  s->d_snap_cur, s->d_snaps, M, T, B, s->KT,
@@ -770,14 +758,8 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         LAUNCH(K_EMBED, dc_launch_front_from_h(st, fs, ss, s->d_model, s->d_h, s->d_recs, s->d_length, M, T, G, B, s->dbg_first));
     else
         LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
-                                              want_stamps_film ? s->d_stamps + 256 : nullptr, narrow, Tx, upc, unit_flags));
+                                              want_stamps_film ? s->d_stamps + 256 : nullptr, narrow, Tx, upc));
     const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
-    if (persistent) {
-        LAUNCH(K_LAYER, dc_launch_layers_persistent(st, fs, s->d_model, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs, s->d_length,
-                                                    x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src, s->d_snaps, M, T, G, B, rec_stride,
-                                                    iter_base, Tx, upc, upd, want_stamps ? s->d_stamps : nullptr));
-        return DC_OK;
-    }
     for (int l = s->dbg_first >= 0 ? s->dbg_first : 0; l < nl_run; ++l) {
         const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
@@ -1048,7 +1030,7 @@ void dc_sampler_destroy(dc_sampler* s) {
     void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
                     s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t, s->d_coef_of_iter,
-                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status, s->d_smooth_coef, s->d_unit_flags, s->d_zslot, s->d_zstep};
+                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status, s->d_smooth_coef, s->d_zslot, s->d_zstep};
     for (void* p : ptrs)
         if (p) hipFree(p);
     dc_music_destroy(s->music);

@@ -94,12 +94,8 @@ struct DcUpdate {
     int* status;         // device status word (DC_STATUS_* bits are OR-ed in), or nullptr
     int flags;           // DC_UPD_*
     int step;            // captured loop: step number inside the graph (iteration = step + *iter_base); eager: -1 (iteration = snap_cur[1])
-    // persistent layer launch (all DC_PERS_LAYERS layers in one kernel): per-unit progress flags (reset by the step's embedding) and
-    // the error word a workgroup raises when its bounded wait for its neighbours runs out; nullptr otherwise
-    unsigned* unit_flags;
+    unsigned long long* stamps;   // diagnostic builds (-DDC_FULL_STAMPS, tools/stage_stamps_full.py): stage stamps of k_layer_full, else nullptr
 };
-#define DC_PERS_LAYERS 8          // the persistent layer kernel is compiled for exactly this many layers (the reference's depth)
-#define DC_STATUS_SYNC_TIMEOUT 4  // status bit: a workgroup of the persistent layer launch gave up waiting for its clip's other units
 
 // k_embed_front's arguments when it rides in the FiLM GEMM's launch (the first `ne` workgroups embed one 256-token unit each, flat units)
 struct DcEmbedArgs {
@@ -110,5 +106,4 @@ struct DcEmbedArgs {
     int M, Tx, ne;
     int upc;         // 0: flat 256-token units (non-split formats); > 0: clip-aligned units, `upc` workgroups per clip (split formats)
     int split_bf16;  // the embedding runs in the split-bf16 format of the "mixed" mode (FiLM GEMM f16, 128-wide GEMMs bf16x3)
-    unsigned* unit_flags;   // persistent layer launch: this unit's progress flag is reset here (nullptr otherwise)
 };

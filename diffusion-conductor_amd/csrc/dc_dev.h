@@ -733,83 +733,9 @@ DEV void partial_tile(const f32x16& K, const f32x16& V, const RowRange& rr, floa
     keep = keep_head_block(P, cx.c);
 }
 
-// ---- records that cross workgroups INSIDE one launch (persistent layer kernel): every byte is stored and loaded `sc1` (write-
-// through to / read from the memory side, past the per-XCD L2s), every storing wave waits for its stores, a workgroup barrier, and
-// one lane publishes the unit's progress flag; the consumer polls the flags with sc1 loads, then a barrier, then sc1 loads of the
-// records (MI355X_MICROARCH.md, hand-offs measured with sc1 loads in place of the acquire, first row: global_ / buffer_ loads of 4 or
-// 16 bytes).  All loads are ones the compiler tracks (atomic dword loads, buffer loads with the sc1 cache-policy bit): it places the
-// waits, and it may spill around them.  SC1 = false: plain accesses (records handed over at a kernel boundary).
-template <bool SC1>
-DEV float ld_rec(const float* p) {
-    if constexpr (SC1)
-        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-        return *p;
-}
-template <bool SC1>
-DEV void st_rec(float* p, float v) {
-    if constexpr (SC1)
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-        *p = v;
-}
-// 32-byte block at base + byte offset `off` (wave-uniform base): two buffer_load_dwordx4 ... sc1
-DEV f32x8 ld_rec8_sc1(const float* base, unsigned off) {
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
-    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16 /* sc1 */);
-    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 16);
-    f32x8 v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v[i] = __uint_as_float(a[i]);
-        v[4 + i] = __uint_as_float(b[i]);
-    }
-    return v;
-}
-template <bool SC1>
-DEV void st_rec8(f32x8* p, const f32x8& v) {
-    if constexpr (SC1) {
-        f32x4 a, b;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a[i] = v[i];
-            b[i] = v[4 + i];
-        }
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(p), "v"(a), "v"(b) : "memory");
-    } else {
-        *p = v;
-    }
-}
-// Per-unit progress flags of the persistent layer kernel.  A workgroup publishes flags[unit] = layers done once its record of that
-// layer is stored; before combining, a workgroup waits until the units of its <= 2 clips have published the layer it needs.  One
-// wave polls (a lane per unit, sc1 loads); the spin is bounded: a workgroup that never sees its neighbours arrive ORs
-// DC_STATUS_SYNC_TIMEOUT into *status and goes on (wrong results, reported by dc_sampler_status) instead of hanging the device.
-DEV void unit_publish(unsigned* flags, int unit, unsigned value) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's record stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flags + unit, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-DEV void units_wait(const unsigned* flags, int u_lo, int u_hi, unsigned target, int* status) {
-    if (threadIdx.x < 64) {
-        const int u = min(u_lo + (int)threadIdx.x, u_hi);
-        unsigned spins = 0;
-        for (;;) {
-            const unsigned v = __hip_atomic_load(flags + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__builtin_amdgcn_ballot_w64(v < target) == 0) break;
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22)) {
-                if (status && threadIdx.x == 0) atomicOr(status, DC_STATUS_SYNC_TIMEOUT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-}
-
 // after the barrier that follows the last partial_tile: wave w sums tile oc = w & 3 of slot w >> 2 over the waves
 // NW = 8: wave w sums tile oc = w & 3 of slot w >> 2; NW = 4 (narrow workgroups): wave w sums tile oc = w of both slots in turn.
-template <int NW = 8, bool SC1 = false>
+template <int NW = 8>
 DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8* pst, const f32x8* xp, const float* ss,
                          int wave, int lane, int ub0, int nact /* active waves of the workgroup (a prefix) */, int M, int T, int wg) {
     const int oc = wave & 3, c = lane & 31;
@@ -842,17 +768,17 @@ DEV void wg_write_record(float* __restrict__ recs, const float* mx, const f32x8*
         }
         float* R = recs + ((size_t)wg * 2 + sl) * DC_REC_FLOATS;
         if (lane < 32) {
-            st_rec<SC1>(R + 32 * oc + c, wg_colmax<NW>(mx, oc, sl, c));
-            st_rec<SC1>(R + 128 + 32 * oc + c, ssum);
+            R[32 * oc + c] = wg_colmax<NW>(mx, oc, sl, c);
+            R[128 + 32 * oc + c] = ssum;
         }
-        st_rec8<SC1>(reinterpret_cast<f32x8*>(R + 256) + oc * 64 + lane, acc);
+        reinterpret_cast<f32x8*>(R + 256)[oc * 64 + lane] = acc;
     }
 }
 // The workgroup's own combine (512 threads): attention operand fragments A[d][l] of clips ub0, ub0+1 from the unit
 // records of the previous kernel -> af [2 clips][8 frags][64 lanes] in LDS (the 8 hi fragments k_attn_combine makes).
 // SPLIT (clip-aligned units only: the workgroup has ONE clip): af [8 hi frags | 8 lo frags][64 lanes] of clip ub0.
 // scratch (LDS): w [2][NU][128] floats, z [2][128] floats.  Summation order is fixed.
-template <class T16, bool SPLIT = false, bool SC1 = false>
+template <class T16, bool SPLIT = false>
 DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scratch, int ub0, int B, int M, int T, int tid, int wg,
                          unsigned long long* st = nullptr) {
 #define CSTAMP(k) do { if (st && (tid & 63) == 0) st[(tid >> 6) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -880,16 +806,13 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
         const float* R = rec_of(bav, min(a_lo + k, a_hi));
-        mr[k] = ld_rec<SC1>(R + f);
-        sr[k] = ld_rec<SC1>(R + 128 + f);
+        mr[k] = R[f];
+        sr[k] = R[128 + f];
     }
     const int bv = live ? b : ub0;
     const int v_lo = (bv * T) / 256, v_hi = (min((bv + 1) * T, M) - 1) / 256;
     auto blk = [&](const float* R) {           // this thread's 32-byte piece of a record's K^T V blocks
-        if constexpr (SC1)
-            return ld_rec8_sc1(recs, (unsigned)((R - recs) * 4 + (256 + (oc * 64 + ln) * 8) * 4));
-        else
-            return reinterpret_cast<const f32x8*>(R + 256)[oc * 64 + ln];
+        return reinterpret_cast<const f32x8*>(R + 256)[oc * 64 + ln];
     };
     f32x8 pre[PRE];
     if (live) {                      // wave-uniform (ci is the wave's half of the workgroup): idle halves issue nothing
@@ -907,7 +830,7 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
             if (sr[k] > 0.f) mstar = fmaxf(mstar, mr[k]);
         for (int k = PRE; k < na; ++k) {          // clips longer than 9 workgroups (T > 2048)
             const float* R = rec_of(ba, a_lo + k);
-            if (ld_rec<SC1>(R + 128 + f) > 0.f) mstar = fmaxf(mstar, ld_rec<SC1>(R + f));
+            if (R[128 + f] > 0.f) mstar = fmaxf(mstar, R[f]);
         }
         float z = 0.f;
 #pragma unroll
@@ -918,8 +841,8 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
         }
         for (int k = PRE; k < na; ++k) {
             const float* R = rec_of(ba, a_lo + k);
-            const float su = ld_rec<SC1>(R + 128 + f);
-            const float ww = su > 0.f ? exp2f_fast(ld_rec<SC1>(R + f) - mstar) : 0.f;
+            const float su = R[128 + f];
+            const float ww = su > 0.f ? exp2f_fast(R[f] - mstar) : 0.f;
             wsc[(ca * NU + k) * 128 + f] = ww;
             z += ww * su;
         }
@@ -1383,39 +1306,24 @@ DEV void ering_issue(const f16x8* __restrict__ Eg, int kt, char* slot, int lane)
 // vmcnt(0)): nothing in this stage waits on HBM.  `prefetch_next` (the next stage's weight image and the next block's
 // ring tiles) is issued as soon as both ring slots have been read.
 struct EPre {
-    f16x8 glo[2], ghi[2], hlo[2], hhi[2];       // the 16-byte halves exactly as loaded: nothing may touch them before they land
+    f16x8 glo[2], ghi[2], hlo[2], hhi[2];       // the 16-byte halves exactly as loaded
 };
-// The loads are inline asm on purpose: hipcc would guard the first use of a load it knows about with a vmcnt wait that
-// also covers the LDS-DMAs issued (invisibly to it) just before that use; these tiles are complete at the preceding
-// stage's closing `s_waitcnt vmcnt(0)`, so no wait is wanted at the use.
-DEV f16x8 ld16_nowait(const f16x8* p) {
-    f16x8 v;
-    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-// SAFE: ordinary loads (the compiler tracks them and waits before any use, including a spill) - for the kernel variants
-// that spill registers (test hooks, persistent form): a register that an untracked load is still writing must never be
-// copied, so the no-wait form is only for the spill-free production instantiation.
-template <bool SAFE>
+// Compiler-tracked non-temporal loads (the tiles are read exactly once).  Until round 4 the production kernel issued them through
+// inline asm the compiler could not see (no wait at the use: they are complete at the preceding stage's closing vmcnt(0)) - sound
+// only while the register allocator never copied or spilled the targets; the tracked form measured equal on the same box
+// (profiles/r04_ab_epre_tracked.txt) and replaced it.
 DEV void epre_load(EPre& e, const f16x8* __restrict__ Eg, int lane) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const f16x8* pg = Eg + (2 + i) * 128 + lane;
         const f16x8* ph = Eg + (4 + 2 + i) * 128 + lane;
-        if constexpr (SAFE) {                      // (non-temporal like the no-wait form: the tiles are read exactly once)
-            e.glo[i] = __builtin_nontemporal_load(pg);
-            e.ghi[i] = __builtin_nontemporal_load(pg + 64);
-            e.hlo[i] = __builtin_nontemporal_load(ph);
-            e.hhi[i] = __builtin_nontemporal_load(ph + 64);
-        } else {
-            e.glo[i] = ld16_nowait(pg);
-            e.ghi[i] = ld16_nowait(pg + 64);
-            e.hlo[i] = ld16_nowait(ph);
-            e.hhi[i] = ld16_nowait(ph + 64);
-        }
+        e.glo[i] = __builtin_nontemporal_load(pg);
+        e.ghi[i] = __builtin_nontemporal_load(pg + 64);
+        e.hlo[i] = __builtin_nontemporal_load(ph);
+        e.hhi[i] = __builtin_nontemporal_load(ph + 64);
     }
 }
-// Tracked (SAFE) prefetch without its price: the compiler guards the FIRST use of a load it knows about with a vmcnt wait, and
+// The tracked prefetch without its price: the compiler guards the FIRST use of a load it knows about with a vmcnt wait, and
 // placed in the middle of the consuming stage that wait would also cover the LDS-DMAs issued just before it.  A use at the very
 // start of the consuming stage - behind the previous stage's closing vmcnt(0), before any new vector-memory operation - puts the
 // compiler's wait where the queue is empty.

@@ -809,8 +809,7 @@ DEV void embed_front_body(const DcModel* __restrict__ dm, const float* __restric
                           unsigned long long* __restrict__ clk /* diagnostic: 100-MHz stamps of one wave, or nullptr */, int l0,
                           int Tx /* frames per clip of x (<= the clip stride T) */,
                           int upc /* workgroups per clip (clip-aligned units, WgMap) or 0 */,
-                          int wg_fixed /* >= 0: this workgroup's unit (the caller's grid is not the unit grid) */,
-                          unsigned* __restrict__ unit_flags = nullptr /* persistent layer launch: this unit's progress flag, reset here */) {
+                          int wg_fixed /* >= 0: this workgroup's unit (the caller's grid is not the unit grid) */) {
     static_assert(!(FROMH && WGR), "the h-injection hook exists for the per-group-record form only");
     static_assert(!NARROW || (WGR && !SPLIT), "narrow workgroups exist for the workgroup-record form of the non-split formats");
     constexpr int NW = (NARROW || (SPLIT && !WGR)) ? 4 : 8;
@@ -823,7 +822,6 @@ DEV void embed_front_body(const DcModel* __restrict__ dm, const float* __restric
     using W = v8<T16>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wg = wg_fixed >= 0 ? wg_fixed : (WGR ? wg_index() : (int)blockIdx.x);
-    if (WGR && unit_flags && threadIdx.x == 0) unit_flags[wg] = 0u;
     const WgMap wm = wg_map(wg, wave, NW, G, M, T, B, WGR ? upc : 0);
     const int g = wm.g;
     const bool active = wm.active;
@@ -979,9 +977,8 @@ DEV void embed_front_body(const DcModel* __restrict__ dm, const float* __restric
 template <class T16, bool SPLIT, bool WGR, bool FROMH = false, bool NARROW = false>
 __global__ __launch_bounds__((NARROW || (SPLIT && !WGR)) ? 256 : 512, (NARROW || (SPLIT && !WGR)) ? 1 : 2)
 void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x, float* __restrict__ hbuf, float* __restrict__ recs,
-                   const int* __restrict__ length, int M, int T, int G, int B, unsigned long long* __restrict__ clk, int l0, int Tx, int upc,
-                   unsigned* __restrict__ unit_flags) {
-    embed_front_body<T16, SPLIT, WGR, FROMH, NARROW>(dm, x, hbuf, recs, length, M, T, G, B, clk, l0, Tx, upc, -1, unit_flags);
+                   const int* __restrict__ length, int M, int T, int G, int B, unsigned long long* __restrict__ clk, int l0, int Tx, int upc) {
+    embed_front_body<T16, SPLIT, WGR, FROMH, NARROW>(dm, x, hbuf, recs, length, M, T, G, B, clk, l0, Tx, upc, -1);
 }
 // The step's two kernels that depend on nothing but x and the conditioning, as ONE launch (default where the layers run wide flat
 // units; DC_NO_FUSE_EMBED=1 keeps them apart): the first `ne` workgroups
@@ -1000,7 +997,7 @@ __global__ __launch_bounds__(512, 2) void k_film_embed(const v8<T16>* __restrict
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     if ((int)blockIdx.x < ea.ne) {
         embed_front_body<TS, SP, true, false, false>(ea.dm, ea.x, ea.hbuf, ea.recs, ea.length, ea.M, T, G, B, nullptr, 0, ea.Tx, ea.upc,
-                                                     (int)blockIdx.x, ea.unit_flags);
+                                                     (int)blockIdx.x);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();            // the embedding's LDS use is over before the slab fill
     }
@@ -1044,32 +1041,13 @@ DEV float ddim_update(float mo, float xt, const float* __restrict__ c, int flags
 // NARROW (WGR, non-split, production build only): 4 waves per workgroup = 128-token units, ONE wave per SIMD.  The kernel is
 // bound by instruction issue, so a wave that has its SIMD to itself runs the layer in about half the time; worth it
 // whenever the batch is small enough for every unit to get its own CU (<= 32 K tokens: e.g. the reference's one clip per call).
-#ifndef DC_PERS_PAIRS
-#define DC_PERS_PAIRS 0          // persistent form: the record tail's projections two feature tiles at a time (0: four, as the per-layer form)
-#endif
-#ifndef DC_PERS_FLAT
-#define DC_PERS_FLAT 1           // persistent form on any units (a workgroup of flat units may span two clips: the tail keeps its two-clip paths)
-#endif
-#ifndef DC_PERS_SAFE_EPRE
-#define DC_PERS_SAFE_EPRE 1      // persistent form: compiler-tracked FiLM-tile prefetch (0: the untracked no-wait form of the per-layer kernel)
-#endif
-#ifndef DC_EPRE_SAFE
-#define DC_EPRE_SAFE 0           // 1: the per-layer kernel's FiLM-tile prefetch as compiler-tracked loads + epre_landed (A/B switch)
-#endif
 #ifndef DC_SPLIT_STYL_PF
 #define DC_SPLIT_STYL_PF 1       // split formats: stylization with the FiLM tiles prefetched two k-tiles ahead (0: all at the point of use)
 #endif
 #ifndef DC_SPLIT_NW
 #define DC_SPLIT_NW 8      // waves per k_layer workgroup in the split modes (4: one wave per SIMD, round 1-2's form)
 #endif
-// PERS (wide non-split workgroup-record form, no test hooks): ALL DC_PERS_LAYERS layers in this one launch.  The residual stream
-// stays in registers from layer to layer (it is neither stored nor loaded), the unit records cross workgroups inside the launch (sc1
-// stores / loads, dc_dev.h) and a workgroup waits only for the units of its own <= 2 clips (per-unit progress flags) - no kernel
-// boundary (8 us per layer of launch ramp / drain), no start-of-kernel load burst, no wait for the slowest of all workgroups.  The
-// unit records alternate between two buffers (recs + parity * rec_stride): a workgroup can only be one layer ahead of the units it
-// shares a clip with, so a record is never overwritten while a neighbour still combines it.  Needs every workgroup co-resident.
-// Same arithmetic in the same order as the per-layer launches: bit-identical results.
-template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR, bool NARROW = false, bool PERS = false>
+template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR, bool NARROW = false>
 __global__ __launch_bounds__((NARROW || (SPLIT && DC_SPLIT_NW == 4)) ? 256 : 512, (NARROW || (SPLIT && DC_SPLIT_NW == 4)) ? 1 : 2)
 void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
              const v8<T16>* __restrict__ a_sa /*[B][16][64]*/, const v8<T16>* __restrict__ a_ca /*[L][B][16][64]*/,
@@ -1081,7 +1059,6 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
              const DcUpdate upd) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     static_assert(!NARROW || (WGR && !SPLIT && !DBG), "narrow workgroups: workgroup-record form, non-split formats, no test hooks");
-    static_assert(!PERS || (WGR && !SPLIT && !DBG && !NARROW), "persistent form: wide non-split workgroup records, no test hooks");
     constexpr int NW = NARROW ? 4 : (SPLIT ? DC_SPLIT_NW : 8);
     constexpr int WM = SPLIT ? 2 : 1;            // operand images per matrix (hi [+ lo])
     constexpr int NFW = 32 * WM;
@@ -1110,13 +1087,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         const int g0 = wg_map(WGR ? wg_index() : (int)blockIdx.x, threadIdx.x >> 6, NW, G, M, T, B, WGR ? upc : 0).g;
         load_h(h, hbuf, g0, threadIdx.x & 63);      // in flight across the first prologue
     }
-  constexpr int NLP = PERS ? DC_PERS_LAYERS : 1;
-#ifdef DC_PERS_UNROLL
-#pragma unroll
-#else
-#pragma unroll 1
-#endif
-  for (int li = 0; li < NLP; ++li, ++l) {
+  {
     const int tid_ = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), lane = tid_ & 63;
     const int wg = WGR ? wg_index() : (int)blockIdx.x;
@@ -1145,8 +1116,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     };
     const W* af = reinterpret_cast<const W*>(lds + OFF_AF);
     const DcLayer& L = dm->layer[l];
-    const bool last = PERS ? li + 1 == NLP : l + 1 >= nl;
-    const bool more = PERS && li + 1 < NLP;      // the next layer runs in this launch
+    const bool last = l + 1 >= nl;
     const f16x8* Eg = reinterpret_cast<const f16x8*>(E) + ((size_t)g * NT + (size_t)l * 24) * 128;   // 3 blocks x 8 tiles
     const W* acl = a_ca + (size_t)l * B * 16 * 64;
     const float* recs_in = recs + (size_t)(l & 1) * rec_stride;
@@ -1158,15 +1128,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
     if constexpr (NARROW)
         wg_combine_attn_narrow<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, wm.Mu, wm.Tu, tid_, wg);
-    else if constexpr (PERS) {   // the records of layers 1.. were written in THIS launch: wait for the units of this workgroup's clips
-        if (li > 0) {
-            const int ub1 = (min((wg + 1) * NW * 32, wm.Mu) - 1) / wm.Tu;
-            units_wait(upd.unit_flags, (ub0 * wm.Tu) / (NW * 32), (min((ub1 + 1) * wm.Tu, wm.Mu) - 1) / (NW * 32), (unsigned)li, upd.status);
-        }
-        DC_STAMP(28);
-        wg_combine_attn<T16, false, true>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, wm.Mu, wm.Tu, tid_, wg,
-                                          (STAMP && stamps && blockIdx.x == 3 && l == 3) ? stamps : nullptr);
-    } else if constexpr (WGR)      // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
+    else if constexpr (WGR)      // self-attention matrices from the previous layer's workgroup records (scratch: buf1)
         wg_combine_attn<T16, SPLIT>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, B, wm.Mu, wm.Tu, tid_, wg,
                                     (STAMP && stamps && blockIdx.x == 3 && l == 3) ? stamps : nullptr);
     else if (wg_lds)
@@ -1203,8 +1165,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
     stage_frags<NW>(L.img_sa_o, buf1, NFW + 1, wave, lane);
     EPre ep;
-    if constexpr (use_ring) epre_load<DBG || DC_EPRE_SAFE || (PERS && DC_PERS_SAFE_EPRE)>(ep, Eg, lane);          // (PERS: the loop-carried residual stream makes the compiler
-                                                                          // spill; an untracked load's target must never be spilled)
+    if constexpr (use_ring) epre_load(ep, Eg, lane);
     ytile<SPLIT> y[4];
     float y_rstd, y_shift;
     // test hook (DBG builds): (dbg >> 16) & 3 = number of leading blocks of the layer to skip (1: no self-attention,
@@ -1220,7 +1181,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(2);
     stage_sync();
     DC_STAMP(3);
-    if constexpr (DC_EPRE_SAFE || (PERS && DC_PERS_SAFE_EPRE)) epre_landed(ep);
+    if constexpr (use_ring) epre_landed(ep);
     // ---- stage 2: SA stylization [buf1]; prefetch CA query -> buf0 (+ cross-attention frags)
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
@@ -1244,7 +1205,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(5);
     // ---- stage 3: CA query + attention apply [buf0]; prefetch CA out-proj -> buf1
     stage_frags<NW>(L.img_ca_o, buf1, NFW + 1, wave, lane);
-    if constexpr (use_ring) epre_load<DBG || DC_EPRE_SAFE || (PERS && DC_PERS_SAFE_EPRE)>(ep, Eg + 8 * 128, lane);
+    if constexpr (use_ring) epre_load(ep, Eg + 8 * 128, lane);
     if (DBG && skip_blocks >= 2) {
     } else if (wg_lds)
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, af + (SPLIT ? 0 : (size_t)(cx.b0 - ub0) * 8 * 64),
@@ -1254,7 +1215,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                                  acl + (size_t)cx.b1 * 16 * 64, cx);
     DC_STAMP(6);
     stage_sync();
-    if constexpr (DC_EPRE_SAFE || (PERS && DC_PERS_SAFE_EPRE)) epre_landed(ep);
+    if constexpr (use_ring) epre_landed(ep);
     // ---- stage 4: CA stylization [buf1]; prefetch FFN W1|W2 (+ b1|b2) -> buf0
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
@@ -1278,7 +1239,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(8);
     // ---- stage 5: FFN [buf0]; prefetch FFN out-proj -> buf1
     stage_frags<NW>(L.img_ffn_o, buf1, NFW + 1, wave, lane);
-    if constexpr (use_ring) epre_load<DBG || DC_EPRE_SAFE || (PERS && DC_PERS_SAFE_EPRE)>(ep, Eg + 16 * 128, lane);
+    if constexpr (use_ring) epre_load(ep, Eg + 16 * 128, lane);
     {
         f32x16 u[2];
         {
@@ -1312,7 +1273,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     }
     DC_STAMP(9);
     stage_sync();
-    if constexpr (DC_EPRE_SAFE || (PERS && DC_PERS_SAFE_EPRE)) epre_landed(ep);
+    if constexpr (use_ring) epre_landed(ep);
     // ---- stage 6: FFN stylization [buf1]; prefetch next layer's key projection (or the output projection) -> buf0
     {
         auto next_w = [&]() {
@@ -1343,7 +1304,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
 #ifdef DC_DIAG_NO_HSTORE
         const bool st_h = false;          // diagnostic build (timing only, results invalid): what the residual-stream stores cost the tail
 #else
-        const bool st_h = active && !more;               // the residual stream only leaves the registers at a launch edge
+        const bool st_h = active;
 #endif
         // Wide non-split workgroups stagger the stores: the 128 KiB of a workgroup take the CU's store path ~1 us, and issued by
         // all eight waves at once they cost the second wave of each SIMD ~2.5 us of queueing in front of its LayerNorm - on the
@@ -1378,8 +1339,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             const RowRange vr1 = valid_rows_clip(cx, ub0 + 1, B, M, T, length, active);
             const int s0 = cx.b0 - ub0;
             const RowRange vr_own = s0 ? vr1 : vr0;
-            const bool strad = !SPLIT && !(PERS && !DC_PERS_FLAT) && active && cx.straddle;      // (split and persistent forms: clip-aligned units)
-            XFrag<T16, SPLIT> efA[4], efB[(SPLIT || (PERS && !DC_PERS_FLAT)) ? 1 : 4];
+            const bool strad = !SPLIT && active && cx.straddle;      // (split formats: clip-aligned units)
+            XFrag<T16, SPLIT> efA[4], efB[SPLIT ? 1 : 4];
             float ssA[4], ssB[4], mA[4], mB[4];
             auto keys_of = [&](const f32x16& K, const RowRange& rr, XFrag<T16, SPLIT>& ef, float& ssum, float& mcol) {
                 float m = -INFINITY;
@@ -1407,42 +1368,21 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 ssum = xhalf_sum(sacc);
                 make_frag<T16, SPLIT>(Ee, ef);
             };
-            if constexpr (PERS && DC_PERS_PAIRS) {
-                // (the residual stream stays in registers through this tail: two feature tiles at a time instead of four - 32 accumulator
-                // registers less at the peak; every tile's chain of MFMAs is the same, so are the results)
+            f32x16 Kp[4] = {splat(c0[cx.c]), splat(c0[32 + cx.c]), splat(c0[64 + cx.c]), splat(c0[96 + cx.c])};
+            mmb_oc_quad<4, 4, T16, SPLIT>(Kp[0], Kp[1], Kp[2], Kp[3], w0, nf, lane);
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    f32x16 Ka = splat(c0[64 * hf + cx.c]), Kb = splat(c0[64 * hf + 32 + cx.c]);
-                    mmb_oc_pair<4, 4, T16>(Ka, Kb, w0, 2 * hf, w0, 2 * hf + 1, nf, lane);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int oc = 2 * hf + q;
-                        keys_of(q ? Kb : Ka, vr_own, efA[oc], ssA[oc], mA[oc]);
-                        mB[oc] = -INFINITY;
-                        if (cx.hh == 0) {
-                            mx[((oc * 2 + s0) * 32 + cx.c) * NW + wave] = mA[oc];
-                            mx[((oc * 2 + (s0 ^ 1)) * 32 + cx.c) * NW + wave] = -INFINITY;
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 4; ++q) {
+                const int oc = q;
+                keys_of(Kp[q], vr_own, efA[oc], ssA[oc], mA[oc]);
+                mB[oc] = -INFINITY;
+                if constexpr (!SPLIT)
+                    if (strad) keys_of(Kp[q], vr1, efB[oc], ssB[oc], mB[oc]);
+                if (cx.hh == 0) {
+                    mx[((oc * 2 + s0) * 32 + cx.c) * NW + wave] = mA[oc];
+                    mx[((oc * 2 + (s0 ^ 1)) * 32 + cx.c) * NW + wave] = s0 ? -INFINITY : mB[oc];
                 }
-            } else {
-                f32x16 Kp[4] = {splat(c0[cx.c]), splat(c0[32 + cx.c]), splat(c0[64 + cx.c]), splat(c0[96 + cx.c])};
-                mmb_oc_quad<4, 4, T16, SPLIT>(Kp[0], Kp[1], Kp[2], Kp[3], w0, nf, lane);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int oc = q;
-                    keys_of(Kp[q], vr_own, efA[oc], ssA[oc], mA[oc]);
-                    mB[oc] = -INFINITY;
-                    if constexpr (!SPLIT)
-                        if (strad) keys_of(Kp[q], vr1, efB[oc], ssB[oc], mB[oc]);
-                    if (cx.hh == 0) {
-                        mx[((oc * 2 + s0) * 32 + cx.c) * NW + wave] = mA[oc];
-                        mx[((oc * 2 + (s0 ^ 1)) * 32 + cx.c) * NW + wave] = s0 ? -INFINITY : mB[oc];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);
             DC_STAMP(20);
             if (st_h && late_store) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -1499,39 +1439,24 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 }
                 return keep;
             };
-            if constexpr (PERS && DC_PERS_PAIRS) {
+            f32x16 Vp[4] = {splat(c1[cx.c]), splat(c1[32 + cx.c]), splat(c1[64 + cx.c]), splat(c1[96 + cx.c])};
+            mmb_oc_quad<4, 4, T16, SPLIT>(Vp[0], Vp[1], Vp[2], Vp[3], w1, nf, lane);
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    f32x16 Va = splat(c1[64 * hf + cx.c]), Vb = splat(c1[64 * hf + 32 + cx.c]);
-                    mmb_oc_pair<4, 4, T16>(Va, Vb, w1, 2 * hf, w1, 2 * hf + 1, nf, lane);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int oc = 2 * hf + q;
-                        pst[(wave * 4 + oc) * 64 + lane] = block_of(efA[oc], q ? Vb : Va, vr_own, scw + (0 * 4 + oc) * 32);
-                        if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssA[oc];
+            for (int q = 0; q < 4; ++q) {
+                const int oc = q;
+                pst[(wave * 4 + oc) * 64 + lane] = block_of(efA[oc], Vp[q], vr_own, scw + (0 * 4 + oc) * 32);
+                if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssA[oc];
+                if constexpr (!SPLIT)
+                    if (strad) {
+                        xp[oc * 64 + lane] = block_of(efB[oc], Vp[q], vr1, scw + (1 * 4 + oc) * 32);
+                        if (cx.hh == 0) ss[(NW * 4 + oc) * 32 + cx.c] = ssB[oc];
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                f32x16 Vp[4] = {splat(c1[cx.c]), splat(c1[32 + cx.c]), splat(c1[64 + cx.c]), splat(c1[96 + cx.c])};
-                mmb_oc_quad<4, 4, T16, SPLIT>(Vp[0], Vp[1], Vp[2], Vp[3], w1, nf, lane);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int oc = q;
-                    pst[(wave * 4 + oc) * 64 + lane] = block_of(efA[oc], Vp[q], vr_own, scw + (0 * 4 + oc) * 32);
-                    if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssA[oc];
-                    if constexpr (!SPLIT)
-                        if (strad) {
-                            xp[oc * 64 + lane] = block_of(efB[oc], Vp[q], vr1, scw + (1 * 4 + oc) * 32);
-                            if (cx.hh == 0) ss[(NW * 4 + oc) * 32 + cx.c] = ssB[oc];
-                        }
-                }
             }
             __builtin_amdgcn_sched_barrier(0);
             DC_STAMP(16);
             __syncthreads();
             DC_STAMP(17);
-            wg_write_record<NW, PERS>(recs_out, mx, pst, xp, ss, wave, lane, ub0, wm.nact, wm.Mu, wm.Tu, wg);
+            wg_write_record<NW>(recs_out, mx, pst, xp, ss, wave, lane, ub0, wm.nact, wm.Mu, wm.Tu, wg);
         } else {
             f32x16 K[4];                  // keys from buf0 while the value image lands in buf1
 #pragma unroll
@@ -1564,10 +1489,6 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         DC_STAMP(13);
         if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0 && l == 3) stamps[(threadIdx.x >> 6) * 32 + 27] = __builtin_amdgcn_s_memtime();
         DC_WGSTAMP(1);
-        if (more) {
-            unit_publish(upd.unit_flags, wg, (unsigned)(li + 1));      // (its barrier also ends this layer's use of LDS)
-            continue;
-        }
         return;
     }
     // ---- output projection [buf0, split] + DDIM update
@@ -1956,10 +1877,10 @@ __global__ __launch_bounds__(512, 2) void k_embed_front_full(const DcModel* __re
 #ifdef DC_FULL_STAMPS          // diagnostic build: s_memrealtime of workgroup 3's waves at the block boundaries of k_layer_full
 #define FSTAMP(i)                                                                                                       \
     do {                                                                                                                \
-        if (upd.unit_flags && blockIdx.x == 3 && (threadIdx.x & 63) == 0)                                               \
-            reinterpret_cast<unsigned long long*>(upd.unit_flags)[(threadIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        if (upd.stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0)                                               \
+            upd.stamps[(threadIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
-#define FSTAMP_PTR(i) ((upd.unit_flags && blockIdx.x == 3) ? reinterpret_cast<unsigned long long*>(upd.unit_flags) + (threadIdx.x >> 6) * 32 + (i) : nullptr)
+#define FSTAMP_PTR(i) ((upd.stamps && blockIdx.x == 3) ? upd.stamps + (threadIdx.x >> 6) * 32 + (i) : nullptr)
 #else
 #define FSTAMP(i) do {} while (0)
 #define FSTAMP_PTR(i) nullptr
@@ -2339,7 +2260,7 @@ template <class T16, bool SP>
 static hipError_t launch_front_from_h_t(hipStream_t st, const DcModel* dm, float* hbuf, float* recs, const int* length,
                                         int M, int T, int G, int B, int l0) {
     constexpr int NW = SP ? 4 : 8;
-    k_embed_front<T16, SP, false, true><<<dim3((G + NW - 1) / NW), dim3(NW * 64), 0, st>>>(dm, nullptr, hbuf, recs, length, M, T, G, B, nullptr, l0, T, 0, nullptr);
+    k_embed_front<T16, SP, false, true><<<dim3((G + NW - 1) / NW), dim3(NW * 64), 0, st>>>(dm, nullptr, hbuf, recs, length, M, T, G, B, nullptr, l0, T, 0);
     return hipGetLastError();
 }
 hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcModel* dm, float* hbuf, float* recs, const int* length,
@@ -2351,7 +2272,7 @@ hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcM
 
 template <class T16, bool SP, bool WGR, bool NARROW = false>
 static hipError_t launch_embed_t(hipStream_t st, const DcModel* dm, const float* x, float* hbuf, float* recs, const int* length,
-                                 int M, int T, int G, int B, unsigned long long* clk, int Tx, int upc, unsigned* unit_flags = nullptr) {
+                                 int M, int T, int G, int B, unsigned long long* clk, int Tx, int upc) {
     constexpr int NW = (NARROW || (SP && !WGR)) ? 4 : 8;
     const size_t shm = !WGR ? 0 : SP ? 8192 + 65 * 1024 + 9 * 4 * 32 * 4 + 65 * 1024 : 8192 + 65536 + 8192 + 9 * 4 * 32 * 4 + 33 * 1024;
     if (WGR) {
@@ -2359,19 +2280,18 @@ static hipError_t launch_embed_t(hipStream_t st, const DcModel* dm, const float*
         if (hipError_t e = lds_optin((const void*)k_embed_front<T16, SP, WGR, false, NARROW>, (int)shm, optin_done)) return e;
     }
     k_embed_front<T16, SP, WGR, false, NARROW><<<dim3((WGR && upc) ? B * upc : (G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(dm, x, hbuf, recs, length, M, T, G, B,
-                                                                                                                         clk, 0, Tx, WGR ? upc : 0, unit_flags);
+                                                                                                                         clk, 0, Tx, WGR ? upc : 0);
     return hipGetLastError();
 }
 hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, const DcModel* dm, const float* x, float* hbuf,
-                                 float* recs, const int* length, int M, int T, int G, int B, unsigned long long* clk, bool narrow, int Tx, int upc,
-                                 unsigned* unit_flags) {
+                                 float* recs, const int* length, int M, int T, int G, int B, unsigned long long* clk, bool narrow, int Tx, int upc) {
     hipError_t e = hipSuccess;
     if (wgr && !split && narrow)
         return fmt == 1 ? launch_embed_t<_Float16, false, true, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc)
                         : launch_embed_t<__bf16, false, true, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc);
     if (wgr && !split) {
-        e = fmt == 1 ? launch_embed_t<_Float16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc, unit_flags)
-                     : launch_embed_t<__bf16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc, unit_flags);
+        e = fmt == 1 ? launch_embed_t<_Float16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc)
+                     : launch_embed_t<__bf16, false, true>(st, dm, x, hbuf, recs, length, M, T, G, B, clk, Tx, upc);
         return e;
     }
     if (wgr) {            // split formats: workgroup records on clip-aligned units only (one clip per workgroup)
@@ -2383,7 +2303,7 @@ hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, 
     return e;
 }
 
-template <class T16, bool SP, bool DBG, bool STAMP, bool WGR, bool NARROW = false, bool PERS = false>
+template <class T16, bool SP, bool DBG, bool STAMP, bool WGR, bool NARROW = false>
 static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
@@ -2393,8 +2313,8 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
     // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
     const size_t shm = SP ? 2 * 65 * 1024 + (WGR ? 16384 + 6144 : 0) : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
     static unsigned long long optin_done = 0;   // > 64 KiB of dynamic LDS needs the opt-in
-    if (hipError_t e = lds_optin((const void*)k_layer<T16, SP, DBG, STAMP, WGR, NARROW, PERS>, (int)shm, optin_done)) return e;
-    k_layer<T16, SP, DBG, STAMP, WGR, NARROW, PERS><<<dim3((WGR && upc) ? B * upc : (G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(
+    if (hipError_t e = lds_optin((const void*)k_layer<T16, SP, DBG, STAMP, WGR, NARROW>, (int)shm, optin_done)) return e;
+    k_layer<T16, SP, DBG, STAMP, WGR, NARROW><<<dim3((WGR && upc) ? B * upc : (G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(
         dm, l, hbuf, (const f16x16*)E, NT, (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
         snaps, M, T, G, B, dbg, stamps, rec_stride, iter_base, Tx, WGR ? upc : 0, upd);
     return hipGetLastError();
@@ -2435,24 +2355,6 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
     }
 #undef LAYER_ARGS
     return e;
-}
-
-// all DC_PERS_LAYERS layers in ONE launch (k_layer, PERS): wide non-split workgroup-record form; the caller guarantees one workgroup
-// per CU (grid <= CU count) and that the step's embedding reset upd.unit_flags
-hipError_t dc_launch_layers_persistent(hipStream_t st, int fmt, const DcModel* dm, float* hbuf, const void* E, int NT, const void* a_sa,
-                                       const void* a_ca, float* recs, const int* length, const float* xin, float* xout, int out_mode,
-                                       const float* coef_cur, const int* snap_cur, float* snaps, int M, int T, int G, int B,
-                                       size_t rec_stride, const int* iter_base, int Tx, int upc, const DcUpdate& upd,
-                                       unsigned long long* stamps) {
-    if (!upd.unit_flags) return hipErrorInvalidValue;
-    const int l = 0, dbg = 0;
-#define LAYER_ARGS st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps, \
-                   rec_stride, iter_base, Tx, upc, upd
-    if (stamps) return fmt == 1 ? launch_layer_t<_Float16, false, false, true, true, false, true>(LAYER_ARGS)
-                                : launch_layer_t<__bf16, false, false, true, true, false, true>(LAYER_ARGS);
-    return fmt == 1 ? launch_layer_t<_Float16, false, false, false, true, false, true>(LAYER_ARGS)
-                    : launch_layer_t<__bf16, false, false, false, true, false, true>(LAYER_ARGS);
-#undef LAYER_ARGS
 }
 
 // ---- no_eff variant ------------------------------------------------------------------

@@ -36,8 +36,7 @@ hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, 
                                  unsigned long long* clk /* diagnostic stamps (8 slots) or nullptr */,
                                  bool narrow /* wgr, non-split: 4-wave workgroups = 128-token units (small batches) */,
                                  int Tx /* frames per clip of x (<= the clip stride T) */,
-                                 int upc /* wgr: workgroups per clip (clip-aligned units, WgMap in dc_dev.h), grid = B * upc; else 0 */,
-                                 unsigned* unit_flags = nullptr /* wgr: per-unit progress flags of the persistent layer launch, reset here */);
+                                 int upc /* wgr: workgroups per clip (clip-aligned units, WgMap in dc_dev.h), grid = B * upc; else 0 */);
 // test hook: front half of layer l0 from the residual stream as it stands in hbuf (per-group records)
 hipError_t dc_launch_front_from_h(hipStream_t st, int fmt, bool split, const DcModel* dm, float* hbuf, float* recs, const int* length,
                                   int M, int T, int G, int B, int l0);
@@ -50,13 +49,6 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            bool narrow /* wgr, non-split, dbg == 0: 4-wave workgroups; recs / rec_stride then count 128-token units */,
                            int Tx /* frames per clip of xin / xout / snaps */, int upc /* as dc_launch_embed_front */,
                            const DcUpdate& upd /* options of the fused DDIM update + the status word (dc_common.h) */);
-// ALL DC_PERS_LAYERS layers in one launch (k_layer PERS: residual stream in registers, sc1 unit records, per-unit progress flags in
-// upd.unit_flags, reset by the step's embedding); fmt non-split; grid <= CU count is the caller's promise
-hipError_t dc_launch_layers_persistent(hipStream_t st, int fmt, const DcModel* dm, float* hbuf, const void* E, int NT, const void* a_sa,
-                                       const void* a_ca, float* recs, const int* length, const float* xin, float* xout, int out_mode,
-                                       const float* coef_cur, const int* snap_cur, float* snaps, int M, int T, int G, int B,
-                                       size_t rec_stride, const int* iter_base, int Tx, int upc, const DcUpdate& upd,
-                                       unsigned long long* stamps = nullptr /* diagnostic stage stamps of layer 3 (tools/stage_stamps.py) */);
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);
 hipError_t dc_launch_set_ptr(hipStream_t st, const float** slot, const float* p);
 // N(0, 1) draws of one DDIM iteration (Philox keyed by seed; iteration = step + *iter_base, else snap_cur[1], else step) into z[0..n)

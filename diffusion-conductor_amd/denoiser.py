@@ -103,8 +103,7 @@ class MotionTransformer(nn.Module):
         none: only precision="auto" switches, only from fp16, and only for a non-finite x0 - a FiLM value outside the fp16
         storage range is outside every mode."""
         from . import native
-        # (exactly NONFINITE: with the saturation bit the values are outside every mode, and any other bit - the persistent
-        # launch's SYNC_TIMEOUT - is not a precision problem)
+        # (exactly NONFINITE: with the saturation bit the values are outside every mode, and no other bit is a precision problem)
         if self.precision != "auto" or self.active_precision != "fp16" or status != native.STATUS_NONFINITE:
             return False
         if self._native is not None:

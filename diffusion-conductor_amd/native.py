@@ -208,9 +208,6 @@ def describe_status(st: int, precision: str) -> str:
     if st & STATUS_NONFINITE:
         msg.append(f"the denoiser produced a non-finite x0 in precision '{precision}' (fp16 operands overflow beyond +-65504): "
                    "use precision='mixed' (bf16-range operands) or precision='auto'")
-    if st & 4:
-        msg.append("a workgroup of the persistent layer launch timed out waiting for its neighbours (GPU shared with another process?): "
-                   "results invalid - unset DC_PERSIST")
     if st & STATUS_F16_SATURATED:
         msg.append("a FiLM modulation value left the fp16 range in which every precision mode stores it: this checkpoint is "
                    "outside what the library supports")

@@ -205,8 +205,6 @@ DC_EXPORT int dc_step_noise_fill(float* d_out, int64_t n, uint64_t seed, int32_t
  * clear != 0 resets the word. */
 #define DC_STATUS_NONFINITE 1
 #define DC_STATUS_F16_SATURATED 2
-#define DC_STATUS_SYNC_TIMEOUT 4   /* a workgroup of the persistent layer launch (opt-in: DC_PERSIST=1) gave up waiting for its clip's other
-                                      units (not co-resident: another process on the GPU?) - the results are invalid */
 DC_EXPORT int dc_sampler_status(dc_sampler* s, int32_t* h_status, int32_t clear);
 
 /* Timing hook for bench.py: device time (ms, HIP events on the library's own stream)

@@ -241,7 +241,7 @@ def test_status_word_reports_on_the_loop_that_was_asked_about():
     out = gd.ddim_sample_loop(m, (B, T, 26), **kw)
     torch.cuda.synchronize()
     assert m._native is nat and m.active_precision == "fp16" and torch.isfinite(out).all()
-    assert not m.numerics_fallback(native.STATUS_NONFINITE | 4) and not m.numerics_fallback(4)     # never on SYNC_TIMEOUT
+    assert not m.numerics_fallback(native.STATUS_NONFINITE | 4) and not m.numerics_fallback(4)     # only for exactly NONFINITE
     assert m.active_precision == "fp16"
 
 
@@ -392,37 +392,3 @@ def test_mixed_mode_clip_aligned_units_edge_shapes(B, T):
     again = gd.ddim_sample_loop(m, (B, T, 26), noise=x.cuda(), clip_denoised=False, progress=False, idxs=[3],
                                 model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor(length)})
     assert torch.equal(again[S], res[S]) and torch.equal(again[3], res[3])
-
-
-@pytest.mark.parametrize("B,T,S,align", [(32, 1800, 50, False), (32, 1800, 25, True), (20, 1024, 25, False), (9, 1800, 25, False),
-                                         (33, 300, 25, False), (40, 1600, 25, False)])
-def test_persistent_layer_launch_equals_per_layer_launches(B, T, S, align):
-    """Round 3, opt-in (DC_PERSIST=1): with every wide workgroup on a CU of its own, the eight layers of a step run as ONE launch
-    (k_layer PERS: residual stream in registers, unit records exchanged inside the launch with sc1 stores / loads behind per-unit
-    progress flags).  Same units, same arithmetic, same order: bit-identical to the per-layer launches, re-runs identical, status
-    clean; ragged lengths; flat and clip-aligned units; shapes that are not eligible (narrow form, more units than CUs) simply keep
-    the per-layer launches."""
-    import os
-    sd = synthetic_state_dict(DenoiserConfig(), seed=0)
-    m = _model(sd, "fp16")
-    xfp, xfo = _features(sd, B, T, 3)
-    noise = torch.from_numpy(batch_noise(B, T, first=3)).cuda()
-    length = [T if b % 3 else max(1, T - 37 * b) for b in range(B)]
-    nat = m.set_conditioning(xfp.cuda(), xfo.cuda(), length)
-    coef = make_diffusion(S).native_coefficients()
-    if align:
-        os.environ["DC_ALIGN"] = "1"
-    try:
-        b, _ = nat.ddim_loop(noise, coef, (3,))
-        os.environ["DC_PERSIST"] = "1"
-        try:
-            a, _ = nat.ddim_loop(noise, coef, (3,))
-            st = nat.status()
-            c, _ = nat.ddim_loop(noise, coef, (3,))
-        finally:
-            del os.environ["DC_PERSIST"]
-    finally:
-        os.environ.pop("DC_ALIGN", None)
-    torch.cuda.synchronize()
-    assert st == 0 and torch.isfinite(a).all()
-    assert torch.equal(a, b) and torch.equal(a, c)

@@ -32,11 +32,7 @@ print("                 ->barrier         " + seg(21, 12))
 print("                 ->pass 2 done     " + seg(12, 16))
 print("                 ->barrier         " + seg(16, 17))
 print("                 ->record written  " + seg(17, 13))
-if st[:, 28].max() > 0:
-    print("persistent form:    0->neighbours' flags seen " + seg(0, 28))
-    print("combine split (us): ->loads issued    " + seg(28, 22))
-else:
-    print("combine split (us): 0->loads issued   " + seg(0, 22))
+print("combine split (us): 0->loads issued   " + seg(0, 22))
 print("                    ->phase A done    " + seg(22, 23))
 print("                    ->barrier         " + seg(23, 24))
 print("                    ->FMAs done       " + seg(24, 25))
