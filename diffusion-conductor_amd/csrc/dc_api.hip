@@ -91,6 +91,22 @@ void pack_weight(const float* w, int n_out, int k_in, bool chained, uint16_t* hi
                     }
 }
 size_t packed_elems(int n_out, int k_in) { return (size_t)cdiv(n_out, 32) * cdiv(k_in, 32) * 2 * 64 * 8; }
+// v_mfma_f32_16x16x32 operand image of the 16-token layer kernel (DcLayer16 in dc_common.h): [m][rb][64][8]
+void pack_weight16(const float* w, int n_out, int k_in, uint16_t* hi, uint16_t* lo, bool f16) {
+    const int RB = cdiv(n_out, 16), KM = cdiv(k_in, 32);
+    for (int m = 0; m < KM; ++m)
+        for (int rb = 0; rb < RB; ++rb)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int row = 16 * rb + (l & 15), col = 32 * m + 16 * (j >> 2) + 4 * (l >> 4) + (j & 3);
+                    const float v = (row < n_out && col < k_in) ? w[(size_t)row * k_in + col] : 0.f;
+                    const size_t o = (((size_t)m * RB + rb) * 64 + l) * 8 + j;
+                    const uint16_t h = f16 ? f2h(v) : f2bf(v);
+                    hi[o] = h;
+                    if (lo) lo[o] = f16 ? f2h(v - h2f(h)) : f2bf(v - bf2f(h));
+                }
+}
+size_t packed_elems16(int n_out, int k_in) { return (size_t)cdiv(n_out, 16) * cdiv(k_in, 32) * 64 * 8; }
 
 // per-feature vector in FT register order: out[(t*2+hh)*16 + r] = v[32t + tile_row(r,hh)]
 void pack_ftvec(const float* v, int n, int NT, float* out) {
@@ -153,6 +169,7 @@ struct dc_sampler {
     float* d_h = nullptr;
     float* d_recs = nullptr;
     void *d_a_sa = nullptr, *d_a_ca = nullptr;
+    void* d_a_ca16 = nullptr;             // cross-attention fragments in the 16-token layer kernel's form (small batches)
     void *d_kv_sa[2] = {nullptr, nullptr}, *d_kv_ca = nullptr;   // no_eff: key-tile arrays (dc_kernels.hip, full attention)
     int KT = 0;                                                   // key tiles per clip array
     float* d_x = nullptr;
@@ -343,13 +360,30 @@ int build_model(dc_sampler* s) {
         return buf;
     };
     const bool ssp = s->split_small;
-    auto add_styl = [&](const bf16x8** dst, const std::string& p) {
+    // 16-token layer kernel (small batches; non-split formats, linear attention): up to two matrices + constants per stage image
+    const bool want16 = !ssp && !c.no_eff;
+    auto add_image16 = [&](const bf16x8** dst, const float* wa, int na_out, int ka, const float* wb, int nb_out, int kb, bool with_lo,
+                           const std::vector<float>& consts) {
+        if (!want16) return;
+        const size_t ea = packed_elems16(na_out, ka), eb = wb ? packed_elems16(nb_out, kb) : 0;
+        std::vector<uint16_t> hi(ea + eb), lo(ea + eb);
+        pack_weight16(wa, na_out, ka, hi.data(), lo.data(), sf16);
+        if (wb) pack_weight16(wb, nb_out, kb, hi.data() + ea, lo.data() + ea, sf16);
+        std::vector<uint8_t> blob((ea + eb) * 2 * (with_lo ? 2 : 1) + 1024, 0);
+        memcpy(blob.data(), hi.data(), (ea + eb) * 2);
+        if (with_lo) memcpy(blob.data() + (ea + eb) * 2, lo.data(), (ea + eb) * 2);
+        memcpy(blob.data() + (ea + eb) * 2 * (with_lo ? 2 : 1), consts.data(), consts.size() * 4);
+        O.fix.push_back({(const void**)dst, A.add(blob.data(), blob.size())});
+    };
+    auto vec = [](const float* p, size_t n) { return std::vector<float>(p, p + n); };
+    auto add_styl = [&](const bf16x8** dst, const std::string& p) -> std::vector<float> {
         const std::vector<float> bo = ftvec(P_(p + ".out_layers.2.bias"), D, 4);
         // the kernels hand over log2(e) * SiLU(.) (silu_l2_pair in dc_kernels.hip): ln 2 goes into the weights
         const float* w = P_(p + ".out_layers.2.weight");
         std::vector<float> ws((size_t)D * D);
         for (size_t i = 0; i < ws.size(); ++i) ws[i] = (float)((double)w[i] * 0.6931471805599453);
         add_image(dst, ws.data(), D, D, ssp, bo.data(), bo.size());
+        return ws;
     };
     // W' = W diag(g), c' = c + W b  (LayerNorm affine folded into the projection that consumes it)
     // `scale` additionally multiplies the whole projection: log2(e) for the query / key projections, whose
@@ -380,6 +414,7 @@ int build_model(dc_sampler* s) {
     for (int i = 0; i < L; ++i) {
         const std::string p = "temporal_decoder_blocks." + std::to_string(i);
         DcLayer& y = m.layer[i];
+        DcLayer16& y16 = m.l16[i];
         std::vector<float> wf, cf;
         const float* sg = P_(p + ".sa_block.norm.weight");
         const float* sb = P_(p + ".sa_block.norm.bias");
@@ -387,17 +422,24 @@ int build_model(dc_sampler* s) {
         {
             const std::vector<float> c = ftvec(cf.data(), D, 4);
             add_image(&y.img_sa_q, wf.data(), D, D, ssp, c.data(), c.size());
+            add_image16(&y16.sa_q, wf.data(), D, D, nullptr, 0, 0, false, cf);
         }
         fold_ln(P_(p + ".sa_block.key.weight"), P_(p + ".sa_block.key.bias"), sg, sb, D, D, wf, cf, KS);
         add_image(&y.img_sa_k, wf.data(), D, D, ssp, cf.data(), cf.size());          // plain bias[128]
+        add_image16(&y16.sa_k, wf.data(), D, D, nullptr, 0, 0, false, cf);
         fold_ln(P_(p + ".sa_block.value.weight"), P_(p + ".sa_block.value.bias"), sg, sb, D, D, wf, cf);
         add_image(&y.img_sa_v, wf.data(), D, D, ssp, cf.data(), cf.size());
-        add_styl(&y.img_sa_o, p + ".sa_block.proj_out");
+        add_image16(&y16.sa_v, wf.data(), D, D, nullptr, 0, 0, false, cf);
+        {
+            const std::vector<float> ws = add_styl(&y.img_sa_o, p + ".sa_block.proj_out");
+            add_image16(&y16.sa_o, ws.data(), D, D, nullptr, 0, 0, false, vec(P_(p + ".sa_block.proj_out.out_layers.2.bias"), D));
+        }
         fold_ln(P_(p + ".ca_block.query.weight"), P_(p + ".ca_block.query.bias"), P_(p + ".ca_block.norm.weight"),
                 P_(p + ".ca_block.norm.bias"), D, D, wf, cf, QS);
         {
             const std::vector<float> c = ftvec(cf.data(), D, 4);
             add_image(&y.img_ca_q, wf.data(), D, D, ssp, c.data(), c.size());
+            add_image16(&y16.ca_q, wf.data(), D, D, nullptr, 0, 0, false, cf);
         }
         // fold text_norm's affine (transformer.py:149,153) into the K/V projections:
         //   W (g*n + b) + c = (W*g) n + (W b + c)
@@ -422,15 +464,25 @@ int build_model(dc_sampler* s) {
                 add_raw(kv ? &y.ca_bv : &y.ca_bk, bf.data(), D);
             }
         }
-        add_styl(&y.img_ca_o, p + ".ca_block.proj_out");
+        {
+            const std::vector<float> ws = add_styl(&y.img_ca_o, p + ".ca_block.proj_out");
+            add_image16(&y16.ca_o, ws.data(), D, D, nullptr, 0, 0, false, vec(P_(p + ".ca_block.proj_out.out_layers.2.bias"), D));
+        }
         add_image(&y.img_ffn_w1, P_(p + ".ffn.linear1.weight"), DC_F, D, ssp, nullptr, 0);
         {
             std::vector<float> c = ftvec(P_(p + ".ffn.linear1.bias"), DC_F, 2);       // 64 floats, then b2
             const std::vector<float> c2 = ftvec(P_(p + ".ffn.linear2.bias"), D, 4);
             c.insert(c.end(), c2.begin(), c2.end());
             add_image(&y.img_ffn_w2, P_(p + ".ffn.linear2.weight"), D, DC_F, ssp, c.data(), c.size());
+            std::vector<float> pc = vec(P_(p + ".ffn.linear1.bias"), DC_F);
+            const std::vector<float> pb2 = vec(P_(p + ".ffn.linear2.bias"), D);
+            pc.insert(pc.end(), pb2.begin(), pb2.end());
+            add_image16(&y16.ffn_w, P_(p + ".ffn.linear1.weight"), DC_F, D, P_(p + ".ffn.linear2.weight"), D, DC_F, false, pc);
         }
-        add_styl(&y.img_ffn_o, p + ".ffn.proj_out");
+        {
+            const std::vector<float> ws = add_styl(&y.img_ffn_o, p + ".ffn.proj_out");
+            add_image16(&y16.ffn_o, ws.data(), D, D, nullptr, 0, 0, false, vec(P_(p + ".ffn.proj_out.out_layers.2.bias"), D));
+        }
         const char* blk[3] = {".sa_block.proj_out", ".ca_block.proj_out", ".ffn.proj_out"};
         for (int j = 0; j < 3; ++j) {
             const size_t row0 = (size_t)(3 * i + j) * 256;
@@ -484,6 +536,9 @@ int build_model(dc_sampler* s) {
         add_image(&m.img_je, P_("joint_embed.weight"), D, P, true, jb.data(), jb.size());
         const std::vector<float> ob = ftvec(P_("out.bias"), P, 1);
         add_image(&m.img_out, P_("out.weight"), P, D, true, ob.data(), ob.size());
+        std::vector<float> ob16(32, 0.f);
+        for (int i = 0; i < P; ++i) ob16[i] = P_("out.bias")[i];
+        add_image16(&m.out16, P_("out.weight"), P, D, nullptr, 0, 0, true, ob16);
     }
     add_raw(&m.seq_emb, P_("sequence_embedding"), (size_t)c.num_frames * D);
     {
@@ -585,6 +640,7 @@ int ensure_workspace(dc_sampler* s, int B, int Tx) {
         if ((rc = dev_alloc(s, s->d_t_clip, (size_t)B * 4))) return rc;
         if ((rc = dev_alloc(s, s->d_a_sa, (size_t)B * 16 * 1024))) return rc;
         if ((rc = dev_alloc(s, s->d_a_ca, (size_t)L * B * 16 * 1024))) return rc;
+        if ((rc = dev_alloc(s, s->d_a_ca16, (size_t)L * B * 8 * 1024))) return rc;
         s->cap_B = (size_t)B;
     }
     if ((size_t)M * P > s->cap_MP) {
@@ -662,7 +718,7 @@ struct Timed {   // RAII-less helper: wraps a launch with events when profiling
 // that one process can A/B them: a change re-captures) and the update options of the loop.
 unsigned long long form_key(const dc_sampler* s) {
     static const char* sw[] = {"DC_NO_WGREC", "DC_NO_NARROW", "DC_NO_ALIGN", "DC_ALIGN", "DC_NO_FUSE_EMBED", "DC_FILM_STATIC",
-                               "DC_BEGIN_STEP", "DC_NO_PAD"};
+                               "DC_BEGIN_STEP", "DC_NO_PAD", "DC_NO_LAYER16"};
     unsigned long long k = 0;
     for (size_t i = 0; i < sizeof sw / sizeof *sw; ++i) k |= (getenv(sw[i]) ? 1ull : 0ull) << i;
     k |= (unsigned long long)(s->upd_flags & 0xff) << 16;     // (the noise tensor's address is not baked in: the kernels read it from d_zslot)
@@ -691,7 +747,8 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         LAUNCH(K_BEGIN, dc_launch_begin_step(st, s->d_iter, s->d_t_of_iter, s->d_coef_of_t, s->d_snap_of_iter,
                                              s->d_t_clip, s->d_coef_cur, s->d_snap_cur, B));
     if (loop_mode && (s->upd_flags & DC_UPD_ZSTEP))       // this iteration's draws (eta > 0, library-generated): consumed by the last layer's epilogue
-        LAUNCH(K_NOISE, dc_launch_step_noise(st, s->d_zstep, (size_t)B * s->Tx * s->cfg.input_feats, s->noise_seed, iter_base, folded ? graph_step : 0,
+        LAUNCH(K_NOISE, dc_launch_step_noise(st, s->d_zstep, (size_t)B * s->Tx * s->cfg.input_feats, 0, reinterpret_cast<const unsigned long long*>(s->d_zslot) + 1,
+                                             iter_base, folded ? graph_step : 0,
                                              folded ? nullptr : s->d_snap_cur));
     if (!fuse_silu)
         LAUNCH(K_SILU, dc_launch_silu_emb(st, ff, sf, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, G, T, B));
@@ -720,6 +777,12 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const bool narrow = wgr && !ss && nwg_narrow <= s->num_cu && T <= 3840 && s->dbg_layers < 0 && s->dbg_stage == 0 &&
                         !getenv("DC_NO_NARROW") && !want_stamps;
     const bool aligned = can_align && (narrow || ss || aligned_env);
+    // 16-token waves (dc_layer16.hip) while every clip-aligned 64-token unit still gets a CU of its own (bs <= 8 at T = 1800): in that
+    // regime the layer is bound by the LENGTH of one wave's dependency chain, and a 16-token wave's is about half as long.  The
+    // embedding stays the narrow 32-token form (its 128-token unit records feed layer 0).  DC_NO_LAYER16=1 keeps the 32-token form.
+    const int upc16 = (T + 63) / 64;
+    const bool layer16 = narrow && aligned && (long long)B * upc16 <= s->num_cu && upc16 <= dc_layer16_max_units() && s->dbg_first < 0 &&
+                         !getenv("DC_NO_LAYER16");
     const int upc = aligned ? (narrow ? upc_narrow : upc_wide) : 0;
     const int nwg = aligned ? B * upc : (narrow ? (G + 3) / 4 : (G + 7) / 8);
     const int Tx = s->Tx;
@@ -762,6 +825,13 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
     for (int l = s->dbg_first >= 0 ? s->dbg_first : 0; l < nl_run; ++l) {
         const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
+        if (layer16) {
+            LAUNCH(K_LAYER, dc_launch_layer16(st, fs, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_ca16, s->d_recs, s->d_length, x_src, x_dst,
+                                              loop_mode ? 1 : 0, coef_src, snap_src, s->d_snaps, M, T, B, upc16, rec_stride,
+                                              l == 0 ? upc_narrow : upc16, l == 0 ? (size_t)2 * DC_REC_FLOATS : (size_t)DC_REC_FLOATS, iter_base, Tx,
+                                              upd));
+            continue;
+        }
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src,
@@ -825,6 +895,7 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
             zbase = d_step_noise;
         } else {
             if (MP > s->cap_zstep) {
+                drop_graph(s);          // (the buffer's address is an argument of the captured k_step_noise launches)
                 s->cap_zstep = 0;
                 if ((rc = dev_alloc(s, s->d_zstep, MP * 4))) return rc;
                 s->cap_zstep = MP;
@@ -839,7 +910,7 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     // the status word reports on THIS loop: bits left by earlier work on the sampler (a dc_sampler_denoise, a loop nobody asked
     // about) must not fail it
     HIP_TRY(hipMemsetAsync(s->d_status, 0, 4, st));
-    HIP_TRY(dc_launch_set_ptr(st, s->d_zslot, zbase));
+    HIP_TRY(dc_launch_set_ptr(st, s->d_zslot, zbase, s->noise_seed));
     if (!same_tables) {
         HIP_TRY(hipStreamSynchronize(st));          // an earlier call's copies out of the member vectors are done
         s->tables_S = 0;
@@ -1030,7 +1101,7 @@ void dc_sampler_destroy(dc_sampler* s) {
     void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
                     s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t, s->d_coef_of_iter,
-                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status, s->d_smooth_coef, s->d_zslot, s->d_zstep};
+                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status, s->d_smooth_coef, s->d_zslot, s->d_zstep, s->d_a_ca16};
     for (void* p : ptrs)
         if (p) hipFree(p);
     dc_music_destroy(s->music);
@@ -1119,6 +1190,7 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
     } else {
         HIP_TRY(dc_launch_ca_partials(st, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_recs_ca, M, T, G, L, Tx));
         HIP_TRY(dc_launch_attn_combine(st, s->small_fmt, s->d_recs_ca, s->d_a_ca, T, G, B, L, 32));
+        if (!s->split_small) HIP_TRY(dc_launch_cond_af16(st, s->small_fmt, s->d_a_ca, s->d_a_ca16, L * B));      // (small batches: dc_layer16.hip)
     }
     HIP_TRY(hipStreamSynchronize(st));   // `len` is host memory
     s->cond_set = true;
@@ -1289,7 +1361,7 @@ int dc_sampler_set_step_noise_seed(dc_sampler* s, uint64_t seed) {
 int dc_step_noise_fill(float* d_out, int64_t n, uint64_t seed, int32_t iteration, void* stream) {
     if (!d_out || n < 0 || iteration < 0) return fail(DC_ERR_INVALID, "bad step-noise arguments");
     if (n == 0) return DC_OK;
-    HIP_TRY(dc_launch_step_noise((hipStream_t)stream, d_out, (size_t)n, seed, nullptr, iteration, nullptr));
+    HIP_TRY(dc_launch_step_noise((hipStream_t)stream, d_out, (size_t)n, seed, nullptr, nullptr, iteration, nullptr));
     return DC_OK;
 }
 

@@ -55,8 +55,19 @@ struct DcLayer {
     const float *ca_bk, *ca_bv;                // plain [128]
 };
 
+// Stage images of the 16-token layer kernel for small batches (dc_layer16.hip; non-split formats, linear attention): fragments
+// of v_mfma_f32_16x16x32 operands, frag (m, rb) at index m * RB + rb, lane l, element j =
+// W[16 rb + (l & 15)][32 m + 16 (j >> 2) + 4 (l >> 4) + (j & 3)]; 32 fragments + 1 KiB of fp32 constants (plain per-feature
+// vectors).  Same folded matrices as DcLayer's images.
+struct DcLayer16 {
+    const bf16x8 *sa_q, *sa_o, *ca_q, *ca_o, *ffn_o, *sa_k, *sa_v;
+    const bf16x8* ffn_w;       // W1 (16 fragments) | W2 (16) | b1[64], b2[128]
+};
+
 struct DcModel {
     DcLayer layer[DC_MAX_LAYERS];
+    DcLayer16 l16[DC_MAX_LAYERS];
+    const bf16x8* out16;     // out: 8 hi + 8 lo fragments (2 row blocks x 4 k-steps) + bias[32]
     const bf16x8* img_je;    // joint_embed: chained pack OT=4 KT=1 (8 frags/half, always used split) + bias ftvec[4]
     const float* seq_emb;    // row-major [num_frames][128]
     const bf16x8* img_out;   // out: chained pack OT=1 KT=4 (8 frags/half, always used split) + bias ftvec[1]

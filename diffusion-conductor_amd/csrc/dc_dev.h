@@ -1240,24 +1240,40 @@ DEV f16x16 join16(const f16x8& lo8, const f16x8& hi8) {
     }
     return v;
 }
-// The same block for the split formats (no LDS left for FiLM rings: two 65-KiB weight images): the FiLM tiles of k-tile kt + 2
-// are requested as soon as those of k-tile kt have been consumed, and the out-projection's MFMAs of a k-tile follow its SiLU
-// directly - two tile pairs (32 registers) in flight instead of all operand fragments of the block (64) plus loads at the point
-// of use.  Same products in the same order per accumulator as styl_accumulate (k-tile-major): identical results.
-template <class T16, bool SPLIT>
-DEV void styl_accumulate_pf(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd, float shift, const f16x8* __restrict__ Eg,
-                            const float* bo, const v8<T16>* w, int lane, int hh) {
+// The same block for the split formats (no LDS left for FiLM rings: two 65-KiB weight images).  The FiLM tiles travel through
+// registers two k-tiles ahead: those of k-tiles 0 and 1 are requested at the END of the preceding stage (epf_fetch in front of a
+// closer that leaves exactly these 8 loads in flight, stage_sync_keep8) and land behind the barrier and the next image's DMA
+// issue; those of k-tile kt + 2 as soon as those of k-tile kt have been consumed; the out-projection's MFMAs of a k-tile follow
+// its SiLU directly - two tile pairs (32 registers) in flight instead of all operand fragments of the block (64) plus loads at
+// the point of use.  Same products in the same order per accumulator as styl_accumulate (k-tile-major): identical results.
+struct EPf {
     f16x8 g0[2], g1[2], h0[2], h1[2];            // [slot]: the 16-byte halves of the (G' - 1, H') tiles of k-tiles kt, kt + 1
-    auto fetch = [&](int kt, int slot) {
-        const f16x8* pg = Eg + kt * 128 + lane;
-        const f16x8* ph = Eg + (4 + kt) * 128 + lane;
-        g0[slot] = __builtin_nontemporal_load(pg);
-        g1[slot] = __builtin_nontemporal_load(pg + 64);
-        h0[slot] = __builtin_nontemporal_load(ph);
-        h1[slot] = __builtin_nontemporal_load(ph + 64);
-    };
-    fetch(0, 0);
-    fetch(1, 1);
+};
+DEV void epf_fetch(EPf& e, const f16x8* __restrict__ Eg, int kt, int slot, int lane) {
+    const f16x8* pg = Eg + kt * 128 + lane;
+    const f16x8* ph = Eg + (4 + kt) * 128 + lane;
+    e.g0[slot] = __builtin_nontemporal_load(pg);
+    e.g1[slot] = __builtin_nontemporal_load(pg + 64);
+    e.h0[slot] = __builtin_nontemporal_load(ph);
+    e.h1[slot] = __builtin_nontemporal_load(ph + 64);
+}
+// stage closer that leaves the wave's 8 youngest vector-memory operations (the FiLM tiles just requested) in flight: vmcnt counts
+// in issue order, so everything older - this wave's share of the next weight image - has landed
+DEV void stage_sync_keep8() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#ifndef DC_DIAG_NO_STAGE_BARRIER
+    __syncthreads();
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class T16, bool SPLIT, bool PRE /* k-tiles 0, 1 were requested by the preceding stage */>
+DEV void styl_accumulate_pf(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd, float shift, const f16x8* __restrict__ Eg, EPf& e,
+                            const float* bo, const v8<T16>* w, int lane, int hh) {
+    if constexpr (!PRE) {
+        epf_fetch(e, Eg, 0, 0, lane);
+        epf_fetch(e, Eg, 1, 1, lane);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const f32x16 bb = ld_ft(bo, t, hh);
@@ -1272,9 +1288,9 @@ DEV void styl_accumulate_pf(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rs
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
         XFrag<T16, SPLIT> zf;
-        styl_tile<T16, SPLIT, ytile<SPLIT>>(zf, y[kt], rstd, shift, join16(g0[kt & 1], g1[kt & 1]), join16(h0[kt & 1], h1[kt & 1]));
+        styl_tile<T16, SPLIT, ytile<SPLIT>>(zf, y[kt], rstd, shift, join16(e.g0[kt & 1], e.g1[kt & 1]), join16(e.h0[kt & 1], e.h1[kt & 1]));
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < 4) fetch(kt + 2, kt & 1);
+        if (kt + 2 < 4) epf_fetch(e, Eg, kt + 2, kt & 1, lane);
         __builtin_amdgcn_sched_barrier(0);
         mma_kt<4, 4, T16, SPLIT>(h, w, kt, zf, lane);
         __builtin_amdgcn_sched_barrier(0);
@@ -1365,5 +1381,24 @@ DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float 
         mma_kt<4, 4, T16, SPLIT>(h, w, kt, zf, lane);
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// ------------------------------------------------------------------------------------
+// The DDIM update of one element (gaussian_diffusion.py:503-521 p_mean_variance's pred_xstart, :812-830 ddim_sample), fp32 with
+// the reference's own fp32 scalars c[0..4] (DC_COEF):  mo = the denoiser's output, xt = x_t, z = this iteration's noise draw.
+//   pred = mo  |  sqrt(1/abar) x_t - sqrt(1/abar - 1) mo  (EPSILON);   clamp(-1, 1) when clip_denoised;
+//   eps  = (sqrt(1/abar) x_t - pred) / sqrt(1/abar - 1);   x_{t-1} = sqrt(abar_prev) pred + sqrt(1 - abar_prev - sigma^2) eps + sigma z
+// (sigma is 0 at t = 0 - abar_prev = 1 there - which is the reference's nonzero_mask.)  Returns x_{t-1}; `bad` collects non-finite pred.
+// ------------------------------------------------------------------------------------
+DEV float ddim_update(float mo, float xt, const float* __restrict__ c, int flags, bool noisy, float z, bool& bad) {
+    const float sr = c[0], srm1 = c[1], cx0 = c[2], ceps = c[3];
+    float pred = mo;
+    if (flags & DC_UPD_EPS) pred = sr * xt - srm1 * mo;
+    bad = bad || !(fabsf(pred) <= 3.0e38f);
+    if (flags & DC_UPD_CLIP) pred = fminf(fmaxf(pred, -1.f), 1.f);
+    const float eps = (sr * xt - pred) / srm1;
+    float xn = pred * cx0 + ceps * eps;
+    if (noisy) xn += c[4] * z;
+    return xn;
 }
 

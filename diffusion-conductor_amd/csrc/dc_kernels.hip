@@ -39,7 +39,10 @@ __global__ void k_begin_step(int* __restrict__ iter, const int* __restrict__ t_o
 
 // end of a captured graph of k steps whose kernels indexed the iteration tables themselves (iter_base): next replay starts k later
 __global__ void k_advance_iter(int* __restrict__ iter, int k) { *iter += k; }
-__global__ void k_set_ptr(const float** slot, const float* p) { *slot = p; }
+__global__ void k_set_ptr(const float** slot, const float* p, unsigned long long seed) {      // [0]: base of the step noise; [1]: the generator's seed
+    slot[0] = p;
+    reinterpret_cast<unsigned long long*>(slot)[1] = seed;
+}
 
 // ------------------------------------------------------------------------------------
 // eta > 0 without a caller-supplied noise tensor: the N(0, 1) draws of ONE iteration (the reference's th.randn_like(x),
@@ -56,8 +59,11 @@ DEV void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
     c[0] = n0;
     c[2] = n2;
 }
-__global__ __launch_bounds__(256) void k_step_noise(float* __restrict__ z, size_t n, unsigned long long seed, const int* __restrict__ iter_base,
-                                                    int step, const int* __restrict__ snap_cur) {
+__global__ __launch_bounds__(256) void k_step_noise(float* __restrict__ z, size_t n, unsigned long long seed,
+                                                    const unsigned long long* __restrict__ seed_slot /* the seed, when given (a captured graph
+                                                    must not bake it in) */, const int* __restrict__ iter_base, int step,
+                                                    const int* __restrict__ snap_cur) {
+    if (seed_slot) seed = *seed_slot;
     const unsigned it = (unsigned)(iter_base ? step + *iter_base : (snap_cur ? snap_cur[1] : step));
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; 4 * q < n; q += (size_t)gridDim.x * 256) {
         unsigned c[4] = {(unsigned)q, (unsigned)(q >> 32), it, 0x5eedu};
@@ -1005,25 +1011,6 @@ __global__ __launch_bounds__(512, 2) void k_film_embed(const v8<T16>* __restrict
 }
 
 // ------------------------------------------------------------------------------------
-// The DDIM update of one element (gaussian_diffusion.py:503-521 p_mean_variance's pred_xstart, :812-830 ddim_sample), fp32 with
-// the reference's own fp32 scalars c[0..4] (DC_COEF):  mo = the denoiser's output, xt = x_t, z = this iteration's noise draw.
-//   pred = mo  |  sqrt(1/abar) x_t - sqrt(1/abar - 1) mo  (EPSILON);   clamp(-1, 1) when clip_denoised;
-//   eps  = (sqrt(1/abar) x_t - pred) / sqrt(1/abar - 1);   x_{t-1} = sqrt(abar_prev) pred + sqrt(1 - abar_prev - sigma^2) eps + sigma z
-// (sigma is 0 at t = 0 - abar_prev = 1 there - which is the reference's nonzero_mask.)  Returns x_{t-1}; `bad` collects non-finite pred.
-// ------------------------------------------------------------------------------------
-DEV float ddim_update(float mo, float xt, const float* __restrict__ c, int flags, bool noisy, float z, bool& bad) {
-    const float sr = c[0], srm1 = c[1], cx0 = c[2], ceps = c[3];
-    float pred = mo;
-    if (flags & DC_UPD_EPS) pred = sr * xt - srm1 * mo;
-    bad = bad || !(fabsf(pred) <= 3.0e38f);
-    if (flags & DC_UPD_CLIP) pred = fminf(fmaxf(pred, -1.f), 1.f);
-    const float eps = (sr * xt - pred) / srm1;
-    float xn = pred * cx0 + ceps * eps;
-    if (noisy) xn += c[4] * z;
-    return xn;
-}
-
-// ------------------------------------------------------------------------------------
 // one decoder layer for NW token groups (one per wave), from the attention matrices onward:
 //   SA back half (transformer.py:104,109,119-121) -> CA (:147,150,156-157) -> FFN (:170-173)
 //   then either the next layer's SA front half, or the output projection (:496) fused with the
@@ -1042,8 +1029,8 @@ DEV float ddim_update(float mo, float xt, const float* __restrict__ c, int flags
 // bound by instruction issue, so a wave that has its SIMD to itself runs the layer in about half the time; worth it
 // whenever the batch is small enough for every unit to get its own CU (<= 32 K tokens: e.g. the reference's one clip per call).
 #ifndef DC_SPLIT_STYL_PF
-#define DC_SPLIT_STYL_PF 1       // split formats: stylization with the FiLM tiles prefetched two k-tiles ahead (0: all at the point of use)
-#endif
+#define DC_SPLIT_STYL_PF 2       // split formats: stylization with the FiLM tiles prefetched two k-tiles ahead (0: all at the point of use;
+#endif                           // 1: first request at the head of the block; 2: by the preceding stage, in flight across its closer)
 #ifndef DC_SPLIT_NW
 #define DC_SPLIT_NW 8      // waves per k_layer workgroup in the split modes (4: one wave per SIMD, round 1-2's form)
 #endif
@@ -1165,6 +1152,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
     stage_frags<NW>(L.img_sa_o, buf1, NFW + 1, wave, lane);
     EPre ep;
+    constexpr bool split_pf = DC_SPLIT_STYL_PF && SPLIT && !DBG;      // split formats: FiLM tiles through registers, two k-tiles ahead
+    EPf epf;
     if constexpr (use_ring) epre_load(ep, Eg, lane);
     ytile<SPLIT> y[4];
     float y_rstd, y_shift;
@@ -1179,14 +1168,20 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, a_sa + (size_t)cx.b0 * 16 * 64,
                                  a_sa + (size_t)cx.b1 * 16 * 64, cx);
     DC_STAMP(2);
-    stage_sync();
+    if constexpr (split_pf && DC_SPLIT_STYL_PF == 2) {       // the next block's first two FiLM tile pairs stay in flight across the closer
+        __builtin_amdgcn_sched_barrier(0);
+        epf_fetch(epf, Eg, 0, 0, lane);
+        epf_fetch(epf, Eg, 1, 1, lane);
+        stage_sync_keep8();
+    } else
+        stage_sync();
     DC_STAMP(3);
     if constexpr (use_ring) epre_landed(ep);
     // ---- stage 2: SA stylization [buf1]; prefetch CA query -> buf0 (+ cross-attention frags)
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
         if (wg_lds) stage_attn(acl);
-        if (!(DBG && skip_blocks >= 1)) { if constexpr (DC_SPLIT_STYL_PF && SPLIT && !DBG) styl_accumulate_pf<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh); }
+        if (!(DBG && skip_blocks >= 1)) { if constexpr (split_pf) styl_accumulate_pf<T16, SPLIT, DC_SPLIT_STYL_PF == 2>(h, y, y_rstd, y_shift, Eg, epf, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh); }
     } else {
         auto next2 = [&]() {
             stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
@@ -1214,13 +1209,19 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         query_attend<T16, SPLIT>(y, y_rstd, y_shift, h, c0, w0, acl + (size_t)cx.b0 * 16 * 64,
                                  acl + (size_t)cx.b1 * 16 * 64, cx);
     DC_STAMP(6);
-    stage_sync();
+    if constexpr (split_pf && DC_SPLIT_STYL_PF == 2) {       // the next block's first two FiLM tile pairs stay in flight across the closer
+        __builtin_amdgcn_sched_barrier(0);
+        epf_fetch(epf, Eg + 8 * 128, 0, 0, lane);
+        epf_fetch(epf, Eg + 8 * 128, 1, 1, lane);
+        stage_sync_keep8();
+    } else
+        stage_sync();
     if constexpr (use_ring) epre_landed(ep);
     // ---- stage 4: CA stylization [buf1]; prefetch FFN W1|W2 (+ b1|b2) -> buf0
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
         stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
-        if (!(DBG && skip_blocks >= 2)) { if constexpr (DC_SPLIT_STYL_PF && SPLIT && !DBG) styl_accumulate_pf<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh); }
+        if (!(DBG && skip_blocks >= 2)) { if constexpr (split_pf) styl_accumulate_pf<T16, SPLIT, DC_SPLIT_STYL_PF == 2>(h, y, y_rstd, y_shift, Eg + 8 * 128, epf, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh); }
     } else {
         auto next4 = [&]() {
             stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
@@ -1272,7 +1273,13 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         st.finish(y_rstd, y_shift);
     }
     DC_STAMP(9);
-    stage_sync();
+    if constexpr (split_pf && DC_SPLIT_STYL_PF == 2) {       // the next block's first two FiLM tile pairs stay in flight across the closer
+        __builtin_amdgcn_sched_barrier(0);
+        epf_fetch(epf, Eg + 16 * 128, 0, 0, lane);
+        epf_fetch(epf, Eg + 16 * 128, 1, 1, lane);
+        stage_sync_keep8();
+    } else
+        stage_sync();
     if constexpr (use_ring) epre_landed(ep);
     // ---- stage 6: FFN stylization [buf1]; prefetch next layer's key projection (or the output projection) -> buf0
     {
@@ -1284,7 +1291,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         };
         if constexpr (!use_ring) {
             next_w();
-            { if constexpr (DC_SPLIT_STYL_PF && SPLIT && !DBG) styl_accumulate_pf<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, c1, w1, lane, cx.hh); }
+            { if constexpr (split_pf) styl_accumulate_pf<T16, SPLIT, DC_SPLIT_STYL_PF == 2>(h, y, y_rstd, y_shift, Eg + 16 * 128, epf, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, c1, w1, lane, cx.hh); }
         } else {
             styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, next_w);
         }
@@ -2131,15 +2138,16 @@ hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k) {
     k_advance_iter<<<1, 1, 0, st>>>(iter, k);
     return hipGetLastError();
 }
-hipError_t dc_launch_set_ptr(hipStream_t st, const float** slot, const float* p) {
-    k_set_ptr<<<1, 1, 0, st>>>(slot, p);
+hipError_t dc_launch_set_ptr(hipStream_t st, const float** slot, const float* p, unsigned long long seed) {
+    k_set_ptr<<<1, 1, 0, st>>>(slot, p, seed);
     return hipGetLastError();
 }
-hipError_t dc_launch_step_noise(hipStream_t st, float* z, size_t n, unsigned long long seed, const int* iter_base, int step, const int* snap_cur) {
+hipError_t dc_launch_step_noise(hipStream_t st, float* z, size_t n, unsigned long long seed, const unsigned long long* seed_slot, const int* iter_base,
+                                int step, const int* snap_cur) {
     const size_t quads = (n + 3) / 4;
     const size_t nb = (quads + 255) / 256;
     const unsigned grid = (unsigned)(nb < 4096 ? nb : 4096);
-    k_step_noise<<<dim3(grid ? grid : 1), dim3(256), 0, st>>>(z, n, seed, iter_base, step, snap_cur);
+    k_step_noise<<<dim3(grid ? grid : 1), dim3(256), 0, st>>>(z, n, seed, seed_slot, iter_base, step, snap_cur);
     return hipGetLastError();
 }
 hipError_t dc_launch_begin_step(hipStream_t st, int* iter, const int* t_of_iter, const float* coef_of_t,

@@ -49,10 +49,23 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            bool narrow /* wgr, non-split, dbg == 0: 4-wave workgroups; recs / rec_stride then count 128-token units */,
                            int Tx /* frames per clip of xin / xout / snaps */, int upc /* as dc_launch_embed_front */,
                            const DcUpdate& upd /* options of the fused DDIM update + the status word (dc_common.h) */);
+// The same layer for SMALL batches on 16-token waves (dc_layer16.hip): non-split formats, clip-aligned 64-token units (grid = B * upc,
+// upc = ceil(T / 64), T = clip stride, a multiple of 32), one unit record per workgroup.  a_ca16 = the cross-attention fragments in
+// that kernel's form (dc_launch_cond_af16, once per conditioning).  nu_in / stride_in: unit records per clip and floats per unit of
+// the records this layer combines (layer 0: k_embed_front's narrow 128-token units, 2 * DC_REC_FLOATS apart; later layers: upc
+// units DC_REC_FLOATS apart).  At most dc_layer16_max_units() records per clip.
+hipError_t dc_launch_layer16(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* E, int NT, const void* a_ca16,
+                             float* recs, const int* length, const float* xin, float* xout, int out_mode, const float* coef_cur,
+                             const int* snap_cur, float* snaps, int M, int T, int B, int upc, size_t rec_stride, int nu_in, size_t stride_in,
+                             const int* iter_base, int Tx, const DcUpdate& upd);
+hipError_t dc_launch_cond_af16(hipStream_t st, int fmt, const void* a_ca, void* a_ca16, int n_matrices);
+int dc_layer16_max_units(void);
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);
-hipError_t dc_launch_set_ptr(hipStream_t st, const float** slot, const float* p);
-// N(0, 1) draws of one DDIM iteration (Philox keyed by seed; iteration = step + *iter_base, else snap_cur[1], else step) into z[0..n)
-hipError_t dc_launch_step_noise(hipStream_t st, float* z, size_t n, unsigned long long seed, const int* iter_base, int step, const int* snap_cur);
+hipError_t dc_launch_set_ptr(hipStream_t st, const float** slot /* 16 bytes */, const float* p, unsigned long long seed);
+// N(0, 1) draws of one DDIM iteration (Philox keyed by *seed_slot when given, else seed; iteration = step + *iter_base, else snap_cur[1],
+// else step) into z[0..n)
+hipError_t dc_launch_step_noise(hipStream_t st, float* z, size_t n, unsigned long long seed, const unsigned long long* seed_slot, const int* iter_base,
+                                int step, const int* snap_cur);
 // diagnosis: OR DC_STATUS_F16_SAT into *status when the fp16 buffer e holds an inf / nan
 hipError_t dc_launch_scan_f16(hipStream_t st, const void* e, size_t bytes, int* status);
 // rec_stride: floats between the two alternating unit-record buffers (0 = single buffer, non-wgr)

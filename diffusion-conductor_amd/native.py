@@ -40,7 +40,7 @@ class DcError(RuntimeError):
     pass
 
 
-SOURCES = ("dc_kernels.hip", "dc_api.hip", "dc_music.hip")
+SOURCES = ("dc_kernels.hip", "dc_api.hip", "dc_music.hip", "dc_layer16.hip")
 HEADERS = ("dc_common.h", "dc_dev.h", "dc_launch.h", "dc_music.h")
 EXTRA_FLAGS = {}      # per-source compiler flags
 

@@ -185,6 +185,38 @@ def test_narrow_workgroups_agree_with_wide_ones(models):
     assert torch.isfinite(a).all() and ea <= TOL_PARITY and eb <= TOL_PARITY and d <= TOL_PARITY
 
 
+@pytest.mark.parametrize("B,T,length", [(1, 1800, [1800]), (2, 1800, [1800, 1237]), (4, 1800, [1800, 1, 911, 1799]), (5, 1000, [1000, 3, 999, 512, 64]),
+                                        (8, 257, [257, 1, 256, 129, 64, 200, 33, 17])])
+def test_layer16_small_batches(models, B, T, length):
+    """While every clip-aligned 64-token unit gets a CU of its own (bs <= 8 at T = 1800: the reference's one clip per call,
+    trainers/ddpm_trainer.py:184) the layers run on 16-token waves (dc_layer16.hip: v_mfma_f32_16x16x32, one wave per SIMD);
+    DC_NO_LAYER16=1 keeps the 32-token narrow form.  Against the oracle (DDIM-10, an intermediate and the final sample), against the
+    32-token form (different unit maxima before the f16 operand rounding: noise level), re-run identical, and - clip-aligned units -
+    every clip bit-identical to sampling it alone."""
+    S = 10
+    xfp, xfo = xf_pair(B, T, first=70)
+    noise = torch.from_numpy(batch_noise(B, T, first=70))
+    with torch.no_grad():
+        ref = O.ddim_sample_loop(oracle_params(), noise, xfp, xfo, length, S, idxs=(4,))
+    m = models["fp16"]
+    a = _ddim(m, S, noise, xfp, xfo, length, idxs=(4,))
+    a2 = _ddim(m, S, noise, xfp, xfo, length, idxs=(4,))
+    os.environ["DC_NO_LAYER16"] = "1"
+    try:
+        b = _ddim(m, S, noise, xfp, xfo, length, idxs=(4,))
+    finally:
+        del os.environ["DC_NO_LAYER16"]
+    e4, eS, d = rel_l2(a[4], ref[4]), rel_l2(a[S], ref[S]), rel_l2(a[S], b[S].cpu().numpy())
+    e32 = rel_l2(b[S], ref[S])
+    print(f"layer16 B={B} T={T}: idx4 {e4:.3e} final {eS:.3e} (32-token form {e32:.3e}); 16- vs 32-token form {d:.3e}")
+    assert torch.isfinite(a[S]).all() and torch.equal(a[S], a2[S]) and torch.equal(a[4], a2[4])
+    assert max(e4, eS) <= TOL_PARITY and d <= TOL_PARITY
+    if B > 1:
+        k = B - 1
+        alone = _ddim(m, S, noise[k:k + 1], xfp[k:k + 1], xfo[k:k + 1], length[k:k + 1])
+        assert torch.equal(alone, a[S][k:k + 1])
+
+
 def test_clip_layouts_agree_and_small_batches_are_batch_invariant(models):
     """Where the workgroup-record kernels run, a clip's stride in the token space is padded to whole 32-frame groups (T = 900 -> 928
     for a small batch) and small batches run clip-aligned 4-wave workgroups: no group and no workgroup spans two clips.  The

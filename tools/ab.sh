@@ -9,7 +9,7 @@ case "$1" in
   build)
     cd "$R/diffusion-conductor_amd/csrc"
     V="$2"; shift 2
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -shared -Wno-unused-value "$@" dc_kernels.hip dc_api.hip dc_music.hip -o "../libdc_ddim_$V.alt"
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -shared -Wno-unused-value "$@" dc_kernels.hip dc_api.hip dc_music.hip dc_layer16.hip -o "../libdc_ddim_$V.alt"
     ls -la "../libdc_ddim_$V.alt" ;;
   run)
     cd "$R"
