@@ -1493,6 +1493,11 @@ int dc_sampler_debug_read(dc_sampler* s, const char* what, void* h_out, int64_t 
     else if (w == "a_ca") { src = s->d_a_ca; have = (size_t)s->cfg.num_layers * s->B * 16 * 1024; }
     else if (w == "stamps") { src = s->d_stamps; have = (8 * 32 + 8 + 1024 + 1024 + 256 + 8) * 8; }
     else if (w == "temb") { src = s->h_model.temb; have = (size_t)s->cfg.max_timesteps * 512 * 4; }
+    else if (w == "full_moves") {      // diagnostic builds only: {visits, moves} of the no_eff key loop's reference point, reset by the read
+        if (nbytes != 16) return fail(DC_ERR_INVALID, "full_moves is 16 bytes");
+        if (dc_full_moves_read((unsigned long long*)h_out, true) != hipSuccess) return fail(DC_ERR_UNSUPPORTED, "not a -DDC_DIAG_FULL_MOVES build");
+        return DC_OK;
+    }
     else return fail(DC_ERR_INVALID, "unknown debug buffer '%s'", what);
     if (!src) return fail(DC_ERR_INVALID, "buffer '%s' not allocated yet", what);
     if ((size_t)nbytes > have) return fail(DC_ERR_INVALID, "buffer '%s' holds %zu bytes, asked for %lld", what, have, (long long)nbytes);

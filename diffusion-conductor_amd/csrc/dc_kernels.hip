@@ -1572,6 +1572,22 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
 #define DC_FULL_SUM_ADDS 2       // a tile's normaliser term: 2 = packed-f16 tree over the operand fragments (7 v_pk_add_f16, f16 mode; -3 % per
                                  // loop, goldens +1e-5), 1 = 16 f32 adds of the unrounded weights, 0 = 8 v_dot2c on the fragments (+3.8 %)
 #endif
+#ifdef DC_DIAG_FULL_MOVES        // diagnostic build (tools/noeff_moves.py): how often the key loop's lazily moved reference point moves
+__device__ unsigned long long g_full_moves[2];      // [0]: (key tile > 0, head, wave) visits, [1]: visits in which the reference point moved
+hipError_t dc_full_moves_read(unsigned long long* out, bool reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_full_moves), 16);
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[2] = {0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_full_moves), z, 16);
+    }
+    return e;
+}
+#else
+hipError_t dc_full_moves_read(unsigned long long* out, bool) {
+    out[0] = out[1] = 0;
+    return hipErrorNotSupported;
+}
+#endif
 #define DC_FULL_ZOFF (32768 + 8 * 8192)          // LDS: key-tile double buffer | per-wave query fragments | 8 KiB of zeros
 #define DC_FULL_LDS (DC_FULL_ZOFF + 8192)
 struct ClipCtx {
@@ -1788,6 +1804,12 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
                             weights(0.f, false);
                         else if (kt > 0)
                             weights(mx[hd], !fold);
+#ifdef DC_DIAG_FULL_MOVES
+                        if (kt > 0 && lane == 0) {
+                            atomicAdd(&g_full_moves[0], 1ull);
+                            if (__builtin_amdgcn_ballot_w64(!(tsum <= 64.f)) != 0) atomicAdd(&g_full_moves[1], 1ull);
+                        }
+#endif
                         if ((!COMMON && kt == 0) || __builtin_amdgcn_ballot_w64(!(tsum <= 64.f)) != 0) {      // (wave-uniform; NaN/inf land here too)
                             const float base = (fold && kt > 0) ? mx[hd] : 0.f;             // what S already has taken off
                             float mt = S[0];

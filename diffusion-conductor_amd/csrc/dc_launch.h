@@ -80,5 +80,8 @@ hipError_t dc_launch_layer_full(hipStream_t st, int fmt, const DcModel* dm, int 
                                 float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps, int M,
                                 int T, int B, int KT, int stop_after, const DcUpdate& upd);
 
+// diagnostic builds (-DDC_DIAG_FULL_MOVES): visits / moves of the no_eff key loop's reference point; hipErrorNotSupported otherwise
+hipError_t dc_full_moves_read(unsigned long long* out /* [2] */, bool reset);
+
 // Savitzky-Golay smoothing along time of [B][T][P] fp32 (coef: hat matrix [win][win]); y != x
 hipError_t dc_launch_savgol(hipStream_t st, const float* x, float* y, const float* coef, int B, int T, int P, int win);
