@@ -826,10 +826,13 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     for (int l = s->dbg_first >= 0 ? s->dbg_first : 0; l < nl_run; ++l) {
         const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
         if (layer16) {
+            DcUpdate u16 = upd;       // (-DDC_L16_STAMPS builds: stage stamps of layer 3, tools/stage_stamps16.py)
+            static const bool stamps16 = getenv("DC_L16_STAMPS") != nullptr;
+            u16.stamps = (stamps16 && l == 3) ? s->d_stamps : nullptr;
             LAUNCH(K_LAYER, dc_launch_layer16(st, fs, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_ca16, s->d_recs, s->d_length, x_src, x_dst,
                                               loop_mode ? 1 : 0, coef_src, snap_src, s->d_snaps, M, T, B, upc16, rec_stride,
                                               l == 0 ? upc_narrow : upc16, l == 0 ? (size_t)2 * DC_REC_FLOATS : (size_t)DC_REC_FLOATS, iter_base, Tx,
-                                              upd));
+                                              u16));
             continue;
         }
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));

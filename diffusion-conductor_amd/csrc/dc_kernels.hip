@@ -981,7 +981,7 @@ DEV void embed_front_body(const DcModel* __restrict__ dm, const float* __restric
     }
 }
 template <class T16, bool SPLIT, bool WGR, bool FROMH = false, bool NARROW = false>
-__global__ __launch_bounds__((NARROW || (SPLIT && !WGR)) ? 256 : 512, (NARROW || (SPLIT && !WGR)) ? 1 : 2)
+__global__ __launch_bounds__((NARROW || (SPLIT && !WGR)) ? 256 : 512, (SPLIT && !WGR) ? 1 : 2)      // (NARROW: as k_layer - no AGPR half)
 void k_embed_front(const DcModel* __restrict__ dm, const float* __restrict__ x, float* __restrict__ hbuf, float* __restrict__ recs,
                    const int* __restrict__ length, int M, int T, int G, int B, unsigned long long* __restrict__ clk, int l0, int Tx, int upc) {
     embed_front_body<T16, SPLIT, WGR, FROMH, NARROW>(dm, x, hbuf, recs, length, M, T, G, B, clk, l0, Tx, upc, -1);
@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(512, 2) void k_film_embed(const v8<T16>* __restrict
 #define DC_SPLIT_NW 8      // waves per k_layer workgroup in the split modes (4: one wave per SIMD, round 1-2's form)
 #endif
 template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR, bool NARROW = false>
-__global__ __launch_bounds__((NARROW || (SPLIT && DC_SPLIT_NW == 4)) ? 256 : 512, (NARROW || (SPLIT && DC_SPLIT_NW == 4)) ? 1 : 2)
+__global__ __launch_bounds__((NARROW || (SPLIT && DC_SPLIT_NW == 4)) ? 256 : 512, (SPLIT && DC_SPLIT_NW == 4) ? 1 : 2)      // (NARROW runs one wave per SIMD by its LDS; bounds of 2 keep hipcc off the AGPR half: 247 VGPRs instead of 247 + 112 and 1 400 accvgpr moves)
 void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
              const v8<T16>* __restrict__ a_sa /*[B][16][64]*/, const v8<T16>* __restrict__ a_ca /*[L][B][16][64]*/,
              float* __restrict__ recs, const int* __restrict__ length, const float* __restrict__ xin,

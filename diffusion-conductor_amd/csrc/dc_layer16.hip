@@ -33,6 +33,7 @@ constexpr int L16_OFF_SS = L16_OFF_PST + 32768;      // tail: column sums [4 wav
 constexpr int L16_OFF_SCW = L16_OFF_SS + 2048;       // tail: per-wave rescale factors [4 waves][128] (2 KiB)
 constexpr int L16_LDS = L16_OFF_SCW + 2048;
 constexpr int L16_MAXU = 32;                         // unit records per clip the combine holds (T <= 2048 at 64 tokens per unit)
+static_assert(L16_LDS - L16_OFF_PST >= 2 * 128 * (L16_MAXU + 4) * 4, "the combine's transposed scalars overlay the tail's staging");
 
 struct C16 {
     int g, half, lane, n, q4;
@@ -127,12 +128,26 @@ DEV void ln16_frags(v8<T16> (&nb)[4], const f32x4 (&x)[8]) {
 }
 
 // acc[rb] += W[rb][:] x   over KM k-steps; weight image [m][rb] fragments in LDS (RB independent accumulator chains per k-step)
+// At one wave per SIMD nobody covers an LDS read's latency: the RB weight fragments of k-step m + 1 are requested before the MFMAs of
+// k-step m issue (hipcc on its own emits read - wait - MFMA per fragment, ~120 exposed cycles per MFMA).
+template <int RB, class T16>
+DEV void wfrags(v8<T16> (&f)[RB], const v8<T16>* __restrict__ w, int first, int lane) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) f[rb] = w[(first + rb) * 64 + lane];
+}
 template <int RB, int KM, class T16>
 DEV void gemm16(f32x4 (&acc)[RB], const v8<T16>* __restrict__ w, const v8<T16> (&xb)[KM], int lane) {
+    v8<T16> cur[RB], nxt[RB];
+    wfrags<RB, T16>(cur, w, 0, lane);
 #pragma unroll
     for (int m = 0; m < KM; ++m) {
+        if (m + 1 < KM) wfrags<RB, T16>(nxt, w, (m + 1) * RB, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma16(w[(m * RB + rb) * 64 + lane], xb[m], acc[rb]);
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma16(cur[rb], xb[m], acc[rb]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) cur[rb] = nxt[rb];
     }
 }
 
@@ -199,11 +214,13 @@ DEV void query_attend16(Y16 (&y)[8], float& y_rstd, float& y_shift, const f32x4 
     __builtin_amdgcn_sched_barrier(0);
     Stats16 st;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    v8<T16> afr[8];
+    wfrags<8, T16>(afr, af, 0, c.lane);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const v8<T16> qb = frag2<T16>(q[2 * m], q[2 * m + 1]);
-        const f32x4 ya = mfma16(af[(2 * m) * 64 + c.lane], qb, z4);
-        const f32x4 yb = mfma16(af[(2 * m + 1) * 64 + c.lane], qb, z4);
+        const f32x4 ya = mfma16(afr[2 * m], qb, z4);
+        const f32x4 yb = mfma16(afr[2 * m + 1], qb, z4);
         st.add(ya);
         st.add(yb);
         y[2 * m] = pack_y(ya);
@@ -254,11 +271,19 @@ DEV void styl_accumulate16(f32x4 (&h)[8], const Y16 (&y)[8], float rstd, float s
                            const v8<T16>* w, const C16& c) {
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb) h[rb] += *reinterpret_cast<const f32x4*>(bo + 16 * rb + 4 * c.q4);
+    v8<T16> cur[8], nxt[8];
+    wfrags<8, T16>(cur, w, 0, c.lane);
+    v8<T16> zb = styl16<T16>(y[0], y[1], rstd, shift, e[0]);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-        const v8<T16> zb = styl16<T16>(y[2 * kt], y[2 * kt + 1], rstd, shift, e[kt]);
+        if (kt + 1 < 4) wfrags<8, T16>(nxt, w, (kt + 1) * 8, c.lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rb = 0; rb < 8; ++rb) h[rb] = mfma16(w[(kt * 8 + rb) * 64 + c.lane], zb, h[rb]);
+        for (int rb = 0; rb < 8; ++rb) h[rb] = mfma16(cur[rb], zb, h[rb]);
+        if (kt + 1 < 4) zb = styl16<T16>(y[2 * kt + 2], y[2 * kt + 3], rstd, shift, e[kt + 1]);     // (vector work beside the matrix pipe)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) cur[rb] = nxt[rb];
     }
 }
 
@@ -267,29 +292,51 @@ DEV void styl_accumulate16(f32x4 (&h)[8], const Y16 (&y)[8], float rstd, float s
 // kernel's form: af [8 heads][64 lanes], lane (l, q4) of head hd = rows l (value feature), k-slots j:
 // (j >> 2) == (hd & 1) ? A[d = 4 q4 + (j & 3)][l] : 0.   Thread (oc, ln) sums both 16-byte pieces of its 32 bytes of the records'
 // K^T V image: old lane ln = (cc, hh) of tile oc, kept values 4 piece + i  <->  head 2 oc + (cc >> 4), d = 8 piece + 4 hh + i,
-// l = cc & 15.  Fixed summation order (unit by unit).  scratch (LDS): w [L16_MAXU][128] floats, z [128] floats.
+// l = cc & 15.  Fixed summation order (unit by unit).  scratch (LDS): w [L16_MAXU][128] + z [128] floats (16.5 KiB); scratch2: the
+// units' scalars transposed, [2][128][L16_MAXU + 4] floats (36 KiB).
 template <class T16>
-DEV void wg_combine_attn16(const float* __restrict__ recs, size_t stride, int nu, int b, v8<T16>* af, float* scratch, int tid) {
-    constexpr int PRE = 16;
-    float* wsc = scratch;
-    float* zsc = scratch + L16_MAXU * 128;
+DEV void wg_combine_attn16(const float* __restrict__ recs, size_t stride, int nu, int b, v8<T16>* af, float* scratch, float* scratch2, int tid) {
+    constexpr int PRE = 8;                           // K^T V blocks per batch (two batches in flight: 128 registers)
+    constexpr int FS = L16_MAXU + 4;                 // floats per feature row of the transposed scalar arrays (36: conflict-free b128 rows)
+    float* wsc = scratch;                            // [L16_MAXU][128]: the units' rescale weights
+    float* zsc = scratch + L16_MAXU * 128;           // [128]
+    float* tsc = scratch2;                           // [2 parts][128 features][FS]: the units' column maxima (part 0) / sums (part 1)
     const float* R0 = recs + (size_t)b * nu * stride;
+    const unsigned st32 = (unsigned)stride, last32 = (unsigned)(nu - 1) * st32;      // (a clip's records span < 2^31 floats)
     const int oc = tid >> 6, ln = tid & 63, cc = ln & 31, hh = ln >> 5;
-    f32x8 pre[PRE];
+    // every load of the combine is issued up front, branch-free (indices clamped to a valid unit), so that ONE memory round trip
+    // covers them: the scalars of all units (thread (part, f): maxima for part 0, sums for part 1), then the first K^T V blocks
+    {
+        const int part = tid >> 7, f = tid & 127;
+        f32x4 v[L16_MAXU / 4];
 #pragma unroll
-    for (int k = 0; k < PRE; ++k) pre[k] = reinterpret_cast<const f32x8*>(R0 + (size_t)min(k, nu - 1) * stride + 256)[oc * 64 + ln];
+        for (int k = 0; k < L16_MAXU; ++k) v[k >> 2][k & 3] = R0[min((unsigned)k * st32, last32) + 128 * part + f];
+        f32x4* dst = reinterpret_cast<f32x4*>(tsc + (part * 128 + f) * FS);
+#pragma unroll
+        for (int k = 0; k < L16_MAXU / 4; ++k) dst[k] = v[k];
+    }
+    auto blk = [&](int k) { return reinterpret_cast<const f32x8*>(R0 + min((unsigned)k * st32, last32) + 256)[oc * 64 + ln]; };
+    f32x8 cur[PRE], nxt[PRE];
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) cur[k] = blk(k);
+    __syncthreads();
     if (tid < 128) {       // per feature: the units' maxima / sums -> rescale weights and the normaliser
         const int f = tid;
-        float mstar = -INFINITY;
-        for (int k = 0; k < nu; ++k) {
-            const float* R = R0 + (size_t)k * stride;
-            if (R[128 + f] > 0.f) mstar = fmaxf(mstar, R[f]);
+        f32x4 mv[L16_MAXU / 4], sv[L16_MAXU / 4];
+#pragma unroll
+        for (int k = 0; k < L16_MAXU / 4; ++k) {
+            mv[k] = reinterpret_cast<const f32x4*>(tsc + f * FS)[k];
+            sv[k] = reinterpret_cast<const f32x4*>(tsc + (128 + f) * FS)[k];
         }
+        float mstar = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < L16_MAXU; ++k)
+            if (k < nu && sv[k >> 2][k & 3] > 0.f) mstar = fmaxf(mstar, mv[k >> 2][k & 3]);
         float z = 0.f;
-        for (int k = 0; k < nu; ++k) {
-            const float* R = R0 + (size_t)k * stride;
-            const float su = R[128 + f];
-            const float ww = su > 0.f ? exp2f_fast(R[f] - mstar) : 0.f;
+#pragma unroll
+        for (int k = 0; k < L16_MAXU; ++k) {
+            const float su = k < nu ? sv[k >> 2][k & 3] : 0.f;
+            const float ww = su > 0.f ? exp2f_fast(mv[k >> 2][k & 3] - mstar) : 0.f;
             wsc[k * 128 + f] = ww;
             z += ww * su;
         }
@@ -308,26 +355,25 @@ DEV void wg_combine_attn16(const float* __restrict__ recs, size_t stride, int nu
             w8[4 + j] = c2[j];
         }
     };
+    // batches of PRE units; the next batch is requested before the current one is summed, so that its round trip overlaps the sums
 #pragma unroll
-    for (int k = 0; k < PRE; ++k)
-        if (k < nu) {
-            float w8[8];
-            wrow(wsc + k * 128, w8);
+    for (int k0 = 0; k0 < L16_MAXU; k0 += PRE) {
+        if (k0 < nu) {
+            if (k0 + PRE < nu) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], pre[k][j], acc[j]);
-        }
-    for (int k0 = PRE; k0 < nu; k0 += 8) {
-        f32x8 pb[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) pb[k] = reinterpret_cast<const f32x8*>(R0 + (size_t)min(k0 + k, nu - 1) * stride + 256)[oc * 64 + ln];
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k0 + k < nu) {
-                float w8[8];
-                wrow(wsc + (k0 + k) * 128, w8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], pb[k][j], acc[j]);
+                for (int k = 0; k < PRE; ++k) nxt[k] = blk(k0 + PRE + k);
             }
+#pragma unroll
+            for (int k = 0; k < PRE; ++k)
+                if (k0 + k < nu) {
+                    float w8[8];
+                    wrow(wsc + (k0 + k) * 128, w8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], cur[k][j], acc[j]);
+                }
+#pragma unroll
+            for (int k = 0; k < PRE; ++k) cur[k] = nxt[k];
+        }
     }
     float z8[8];
     wrow(zsc, z8);
@@ -355,7 +401,7 @@ DEV void wg_combine_attn16(const float* __restrict__ recs, size_t stride, int nu
 // the head of the stage in front of it (registers are plentiful at one wave per SIMD).
 // ------------------------------------------------------------------------------------------------------------------
 template <class T16>
-__global__ __launch_bounds__(256, 1)
+__global__ __launch_bounds__(256, 2)      // (one workgroup per CU by its LDS; "2" keeps the compiler off the AGPR half: 232 VGPRs, no accvgpr moves)
 void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
                const v8<T16>* __restrict__ a_ca /*[L][B][8 heads][64] 16-token form*/, float* __restrict__ recs, const int* __restrict__ length,
                const float* __restrict__ xin, float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur,
@@ -366,6 +412,16 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using W = v8<T16>;
     constexpr int NW = L16_NW;
+#ifdef DC_L16_STAMPS      // diagnostic build (tools/stage_stamps16.py): s_memrealtime of workgroup 3's waves at the stage boundaries
+#define LSTAMP(k)                                                                                                          \
+    do {                                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        if (upd.stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0) upd.stamps[(threadIdx.x >> 6) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    } while (0)
+#else
+#define LSTAMP(k) do {} while (0)
+#endif
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wg = wg_index();
@@ -398,33 +454,45 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
     float* recs_out = recs + (size_t)((l + 1) & 1) * rec_stride;
 
     f32x4 h[8];
+    LSTAMP(0);
     load_h16(h, hbuf, c);
     stage_frags<NW>(L.sa_q, buf0, 33, wave, lane);
     E16 e[4];
     e16_load(e, Eg, c);
-    wg_combine_attn16<T16>(recs_in, stride_in, nu_in, c.b, reinterpret_cast<W*>(lds + L16_OFF_AF), reinterpret_cast<float*>(buf1), tid);
+    wg_combine_attn16<T16>(recs_in, stride_in, nu_in, c.b, reinterpret_cast<W*>(lds + L16_OFF_AF), reinterpret_cast<float*>(buf1),
+                           reinterpret_cast<float*>(lds + L16_OFF_PST) /* the tail's 36 KiB: free until then */, tid);
+    LSTAMP(1);
     stage_sync();
+    LSTAMP(2);
 
     // ---- self-attention
     stage_frags<NW>(L.sa_o, buf1, 33, wave, lane);
     Y16 y[8];
     float y_rstd, y_shift;
     query_attend16<T16>(y, y_rstd, y_shift, h, c0, w0, af, c);
+    LSTAMP(3);
     stage_sync();
+    LSTAMP(4);
     {   // cross-attention query image + the clip's cross-attention fragments (16-token form, k_cond_af16)
         stage_frags<NW>(L.ca_q, buf0, 33, wave, lane);
         stage_frags<NW>(a_ca + ((size_t)l * B + c.b) * 8 * 64, lds + L16_OFF_AF, 8, wave, lane);
     }
     styl_accumulate16<T16>(h, y, y_rstd, y_shift, e, c1, w1, c);
+    LSTAMP(5);
     stage_sync();
+    LSTAMP(6);
     // ---- cross-attention
     stage_frags<NW>(L.ca_o, buf1, 33, wave, lane);
     e16_load(e, Eg + 8 * 128, c);
     query_attend16<T16>(y, y_rstd, y_shift, h, c0, w0, af, c);
+    LSTAMP(7);
     stage_sync();
+    LSTAMP(8);
     stage_frags<NW>(L.ffn_w, buf0, 33, wave, lane);          // W1 (16 fragments) | W2 (16) | b1[64], b2[128]
     styl_accumulate16<T16>(h, y, y_rstd, y_shift, e, c1, w1, c);
+    LSTAMP(9);
     stage_sync();
+    LSTAMP(10);
     // ---- FFN
     stage_frags<NW>(L.ffn_o, buf1, 33, wave, lane);
     e16_load(e, Eg + 16 * 128, c);
@@ -464,13 +532,17 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
         }
         st.finish(y_rstd, y_shift);
     }
+    LSTAMP(11);
     stage_sync();
+    LSTAMP(12);
     if (!last)
         stage_frags<NW>(dm->l16[l + 1].sa_k, buf0, 33, wave, lane);
     else
         stage_frags<NW>(dm->out16, buf0, 17, wave, lane);        // 8 hi + 8 lo fragments + bias: always runs split
     styl_accumulate16<T16>(h, y, y_rstd, y_shift, e, c1, w1, c);
+    LSTAMP(13);
     stage_sync();
+    LSTAMP(14);
 
     if (!last) {
         // ---- next layer's self-attention front half (transformer.py:104-117): K [buf0], V [buf1] in TF form (token on the ROW:
@@ -491,12 +563,22 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
         for (int i = 0; i < 4; ++i) ok[i] = active && c.n0 + 4 * c.q4 + i < len;
         v4<T16> ef[8];
         float ssw[8], mw[8];
+        auto col_frags = [&](W (&fr)[4], const W* w, int cb) {      // the four k-steps of output block cb
+#pragma unroll
+            for (int m = 0; m < 4; ++m) fr[m] = w[(m * 8 + cb) * 64 + lane];
+        };
+        W kc[4], kn[4];
+        col_frags(kc, w0, 0);
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) {
             const float bk = c0[16 * cb + f];
             f32x4 K = {bk, bk, bk, bk};
+            if (cb + 1 < 8) col_frags(kn, w0, cb + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) K = mfma16(nb[m], w0[(m * 8 + cb) * 64 + lane], K);
+            for (int m = 0; m < 4; ++m) K = mfma16(nb[m], kc[m], K);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) kc[m] = kn[m];
             float m = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 4; ++i) m = ok[i] ? fmaxf(m, K[i]) : m;
@@ -514,12 +596,14 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
             if (c.q4 == 0) mx[(16 * cb + f) * 4 + wave] = m;
         }
         __builtin_amdgcn_sched_barrier(0);
+        LSTAMP(15);
         if (active)
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // all but the 8 stores of h: the value image has landed
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
+        LSTAMP(16);
         auto unit_max = [&](int feat) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(mx + feat * 4);
             const float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
@@ -536,12 +620,17 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        col_frags(kc, w1, 0);
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) {
             const float bv = c1[16 * cb + f];
             f32x4 V = {bv, bv, bv, bv};
+            if (cb + 1 < 8) col_frags(kn, w1, cb + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) V = mfma16(nb[m], w1[(m * 8 + cb) * 64 + lane], V);
+            for (int m = 0; m < 4; ++m) V = mfma16(nb[m], kc[m], V);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) kc[m] = kn[m];
             f32x4 va;
 #pragma unroll
             for (int i = 0; i < 4; ++i) va[i] = ok[i] ? V[i] : 0.f;      // value rows of masked frames are zero (transformer.py:114)
@@ -557,7 +646,9 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
             pst[(size_t)(wave * 8 + cb) * 64 + lane] = PA;
         }
         __builtin_amdgcn_sched_barrier(0);
+        LSTAMP(17);
         __syncthreads();
+        LSTAMP(18);
         // wave w sums blocks 2 w, 2 w + 1 over the unit's waves in wave order and writes them in the 32-token kernels' record format
         float* R = recs_out + (size_t)wg * DC_REC_FLOATS;
 #pragma unroll
@@ -579,6 +670,7 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
             // 16 (cb & 1) + l + 32 (q4 & 1), values 4 (q4 >> 1) + i
             reinterpret_cast<f32x4*>(R + 256 + ((cb >> 1) * 64 + 16 * (cb & 1) + f + 32 * (c.q4 & 1)) * 8)[c.q4 >> 1] = acc;
         }
+        LSTAMP(19);
         return;
     }
     // ---- output projection (transformer.py:496) [buf0: 8 hi + 8 lo fragments, bias behind them] + DDIM update

@@ -190,10 +190,10 @@ def test_narrow_workgroups_agree_with_wide_ones(models):
 def test_layer16_small_batches(models, B, T, length):
     """While every clip-aligned 64-token unit gets a CU of its own (bs <= 8 at T = 1800: the reference's one clip per call,
     trainers/ddpm_trainer.py:184) the layers run on 16-token waves (dc_layer16.hip: v_mfma_f32_16x16x32, one wave per SIMD);
-    DC_NO_LAYER16=1 keeps the 32-token narrow form.  Against the oracle (DDIM-10, an intermediate and the final sample), against the
+    DC_NO_LAYER16=1 keeps the 32-token narrow form.  Against the oracle (DDIM-25, an intermediate and the final sample), against the
     32-token form (different unit maxima before the f16 operand rounding: noise level), re-run identical, and - clip-aligned units -
     every clip bit-identical to sampling it alone."""
-    S = 10
+    S = 25                       # (the linear schedule needs S > 20: beta_end = 20 / S < 1)
     xfp, xfo = xf_pair(B, T, first=70)
     noise = torch.from_numpy(batch_noise(B, T, first=70))
     with torch.no_grad():
@@ -496,6 +496,60 @@ def test_no_eff_ddim50_long_goldens_g10(model_no_eff):
     print(f"no_eff DDIM-50 B=2 T=900 ragged, stress checkpoint, vs reference: rel-L2 {e2:.3e}")
     assert torch.isfinite(out).all() and torch.isfinite(out2).all()
     assert e1 <= TOL_PARITY and e2 <= TOL_PARITY, (e1, e2)
+
+
+def _peaky_state_dict(scale=5.0):
+    """seed-0 checkpoint with the self-attention query / key projections scaled: scores x scale^2, i.e. attention rows with a few
+    dominant keys - later key tiles then hold scores far above tile 0's maximum, which is what makes the no_eff key loop MOVE its
+    lazily kept reference point (on the plain synthetic checkpoints it never does: tools/noeff_moves.py counts 0 moves in 2e7 visits)."""
+    from helpers import state_dict_np
+    sd = dict(state_dict_np())
+    for k in list(sd):
+        if ".sa_block.query." in k or ".sa_block.key." in k:
+            sd[k] = (sd[k] * scale).astype(np.float32)
+    return sd
+
+
+@pytest.mark.parametrize("scale", [3.0, 5.0])
+def test_no_eff_peaky_attention_moves_the_reference_point(scale):
+    """The key loop's softmax reference point is fixed by key tile 0 and moves only when a later tile's weights sum past 64 in some
+    lane.  A checkpoint with sharpened self-attention (scores x scale^2) makes that happen (the diagnostic build counts the moves:
+    tools/noeff_moves.py, 1.5 % of the visits at scale 5; never on the plain checkpoints).  Sharp attention is also where 16-bit
+    operands lose ABSOLUTE precision in the scores (a score of 50 carries +-0.02), so the gate is the oracle's own f16-operand
+    emulation of the same model: the kernels must be as accurate as f16 arithmetic permits (<= 1e-3, or twice the emulation's
+    error where that is larger) - a wrong rescale in the move path would be off by orders of magnitude.  One forward at T = 900,
+    ragged, per-clip timesteps, and a DDIM-25 at T = 320."""
+    from diffusion_conductor_amd import MotionTransformer
+    sd = _peaky_state_dict(scale)
+    m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cuda", no_clip=True,
+                          precision="fp16", no_eff=True)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda").eval()
+    p = O.to_torch_params(sd, torch.float32)
+    emu = O.Emu("fp16")
+    B, T = 2, 900
+    xfp, xfo = xf_pair(B, T, first=80)
+    x = torch.from_numpy(batch_noise(B, T, first=80))
+    t = torch.tensor([30, 5])
+    length = [900, 433]
+    with torch.no_grad():
+        ref = O.denoiser_forward(p, x, t, length, xfp, xfo, no_eff=True)
+        ref_emu = O.denoiser_forward(p, x, t, length, xfp, xfo, no_eff=True, emu=emu)
+    out = m(x.cuda(), t, length=torch.tensor(length), xf_proj=xfp.cuda(), xf_out=xfo.cuda())
+    torch.cuda.synchronize()
+    e_fwd, emu_fwd = rel_l2(out, ref), rel_l2(ref_emu, ref)
+    B2, T2, S = 2, 320, 25
+    xfp2, xfo2 = xf_pair(B2, T2, first=82)
+    nz = torch.from_numpy(batch_noise(B2, T2, first=82))
+    with torch.no_grad():
+        ref2 = O.ddim_sample_loop(p, nz, xfp2, xfo2, [320, 211], S, no_eff=True)
+        ref2_emu = O.ddim_sample_loop(p, nz, xfp2, xfo2, [320, 211], S, no_eff=True, emu=emu)
+    out2 = _ddim(m, S, nz, xfp2, xfo2, [320, 211])
+    e_x0, emu_x0 = rel_l2(out2, ref2), rel_l2(ref2_emu, ref2)
+    print(f"no_eff peaky attention x{scale}: forward T=900 rel-L2 {e_fwd:.3e} (f16 emulation on the CPU: {emu_fwd:.3e}); "
+          f"DDIM-25 T=320 x0 rel-L2 {e_x0:.3e} (emulation {emu_x0:.3e})")
+    assert torch.isfinite(out).all() and torch.isfinite(out2).all()
+    assert e_fwd <= max(5e-3, 2 * emu_fwd) and e_x0 <= max(TOL_PARITY, 2 * emu_x0)
 
 
 def test_no_eff_straddling_clips_vs_oracle(model_no_eff):

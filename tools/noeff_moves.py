@@ -30,3 +30,21 @@ xf2 = torch.from_numpy(batch_music_features(2, 900, first=52))
 xfp2 = torch.nn.functional.linear(xf2, q["proj.weight"], q["proj.bias"])
 run(m2, torch.from_numpy(batch_noise(2, 900, first=52)), xfp2, xf2, [int(v) for v in g["stress_t900_length"]], g["stress_t900_x0"],
     "stress checkpoint, B=2, T=900 ragged, DDIM-50")
+# sharpened self-attention (tests/test_gpu_parity.py::_peaky_state_dict): the case that does move the reference point
+from test_gpu_parity import _peaky_state_dict
+sd3 = _peaky_state_dict()
+m3 = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cuda", no_clip=True, precision="fp16", no_eff=True)
+m3.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd3.items()}, strict=True)
+m3 = m3.to("cuda").eval()
+q3 = O.to_torch_params(sd3, torch.float32)
+xfp3, xfo3 = xf_pair(2, 320, first=82)
+nz3 = torch.from_numpy(batch_noise(2, 320, first=82))
+gd25 = make_diffusion(25)
+with torch.no_grad():
+    ref3 = O.ddim_sample_loop(q3, nz3, xfp3, xfo3, [320, 211], 25, no_eff=True)
+nat = m3.set_conditioning(xfp3.cuda(), xfo3.cuda(), [320, 211])
+nat.debug_read("full_moves", np.uint64, 2)
+out3, _ = nat.ddim_loop(nz3.cuda(), gd25.native_coefficients())
+torch.cuda.synchronize()
+v, mv = [int(x) for x in nat.debug_read("full_moves", np.uint64, 2)]
+print(f"sharpened self-attention (query / key x 5), B=2, T=320 ragged, DDIM-25: rel-L2 vs the oracle {rel_l2(out3, ref3):.3e};  visits {v}, reference point moved in {mv} = {100.0 * mv / max(v, 1):.3f} %")
