@@ -297,6 +297,7 @@ DEV void styl_accumulate16(f32x4 (&h)[8], const Y16 (&y)[8], float rstd, float s
 template <class T16>
 DEV void wg_combine_attn16(const float* __restrict__ recs, size_t stride, int nu, int b, v8<T16>* af, float* scratch, float* scratch2, int tid) {
     constexpr int PRE = 8;                           // K^T V blocks per batch (two batches in flight: 128 registers)
+    static_assert(L16_MAXU == 4 * PRE, "four batches");
     constexpr int FS = L16_MAXU + 4;                 // floats per feature row of the transposed scalar arrays (36: conflict-free b128 rows)
     float* wsc = scratch;                            // [L16_MAXU][128]: the units' rescale weights
     float* zsc = scratch + L16_MAXU * 128;           // [128]
@@ -316,9 +317,11 @@ DEV void wg_combine_attn16(const float* __restrict__ recs, size_t stride, int nu
         for (int k = 0; k < L16_MAXU / 4; ++k) dst[k] = v[k];
     }
     auto blk = [&](int k) { return reinterpret_cast<const f32x8*>(R0 + min((unsigned)k * st32, last32) + 256)[oc * 64 + ln]; };
-    f32x8 cur[PRE], nxt[PRE];
+    f32x8 bA[PRE], bB[PRE];                          // units 0..7 and 8..15 are requested up front, 16..23 / 24..31 as these are consumed
 #pragma unroll
-    for (int k = 0; k < PRE; ++k) cur[k] = blk(k);
+    for (int k = 0; k < PRE; ++k) bA[k] = blk(k);
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) bB[k] = blk(PRE + k);
     __syncthreads();
     if (tid < 128) {       // per feature: the units' maxima / sums -> rescale weights and the normaliser
         const int f = tid;
@@ -355,26 +358,28 @@ DEV void wg_combine_attn16(const float* __restrict__ recs, size_t stride, int nu
             w8[4 + j] = c2[j];
         }
     };
-    // batches of PRE units; the next batch is requested before the current one is summed, so that its round trip overlaps the sums
+    auto consume = [&](const f32x8 (&blkv)[PRE], int k0) {
 #pragma unroll
-    for (int k0 = 0; k0 < L16_MAXU; k0 += PRE) {
-        if (k0 < nu) {
-            if (k0 + PRE < nu) {
+        for (int k = 0; k < PRE; ++k)
+            if (k0 + k < nu) {
+                float w8[8];
+                wrow(wsc + (k0 + k) * 128, w8);
 #pragma unroll
-                for (int k = 0; k < PRE; ++k) nxt[k] = blk(k0 + PRE + k);
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], blkv[k][j], acc[j]);
             }
+    };
+    consume(bA, 0);
+    if (nu > 2 * PRE) {
 #pragma unroll
-            for (int k = 0; k < PRE; ++k)
-                if (k0 + k < nu) {
-                    float w8[8];
-                    wrow(wsc + (k0 + k) * 128, w8);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w8[j], cur[k][j], acc[j]);
-                }
-#pragma unroll
-            for (int k = 0; k < PRE; ++k) cur[k] = nxt[k];
-        }
+        for (int k = 0; k < PRE; ++k) bA[k] = blk(2 * PRE + k);
     }
+    consume(bB, PRE);
+    if (nu > 3 * PRE) {
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) bB[k] = blk(3 * PRE + k);
+    }
+    if (nu > 2 * PRE) consume(bA, 2 * PRE);
+    if (nu > 3 * PRE) consume(bB, 3 * PRE);
     float z8[8];
     wrow(zsc, z8);
     const int hd = 2 * oc + (cc >> 4), e = hd & 1, l = cc & 15;
@@ -458,11 +463,16 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
     load_h16(h, hbuf, c);
     stage_frags<NW>(L.sa_q, buf0, 33, wave, lane);
     E16 e[4];
-    e16_load(e, Eg, c);
     wg_combine_attn16<T16>(recs_in, stride_in, nu_in, c.b, reinterpret_cast<W*>(lds + L16_OFF_AF), reinterpret_cast<float*>(buf1),
                            reinterpret_cast<float*>(lds + L16_OFF_PST) /* the tail's 36 KiB: free until then */, tid);
+    e16_load(e, Eg, c);                          // (behind the combine, whose record batches need the registers; first used in stage 2)
     LSTAMP(1);
-    stage_sync();
+    // closer that leaves the 16 FiLM-tile loads just issued in flight (they are the wave's youngest vector-memory operations; the
+    // compiler waits for them where stage 2 first uses them): everything older - h, the records, the query image - has landed
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     LSTAMP(2);
 
     // ---- self-attention
