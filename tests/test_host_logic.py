@@ -309,6 +309,13 @@ def test_production_layer_kernel_has_no_register_spills():
     prod = [k for k in spills if re.match(r"_Z7k_layerIDF16[_b]Lb0ELb0ELb[01]ELb1ELb[01]EE", k)]
     assert len(prod) == 6, prod
     assert all(spills[k] == 0 for k in prod), {k: spills[k] for k in prod}
+    # the 16-token kernel of the small-batch path (one wave per SIMD, bounds of 2: no AGPR half, no spills)
+    src16 = os.path.join(ROOT, "diffusion-conductor_amd", "csrc", "dc_layer16.hip")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "--cuda-device-only", "-Wno-unused-value",
+                          src16, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    l16 = re.findall(r"Function Name: (_Z9k_layer16\S+).*?AGPRs: (\d+).*?VGPRs Spill: (\d+)", out.stderr, flags=re.S)
+    assert len(l16) == 2 and all(int(a) == 0 and int(sp) == 0 for _, a, sp in l16), l16
 
 
 # ---- tools/visualization.py-shaped entry point: reading a training run's opt.txt ------------------------------------------
