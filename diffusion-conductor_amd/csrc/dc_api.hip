@@ -652,7 +652,7 @@ int ensure_workspace(dc_sampler* s, int B, int Tx) {
     }
     if (!s->d_iter) {
         int rc;
-        if ((rc = dev_alloc(s, s->d_stamps, (8 * 32 + 8 + 1024 + 1024 + 256 + 8) * 8))) return rc;
+        if ((rc = dev_alloc(s, s->d_stamps, (8 * 32 + 8 + 1024 + 1024 + 256 + 8 + 512) * 8))) return rc;
         if ((rc = dev_alloc(s, s->d_film_rate, 2 * 1024 * sizeof(float)))) return rc;
         HIP_TRY(hipMemset(s->d_film_rate, 0, 2 * 1024 * sizeof(float)));      // 0 = not measured yet: equal shares
         if ((rc = dev_alloc(s, s->d_status, 16))) return rc;
@@ -1494,7 +1494,7 @@ int dc_sampler_debug_read(dc_sampler* s, const char* what, void* h_out, int64_t 
     else if (w == "recs") { src = s->d_recs; have = g * 2 * DC_REC_FLOATS * 4; }
     else if (w == "a_sa") { src = s->d_a_sa; have = (size_t)s->B * 16 * 1024; }
     else if (w == "a_ca") { src = s->d_a_ca; have = (size_t)s->cfg.num_layers * s->B * 16 * 1024; }
-    else if (w == "stamps") { src = s->d_stamps; have = (8 * 32 + 8 + 1024 + 1024 + 256 + 8) * 8; }
+    else if (w == "stamps") { src = s->d_stamps; have = (8 * 32 + 8 + 1024 + 1024 + 256 + 8 + 512) * 8; }
     else if (w == "temb") { src = s->h_model.temb; have = (size_t)s->cfg.max_timesteps * 512 * 4; }
     else if (w == "full_moves") {      // diagnostic builds only: {visits, moves} of the no_eff key loop's reference point, reset by the read
         if (nbytes != 16) return fail(DC_ERR_INVALID, "full_moves is 16 bytes");

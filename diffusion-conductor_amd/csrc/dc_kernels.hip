@@ -1068,6 +1068,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     constexpr int OFF_SS = SPLIT ? OFF_AF + 16384 : OFF_ER + 8 * 8192;    // column sums of the workgroup record (4.5 KiB)
     static_assert(!(SPLIT && WGR) || NW == 8, "split workgroup records: 8-wave workgroups");
     using W = v8<T16>;
+    // (stamped builds: the clock at the kernel's first instruction - before the kernel arguments, the model record and the workgroup map
+    // have been read - so that a workgroup's start-up can be told from the gap between two launches)
+    const unsigned long long t_first = STAMP ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int nl = dm->num_layers;
     f32x16 h[4];
     {
@@ -1112,6 +1115,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     DC_STAMP(0);
     if (STAMP && stamps && blockIdx.x == 3 && (threadIdx.x & 63) == 0 && l == 3) stamps[(threadIdx.x >> 6) * 32 + 26] = __builtin_amdgcn_s_memtime();
     DC_WGSTAMP(0);
+    if (STAMP && stamps && threadIdx.x == 0 && (l == 3 || l == 4) && blockIdx.x < 256) stamps[2576 + (l - 3) * 256 + blockIdx.x] = t_first;
     stage_frags<NW>(L.img_sa_q, buf0, NFW + 1, wave, lane);
     if constexpr (NARROW)
         wg_combine_attn_narrow<T16>(recs_in, reinterpret_cast<W*>(lds + OFF_AF), reinterpret_cast<float*>(buf1), ub0, wm.Mu, wm.Tu, tid_, wg);

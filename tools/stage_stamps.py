@@ -57,6 +57,16 @@ if wg[0, :, 1].max() > 0:
         print(f"  {name} begin {q(wg[i, :, 0] - t0)}   end {q(wg[i, :, 1] - t0)}   lifetime {q(wg[i, :, 1] - wg[i, :, 0])}")
     print(f"  last end of layer 3 -> first begin of layer 4: {(wg[1, :, 0].min() - wg[0, :, 1].max()) / 100.0:.2f} us;"
           f"  first begin to first begin: {(wg[1, :, 0].min() - wg[0, :, 0].min()) / 100.0:.2f} us")
+    try:
+        first = nat.debug_read("stamps", np.uint64, 8 * 32 + 8 + 1024 + 1024 + 256 + 8 + 512).astype(np.int64)[2576:].reshape(2, 256)[:, :nwg]
+        if first[1].max() > 0:
+            su = (wg[:, :, 0] - first) / 100.0
+            print(f"  first instruction -> begin stamp (kernel arguments, model record, workgroup map, residual-stream loads issued): "
+                  f"layer 3 {q(wg[0, :, 0] - first[0])}   layer 4 {q(wg[1, :, 0] - first[1])}")
+            print(f"  last end of layer 3 -> FIRST INSTRUCTION of layer 4: {(first[1].min() - wg[0, :, 1].max()) / 100.0:.2f} us;  "
+                  f"first instructions of layer 4 spread over {(first[1].max() - first[1].min()) / 100.0:.2f} us")
+    except Exception as e:
+        print("  (no first-instruction stamps:", e, ")")
 if wg[0, :, 1].max() > 0:
     # which workgroups are the slow ones?  logical index (wg_index: contiguous runs per XCD) and whether the 256-token unit spans two clips
     q_, r_ = nwg >> 3, nwg & 7
