@@ -1071,6 +1071,20 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     // (stamped builds: the clock at the kernel's first instruction - before the kernel arguments, the model record and the workgroup map
     // have been read - so that a workgroup's start-up can be told from the gap between two launches)
     const unsigned long long t_first = STAMP ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#ifndef DC_NO_EARLY_ARGS
+    // Every launch starts with a cold scalar cache, and hipcc sinks each kernel-argument load to its first use: the prologue then pays
+    // several scalar-memory round trips one after the other (arguments in three batches, among them the grid size) before its first load
+    // is issued - 1.7 us per workgroup (profiles/r04_diag_launch_gap.txt).  Naming the arguments the prologue needs as inputs of one
+    // asm statement makes them ONE round trip.  (Not `volatile`, kept alive - and early - through `T`, which the workgroup map uses at once:
+    // a volatile asm counts as a possible store and
+    // turns every scalar load of the model record behind it into a vector load with a vmcnt wait; and not through `l`: an opaque `l`
+    // keeps the layer's image-pointer loads from being hoisted in front of the LDS-DMA statements, with the same effect - as does naming
+    // `dm` itself: a pointer that has been an asm input counts as escaped, and the LDS-DMA statements' memory clobbers then cover it.)
+    {
+        const unsigned grid_x = gridDim.x;
+        asm("" : "+s"(T) : "s"(l), "s"(hbuf), "s"(E), "s"(recs), "s"(a_ca), "s"(NT), "s"(M), "s"(Tx), "s"(G), "s"(B), "s"(rec_stride), "s"(upc), "s"(grid_x));
+    }
+#endif
     const int nl = dm->num_layers;
     f32x16 h[4];
     {

@@ -427,6 +427,7 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
 #else
 #define LSTAMP(k) do {} while (0)
 #endif
+    // (k_layer's one-round-trip kernel-argument trick measured 1 % SLOWER here - hipcc splits the batch in two around an SGPR reuse - and is not used)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wg = wg_index();
