@@ -217,6 +217,26 @@ def test_layer16_small_batches(models, B, T, length):
         assert torch.equal(alone, a[S][k:k + 1])
 
 
+def test_layer16_bf16_build(models):
+    """The bf16 instantiation of the 16-token kernel (plain bf16 operands: loosely bounded like every plain-bf16 result) against the
+    oracle and against the 32-token narrow form of the same mode."""
+    B, T, S = 2, 1800, 25
+    length = [1800, 977]
+    xfp, xfo = xf_pair(B, T, first=72)
+    noise = torch.from_numpy(batch_noise(B, T, first=72))
+    with torch.no_grad():
+        ref = O.ddim_sample_loop(oracle_params(), noise, xfp, xfo, length, S)
+    a = _ddim(models["bf16"], S, noise, xfp, xfo, length)
+    os.environ["DC_NO_LAYER16"] = "1"
+    try:
+        b = _ddim(models["bf16"], S, noise, xfp, xfo, length)
+    finally:
+        del os.environ["DC_NO_LAYER16"]
+    ea, eb = rel_l2(a, ref), rel_l2(b, ref)
+    print(f"layer16 bf16: 16-token {ea:.3e}, 32-token {eb:.3e}, apart {rel_l2(a, b.cpu().numpy()):.3e}")
+    assert torch.isfinite(a).all() and ea <= 1e-2 and eb <= 1e-2 and ea <= 2 * eb + 1e-3
+
+
 def test_clip_layouts_agree_and_small_batches_are_batch_invariant(models):
     """Where the workgroup-record kernels run, a clip's stride in the token space is padded to whole 32-frame groups (T = 900 -> 928
     for a small batch) and small batches run clip-aligned 4-wave workgroups: no group and no workgroup spans two clips.  The
