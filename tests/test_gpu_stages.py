@@ -172,6 +172,10 @@ tr.eval_mode()
 mel = batch_mel(3, 810)
 a = tr.generate_music_motion(mel, 26, seed=3)            # sharded path: world-size-1 group, RCCL all_gather_into_tensor
 g = gather_poses(a, 3)                                   # the collective on HIP tensors, directly
+mel_h = torch.from_numpy(batch_mel(17, 810)).pin_memory()   # a pinned host batch stays on the host: the rank copies only its own clips,
+p_ = tr.generate_music_motion(mel_h, 26, seed=4)            # in chunks beside the encoder (17 >= 2 * h2d_chunk: the pipelined path)
+d_ = tr.generate_music_motion(mel_h.cuda(), 26, seed=4)     # the same batch already on the device
+assert tuple(p_.shape) == (17, 270, 26) and torch.equal(p_, d_)
 torch.cuda.synchronize()
 dist.barrier()
 dist.destroy_process_group()
