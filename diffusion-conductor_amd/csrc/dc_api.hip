@@ -792,15 +792,22 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const bool mixed_form = ss && !sf && ff == 1 && fs == 0;
     const bool fuse_embed = wgr && !narrow && (ss ? (aligned && mixed_form) : ff == fs) && fuse_silu && s->dbg_layers < 0 &&
                             s->dbg_stage == 0 && nwg <= s->num_cu && !want_stamps && !s->prof.on && !getenv("DC_NO_FUSE_EMBED");
+    // small batches (narrow clip-aligned units): the embedding's workgroups ride BEHIND the GEMM's while both fit the chip and the GEMM
+    // keeps its rounds (dc_film_extra_workgroups): one launch (15 us at one clip) and one kernel boundary less per step.
+    // DC_NO_FUSE_EMBED=1 keeps the two launches.
+    const bool fuse_extra = narrow && aligned && !ss && ff == fs && fuse_silu && s->h_model.film_w16 && s->dbg_first < 0 && !s->prof.on &&
+                            !getenv("DC_NO_FUSE_EMBED") &&
+                            dc_film_extra_workgroups((long long)((G + 3) / 4) * (s->NT / 16), (G + 3) / 4, nwg, s->num_cu) > 0;
     DcEmbedArgs ea{};
-    if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, aligned ? upc : 0, ss ? 1 : 0};
+    if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, aligned ? upc : 0, ss ? 1 : 0, 0};
+    if (fuse_extra) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, upc, 0, 1};
     const DcUpdate upd{s->d_zslot, s->d_status, loop_mode ? s->upd_flags : 0, folded ? graph_step : -1, nullptr};
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
                                        s->NT / 16, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
                                        want_stamps_film ? s->d_stamps + 252 : nullptr,
                                        adapt ? s->d_film_rate + 1024 * s->film_rate_parity : nullptr,
                                        adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr, iter_base,
-                                       s->h_model.film_w16, s->h_model.film_b16, fuse_embed ? &ea : nullptr, s->d_status));
+                                       s->h_model.film_w16, s->h_model.film_b16, (fuse_embed || fuse_extra) ? &ea : nullptr, s->d_status));
     s->film_rate_parity ^= 1;
     const int nl_run = (s->dbg_layers >= 0 && s->dbg_layers < L) ? s->dbg_layers : L;
     if (s->cfg.no_eff) {
@@ -815,7 +822,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         }
         return DC_OK;
     }
-    if (fuse_embed) {
+    if (fuse_embed || fuse_extra) {
         // (embedded by the FiLM launch)
     } else if (s->dbg_first >= 0)
         LAUNCH(K_EMBED, dc_launch_front_from_h(st, fs, ss, s->d_model, s->d_h, s->d_recs, s->d_length, M, T, G, B, s->dbg_first));

@@ -117,4 +117,5 @@ struct DcEmbedArgs {
     int M, Tx, ne;
     int upc;         // 0: flat 256-token units (non-split formats); > 0: clip-aligned units, `upc` workgroups per clip (split formats)
     int split_bf16;  // the embedding runs in the split-bf16 format of the "mixed" mode (FiLM GEMM f16, 128-wide GEMMs bf16x3)
+    int extra;       // small batches: the `ne` narrow (128-token, clip-aligned) units are EXTRA workgroups behind the GEMM's
 };

@@ -525,8 +525,8 @@ __global__ __launch_bounds__(256) void k_film_gemm(const v8<T16>* __restrict__ W
 
 
 // Work shares of the persistent FiLM GEMM: every wave derives the same integer boundaries (see k_film_gemm3).
-DEV void film_shares(int& u0, int& u1, long long nunit, const float* __restrict__ rate_in, int lane) {
-    const int nw = gridDim.x, b = blockIdx.x;
+DEV void film_shares(int& u0, int& u1, long long nunit, const float* __restrict__ rate_in, int lane, int nw /* GEMM workgroups: the first nw of the grid */) {
+    const int b = blockIdx.x;
     float xs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // lane i covers workgroups i, i + 64, ...: all on XCD i & 7
     int nzero = 0;
     for (int i = lane; i < nw; i += 64) {
@@ -547,7 +547,9 @@ DEV void film_shares(int& u0, int& u1, long long nunit, const float* __restrict_
     float tot = xsum;                                           // sum over all workgroups
 #pragma unroll
     for (int m = 4; m >= 1; m >>= 1) tot += __shfl_xor(tot, m);
-    const bool adaptive = rate_in && nzero == 0 && nw >= 64;
+    // (few units per workgroup - small batches - : equal shares; a +-20 % weight there only moves WHOLE units, e.g. at one clip,
+    // 180 units on 180 workgroups, it left some workgroups with two units and others with none: 25 vs 18 us per launch)
+    const bool adaptive = rate_in && nzero == 0 && nw >= 64 && nunit >= 8ll * nw;
     // this lane's XCD weight (relative speed, clamped), as an integer
     int wx = 4096;
     if (adaptive) wx = (int)(fminf(fmaxf((xsum / (float)cnt) * ((float)nw / tot), 0.8f), 1.2f) * 4096.f + 0.5f);
@@ -592,7 +594,7 @@ DEV void film_gemm3_body(const v8<T16>* __restrict__ W, const float* __restrict_
                          const int* __restrict__ t_clip, int T, int B,
                          unsigned long long* __restrict__ clk, const float* __restrict__ rate_in,
                          float* __restrict__ rate_out, const int* __restrict__ iter_base, unsigned long long t_begin,
-                         int* __restrict__ status) {
+                         int* __restrict__ status, int nw_film) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using OP = v8<T16>;
 #ifndef DC_FILM3_PF
@@ -613,7 +615,7 @@ DEV void film_gemm3_body(const v8<T16>* __restrict__ W, const float* __restrict_
     const int nblk = (G + 3) / 4;
     const long long nunit = (long long)nblk * nround;
     int u0, u1;
-    film_shares(u0, u1, nunit, rate_in, lane);
+    film_shares(u0, u1, nunit, rate_in, lane, nw_film);
     OP a[PF][4];                           // ring slot q: (tile 0 fb 0, tile 0 fb 1, tile 1 fb 0, tile 1 fb 1)
     auto wpair = [&](int p) { return W + (size_t)(2 * p) * 2 * KS * 64 + lane; };        // tile pair p = round * 8 + slot
     auto wfrag = [&](const OP* w, int ks, int i) { return w[((size_t)(i >> 1) * 2 * KS + ks * 2 + (i & 1)) * 64]; };
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(512, 2) void k_film_gemm3(const v8<T16>* __restrict
                                                        float* __restrict__ rate_out, const int* __restrict__ iter_base,
                                                        int* __restrict__ status) {
     film_gemm3_body<T16>(W, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base,
-                         __builtin_amdgcn_s_memrealtime(), status);
+                         __builtin_amdgcn_s_memrealtime(), status, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1001,13 +1003,29 @@ __global__ __launch_bounds__(512, 2) void k_film_embed(const v8<T16>* __restrict
                                                        float* __restrict__ rate_out, const int* __restrict__ iter_base, const DcEmbedArgs ea,
                                                        int* __restrict__ status) {
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    if constexpr (!SP) {
+        if (ea.extra) {
+            // small batches (narrow 128-token units, every workgroup of the launch on a CU of its own): the embedding's units are EXTRA
+            // workgroups behind the GEMM's, four of their eight waves at work - the step loses a 15-us launch and a kernel boundary
+            const int nf = (int)gridDim.x - ea.ne;
+            if ((int)blockIdx.x >= nf) {
+                if (threadIdx.x >= 256) return;      // (ended waves leave the workgroup's barriers)
+                embed_front_body<TS, false, true, false, true>(ea.dm, ea.x, ea.hbuf, ea.recs, ea.length, ea.M, T, G, B, nullptr, 0, ea.Tx, ea.upc,
+                                                               (int)blockIdx.x - nf);
+                return;
+            }
+            film_gemm3_body<T16>(W, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base, t_begin, status, nf);
+            return;
+        }
+    }
     if ((int)blockIdx.x < ea.ne) {
         embed_front_body<TS, SP, true, false, false>(ea.dm, ea.x, ea.hbuf, ea.recs, ea.length, ea.M, T, G, B, nullptr, 0, ea.Tx, ea.upc,
                                                      (int)blockIdx.x);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();            // the embedding's LDS use is over before the slab fill
     }
-    film_gemm3_body<T16>(W, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base, t_begin, status);
+    film_gemm3_body<T16>(W, bias16, E, G, NT, round0, nround, pp, temb, t_clip, T, B, clk, rate_in, rate_out, iter_base, t_begin, status,
+                         (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------
@@ -2251,6 +2269,16 @@ static void launch_film_t(hipStream_t st, const void* W, const float* bias_ft,
                                                                          (const v8<T16>*)s_hi, (const v8<T16>*)s_lo,
                                                                          (f16x16*)E, G, NT, status);
 }
+// GEMM workgroups of a FiLM launch that also carries `ne` embedding workgroups (every workgroup on a CU of its own), or 0 when that
+// would cost the GEMM a round of units: the embedding then stays a launch of its own
+int dc_film_extra_workgroups(long long nunit, int nblk, int ne, int ncu) {
+    const int room = ncu - ne;
+    if (room < nblk || room < 1) return 0;
+    const long long alone = nunit < ncu ? nunit : ncu;
+    const int nf = (int)(nunit < room ? nunit : room);
+    if ((nunit + nf - 1) / nf != (nunit + alone - 1) / alone) return 0;
+    return nf;
+}
 template <class T16>
 static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* bias16, void* E, int G, int NT, int round0, int nround,
                                  const float* pp, const float* temb, const int* t_clip, int T, int B, unsigned long long* clk,
@@ -2268,6 +2296,16 @@ static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* b
     int nwg = (int)(nunit < ncu ? nunit : ncu);
     if (nwg < nblk) nwg = nblk < ncu ? nblk : ncu;
     if (nwg < 1) nwg = 1;
+    if (ea && ea->x && ea->extra) {              // small batches: the embedding's narrow units as extra workgroups of this launch (k_film_embed)
+        if (ea->split_bf16 || ea->upc <= 0) return hipErrorInvalidValue;
+        const int nf = dc_film_extra_workgroups(nunit, nblk, ea->ne, ncu);
+        if (nf <= 0) return hipErrorInvalidValue;       // (the caller asked dc_film_extra_workgroups first)
+        static unsigned long long optin4 = 0;
+        if (hipError_t e = lds_optin((const void*)k_film_embed<T16>, (int)shm, optin4)) return e;
+        k_film_embed<T16><<<dim3(nf + ea->ne), dim3(512), shm, st>>>((const v8<T16>*)W16, bias16, (f16x16*)E, G, NT, round0, nround, pp, temb, t_clip, T, B,
+                                                                     clk, rate_in, rate_out, iter_base, *ea, status);
+        return hipGetLastError();
+    }
     if (ea && ea->x && nwg >= ea->ne) {          // fused with k_embed_front (its LDS image is smaller than the slab)
         if (ea->split_bf16) {                    // "mixed": split-bf16 embedding (two 65-KiB images: more LDS than the slab) beside the f16 GEMM
             if (!std::is_same<T16, _Float16>::value || ea->upc <= 0) return hipErrorInvalidValue;

@@ -5,7 +5,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from helpers import make_model, make_diffusion, xf_pair, batch_noise
-B, T = 32, 1800
+B, T = int(os.environ.get("DC_STAMP_BS", "32")), 1800
 m = make_model(os.environ.get("DC_STAMP_PREC", "fp16"))
 xfp, xfo = xf_pair(B, T); noise = torch.from_numpy(batch_noise(B, T)).cuda()
 nat = m.set_conditioning(xfp.cuda(), xfo.cuda(), [T] * B)
@@ -73,32 +73,38 @@ if wg[0, :, 1].max() > 0:
     logical = np.array([(b & 7) * q_ + min(b & 7, r_) + (b >> 3) for b in range(nwg)])
     strad = np.array([(w * 256) // Tp != min(w * 256 + 255, B * Tp - 1) // Tp for w in logical])
     life = (wg[0, :, 1] - wg[0, :, 0]) / 100.0
-    print(f"  layer 3 lifetime: straddling units ({strad.sum()}) mean {life[strad].mean():.2f} max {life[strad].max():.2f};"
-          f"  others mean {life[~strad].mean():.2f} max {life[~strad].max():.2f}")
-    for x in range(8):
+    if strad.any() and (~strad).any():
+        print(f"  layer 3 lifetime: straddling units ({strad.sum()}) mean {life[strad].mean():.2f} max {life[strad].max():.2f};"
+              f"  others mean {life[~strad].mean():.2f} max {life[~strad].max():.2f}")
+    for x in range(min(8, nwg)):
         sel = (np.arange(nwg) & 7) == x
         print(f"  XCD {x}: {sel.sum()} workgroups, lifetime mean {life[sel].mean():.2f} max {life[sel].max():.2f}, end max {(wg[0, sel, 1].max() - t0) / 100.0:.2f}")
 raw = nat.debug_read("stamps", np.uint64, 8 * 32 + 8 + 1024 + 1024 + 256 + 8).astype(np.int64)
 fk = raw[1288:2312].reshape(256, 4)
 units = raw[2312:2568]
 if fk[:, 3].max() > 0:
-    t0f = fk[:, 1].min()
+    live = fk[:, 3] > 0
+    nlive = int(live.sum())
+    t0f = fk[live, 1].min()
+    print(f"k_film_gemm: {nlive} workgroups; first start -> last start {(fk[live, 1].max() - t0f) / 100.0:.1f} us; first start -> last finish {(fk[live, 3].max() - t0f) / 100.0:.1f} us")
     print("k_film_gemm per XCD (workgroup b runs on XCD b & 7): core clock MHz (mean), sweep us (mean / max), finish us after the first start (max)")
     for x in range(8):
-        sel = (np.arange(256) & 7) == x
+        sel = ((np.arange(256) & 7) == x) & live
+        if not sel.any(): continue
         mhz = (fk[sel, 2] - fk[sel, 0]) / (fk[sel, 3] - fk[sel, 1]) * 100.0
         us = (fk[sel, 3] - fk[sel, 1]) / 100.0
         print(f"  XCD {x}: {mhz.mean():6.0f} MHz   {us.mean():6.1f} / {us.max():6.1f}   {(fk[sel, 3].max() - t0f) / 100.0:6.1f}")
-    us_all = (fk[:, 3] - fk[:, 1]) / 100.0
-    print("  all workgroups: sweep us min/p10/p50/p90/max " + " ".join(f"{v:.1f}" for v in np.percentile(us_all, [0, 10, 50, 90, 100]))
-          + f";  units per workgroup min/mean/max {units.min()} / {units.mean():.2f} / {units.max()}")
-    order = np.argsort(us_all)
+    us_all = np.where(live, (fk[:, 3] - fk[:, 1]) / 100.0, 0.0)
+    print("  all workgroups: sweep us min/p10/p50/p90/max " + " ".join(f"{v:.1f}" for v in np.percentile(us_all[live], [0, 10, 50, 90, 100]))
+          + f";  units per workgroup min/mean/max {units[live].min()} / {units[live].mean():.2f} / {units[live].max()}")
+    order = np.argsort(np.where(live, us_all, np.inf))[:nlive]
     print("  slowest 8 workgroups (id, units, us, us per unit): " + "  ".join(f"{i}:{units[i]}:{us_all[i]:.0f}:{us_all[i] / max(units[i], 1):.2f}" for i in order[-8:]))
     print("  fastest 8 workgroups (id, units, us, us per unit): " + "  ".join(f"{i}:{units[i]}:{us_all[i]:.0f}:{us_all[i] / max(units[i], 1):.2f}" for i in order[:8]))
-    nfill = np.array([len(set(range(int(units[:i].sum()) // 12, (int(units[:i + 1].sum()) - 1) // 12 + 1))) for i in range(256)])
-    for f in sorted(set(nfill)):
-        sel = nfill == f
-        print(f"  workgroups with {f} slab fills: {sel.sum()}, us per unit mean {np.mean(us_all[sel] / np.maximum(units[sel], 1)):.2f}")
+    if nlive == 256:
+        nfill = np.array([len(set(range(int(units[:i].sum()) // 12, (int(units[:i + 1].sum()) - 1) // 12 + 1))) for i in range(256)])
+        for f in sorted(set(nfill)):
+            sel = nfill == f
+            print(f"  workgroups with {f} slab fills: {sel.sum()}, us per unit mean {np.mean(us_all[sel] / np.maximum(units[sel], 1)):.2f}")
     ft = raw[2568:2572]
     if ft[3] > 0:
         print(f"  workgroup 5: {ft[3]} slab fills, per fill (us): wait for the previous slab's slowest wave {ft[0] / ft[3] / 100.0:.2f},"
