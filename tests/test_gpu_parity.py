@@ -217,6 +217,29 @@ def test_layer16_small_batches(models, B, T, length):
         assert torch.equal(alone, a[S][k:k + 1])
 
 
+@pytest.mark.parametrize("B,T,length", [(1, 1800, [1800]), (3, 1800, [1800, 77, 1500]), (4, 1800, [1800, 1, 911, 1799]), (12, 1800, None), (6, 512, None)])
+def test_small_batch_embedding_rides_in_the_film_launch(models, B, T, length):
+    """Small batches: the embedding's narrow units are extra workgroups of the FiLM launch while both fit the chip and the GEMM keeps
+    its rounds (dc_film_extra_workgroups; bs <= 3 at T = 1800, not at bs = 4 or 12, where the launches stay apart).  Same kernels'
+    bodies either way: bit-identical to DC_NO_FUSE_EMBED=1, graph and eager."""
+    S = 25
+    length = length or [T - 13 * i for i in range(B)]
+    xfp, xfo = xf_pair(B, T, first=74)
+    noise = torch.from_numpy(batch_noise(B, T, first=74))
+    m = models["fp16"]
+    a = _ddim(m, S, noise, xfp, xfo, length, idxs=(3,))
+    os.environ["DC_NO_FUSE_EMBED"] = "1"
+    try:
+        b = _ddim(m, S, noise, xfp, xfo, length, idxs=(3,))
+        os.environ["DC_DISABLE_GRAPH"] = "1"
+        c = _ddim(m, S, noise, xfp, xfo, length, idxs=(3,))
+    finally:
+        del os.environ["DC_NO_FUSE_EMBED"]
+        os.environ.pop("DC_DISABLE_GRAPH", None)
+    assert torch.isfinite(a[S]).all()
+    assert torch.equal(a[S], b[S]) and torch.equal(a[3], b[3]) and torch.equal(a[S], c[S])
+
+
 def test_layer16_bf16_build(models):
     """The bf16 instantiation of the 16-token kernel (plain bf16 operands: loosely bounded like every plain-bf16 result) against the
     oracle and against the 32-token narrow form of the same mode."""

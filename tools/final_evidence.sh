@@ -14,5 +14,5 @@ python bench.py --ddim 1000 --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2
 python bench.py --bs 128 --frames 900 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${TAG}_bench_t900.json
 python bench.py --no-eff --steps 5 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${TAG}_bench_noeff.json
 python bench.py --precision mixed --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${TAG}_bench_mixed.json
-timeout 600 python tools/time_small_batch.py 1 2 4 8 2>/dev/null > $O/${TAG}_small_batch.txt
+timeout 600 python tools/time_small_batch.py 1 2 3 4 8 2>/dev/null > $O/${TAG}_small_batch.txt
 cat $O/${TAG}_pytest_gpu.txt; for f in default ddim1000 t900 noeff mixed; do echo -n "$f: "; grep -o "ms_per_step\": [0-9.]*" $O/${TAG}_bench_$f.json; done
