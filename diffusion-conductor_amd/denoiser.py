@@ -157,10 +157,18 @@ class MotionTransformer(nn.Module):
         if getattr(self, "_copy_stream", None) is None or self._copy_stream.device != device:
             self._copy_stream = torch.cuda.Stream(device)
         cs = self._copy_stream
-        mel = torch.empty(tuple(mel_host.shape), dtype=torch.float32, device=device)
+        # the device-side staging buffer is the module's own and is reused call after call: a fresh 88-MB tensor per call goes through
+        # the caching allocator's cross-stream bookkeeping (record_stream) and, whenever that ends in a hipMalloc, costs the call 6 ms
+        st = getattr(self, "_mel_stage", None)
+        n = mel_host.numel()
+        if st is None or st.device != device or st.numel() < n:
+            st = self._mel_stage = torch.empty(n, dtype=torch.float32, device=device)
+        mel = st[:n].view(tuple(mel_host.shape))
         xf_proj = torch.empty((B, T, 64), dtype=torch.float32, device=device)
         xf_out = torch.empty_like(xf_proj)
         cs.wait_stream(cur)                       # the allocations above are ordered on `cur`
+        if getattr(self, "_mel_done", None) is not None:
+            cs.wait_event(self._mel_done)         # the previous call's encodes (possibly on another stream) have read the staging buffer
         events = []
         sched = os.environ.get("DC_H2D_CHUNKS")          # diagnostic: explicit chunk sizes, e.g. "4,12,16"
         # default: a first chunk of h2d_chunk clips (its copy is the only one the encoder waits for), then the rest in one piece -
@@ -175,7 +183,8 @@ class MotionTransformer(nn.Module):
         for lo, hi, ev in events:
             cur.wait_event(ev)
             nat.encode_music(mel[lo:hi], out=(xf_proj[lo:hi], xf_out[lo:hi]))
-        mel.record_stream(cs)
+        self._mel_done = torch.cuda.Event()
+        self._mel_done.record(cur)
         return xf_proj, xf_out
 
     def set_conditioning(self, xf_proj, xf_out, length=None):
