@@ -792,12 +792,10 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const bool mixed_form = ss && !sf && ff == 1 && fs == 0;
     const bool fuse_embed = wgr && !narrow && (ss ? (aligned && mixed_form) : ff == fs) && fuse_silu && s->dbg_layers < 0 &&
                             s->dbg_stage == 0 && nwg <= s->num_cu && !want_stamps && !s->prof.on && !getenv("DC_NO_FUSE_EMBED");
-    // small batches (narrow clip-aligned units): the embedding's workgroups ride BEHIND the GEMM's while both fit the chip and the GEMM
-    // keeps its rounds (dc_film_extra_workgroups): one launch (15 us at one clip) and one kernel boundary less per step.
-    // DC_NO_FUSE_EMBED=1 keeps the two launches.
+    // small batches (narrow clip-aligned units): the embedding's workgroups ride BEHIND the GEMM's in the FiLM launch
+    // (dc_film_extra_workgroups): one launch (15 us at one clip) and one kernel boundary less per step.  DC_NO_FUSE_EMBED=1 keeps the two launches.
     const bool fuse_extra = narrow && aligned && !ss && ff == fs && fuse_silu && s->h_model.film_w16 && s->dbg_first < 0 && !s->prof.on &&
-                            !getenv("DC_NO_FUSE_EMBED") &&
-                            dc_film_extra_workgroups((long long)((G + 3) / 4) * (s->NT / 16), (G + 3) / 4, nwg, s->num_cu) > 0;
+                            !getenv("DC_NO_FUSE_EMBED");
     DcEmbedArgs ea{};
     if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, aligned ? upc : 0, ss ? 1 : 0, 0};
     if (fuse_extra) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, upc, 0, 1};

@@ -2269,15 +2269,20 @@ static void launch_film_t(hipStream_t st, const void* W, const float* bias_ft,
                                                                          (const v8<T16>*)s_hi, (const v8<T16>*)s_lo,
                                                                          (f16x16*)E, G, NT, status);
 }
-// GEMM workgroups of a FiLM launch that also carries `ne` embedding workgroups (every workgroup on a CU of its own), or 0 when that
-// would cost the GEMM a round of units: the embedding then stays a launch of its own
+// GEMM workgroups of a FiLM launch that also carries `ne` embedding workgroups behind them (DcEmbedArgs::extra; small batches).  While
+// both fit the chip and the GEMM keeps its rounds, the GEMM gives up CUs (every workgroup on a CU of its own).  With the chip full the
+// GEMM keeps all its workgroups and the embedding's are dispatched as the first GEMM workgroups retire - into the ragged end of the
+// GEMM's equal shares where there is one (bs=4 at T=1800: 84 of 256 workgroups hold 2 units, the others 3: -4.9 % per loop), and
+// otherwise behind it, which still saves the kernel boundary (same box, bs = 3 ... 16: never slower than two launches,
+// profiles/r04_small_batch_fused.txt).
 int dc_film_extra_workgroups(long long nunit, int nblk, int ne, int ncu) {
     const int room = ncu - ne;
-    if (room < nblk || room < 1) return 0;
     const long long alone = nunit < ncu ? nunit : ncu;
-    const int nf = (int)(nunit < room ? nunit : room);
-    if ((nunit + nf - 1) / nf != (nunit + alone - 1) / alone) return 0;
-    return nf;
+    if (room >= nblk && room >= 1) {
+        const int nf = (int)(nunit < room ? nunit : room);
+        if ((nunit + nf - 1) / nf == (nunit + alone - 1) / alone) return nf;
+    }
+    return (int)alone;
 }
 template <class T16>
 static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* bias16, void* E, int G, int NT, int round0, int nround,
@@ -2299,7 +2304,7 @@ static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* b
     if (ea && ea->x && ea->extra) {              // small batches: the embedding's narrow units as extra workgroups of this launch (k_film_embed)
         if (ea->split_bf16 || ea->upc <= 0) return hipErrorInvalidValue;
         const int nf = dc_film_extra_workgroups(nunit, nblk, ea->ne, ncu);
-        if (nf <= 0) return hipErrorInvalidValue;       // (the caller asked dc_film_extra_workgroups first)
+        if (nf <= 0) return hipErrorInvalidValue;
         static unsigned long long optin4 = 0;
         if (hipError_t e = lds_optin((const void*)k_film_embed<T16>, (int)shm, optin4)) return e;
         k_film_embed<T16><<<dim3(nf + ea->ne), dim3(512), shm, st>>>((const v8<T16>*)W16, bias16, (f16x16*)E, G, NT, round0, nround, pp, temb, t_clip, T, B,
