@@ -406,7 +406,7 @@ DEV void wg_combine_attn16(const float* __restrict__ recs, size_t stride, int nu
 // the head of the stage in front of it (registers are plentiful at one wave per SIMD).
 // ------------------------------------------------------------------------------------------------------------------
 template <class T16>
-__global__ __launch_bounds__(256, 2)      // (one workgroup per CU by its LDS; "2" keeps the compiler off the AGPR half: 232 VGPRs, no accvgpr moves)
+__global__ __launch_bounds__(256, 2)      // (one workgroup per CU by its LDS; "2" keeps the compiler off the AGPR half: 250 VGPRs, no accvgpr moves)
 void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
                const v8<T16>* __restrict__ a_ca /*[L][B][8 heads][64] 16-token form*/, float* __restrict__ recs, const int* __restrict__ length,
                const float* __restrict__ xin, float* __restrict__ xout, int out_mode, const float* __restrict__ coef_cur,
