@@ -407,6 +407,22 @@ def test_bs32_interior_clips_vs_oracle(models):
     assert worst["fp16"] <= TOL_PARITY and worst["mixed"] <= TOL_PARITY, worst
 
 
+def test_bs32_every_clip_vs_oracle(models):
+    """All 32 clips of the headline batch (bs=32 x 1800, DDIM-50, flat 256-token units: 28 of the 32 clips share a unit with a
+    neighbour at one end or both) against the CPU oracle's DDIM-50 of the same batch (the oracle has no cross-clip operation), per
+    clip, in the default f16 mode and the bf16-MFMA mode."""
+    B, T = 32, 1800
+    xfp, xfo = xf_pair(B, T)
+    noise = torch.from_numpy(batch_noise(B, T))
+    with torch.no_grad():
+        ref = O.ddim_sample_loop(oracle_params(), noise, xfp, xfo, [T] * B, 50)
+    for mode in ("fp16", "mixed"):
+        a = _ddim(models[mode], 50, noise, xfp, xfo, [T] * B)
+        errs = [rel_l2(a[c:c + 1], ref[c:c + 1]) for c in range(B)]
+        print(f"bs32, every clip vs oracle ({mode}): min {min(errs):.3e} max {max(errs):.3e} (clip {int(np.argmax(errs))})")
+        assert max(errs) <= TOL_PARITY, errs
+
+
 def test_harness_generate_music_motion_golden(models):
     """G7: DDPMTrainer.generate_music_motion end to end (encode_music + DDIM-50) on the reference's
     own call pattern: np mel [5400,128] in, tensor [1,1800,26] out."""
