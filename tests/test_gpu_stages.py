@@ -135,6 +135,13 @@ def test_config5_t900_bs128_full_size(models):
     err = rel_l2(a[:2], golden("g6_variants.npz")["t900_x0"])
     print(f"config 5 clips 0-1 rel-L2 {err:.3e}")
     assert err <= 1e-3
+    # ... and eight clips from inside the batch (ragged lengths, flat units shared with their neighbours) against the oracle's run of those clips
+    idx = [5, 31, 32, 63, 64, 77, 126, 127]
+    with torch.no_grad():
+        ref = O.ddim_sample_loop(oracle_params(), noise[idx], xfp[idx], xfo[idx], [length[i] for i in idx], 50)
+    errs = [rel_l2(a[i:i + 1], ref[k:k + 1]) for k, i in enumerate(idx)]
+    print("config 5 interior clips vs oracle: " + "  ".join(f"clip {i}: {e:.3e}" for i, e in zip(idx, errs)))
+    assert max(errs) <= 1e-3
 
 
 # ---- harness: seed= with a mel length that is not a multiple of 3 ---------------------------------------------------------
