@@ -693,6 +693,13 @@ def test_no_eff_bs32_full_size_properties(model_no_eff):
     print(f"no_eff bs=32: clips 5..8 inside the batch vs alone: equal {torch.equal(a[sub], c)}, rel-L2 {err:.3e}")
     assert torch.isfinite(a).all() and torch.equal(a, b)
     assert err <= TOL_PARITY
+    # ... and clips from inside the batch (13: shortened, 30: full length) against the oracle's full-attention run of those clips
+    idx = [13, 30]
+    with torch.no_grad():
+        ref = O.ddim_sample_loop(oracle_params(), noise[idx], xfp[idx], xfo[idx], [length[i] for i in idx], S, no_eff=True)
+    errs = [rel_l2(a[i:i + 1], ref[k:k + 1]) for k, i in enumerate(idx)]
+    print("no_eff bs=32, clips inside the batch vs oracle: " + "  ".join(f"clip {i}: {e:.3e}" for i, e in zip(idx, errs)))
+    assert max(errs) <= TOL_PARITY
 
 
 def test_no_eff_bf16_mode_vs_oracle():
