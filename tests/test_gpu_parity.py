@@ -94,6 +94,24 @@ def test_forward_padded_clip_strides(models, B, T):
     assert torch.isfinite(out).all() and err <= TOL_PARITY
 
 
+@pytest.mark.parametrize("B,T", [(33, 300), (20, 1000), (40, 777), (18, 1800), (70, 511)])
+def test_ddim25_odd_shapes_wide_units_vs_oracle(models, B, T):
+    """Whole DDIM-25 loops at shapes off the benchmark's grid, with ragged lengths down to one frame, against the oracle: batches
+    past the narrow-workgroup limit (flat 256-token units that contain clip edges at every offset; 777 and 1000 are padded to a
+    multiple of 32, 300 and 511 are not), 18 x 1800 (the first batch size on wide units); f16 and the bf16-MFMA mode."""
+    S = 25
+    xfp, xfo = xf_pair(B, T, first=80)
+    noise = torch.from_numpy(batch_noise(B, T, first=80))
+    length = [T if b % 3 == 0 else (1 if b % 7 == 1 else max(1, T - 29 * b - 1)) for b in range(B)]
+    with torch.no_grad():
+        ref = O.ddim_sample_loop(oracle_params(), noise, xfp, xfo, length, S)
+    for mode in ("fp16", "mixed"):
+        a = _ddim(models[mode], S, noise, xfp, xfo, length)
+        errs = [rel_l2(a[c:c + 1], ref[c:c + 1]) for c in range(B)]
+        print(f"ddim25 B={B} T={T} ({mode}): whole batch {rel_l2(a, ref):.3e}, worst clip {max(errs):.3e} (clip {int(np.argmax(errs))}, length {length[int(np.argmax(errs))]})")
+        assert torch.isfinite(a).all() and max(errs) <= TOL_PARITY, errs
+
+
 @pytest.mark.parametrize("prec,tol", [("fp16", TOL_PARITY), ("mixed", TOL_PARITY), ("bf16x3", TOL_X3), ("bf16", TOL_BF16)])
 def test_ddim50_config1_golden(models, prec, tol):
     """G5 = BASELINE config 1: single 60 s clip, DDIM-50, with the idxs=[0,24] intermediates."""
