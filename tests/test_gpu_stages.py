@@ -151,6 +151,29 @@ def test_config5_t900_bs128_full_size(models):
     assert max(errs) <= 1e-3
 
 
+# ---- harness: a pinned host batch at production length (chunked H2D beside the encoder) against the oracle end to end ---------------
+def test_harness_pinned_batch_production_length_vs_oracle(models):
+    """DDPMTrainer.generate_music_motion on a pinned host batch of 17 x 60 s of mel (the path bench.py's end_to_end times: from 16
+    clips on the copy runs in two chunks, 8 + 9 here, beside the MusicEncoder, denoiser.py) against the oracle's encode_music + DDIM-25 of the same batch
+    (transformer.py:289-340,447-459; gaussian_diffusion.py:871-915), per clip."""
+    import types
+    from diffusion_conductor_amd import DDPMTrainer
+    B, S = 17, 25
+    opt = types.SimpleNamespace(device=torch.device("cuda:0"), diffusion_steps=S, is_train=False)
+    tr = DDPMTrainer(opt, models["fp16"])
+    tr.eval_mode()
+    assert B >= 2 * models["fp16"].h2d_chunk          # (the chunked path)
+    mel = batch_mel(B, 5400)
+    noise = torch.from_numpy(batch_noise(B, 1800, first=90))
+    a = tr.generate_music_motion(torch.from_numpy(mel).pin_memory(), 26, noise=noise)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.generate_music_motion(oracle_params(), torch.from_numpy(mel), 26, S, noise)
+    errs = [rel_l2(a[c:c + 1], ref[c:c + 1]) for c in range(B)]
+    print(f"harness, pinned batch of {B}: per-clip rel-L2 " + " ".join(f"{e:.2e}" for e in errs))
+    assert tuple(a.shape) == (B, 1800, 26) and max(errs) <= 1e-3
+
+
 # ---- harness: seed= with a mel length that is not a multiple of 3 ---------------------------------------------------------
 def test_harness_seed_odd_mel_length(models):
     import types
