@@ -793,7 +793,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const bool fuse_embed = wgr && !narrow && (ss ? (aligned && mixed_form) : ff == fs) && fuse_silu && s->dbg_layers < 0 &&
                             s->dbg_stage == 0 && nwg <= s->num_cu && !want_stamps && !s->prof.on && !getenv("DC_NO_FUSE_EMBED");
     // small batches (narrow clip-aligned units): the embedding's workgroups ride BEHIND the GEMM's in the FiLM launch
-    // (dc_film_extra_workgroups): one launch (15 us at one clip) and one kernel boundary less per step.  DC_NO_FUSE_EMBED=1 keeps the two launches.
+    // (film_extra_workgroups, dc_kernels.hip): one launch (15 us at one clip) and one kernel boundary less per step.  DC_NO_FUSE_EMBED=1 keeps the two launches.
     const bool fuse_extra = narrow && aligned && !ss && ff == fs && fuse_silu && s->h_model.film_w16 && s->dbg_first < 0 && !s->prof.on &&
                             !getenv("DC_NO_FUSE_EMBED");
     DcEmbedArgs ea{};

@@ -1005,8 +1005,9 @@ __global__ __launch_bounds__(512, 2) void k_film_embed(const v8<T16>* __restrict
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     if constexpr (!SP) {
         if (ea.extra) {
-            // small batches (narrow 128-token units, every workgroup of the launch on a CU of its own): the embedding's units are EXTRA
-            // workgroups behind the GEMM's, four of their eight waves at work - the step loses a 15-us launch and a kernel boundary
+            // small batches (narrow 128-token units): the embedding's units are EXTRA workgroups behind the GEMM's (beside them while the
+            // launch fits the chip, dispatched as they retire otherwise: film_extra_workgroups), four of their eight waves at work - the
+            // step loses a 15-us launch and a kernel boundary
             const int nf = (int)gridDim.x - ea.ne;
             if ((int)blockIdx.x >= nf) {
                 if (threadIdx.x >= 256) return;      // (ended waves leave the workgroup's barriers)
@@ -2275,7 +2276,7 @@ static void launch_film_t(hipStream_t st, const void* W, const float* bias_ft,
 // GEMM's equal shares where there is one (bs=4 at T=1800: 84 of 256 workgroups hold 2 units, the others 3: -4.9 % per loop), and
 // otherwise behind it, which still saves the kernel boundary (same box, bs = 3 ... 16: never slower than two launches,
 // profiles/r04_small_batch_fused.txt).
-int dc_film_extra_workgroups(long long nunit, int nblk, int ne, int ncu) {
+static int film_extra_workgroups(long long nunit, int nblk, int ne, int ncu) {
     const int room = ncu - ne;
     const long long alone = nunit < ncu ? nunit : ncu;
     if (room >= nblk && room >= 1) {
@@ -2303,7 +2304,7 @@ static hipError_t launch_film3_t(hipStream_t st, const void* W16, const float* b
     if (nwg < 1) nwg = 1;
     if (ea && ea->x && ea->extra) {              // small batches: the embedding's narrow units as extra workgroups of this launch (k_film_embed)
         if (ea->split_bf16 || ea->upc <= 0) return hipErrorInvalidValue;
-        const int nf = dc_film_extra_workgroups(nunit, nblk, ea->ne, ncu);
+        const int nf = film_extra_workgroups(nunit, nblk, ea->ne, ncu);
         if (nf <= 0) return hipErrorInvalidValue;
         static unsigned long long optin4 = 0;
         if (hipError_t e = lds_optin((const void*)k_film_embed<T16>, (int)shm, optin4)) return e;

@@ -19,9 +19,6 @@ hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, vo
 hipError_t dc_launch_silu_emb(hipStream_t st, int fmt, bool split, const float* pp, const float* temb, const int* t_clip,
                               void* s_hi, void* s_lo, int G, int T, int B,
                               const int* iter_base = nullptr /* captured loop: t_clip = &t_of_iter[step], indexed by *iter_base */);
-// GEMM workgroups of a FiLM launch that also carries `ne` embedding workgroups as EXTRA workgroups behind them (DcEmbedArgs::extra:
-// small batches; dc_kernels.hip)
-int dc_film_extra_workgroups(long long nunit, int nblk, int ne, int ncu);
 hipError_t dc_launch_film_gemm(hipStream_t st, int fmt, bool split, const void* W, const float* bias_ft, const void* s_hi, const void* s_lo, void* E, int G, int NT, int round0,
                                int nround, const float* pp, const float* temb, const int* t_clip, int T, int B,
                                unsigned long long* clk /* diagnostic clock stamps or nullptr */,

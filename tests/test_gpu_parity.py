@@ -238,7 +238,7 @@ def test_layer16_small_batches(models, B, T, length):
 @pytest.mark.parametrize("B,T,length", [(1, 1800, [1800]), (3, 1800, [1800, 77, 1500]), (4, 1800, [1800, 1, 911, 1799]), (12, 1800, None), (6, 512, None)])
 def test_small_batch_embedding_rides_in_the_film_launch(models, B, T, length):
     """Small batches (narrow clip-aligned units): the embedding's units are extra workgroups of the FiLM launch - beside the GEMM's
-    while both fit the chip (dc_film_extra_workgroups; bs <= 3 at T = 1800), dispatched behind them with the chip full (bs = 4, 12).
+    while both fit the chip (film_extra_workgroups; bs <= 3 at T = 1800), dispatched behind them with the chip full (bs = 4, 12).
     Same kernels' bodies either way: bit-identical to DC_NO_FUSE_EMBED=1, graph and eager."""
     S = 25
     length = length or [T - 13 * i for i in range(B)]
