@@ -1056,12 +1056,34 @@ DEV void stage_frags(const void* __restrict__ src, char* dst, int nfrags, int wa
     const bf16x8* s = reinterpret_cast<const bf16x8*>(src);
     for (int f = wave; f < nfrags; f += NW) lds_dma16(s + (size_t)f * 64 + lane, dst + f * 1024);
 }
+// Progress priority: a wave lowers its issue priority as it advances through a stage (s_setprio 3 at the stage's head ... 0 near its
+// closer), so that of the two waves of a SIMD the one that is BEHIND wins arbitration and both reach the closer together - under the
+// hardware's oldest-first rule the older wave runs ahead and then idles at every closer while its partner finishes alone at
+// single-wave efficiency.  Same-box A/B (profiles/r04_ab_stage_prio.txt): k_layer -1.2 ... -1.9 % per launch, loop -0.7 % on average
+// over three boxes (-1.3 / +-0 / -0.9); the inverse mapping (control) +0.3 %.  -DDC_STAGE_PRIO=0 builds without it, =1 without the
+// record tail's checkpoints.
+#ifndef DC_STAGE_PRIO
+#define DC_STAGE_PRIO 2
+#endif
+template <int P, int LEVEL = 1>
+DEV void sprio() {
+#if DC_STAGE_PRIO
+    if constexpr (DC_STAGE_PRIO >= LEVEL) {
+#ifdef DC_STAGE_PRIO_INV      // control: the wave that is AHEAD wins
+        __builtin_amdgcn_s_setprio(3 - P);
+#else
+        __builtin_amdgcn_s_setprio(P);
+#endif
+    }
+#endif
+}
 DEV void stage_sync() {
     __builtin_amdgcn_sched_barrier(0);           // stages do not interleave: keeps each stage's live set separate
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef DC_DIAG_NO_STAGE_BARRIER                 // diagnostic build (timing only, results invalid): the waves of a workgroup free-run
     __syncthreads();                             // through the stage closers - the bound on what any point-to-point hand-off can gain
 #endif
+    sprio<3>();
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -1128,11 +1150,14 @@ DEV void query_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const
         gemm_wa<4, 4, T16, SPLIT>(q, w, nf, cx.lane);
     }
     __builtin_amdgcn_sched_barrier(0);
+    sprio<2>();
     softmax_heads_ft(q);
     __builtin_amdgcn_sched_barrier(0);
+    sprio<1>();
     RowStats st;
 #pragma unroll
     for (int oc = 0; oc < 4; ++oc) {
+        if (oc == 2) sprio<0>();
         f32x16 acc = splat(0.f);
         XFrag<T16, SPLIT> qf;
         make_frag<T16, SPLIT>(q[oc], qf);
@@ -1265,6 +1290,7 @@ DEV void stage_sync_keep8() {
 #ifndef DC_DIAG_NO_STAGE_BARRIER
     __syncthreads();
 #endif
+    sprio<3>();
     __builtin_amdgcn_sched_barrier(0);
 }
 template <class T16, bool SPLIT, bool PRE /* k-tiles 0, 1 were requested by the preceding stage */>
@@ -1294,6 +1320,9 @@ DEV void styl_accumulate_pf(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rs
         __builtin_amdgcn_sched_barrier(0);
         mma_kt<4, 4, T16, SPLIT>(h, w, kt, zf, lane);
         __builtin_amdgcn_sched_barrier(0);
+        if (kt == 0) sprio<2>();
+        if (kt == 1) sprio<1>();
+        if (kt == 2) sprio<0>();
     }
 }
 
@@ -1380,6 +1409,9 @@ DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float 
         styl_tile<T16, SPLIT, ytile<SPLIT>>(zf, y[kt], rstd, shift, gp, hp);
         mma_kt<4, 4, T16, SPLIT>(h, w, kt, zf, lane);
         __builtin_amdgcn_sched_barrier(0);
+        if (kt == 0) sprio<2>();
+        if (kt == 1) sprio<1>();
+        if (kt == 2) sprio<0>();
     }
 }
 

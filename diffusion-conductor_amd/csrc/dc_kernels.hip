@@ -1181,7 +1181,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     }
     DC_STAMP(15);
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
+    __syncthreads(); sprio<3>();
     __builtin_amdgcn_sched_barrier(0);
 #endif
     DC_STAMP(1);
@@ -1288,6 +1288,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             for (int t = 0; t < 2; ++t) u[t] = ld_ft(c0, t, cx.hh);                 // b1
             gemm_wa<2, 4, T16, SPLIT>(u, w0, hf, lane);
         }
+        sprio<2>();
         XFrag<T16, SPLIT> uf[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -1300,8 +1301,10 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             make_frag<T16, SPLIT>(u[kt], uf[kt]);
         }
         RowStats st;
+        sprio<1>();
 #pragma unroll
         for (int t = 0; t < 4; ++t) {                                              // one output tile at a time
+            if (t == 2) sprio<0>();
             f32x16 yf = ld_ft(c0 + 64, t, cx.hh);                                  // b2
             mma_ot<4, 2, T16, SPLIT>(yf, w0 + 16 * WM * 64, t, uf, lane);
             st.add(yf);
@@ -1414,9 +1417,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             };
             f32x16 Kp[4] = {splat(c0[cx.c]), splat(c0[32 + cx.c]), splat(c0[64 + cx.c]), splat(c0[96 + cx.c])};
             mmb_oc_quad<4, 4, T16, SPLIT>(Kp[0], Kp[1], Kp[2], Kp[3], w0, nf, lane);
+            sprio<2, 2>();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int oc = q;
+                if (q == 1) sprio<1, 2>();
+                if (q == 3) sprio<0, 2>();
                 keys_of(Kp[q], vr_own, efA[oc], ssA[oc], mA[oc]);
                 mB[oc] = -INFINITY;
                 if constexpr (!SPLIT)
@@ -1438,7 +1444,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             DC_STAMP(21);
-            __syncthreads();
+            __syncthreads(); sprio<3>();
             __builtin_amdgcn_sched_barrier(0);
             DC_STAMP(12);
             // rescale factors of this wave's columns, through its own LDS strip (each lane needs 8 of them as row factors)
@@ -1485,9 +1491,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             };
             f32x16 Vp[4] = {splat(c1[cx.c]), splat(c1[32 + cx.c]), splat(c1[64 + cx.c]), splat(c1[96 + cx.c])};
             mmb_oc_quad<4, 4, T16, SPLIT>(Vp[0], Vp[1], Vp[2], Vp[3], w1, nf, lane);
+            sprio<2, 2>();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int oc = q;
+                if (q == 1) sprio<1, 2>();
+                if (q == 3) sprio<0, 2>();
                 pst[(wave * 4 + oc) * 64 + lane] = block_of(efA[oc], Vp[q], vr_own, scw + (0 * 4 + oc) * 32);
                 if (cx.hh == 0) ss[(wave * 4 + oc) * 32 + cx.c] = ssA[oc];
                 if constexpr (!SPLIT)
@@ -1498,7 +1507,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             }
             __builtin_amdgcn_sched_barrier(0);
             DC_STAMP(16);
-            __syncthreads();
+            __syncthreads(); sprio<3>();
             DC_STAMP(17);
             wg_write_record<NW>(recs_out, mx, pst, xp, ss, wave, lane, ub0, wm.nact, wm.Mu, wm.Tu, wg);
         } else {
@@ -1513,7 +1522,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            __syncthreads(); sprio<3>();
             __builtin_amdgcn_sched_barrier(0);
             DC_STAMP(12);
             float* rec = recs + (size_t)cx.g * 2 * DC_REC_FLOATS;
