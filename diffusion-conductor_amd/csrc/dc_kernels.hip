@@ -1694,6 +1694,9 @@ DEV void front_full(const XFrag<T16, false> (&nf)[4], const v8<T16>* __restrict_
 // y = softmax_keys(Q K^T) V per head for this wave's 32 queries against all keys of the clip.
 // wq: query projection image (LayerNorm affine and the 1/4 folded in), bias ftvec behind it (global memory).
 // kv: the clip's key-tile array; keys are valid for flat tokens in [key_lo, key_hi).
+#ifndef DC_FULL_PRIO
+#define DC_FULL_PRIO 1
+#endif
 template <class T16>
 DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const f32x16 (&h)[4],
                      const v8<T16>* __restrict__ wq, const v8<T16>* __restrict__ kv, int nkt, int tok0, int key_lo,
@@ -1791,6 +1794,15 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
                 f32x16 Snext = scores(fr, 0);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
+                    // progress priority across the tile's eight heads (dc_dev.h, sprio): the waves of a workgroup meet at a barrier per
+                    // key tile, and under oldest-first arbitration the older wave of a SIMD ran ahead and idled there - same box,
+                    // -4.2 % per loop (171.8 -> 164.7 ms, profiles/r04_ab_stage_prio.txt); -DDC_FULL_PRIO=0 builds without it
+#if DC_FULL_PRIO
+                    if (t == 0) __builtin_amdgcn_s_setprio(3);
+                    if (t == 1) __builtin_amdgcn_s_setprio(2);
+                    if (t == 2) __builtin_amdgcn_s_setprio(1);
+                    if (t == 3) __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
                     for (int sh = 0; sh < 2; ++sh) {
                         const int hd = 2 * t + sh;
