@@ -162,6 +162,7 @@ struct dc_sampler {
     int B = 0, T = 0, M = 0, G = 0;          // T: clip stride of the token space (the caller's frames per clip, padded: below)
     int Tx = 0;                              // the caller's frames per clip: x, xf, snapshots are [B][Tx][..]
     size_t cap_G = 0, cap_B = 0, cap_MP = 0, cap_steps = 0, cap_snap = 0, cap_kv = 0;
+    size_t cap_rec_floats = 0;      // floats behind d_recs
     int* d_length = nullptr;
     float* d_pp = nullptr;
     void *d_s_hi = nullptr, *d_s_lo = nullptr;
@@ -202,8 +203,8 @@ struct dc_sampler {
     const float** d_zslot = nullptr;    // device slot holding the base address of the per-iteration noise (DcUpdate::zslot)
     float* d_zstep = nullptr;       // library-generated draws of one iteration [B][Tx][P] (dc_sampler_set_step_noise_seed)
     size_t cap_zstep = 0;
-    unsigned long long noise_seed = 0;
-    bool noise_seed_set = false;
+    unsigned long long noise_seed = 0, noise_first = 0;      // Philox key; index of this sampler's first element in the whole batch's draw
+    bool noise_seed_set = false;                             // a seed is consumed by the loop that uses it
     int* d_status = nullptr;
     // Savitzky-Golay smoothing applied by the loop's final write (dc_sampler_set_smoothing; window 0 = off)
     int smooth_window = 0, smooth_order = 0, smooth_table_window = 0;     // (table_window: the hat matrix d_smooth_coef holds)
@@ -612,7 +613,11 @@ int ensure_workspace(dc_sampler* s, int B, int Tx) {
         if ((rc = dev_alloc(s, s->d_E, g * s->NT * 64 * 32))) return rc;
         if ((rc = dev_alloc(s, s->d_h, g * 4 * 64 * 64))) return rc;
         HIP_TRY(hipMemset(s->d_h, 0, g * 4 * 64 * 64));     // rows past M are read (never written) by the full-attention front half
-        if ((rc = dev_alloc(s, s->d_recs, g * 2 * DC_REC_FLOATS * 4))) return rc;
+        // unit records: per-group form 2 slots per group; workgroup-record forms two alternating buffers of 2 slots per workgroup,
+        // i.e. 4 * nwg records with nwg <= ceil(g / 4) (narrow flat units) or B * ceil(T / 128) (clip-aligned): both <= g for the
+        // T >= 256 those forms need - sized for the larger of the two explicitly, and checked against the launch form in enqueue_step
+        s->cap_rec_floats = std::max(g * 2, 4 * ((g + 3) / 4) + 8) * DC_REC_FLOATS;
+        if ((rc = dev_alloc(s, s->d_recs, s->cap_rec_floats * 4))) return rc;
         if ((rc = dev_alloc(s, s->d_nh_hi, g * 32 * 64 * 16))) return rc;
         if ((rc = dev_alloc(s, s->d_nh_lo, g * 32 * 64 * 16))) return rc;
         if (!s->cfg.no_eff && (rc = dev_alloc(s, s->d_recs_ca, (size_t)L * g * 2 * DC_REC_FLOATS * 4))) return rc;
@@ -657,8 +662,8 @@ int ensure_workspace(dc_sampler* s, int B, int Tx) {
         HIP_TRY(hipMemset(s->d_film_rate, 0, 2 * 1024 * sizeof(float)));      // 0 = not measured yet: equal shares
         if ((rc = dev_alloc(s, s->d_status, 16))) return rc;
         HIP_TRY(hipMemset(s->d_status, 0, 16));
-        if ((rc = dev_alloc(s, s->d_zslot, 16))) return rc;
-        HIP_TRY(hipMemset(s->d_zslot, 0, 16));
+        if ((rc = dev_alloc(s, s->d_zslot, 32))) return rc;
+        HIP_TRY(hipMemset(s->d_zslot, 0, 32));
         if ((rc = dev_alloc(s, s->d_iter, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_snap_cur, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_coef_cur, DC_COEF * 4))) return rc;
@@ -749,7 +754,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     if (loop_mode && (s->upd_flags & DC_UPD_ZSTEP))       // this iteration's draws (eta > 0, library-generated): consumed by the last layer's epilogue
         LAUNCH(K_NOISE, dc_launch_step_noise(st, s->d_zstep, (size_t)B * s->Tx * s->cfg.input_feats, 0, reinterpret_cast<const unsigned long long*>(s->d_zslot) + 1,
                                              iter_base, folded ? graph_step : 0,
-                                             folded ? nullptr : s->d_snap_cur));
+                                             folded ? nullptr : s->d_snap_cur, 0));
     if (!fuse_silu)
         LAUNCH(K_SILU, dc_launch_silu_emb(st, ff, sf, s->d_pp, s->h_model.temb, s->d_t_clip, s->d_s_hi, s->d_s_lo, G, T, B));
     static const bool want_stamps_film = getenv("DC_STAMPS") != nullptr;       // clock stamps land in stamp slots 28..31 of wave 7
@@ -785,6 +790,11 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
                          !getenv("DC_NO_LAYER16");
     const int upc = aligned ? (narrow ? upc_narrow : upc_wide) : 0;
     const int nwg = aligned ? B * upc : (narrow ? (G + 3) / 4 : (G + 7) / 8);
+    const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
+    // (the kernels write records at recs + rec_stride + wg * 2 * DC_REC_FLOATS: both alternating buffers must lie inside d_recs)
+    if ((wgr ? 2 * rec_stride : (size_t)G * 2 * DC_REC_FLOATS) > s->cap_rec_floats)
+        return fail(DC_ERR_INVALID, "unit records of this launch form (%zu floats) exceed the workspace (%zu)",
+                    wgr ? 2 * rec_stride : (size_t)G * 2 * DC_REC_FLOATS, s->cap_rec_floats);
     const int Tx = s->Tx;
     // k_embed_front rides in the FiLM GEMM's launch (wide flat units, non-split formats, no test hooks; DC_NO_FUSE_EMBED=1 and the
     // per-kernel profile pass keep the two launches): one kernel boundary less per step, -1.3 % per loop at bs=32
@@ -800,8 +810,13 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, aligned ? upc : 0, ss ? 1 : 0, 0};
     if (fuse_extra) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, upc, 0, 1};
     const DcUpdate upd{s->d_zslot, s->d_status, loop_mode ? s->upd_flags : 0, folded ? graph_step : -1, nullptr};
+#ifdef DC_E_CHUNK2
+    const int film_rounds = 3;           // experiment: 2 layers' FiLM tiles per launch, in front of their consumers (layer loop below)
+#else
+    const int film_rounds = s->NT / 16;
+#endif
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
-                                       s->NT / 16, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
+                                       film_rounds, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
                                        want_stamps_film ? s->d_stamps + 252 : nullptr,
                                        adapt ? s->d_film_rate + 1024 * s->film_rate_parity : nullptr,
                                        adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr, iter_base,
@@ -827,7 +842,6 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     else
         LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
                                               want_stamps_film ? s->d_stamps + 256 : nullptr, narrow, Tx, upc));
-    const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
     for (int l = s->dbg_first >= 0 ? s->dbg_first : 0; l < nl_run; ++l) {
         const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
         if (layer16) {
@@ -840,6 +854,16 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
                                               u16));
             continue;
         }
+#ifdef DC_E_CHUNK2
+        if (l > 0 && (l & 1) == 0) {
+            LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 3 * (l / 2),
+                                               3, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B, nullptr,
+                                               adapt ? s->d_film_rate + 1024 * s->film_rate_parity : nullptr,
+                                               adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr, iter_base,
+                                               s->h_model.film_w16, s->h_model.film_b16, nullptr, s->d_status));
+            s->film_rate_parity ^= 1;
+        }
+#endif
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src,
@@ -918,7 +942,8 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     // the status word reports on THIS loop: bits left by earlier work on the sampler (a dc_sampler_denoise, a loop nobody asked
     // about) must not fail it
     HIP_TRY(hipMemsetAsync(s->d_status, 0, 4, st));
-    HIP_TRY(dc_launch_set_ptr(st, s->d_zslot, zbase, s->noise_seed));
+    HIP_TRY(dc_launch_set_ptr(st, s->d_zslot, zbase, s->noise_seed, s->noise_first));
+    if (flags & DC_UPD_ZSTEP) s->noise_seed_set = false;       // a seed serves ONE loop: a later loop without a new one must not replay its draws
     if (!same_tables) {
         HIP_TRY(hipStreamSynchronize(st));          // an earlier call's copies out of the member vectors are done
         s->tables_S = 0;
@@ -1362,6 +1387,15 @@ int dc_sampler_ddim_loop_ex(dc_sampler* s, const float* d_noise, float* d_out, i
 int dc_sampler_set_step_noise_seed(dc_sampler* s, uint64_t seed) {
     if (!s) return fail(DC_ERR_INVALID, "null sampler");
     s->noise_seed = seed;
+    s->noise_first = 0;
+    s->noise_seed_set = true;
+    return DC_OK;
+}
+
+int dc_sampler_set_step_noise_seed_at(dc_sampler* s, uint64_t seed, uint64_t first_element) {
+    if (!s) return fail(DC_ERR_INVALID, "null sampler");
+    s->noise_seed = seed;
+    s->noise_first = first_element;
     s->noise_seed_set = true;
     return DC_OK;
 }
@@ -1369,7 +1403,7 @@ int dc_sampler_set_step_noise_seed(dc_sampler* s, uint64_t seed) {
 int dc_step_noise_fill(float* d_out, int64_t n, uint64_t seed, int32_t iteration, void* stream) {
     if (!d_out || n < 0 || iteration < 0) return fail(DC_ERR_INVALID, "bad step-noise arguments");
     if (n == 0) return DC_OK;
-    HIP_TRY(dc_launch_step_noise((hipStream_t)stream, d_out, (size_t)n, seed, nullptr, nullptr, iteration, nullptr));
+    HIP_TRY(dc_launch_step_noise((hipStream_t)stream, d_out, (size_t)n, seed, nullptr, nullptr, iteration, nullptr, 0));
     return DC_OK;
 }
 

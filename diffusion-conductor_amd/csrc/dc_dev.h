@@ -536,7 +536,16 @@ DEV void store_etile(f16x16* __restrict__ E, size_t tile, int lane, const f16x16
     }
     // written once and read by a later kernel: non-temporal stores keep the 708 MB per step from evicting the FiLM
     // weights (and later the layer kernels' own lines) from L2 - measured -1.8 % on the whole loop (tools/ab.sh)
-#ifdef DC_E_SC1
+#if defined(DC_DIAG_NO_ESTORE)
+    // diagnostic build (timing only, results invalid): conversion and lane swaps kept, the stores never execute (E is never 1)
+    if (reinterpret_cast<size_t>(E) == 1) {
+        __builtin_nontemporal_store(lo8, p);
+        __builtin_nontemporal_store(hi8, p + 64);
+    }
+#elif defined(DC_E_PLAIN)
+    p[0] = lo8;          // experiment: default cache policy for the FiLM tiles (a chunk that is meant to stay in the Infinity Cache)
+    p[64] = hi8;
+#elif defined(DC_E_SC1)
     asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(lo8) : "memory");
     asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p + 64), "v"(hi8) : "memory");
 #else
@@ -1333,12 +1342,19 @@ DEV void lds_dma16_nt(const void* gsrc, const char* lds_dst) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_dst);
     unsigned keep;
+#ifdef DC_E_PLAIN
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+#else
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+#endif
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(dst)
                  : "memory");
 }
 DEV void ering_issue(const f16x8* __restrict__ Eg, int kt, char* slot, int lane) {
+#ifdef DC_DIAG_NO_ELOAD
+    return;      // diagnostic build (timing only, results invalid): what the FiLM tile reads cost the layer kernel
+#endif
     const f16x8* gsrc = Eg + kt * 128 + lane;
     const f16x8* hsrc = Eg + (4 + kt) * 128 + lane;
     lds_dma16_nt(gsrc, slot);
@@ -1362,10 +1378,22 @@ DEV void epre_load(EPre& e, const f16x8* __restrict__ Eg, int lane) {
     for (int i = 0; i < 2; ++i) {
         const f16x8* pg = Eg + (2 + i) * 128 + lane;
         const f16x8* ph = Eg + (4 + 2 + i) * 128 + lane;
+#if defined(DC_DIAG_NO_ELOAD)
+        // (values that are not compile-time constants, so that the stylization arithmetic stays)
+        const f16x8 z = __builtin_bit_cast(f16x8, (f32x4){(float)lane, (float)i, 1.f, 2.f});
+        e.glo[i] = e.ghi[i] = e.hlo[i] = e.hhi[i] = z;
+        (void)pg; (void)ph;
+#elif defined(DC_E_PLAIN)
+        e.glo[i] = pg[0];
+        e.ghi[i] = pg[64];
+        e.hlo[i] = ph[0];
+        e.hhi[i] = ph[64];
+#else
         e.glo[i] = __builtin_nontemporal_load(pg);
         e.ghi[i] = __builtin_nontemporal_load(pg + 64);
         e.hlo[i] = __builtin_nontemporal_load(ph);
         e.hhi[i] = __builtin_nontemporal_load(ph + 64);
+#endif
     }
 }
 // The tracked prefetch without its price: the compiler guards the FIRST use of a load it knows about with a vmcnt wait, and

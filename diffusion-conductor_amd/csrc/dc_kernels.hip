@@ -39,9 +39,10 @@ __global__ void k_begin_step(int* __restrict__ iter, const int* __restrict__ t_o
 
 // end of a captured graph of k steps whose kernels indexed the iteration tables themselves (iter_base): next replay starts k later
 __global__ void k_advance_iter(int* __restrict__ iter, int k) { *iter += k; }
-__global__ void k_set_ptr(const float** slot, const float* p, unsigned long long seed) {      // [0]: base of the step noise; [1]: the generator's seed
-    slot[0] = p;
-    reinterpret_cast<unsigned long long*>(slot)[1] = seed;
+__global__ void k_set_ptr(const float** slot, const float* p, unsigned long long seed, unsigned long long first) {
+    slot[0] = p;                                                   // [0]: base of the step noise
+    reinterpret_cast<unsigned long long*>(slot)[1] = seed;         // [1]: the generator's seed
+    reinterpret_cast<unsigned long long*>(slot)[2] = first;        // [2]: index of z[0] in the whole batch's [B][T][P] draw (clip shards)
 }
 
 // ------------------------------------------------------------------------------------
@@ -49,7 +50,8 @@ __global__ void k_set_ptr(const float** slot, const float* p, unsigned long long
 // gaussian_diffusion.py:822), generated at the head of the step that consumes them - a [B][Tx][P] buffer instead of the
 // [S][B][Tx][P] tensor (6 GB at S = 1000, bs = 32).  Philox4x32-10 keyed by the seed, counter = (element quad, iteration);
 // Box-Muller on the four words.  Element e of iteration it depends on (seed, it, e) only: batch layout, graph form and
-// launch geometry do not enter.
+// launch geometry do not enter.  `first` (seed_slot[1], or the argument) is the index of z[0] in the WHOLE batch's draw: a rank that
+// samples clips [lo, hi) of a sharded batch passes lo*T*P and gets exactly the rows the unsharded run would have drawn for them.
 // ------------------------------------------------------------------------------------
 DEV void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
     const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
@@ -62,10 +64,14 @@ DEV void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
 __global__ __launch_bounds__(256) void k_step_noise(float* __restrict__ z, size_t n, unsigned long long seed,
                                                     const unsigned long long* __restrict__ seed_slot /* the seed, when given (a captured graph
                                                     must not bake it in) */, const int* __restrict__ iter_base, int step,
-                                                    const int* __restrict__ snap_cur) {
-    if (seed_slot) seed = *seed_slot;
+                                                    const int* __restrict__ snap_cur, unsigned long long first) {
+    if (seed_slot) {
+        seed = seed_slot[0];
+        first = seed_slot[1];
+    }
     const unsigned it = (unsigned)(iter_base ? step + *iter_base : (snap_cur ? snap_cur[1] : step));
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; 4 * q < n; q += (size_t)gridDim.x * 256) {
+    const size_t q0 = first >> 2, q1 = (first + n + 3) >> 2;          // the global element quads that cover [first, first + n)
+    for (size_t q = q0 + (size_t)blockIdx.x * 256 + threadIdx.x; q < q1; q += (size_t)gridDim.x * 256) {
         unsigned c[4] = {(unsigned)q, (unsigned)(q >> 32), it, 0x5eedu};
         unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
@@ -86,8 +92,10 @@ __global__ __launch_bounds__(256) void k_step_noise(float* __restrict__ z, size_
             o[2 * h + 1] = rad * sn;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (4 * q + i < n) z[4 * q + i] = o[i];
+        for (int i = 0; i < 4; ++i) {
+            const size_t e = 4 * q + i;
+            if (e >= first && e - first < n) z[e - first] = o[i];
+        }
     }
 }
 
@@ -766,7 +774,11 @@ DEV void film_gemm3_body(const v8<T16>* __restrict__ W, const float* __restrict_
                         o[4 * fb + h2] = r[0];            // registers 8 fb + 2 h2, +1     (block rows 0..3 | 8..11 of this lane half)
                         o[4 * fb + 2 + h2] = r[1];        // registers 8 fb + 4 + 2 h2, +1 (block rows 4..7 | 12..15)
                     }
+#ifdef DC_E_CHUNK2
+                store_etile(E, (size_t)(g0 + g) * 48 + (blk - 2 * round0) * 8 + 4 * ti + t, lane, __builtin_bit_cast(f16x16, o));
+#else
                 store_etile(E, (size_t)(g0 + g) * NT + blk * 8 + 4 * ti + t, lane, __builtin_bit_cast(f16x16, o));
+#endif
             }
         }
         my = nxt;
@@ -1140,7 +1152,13 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const W* af = reinterpret_cast<const W*>(lds + OFF_AF);
     const DcLayer& L = dm->layer[l];
     const bool last = l + 1 >= nl;
+#ifdef DC_E_CHUNK2
+    // experiment (EXPERIMENTS.md, round 5): the FiLM GEMM runs in four 2-layer chunks in front of their consumers into ONE aliased
+    // [G][48 tiles] buffer (177 MB at bs=32)
+    const f16x8* Eg = reinterpret_cast<const f16x8*>(E) + ((size_t)g * 48 + (size_t)(l & 1) * 24) * 128;
+#else
     const f16x8* Eg = reinterpret_cast<const f16x8*>(E) + ((size_t)g * NT + (size_t)l * 24) * 128;   // 3 blocks x 8 tiles
+#endif
     const W* acl = a_ca + (size_t)l * B * 16 * 64;
     const float* recs_in = recs + (size_t)(l & 1) * rec_stride;
     float* recs_out = recs + (size_t)((l + 1) & 1) * rec_stride;
@@ -1175,7 +1193,11 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if constexpr (use_ring) {
         ering_issue(Eg, 0, ring, lane);
         ering_issue(Eg, 1, ring + 4096, lane);
+#ifdef DC_DIAG_NO_ELOAD
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (no ring loads were issued: the 8 youngest operations are others)
+#else
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -2218,16 +2240,16 @@ hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k) {
     k_advance_iter<<<1, 1, 0, st>>>(iter, k);
     return hipGetLastError();
 }
-hipError_t dc_launch_set_ptr(hipStream_t st, const float** slot, const float* p, unsigned long long seed) {
-    k_set_ptr<<<1, 1, 0, st>>>(slot, p, seed);
+hipError_t dc_launch_set_ptr(hipStream_t st, const float** slot, const float* p, unsigned long long seed, unsigned long long first) {
+    k_set_ptr<<<1, 1, 0, st>>>(slot, p, seed, first);
     return hipGetLastError();
 }
 hipError_t dc_launch_step_noise(hipStream_t st, float* z, size_t n, unsigned long long seed, const unsigned long long* seed_slot, const int* iter_base,
-                                int step, const int* snap_cur) {
-    const size_t quads = (n + 3) / 4;
+                                int step, const int* snap_cur, unsigned long long first) {
+    const size_t quads = (n + 3) / 4 + 1;             // (a `first` that is not a multiple of 4 touches one quad more)
     const size_t nb = (quads + 255) / 256;
     const unsigned grid = (unsigned)(nb < 4096 ? nb : 4096);
-    k_step_noise<<<dim3(grid ? grid : 1), dim3(256), 0, st>>>(z, n, seed, seed_slot, iter_base, step, snap_cur);
+    k_step_noise<<<dim3(grid ? grid : 1), dim3(256), 0, st>>>(z, n, seed, seed_slot, iter_base, step, snap_cur, first);
     return hipGetLastError();
 }
 hipError_t dc_launch_begin_step(hipStream_t st, int* iter, const int* t_of_iter, const float* coef_of_t,

@@ -61,11 +61,12 @@ hipError_t dc_launch_layer16(hipStream_t st, int fmt, const DcModel* dm, int l, 
 hipError_t dc_launch_cond_af16(hipStream_t st, int fmt, const void* a_ca, void* a_ca16, int n_matrices);
 int dc_layer16_max_units(void);
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);
-hipError_t dc_launch_set_ptr(hipStream_t st, const float** slot /* 16 bytes */, const float* p, unsigned long long seed);
+hipError_t dc_launch_set_ptr(hipStream_t st, const float** slot /* 24 bytes: base, seed, first element */, const float* p, unsigned long long seed,
+                             unsigned long long first);
 // N(0, 1) draws of one DDIM iteration (Philox keyed by *seed_slot when given, else seed; iteration = step + *iter_base, else snap_cur[1],
-// else step) into z[0..n)
+// else step) into z[0..n); z[0] is element `first` (seed_slot[1] when a slot is given) of the whole batch's draw
 hipError_t dc_launch_step_noise(hipStream_t st, float* z, size_t n, unsigned long long seed, const unsigned long long* seed_slot, const int* iter_base,
-                                int step, const int* snap_cur);
+                                int step, const int* snap_cur, unsigned long long first);
 // diagnosis: OR DC_STATUS_F16_SAT into *status when the fp16 buffer e holds an inf / nan
 hipError_t dc_launch_scan_f16(hipStream_t st, const void* e, size_t bytes, int* status);
 // rec_stride: floats between the two alternating unit-record buffers (0 = single buffer, non-wgr)

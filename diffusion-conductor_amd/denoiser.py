@@ -153,6 +153,8 @@ class MotionTransformer(nn.Module):
         chunks that have landed - the 88 MB of a 32-clip batch (1.8 ms) hide behind the 4 ms of convolutions."""
         B, Tm, _ = mel_host.shape
         T = (Tm - 1) // 3 + 1
+        if device.index is None:              # "cuda" never equals a tensor's "cuda:0": the buffer and the stream would be re-made per call
+            device = torch.device("cuda", torch.cuda.current_device())
         cur = torch.cuda.current_stream(device)
         if getattr(self, "_copy_stream", None) is None or self._copy_stream.device != device:
             self._copy_stream = torch.cuda.Stream(device)

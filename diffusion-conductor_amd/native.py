@@ -24,7 +24,7 @@ EXPORTS = [
     "dc_kernel_name", "dc_kernel_count", "dc_sampler_workspace_bytes", "dc_sampler_clip_stride", "dc_sampler_debug_denoise",
     "dc_sampler_debug_read", "dc_sampler_debug_layer", "dc_savgol_coefficients", "dc_savgol_filter",
     "dc_ddim_coefficients_ex", "dc_sampler_ddim_loop_ex", "dc_sampler_status", "dc_sampler_set_smoothing",
-    "dc_sampler_set_step_noise_seed", "dc_step_noise_fill",
+    "dc_sampler_set_step_noise_seed", "dc_sampler_set_step_noise_seed_at", "dc_step_noise_fill",
 ]
 
 UPDATE_CLIP_DENOISED, UPDATE_EPSILON = 1, 2          # flags of dc_sampler_ddim_loop_ex
@@ -122,6 +122,7 @@ def lib():
     L.dc_sampler_ddim_loop_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, fp, C.c_int32, C.c_void_p, ip, C.c_int32,
                                           C.c_void_p, C.c_void_p]
     L.dc_sampler_set_step_noise_seed.argtypes = [C.c_void_p, C.c_uint64]
+    L.dc_sampler_set_step_noise_seed_at.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
     L.dc_step_noise_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_int32, C.c_void_p]
     L.dc_sampler_status.argtypes = [C.c_void_p, ip, C.c_int32]
     L.dc_sampler_set_smoothing.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
@@ -334,7 +335,8 @@ class NativeSampler:
     def ddim_loop(self, noise, coef, snap_iters=(), flags=0, step_noise=None, noise_seed=None):
         """coef [S, 4] (dc_sampler_ddim_loop: START_X, no clipping, eta = 0) or [S, 8] (dc_sampler_ddim_loop_ex with `flags` =
         UPDATE_* and, when any sigma != 0, either step_noise [S, B, T, P] on the device or noise_seed: the library then generates
-        each iteration's draws at the head of its step, dc_sampler_set_step_noise_seed)."""
+        each iteration's draws at the head of its step, dc_sampler_set_step_noise_seed; a pair (seed, first_element) places this
+        sampler's clips inside a larger batch's draw, dc_sampler_set_step_noise_seed_at).  A seed serves one loop."""
         import torch
         assert noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous()
         assert tuple(noise.shape) == (self.B, self.T, self.cfg.input_feats)
@@ -355,7 +357,10 @@ class NativeSampler:
                 assert tuple(step_noise.shape) == (S,) + tuple(noise.shape)
                 zp = step_noise.data_ptr()
             elif noise_seed is not None:
-                _check(lib().dc_sampler_set_step_noise_seed(self._h, C.c_uint64(int(noise_seed) & (2 ** 64 - 1))))
+                seed, first = noise_seed if isinstance(noise_seed, (tuple, list)) else (noise_seed, 0)
+                _check(lib().dc_sampler_set_step_noise_seed_at(self._h, C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint64(int(first))))
+            else:
+                assert not np.any(coef[:, 4] != 0), "eta > 0 needs step_noise or noise_seed (a seed serves one loop)"
             _check(lib().dc_sampler_ddim_loop_ex(self._h, noise.data_ptr(), out.data_ptr(), S, _fptr(coef), int(flags), zp, sip,
                                                  len(si), snp, self._stream()))
         return out, snaps

@@ -173,7 +173,7 @@ class GaussianDiffusion:
             self._native_coef[key] = native.ddim_coefficients(self.alphas_cumprod, key)
         return self._native_coef[key]
 
-    def _native_loop(self, model, img, mk, clip_denoised, eta, snap, step_noise, smooth=None):
+    def _native_loop(self, model, img, mk, clip_denoised, eta, snap, step_noise, smooth=None, step_noise_seed=None):
         """The captured loop on `model`'s sampler; returns (out, snaps).  Numeric health is checked once per call
         (`model.check_numerics`): a non-finite x0 under precision="auto" falls back to the bf16-range mode in a fresh sampler."""
         flags = (native.UPDATE_CLIP_DENOISED if clip_denoised else 0) | \
@@ -184,10 +184,13 @@ class GaussianDiffusion:
                 shape = (self.num_timesteps,) + tuple(img.shape)
                 z = step_noise.to(device=img.device, dtype=th.float32).contiguous()
                 assert tuple(z.shape) == shape, f"step_noise must be {shape}"
+            elif step_noise_seed is not None:
+                zseed = step_noise_seed
             else:
                 # the reference draws th.randn_like(x) once per step (gaussian_diffusion.py:822); so does the library, at the head
                 # of each step, from a seed taken off torch's default generator (torch.manual_seed makes a run reproducible) -
-                # never the whole [S, B, T, P] tensor up front (6 GB at S = 1000, bs = 32)
+                # never the whole [S, B, T, P] tensor up front (6 GB at S = 1000, bs = 32).  Ranks of a sharded run that seed
+                # torch alike must pass step_noise_seed=(seed, lo*T*P) instead, or every shard would add the same draws.
                 zseed = int(th.randint(0, 2 ** 62, (1,)).item())
         plain = flags == 0 and eta == 0.0
         coef = self.native_coefficients(None if plain else eta)
@@ -204,10 +207,13 @@ class GaussianDiffusion:
                 raise FloatingPointError(native.describe_status(st, model.active_precision))
 
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
-                         model_kwargs=None, device=None, progress=False, eta=0.0, idxs=[], step_noise=None, smooth=None):
+                         model_kwargs=None, device=None, progress=False, eta=0.0, idxs=[], step_noise=None, smooth=None,
+                         step_noise_seed=None):
         """gaussian_diffusion.py:871-915.  Returns the final sample, or when `idxs` is non-empty a
         dict {iteration: sample} for the listed iterations plus {num_timesteps: final}.
         `step_noise` (extension, eta > 0): [S, B, T, P], the draw for iteration i in place of th.randn_like.
+        `step_noise_seed` (extension, eta > 0, native loop only): seed of the library's own per-step draws, or (seed, first_element)
+        for a shard that holds clips [lo, hi) of a larger batch (first_element = lo*T*P: the rows the whole batch's draw gives them).
         `smooth` (extension): (window, order) of the Savitzky-Golay filter tools/visualization.py:126 applies to the result,
         folded into the loop's final write (native loop only)."""
         if self._fast_path_ok(model, denoised_fn, cond_fn):
@@ -221,7 +227,7 @@ class GaussianDiffusion:
                 mk = dict(mk)
                 mk["xf_proj"], mk["xf_out"] = model.encode_music(mk["text"], device)
             snap = sorted(int(i) for i in set(idxs) if 0 <= int(i) < self.num_timesteps)
-            out, snaps = self._native_loop(model, img, mk, bool(clip_denoised), float(eta), snap, step_noise, smooth)
+            out, snaps = self._native_loop(model, img, mk, bool(clip_denoised), float(eta), snap, step_noise, smooth, step_noise_seed)
             if len(idxs) == 0:
                 return out
             result = {it: snaps[k] for k, it in enumerate(snap)}

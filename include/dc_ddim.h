@@ -187,8 +187,15 @@ DC_EXPORT int dc_sampler_ddim_loop_ex(dc_sampler* s, const float* d_noise, float
  * Draw (seed, iteration, element) does not depend on the batch layout or launch form.  The reference draws with
  * th.randn_like on its own device generator (:822), which no other implementation can reproduce - parity tests pass the
  * draws explicitly (d_step_noise); dc_step_noise_fill writes the library's draws of one iteration into a caller buffer
- * (n = B*T*P elements), so a [S,B,T,P] tensor that reproduces a seeded run can be assembled. */
+ * (n = B*T*P elements), so a [S,B,T,P] tensor that reproduces a seeded run can be assembled.
+ * A seed serves ONE loop: the dc_sampler_ddim_loop_ex that uses it consumes it, and a later loop with sigma != 0, no tensor and no
+ * new seed fails with DC_ERR_INVALID instead of replaying the same draws.
+ * dc_sampler_set_step_noise_seed_at: the same for a sampler that holds clips [lo, hi) of a larger batch (one rank of a sharded
+ * run, sharding.py): first_element = lo*T*P is the index of its first element in the whole batch's [B,T,P] draw, so that every
+ * rank seeded alike draws exactly the rows the unsharded run (gaussian_diffusion.py:822: ONE th.randn_like over the batch) gives
+ * its clips - never the same rows on every rank. */
 DC_EXPORT int dc_sampler_set_step_noise_seed(dc_sampler* s, uint64_t seed);
+DC_EXPORT int dc_sampler_set_step_noise_seed_at(dc_sampler* s, uint64_t seed, uint64_t first_element);
 DC_EXPORT int dc_step_noise_fill(float* d_out, int64_t n, uint64_t seed, int32_t iteration, void* stream);
 
 /* Numeric health of the sampler's LAST sampling loop (the word is reset when a loop starts), plus whatever a

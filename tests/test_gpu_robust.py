@@ -269,6 +269,23 @@ def test_seeded_step_noise_equals_the_explicit_tensor():
     print(f"library draws: mean {zc.mean():.4f} std {zc.std():.4f} kurtosis {((zc - zc.mean()) ** 4).mean() / zc.var() ** 2:.3f}")
     assert abs(float(zc.mean())) < 0.01 and abs(float(zc.std()) - 1.0) < 0.01 and abs(float(((zc - zc.mean()) ** 4).mean() / zc.var() ** 2) - 3.0) < 0.1
     assert not torch.equal(z[0], z[1]) and abs(float((zc[0] * zc[1]).mean())) < 0.02
+    # a seed serves one loop: without a new one (and without a tensor) the next eta > 0 loop fails instead of replaying the draws
+    with pytest.raises(AssertionError, match="noise_seed"):
+        nat.ddim_loop(noise, coef)
+    lib, Cc = native.lib(), __import__("ctypes")
+    out = torch.empty_like(noise)
+    rc = lib.dc_sampler_ddim_loop_ex(nat._h, noise.data_ptr(), out.data_ptr(), S, coef.ctypes.data_as(Cc.POINTER(Cc.c_float)), 0, None, None, 0, None,
+                                     nat._stream())
+    assert rc == -1 and b"seed" in lib.dc_last_error()          # DC_ERR_INVALID
+    # a shard of a larger batch draws the rows the whole batch's draw gives its clips (identically seeded ranks)
+    if B >= 2:
+        lo = 1
+        nat1 = m.set_conditioning(xfp[lo:], xfo[lo:], length[lo:])
+        shard, _ = nat1.ddim_loop(noise[lo:].contiguous(), coef, noise_seed=(1234, lo * T * 26))
+        same_rows, _ = nat1.ddim_loop(noise[lo:].contiguous(), coef, noise_seed=1234)
+        torch.cuda.synchronize()
+        assert torch.equal(shard, seeded[lo:]) and not torch.equal(same_rows, seeded[lo:])
+        nat = m.set_conditioning(xfp, xfo, length)
     # through the Python surface: torch.manual_seed makes an eta > 0 run reproducible
     kw = dict(noise=noise, clip_denoised=False, progress=False, eta=0.5,
               model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.LongTensor(length)})

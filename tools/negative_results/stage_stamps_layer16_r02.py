@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-stage time (us) of the 16 waves of one k_layer16 workgroup (layer 3), from s_memrealtime stamps.
+"""(round 2, rejected 16-waves-per-unit kernel - not the shipped k_layer16: see tools/stage_stamps16.py)  Diagnostic: per-stage time (us) of the 16 waves of one k_layer16 workgroup (layer 3), from s_memrealtime stamps.
 Run on the GPU box:  DC_LAYER16=1 DC_STAMPS=1 DC_DISABLE_GRAPH=1 python tools/stage_stamps16.py"""
 import os, sys
 import numpy as np, torch
