@@ -163,6 +163,8 @@ struct dc_sampler {
     int Tx = 0;                              // the caller's frames per clip: x, xf, snapshots are [B][Tx][..]
     size_t cap_G = 0, cap_B = 0, cap_MP = 0, cap_steps = 0, cap_snap = 0, cap_kv = 0;
     size_t cap_rec_floats = 0;      // floats behind d_recs
+    std::vector<int> len_dev;       // the clip lengths d_length holds (dc_sampler_set_conditioning), valid while len_dev_ptr == d_length
+    const int* len_dev_ptr = nullptr;
     int* d_length = nullptr;
     float* d_pp = nullptr;
     void *d_s_hi = nullptr, *d_s_lo = nullptr;
@@ -196,8 +198,18 @@ struct dc_sampler {
 
     // graph cache: one per (B, T, steps_per_graph, launch form, update options)
     hipGraphExec_t graph = nullptr;
-    int graph_B = 0, graph_T = 0, graph_K = 0;
+    int graph_B = 0, graph_T = 0, graph_Tx = 0, graph_K = 0;
     unsigned long long graph_form = 0;     // form_key() of the captured launches
+    // ... and up to three more for other batch shapes (a dataset's last, smaller batch; a service whose batch size varies): a shape
+    // seen before replays its graph instead of paying a capture (tens of ms) every time the shape changes.  The workspace's
+    // addresses are baked into every captured graph, so whatever re-allocates a buffer drops them all (drop_graph).
+    struct GraphSlot {
+        hipGraphExec_t exec;
+        int B, T, Tx, K;
+        unsigned long long form;
+        bool folded;
+    };
+    std::vector<GraphSlot> graph_park;
     // DDIM update options of the loop being enqueued (dc_sampler_ddim_loop_ex) and the device status word
     int upd_flags = 0;              // DC_UPD_* of the loop being enqueued (incl. the internal NOISY / ZSTEP bits)
     const float** d_zslot = nullptr;    // device slot holding the base address of the per-iteration noise (DcUpdate::zslot)
@@ -211,6 +223,7 @@ struct dc_sampler {
     float* d_smooth_coef = nullptr;
 
     dc_music* music = nullptr;   // MusicEncoder (built when its parameters were supplied)
+    bool host_only = false;      // -DDC_HOST_SANITIZE builds without a device: the host half only (tests/test_host_sanitize.py)
 
     Prof prof;
     int dbg_layers = -1, dbg_stage = 0;   // test hooks (dc_sampler_debug_denoise)
@@ -242,6 +255,8 @@ int dev_alloc(dc_sampler* s, P*& p, size_t bytes) {
 }
 
 void drop_graph(dc_sampler* s) {
+    for (auto& g : s->graph_park) hipGraphExecDestroy(g.exec);
+    s->graph_park.clear();
     if (s->graph) {
         hipGraphExecDestroy(s->graph);
         s->graph = nullptr;
@@ -576,6 +591,14 @@ int build_model(dc_sampler* s) {
     m.num_frames = c.num_frames;
     m.max_timesteps = nt;
 
+    if (s->host_only) {          // sanitizer build without a device: the arena stays on the host, the model's pointers point into it
+        free(s->d_arena);
+        s->arena_bytes = A.host.size();
+        s->d_arena = (uint8_t*)malloc(s->arena_bytes);
+        memcpy(s->d_arena, A.host.data(), s->arena_bytes);
+        for (auto& f : O.fix) *f.first = s->d_arena + f.second;
+        return DC_OK;
+    }
     if (s->d_arena) hipFree(s->d_arena);
     s->arena_bytes = A.host.size();
     HIP_TRY(hipMalloc((void**)&s->d_arena, s->arena_bytes));
@@ -668,7 +691,6 @@ int ensure_workspace(dc_sampler* s, int B, int Tx) {
         if ((rc = dev_alloc(s, s->d_snap_cur, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_coef_cur, DC_COEF * 4))) return rc;
     }
-    if (s->B != B || s->T != T || s->Tx != Tx) drop_graph(s);
     s->B = B;
     s->T = T;
     s->Tx = Tx;
@@ -974,8 +996,29 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     } else {
         const int K = steps_per_graph(S);
         const unsigned long long fk = form_key(s);
-        if (!s->graph || s->graph_B != s->B || s->graph_T != s->T || s->graph_K != K || s->graph_form != fk) {
-            drop_graph(s);
+        auto current = [&]() {
+            return s->graph && s->graph_B == s->B && s->graph_T == s->T && s->graph_Tx == s->Tx && s->graph_K == K && s->graph_form == fk;
+        };
+        if (!current()) {       // park the graph at hand, take this shape's from the park when it has been captured before
+            if (s->graph) {
+                if (s->graph_park.size() >= 3) {
+                    hipGraphExecDestroy(s->graph_park.front().exec);
+                    s->graph_park.erase(s->graph_park.begin());
+                }
+                s->graph_park.push_back({s->graph, s->graph_B, s->graph_T, s->graph_Tx, s->graph_K, s->graph_form, s->graph_folded});
+                s->graph = nullptr;
+            }
+            for (size_t i = 0; i < s->graph_park.size(); ++i) {
+                const auto& g = s->graph_park[i];
+                if (g.B == s->B && g.T == s->T && g.Tx == s->Tx && g.K == K && g.form == fk) {
+                    s->graph = g.exec;
+                    s->graph_B = g.B, s->graph_T = g.T, s->graph_Tx = g.Tx, s->graph_K = g.K, s->graph_form = g.form, s->graph_folded = g.folded;
+                    s->graph_park.erase(s->graph_park.begin() + i);
+                    break;
+                }
+            }
+        }
+        if (!current()) {
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             for (int i = 0; i < K; ++i)
@@ -999,6 +1042,7 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
             if (e != hipSuccess) return fail(DC_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
             s->graph_B = s->B;
             s->graph_T = s->T;
+            s->graph_Tx = s->Tx;
             s->graph_K = K;
             s->graph_form = fk;
         }
@@ -1102,6 +1146,23 @@ int dc_sampler_create(const dc_config* cfg, dc_sampler** out) {
     if (cfg->precision < DC_PREC_BF16 || cfg->precision > DC_PREC_FP16) return fail(DC_ERR_INVALID, "unknown precision %d", cfg->precision);
     if (cfg->max_timesteps < 1) return fail(DC_ERR_INVALID, "max_timesteps must be >= 1");
     int ndev = 0;
+#ifdef DC_HOST_SANITIZE
+    // Sanitizer build of the HOST half (address + undefined-behaviour sanitizers on the CPU; GPU sanitizers are not available on this
+    // pool): without a device the sampler is created "host only" - parameter store, validation, weight folding and packing into the
+    // arena run as in production, nothing is uploaded or launched, and every entry point that needs the device fails with NO_DEVICE.
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        dc_sampler* h = new dc_sampler();
+        h->cfg = *cfg;
+        h->host_only = true;
+        h->num_cu = 256;
+        h->split_small = cfg->precision == DC_PREC_MIXED || cfg->precision == DC_PREC_BF16X3;
+        h->split_film = cfg->precision == DC_PREC_BF16X3;
+        h->small_fmt = cfg->precision == DC_PREC_FP16 ? 1 : 0;
+        h->film_fmt = (cfg->precision == DC_PREC_FP16 || cfg->precision == DC_PREC_MIXED) ? 1 : 0;
+        *out = h;
+        return DC_OK;
+    }
+#endif
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(DC_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(DC_ERR_INVALID, "device %d out of range (0..%d)", cfg->device, ndev - 1);
     HIP_TRY(hipSetDevice(cfg->device));
@@ -1128,6 +1189,11 @@ int dc_sampler_create(const dc_config* cfg, dc_sampler** out) {
 
 void dc_sampler_destroy(dc_sampler* s) {
     if (!s) return;
+    if (s->host_only) {          // (sanitizer build without a device: the arena is host memory)
+        free(s->d_arena);
+        delete s;
+        return;
+    }
     hipSetDevice(s->cfg.device);
     hipDeviceSynchronize();
     drop_graph(s);
@@ -1171,11 +1237,16 @@ int dc_sampler_finalize_params(dc_sampler* s) {
     if (!s) return fail(DC_ERR_INVALID, "null sampler");
     for (const auto& r : required_params(s->cfg))
         if (!find(s, r.name)) return fail(DC_ERR_PARAM, "missing parameter '%s'", r.name.c_str());
-    HIP_TRY(hipSetDevice(s->cfg.device));
+    if (!s->host_only) HIP_TRY(hipSetDevice(s->cfg.device));
     drop_graph(s);
     s->cap_G = 0;   // NT may have changed: force workspace rebuild
     int rc = build_model(s);
     if (rc) return rc;
+    if (s->host_only) {          // (the music encoder's weights are folded straight into device memory: not built without one)
+        s->finalized = true;
+        s->cond_set = false;
+        return DC_OK;
+    }
     if (s->music) {
         dc_music_destroy(s->music);
         s->music = nullptr;
@@ -1198,6 +1269,7 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
     if (!d_xf_proj || !d_xf_out || B < 1 || T < 32) return fail(DC_ERR_INVALID, "bad conditioning arguments (need B >= 1, T >= 32)");
     if (clip_stride(s, B, T) / 32 + 2 > 128) return fail(DC_ERR_UNSUPPORTED, "T=%d: the attention combine holds at most 128 token groups per clip (T <= 4032)", T);
     if (T > s->cfg.num_frames) return fail(DC_ERR_INVALID, "T=%d exceeds num_frames=%d rows of sequence_embedding", T, s->cfg.num_frames);
+    if (s->host_only) return fail(DC_ERR_NO_DEVICE, "host-only sampler (sanitizer build without a device)");
     HIP_TRY(hipSetDevice(s->cfg.device));
     int rc;
     if ((rc = ensure_workspace(s, B, T))) return rc;
@@ -1212,7 +1284,16 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
     const int M = s->M, G = s->G, L = s->cfg.num_layers;
     const int Tx = T;
     T = s->T;                         // clip stride of the token space from here on (>= Tx)
-    HIP_TRY(hipMemcpyAsync(s->d_length, len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    // The clip lengths are uploaded only when they differ from what the device holds (a service or an evaluation run passes the same
+    // ones batch after batch): the upload reads host memory and needs the stream synchronisation below, which would otherwise make
+    // every call wait for the previous batch's sampling loop (evaluate.py keeps the GPU's queue full).
+    const bool same_len = s->len_dev == len && s->len_dev_ptr == s->d_length;
+    if (!same_len) {
+        HIP_TRY(hipStreamSynchronize(st));                 // an earlier upload out of the member vector is done
+        s->len_dev = len;
+        s->len_dev_ptr = nullptr;
+        HIP_TRY(hipMemcpyAsync(s->d_length, s->len_dev.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    }
     // emb's step-invariant term: linear(xf_proj) as fp32 operand image
     HIP_TRY(dc_launch_cond_embed(st, 0, d_xf_proj, s->h_model.lin_wt, s->h_model.lin_b, s->d_pp, nullptr, nullptr, M, G, T, Tx));
     // cross-attention: linear(xf_out) -> text_norm (affine folded into K/V) as bf16 hi / lo operand images -> per-layer K,V -> A_ca
@@ -1225,7 +1306,10 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
         HIP_TRY(dc_launch_attn_combine(st, s->small_fmt, s->d_recs_ca, s->d_a_ca, T, G, B, L, 32));
         if (!s->split_small) HIP_TRY(dc_launch_cond_af16(st, s->small_fmt, s->d_a_ca, s->d_a_ca16, L * B));      // (small batches: dc_layer16.hip)
     }
-    HIP_TRY(hipStreamSynchronize(st));   // `len` is host memory
+    if (!same_len) {
+        HIP_TRY(hipStreamSynchronize(st));   // the lengths came out of host memory
+        s->len_dev_ptr = s->d_length;
+    }
     s->cond_set = true;
     return sync_out(s, user);
 }

@@ -30,9 +30,17 @@ DEV float xhalf_sum(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// v_max_f32 as the hardware does it.  fmaxf() makes hipcc canonicalise both inputs first (v_max_f32 x, x, x - two extra instructions per
+// maximum, and a third for a negated result): the values compared here are accumulators or maxima of accumulators, where a signalling
+// NaN cannot occur and a quiet one propagates to the result either way (it ends in the status word's NONFINITE bit).
+DEV float max2(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 DEV float xhalf_max(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    return max2(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 DEV float exp2f_fast(float x) { return __builtin_amdgcn_exp2f(x); }     // v_exp_f32
@@ -259,7 +267,7 @@ DEV void ln_stats(const f32x16 (&x)[NT], float& mean, float& rstd) {
     const float q = xhalf_sum(q2.x + q2.y);
     mean = s * (1.f / (32 * NT));
     const float var = fmaxf(fmaf(-mean, mean, q * (1.f / (32 * NT))), 0.f);
-    rstd = rsqrtf(var + 1e-5f);
+    rstd = __builtin_amdgcn_rsqf(var + 1e-5f);       // v_rsq_f32 (1 ulp; var + eps >= 1e-5 is never subnormal: rsqrtf()'s range scaling - five more instructions - buys nothing)
 }
 // operand fragments of the normalised x (the LayerNorm affine is folded into the projection that follows)
 template <class T16, bool SPLIT>
@@ -296,7 +304,7 @@ DEV float absmax3(float a, float b, float c) {    // max(|a|, |b|, |c|)
     return d;
 }
 DEV float max8(const f32x16& q, int o) {
-    return max3(max3(q[o], q[o + 1], q[o + 2]), max3(q[o + 3], q[o + 4], q[o + 5]), fmaxf(q[o + 6], q[o + 7]));
+    return max3(max3(q[o], q[o + 1], q[o + 2]), max3(q[o + 3], q[o + 4], q[o + 5]), max2(q[o + 6], q[o + 7]));
 }
 DEV void softmax_heads_ft(f32x16 (&q)[4]) {
 #pragma unroll
@@ -701,10 +709,12 @@ DEV void wg_put_maxes(const f32x16 (&K)[4], const GroupCtx& cx, const RowRange (
 template <int NW = 8>
 DEV float wg_colmax(const float* mx, int oc, int sl, int c) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(mx + ((oc * 2 + sl) * 32 + c) * NW);
-    float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+    float m;
     if constexpr (NW == 8) {
         const f32x4 b = *reinterpret_cast<const f32x4*>(mx + ((oc * 2 + sl) * 32 + c) * 8 + 4);
-        m = fmaxf(m, fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+        m = max3(max3(a[0], a[1], a[2]), max3(a[3], b[0], b[1]), max2(b[2], b[3]));
+    } else {
+        m = max2(max3(a[0], a[1], a[2]), a[3]);
     }
     return m == -INFINITY ? 0.f : m;
 }
@@ -836,7 +846,10 @@ DEV void wg_combine_attn(const float* __restrict__ recs, v8<T16>* af, float* scr
         float mstar = -INFINITY;
 #pragma unroll
         for (int k = 0; k < PRE; ++k)
-            if (sr[k] > 0.f) mstar = fmaxf(mstar, mr[k]);
+        {
+            const float cand = max2(mstar, mr[k]);      // (unconditional + a select: an asm statement under `if` becomes a branch)
+            mstar = sr[k] > 0.f ? cand : mstar;
+        }
         for (int k = PRE; k < na; ++k) {          // clips longer than 9 workgroups (T > 2048)
             const float* R = rec_of(ba, a_lo + k);
             if (R[128 + f] > 0.f) mstar = fmaxf(mstar, R[f]);
@@ -951,7 +964,10 @@ DEV void wg_combine_attn_narrow(const float* __restrict__ recs, v8<T16>* af, flo
         float mstar = -INFINITY;
 #pragma unroll
         for (int k = 0; k < PRE; ++k)
-            if (sr[k] > 0.f) mstar = fmaxf(mstar, mr[k]);
+        {
+            const float cand = max2(mstar, mr[k]);      // (unconditional + a select: an asm statement under `if` becomes a branch)
+            mstar = sr[k] > 0.f ? cand : mstar;
+        }
         for (int k = PRE; k < na; ++k) {                       // clips longer than 16 units (T > 1920)
             const float* R = rec_of(ba, a_lo + k);
             if (R[128 + f] > 0.f) mstar = fmaxf(mstar, R[f]);
@@ -1049,21 +1065,39 @@ using namespace dc;
 // LDS-DMA of one 1-KiB fragment: lane i's 16 bytes at gsrc land at lds_dst + 16*i.  Issued through inline asm
 // on purpose: for the builtin form hipcc inserts `s_waitcnt vmcnt(0)` before the next LDS read of ANY address
 // (it assumes the DMA may alias), which would turn every "one stage ahead" prefetch into a synchronous copy.
-// All waits for these copies are explicit (stage_sync, the FiLM ring); M0 is saved/restored in the statement.
+// All waits for these copies are explicit (stage_sync, the FiLM ring).  The statements overwrite M0 (the DMA's LDS base) and do NOT
+// restore it: hipcc treats M0 as reserved (a clobber is refused with a warning) and itself touches it only for indirect register
+// indexing, LDS-direct and message instructions, none of which these translation units contain -
+// tests/test_host_logic.py::test_production_layer_kernel_has_no_register_spills checks the ISA for it.
+// Round 5 (instruction diet, profiles/r05_census.md): the LDS address is the low half of the generic pointer (a generic LDS pointer is
+// aperture << 32 | offset; the addrspace cast the old form used costs a null check of 5 scalar instructions per copy), M0 is no longer
+// saved and restored around every copy, and the *_s forms take a wave-uniform base in SGPRs plus ONE per-lane byte offset, so that a
+// stage image costs scalar adds instead of a 64-bit vector add per fragment.
+DEV unsigned lds_addr(const char* p) { return (unsigned)(size_t)p; }
 DEV void lds_dma16(const void* gsrc /*per-lane*/, const char* lds_dst /*wave-uniform*/) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane(
-        (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_dst);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(dst)
-                 : "memory");
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(lds_dst));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(dst) : "memory");
+}
+template <int OFF = 0, bool NT = false>
+DEV void lds_dma16_s(const void* sbase /*wave-uniform*/, unsigned voff /*per-lane byte offset*/, unsigned lds_dst /*wave-uniform LDS address*/) {
+    // OFF: the instruction's immediate offset - it is added to the global address AND to the LDS address
+    static_assert(OFF >= 0 && OFF < 4096, "immediate offset field");
+    if constexpr (NT)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3 nt" : : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(OFF) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" : : "v"(voff), "s"(sbase), "s"(lds_dst), "n"(OFF) : "memory");
 }
 
 template <int NW>
-DEV void stage_frags(const void* __restrict__ src, char* dst, int nfrags, int wave, int lane) {
-    const bf16x8* s = reinterpret_cast<const bf16x8*>(src);
-    for (int f = wave; f < nfrags; f += NW) lds_dma16(s + (size_t)f * 64 + lane, dst + f * 1024);
+DEV void stage_frags(const void* __restrict__ src /*wave-uniform*/, char* dst, int nfrags, int wave /*wave-uniform*/, int lane) {
+    const char* s = reinterpret_cast<const char*>(src) + (size_t)wave * 1024;
+    unsigned d = __builtin_amdgcn_readfirstlane(lds_addr(dst)) + wave * 1024;
+    const unsigned voff = lane * 16;
+    for (int f = wave; f < nfrags; f += NW) {
+        lds_dma16_s(s, voff, d);
+        s += NW * 1024;
+        d += NW * 1024;
+    }
 }
 // Progress priority: a wave lowers its issue priority as it advances through a stage (s_setprio 3 at the stage's head ... 0 near its
 // closer), so that of the two waves of a SIMD the one that is BEHIND wins arbitration and both reach the closer together - under the
@@ -1132,7 +1166,7 @@ struct RowStats {
         const float ss = xhalf_sum(s.x + s.y), qq = xhalf_sum(q.x + q.y);
         const float mean = ss * (1.f / 128.f);
         const float var = fmaxf(fmaf(-mean, mean, qq * (1.f / 128.f)), 0.f);
-        rstd = rsqrtf(var + 1e-5f) * 1.4426950408889634f;
+        rstd = __builtin_amdgcn_rsqf(var + 1e-5f) * 1.4426950408889634f;
         shift = -mean * rstd;
     }
 };
@@ -1338,29 +1372,29 @@ DEV void styl_accumulate_pf(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rs
 // Per-wave FiLM tile ring in LDS: two 4-KiB slots, each holding one k-tile's (G'-1, H') tile pair.
 // FiLM tiles are read exactly once: non-temporal, so that 88 MB per layer do not flush the weights, attention fragments and
 // records the workgroups of an XCD share through L2 (same-box A/B: -4 % k_layer, -3.5 % loop)
-DEV void lds_dma16_nt(const void* gsrc, const char* lds_dst) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane(
-        (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds_dst);
-    unsigned keep;
-#ifdef DC_E_PLAIN
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-#else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-#endif
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(dst)
-                 : "memory");
-}
-DEV void ering_issue(const f16x8* __restrict__ Eg, int kt, char* slot, int lane) {
+DEV void ering_issue(const f16x8* __restrict__ Eg /*wave-uniform: the block's 8 tiles for this wave's group*/, int kt, char* slot, int lane) {
 #ifdef DC_DIAG_NO_ELOAD
     return;      // diagnostic build (timing only, results invalid): what the FiLM tile reads cost the layer kernel
 #endif
-    const f16x8* gsrc = Eg + kt * 128 + lane;
-    const f16x8* hsrc = Eg + (4 + kt) * 128 + lane;
-    lds_dma16_nt(gsrc, slot);
-    lds_dma16_nt(gsrc + 64, slot + 1024);
-    lds_dma16_nt(hsrc, slot + 2048);
-    lds_dma16_nt(hsrc + 64, slot + 3072);
+    const unsigned voff = lane * 16, d = __builtin_amdgcn_readfirstlane(lds_addr(slot));
+    const f16x8* gsrc = Eg + kt * 128;
+    const f16x8* hsrc = Eg + (4 + kt) * 128;
+#ifdef DC_E_PLAIN
+    constexpr bool nt = false;
+#else
+    constexpr bool nt = true;
+#endif
+#ifdef DC_DMA_NO_IMM          // (A/B hedge: no immediate offsets)
+    lds_dma16_s<0, nt>(gsrc, voff, d);
+    lds_dma16_s<0, nt>(gsrc + 64, voff, d + 1024);
+    lds_dma16_s<0, nt>(hsrc, voff, d + 2048);
+    lds_dma16_s<0, nt>(hsrc + 64, voff, d + 3072);
+#else
+    lds_dma16_s<0, nt>(gsrc, voff, d);            // (the immediate offset moves the global AND the LDS address: the second half of a
+    lds_dma16_s<1024, nt>(gsrc, voff, d);         // tile lands 1 KiB behind the first without a second LDS base)
+    lds_dma16_s<0, nt>(hsrc, voff, d + 2048);
+    lds_dma16_s<1024, nt>(hsrc, voff, d + 2048);
+#endif
 }
 // same StylizationBlock with the FiLM tiles of k-tiles 0,1 arriving through the ring (issued a stage ago) and those of
 // k-tiles 2,3 prefetched into registers at the start of the preceding stage (EPre; they landed with that stage's closing

@@ -6,10 +6,10 @@ walk a dataset directory of ``<clip id>/mel.npy`` (``[5400,128]``) + ``<clip id>
 on-disk format of the reference's README.md:53-84), sample every clip and report the per-clip MSE the way
 eval_new.py does (``np.mean((pred - gt) ** 2)``, summed in directory order, then divided by the clip count).
 
-Here the clips go through the sampler ``batch_size`` at a time: mel files are read by a background thread
-into pinned host buffers while the GPU samples the previous batch, the batch is sharded over the ranks of an
-initialised ``torch.distributed`` group by ``DDPMTrainer.generate_music_motion``, and the poses come back
-with one copy.  ``smooth_motion`` is tools/visualization.py:20-26 (Savitzky-Golay, kernel 19, order 5 at
+Here the clips go through the sampler ``batch_size`` at a time: mel files and noise are prepared by background
+threads in pinned host buffers while the GPU samples the previous batch, the batch is sharded over the ranks of an
+initialised ``torch.distributed`` group by ``DDPMTrainer.generate_music_motion``, the poses come back with one
+copy behind an event and are scored on a third thread - the GPU's queue never runs dry (tools/time_evaluate.py).  ``smooth_motion`` is tools/visualization.py:20-26 (Savitzky-Golay, kernel 19, order 5 at
 :126) on the GPU.
 """
 from __future__ import annotations
@@ -53,19 +53,37 @@ def clip_noise(seed, index, T, dim_pose):
     return torch.randn(T, dim_pose, generator=g)
 
 
-class _Prefetcher:
-    """Reads the next batch's .npy files into a pinned buffer on a background thread."""
+def _read_npy_into(path, dst):
+    """One clip's mel.npy into a row of the pinned batch buffer with a single copy (np.load would allocate an array first and the
+    batch of 32 x 2.8 MB would be copied twice per 40 ms of GPU work)."""
+    m = np.load(path, mmap_mode="r")
+    if m.shape != tuple(dst.shape):
+        raise ValueError(f"{os.path.basename(os.path.dirname(path))}/mel.npy has shape {m.shape}, expected {tuple(dst.shape)}")
+    np.copyto(dst.numpy(), m, casting="same_kind")
 
-    def __init__(self, root, ids, batch_size, mel_shape):
+
+class _Prefetcher:
+    """Prepares the next batch on background threads while the GPU samples the current one: the .npy files into a pinned buffer
+    (a small pool reads the clips of a batch side by side), the ground-truth motions, and - `noise=(seed, T, dim_pose)` - every
+    clip's x_T into a second pinned buffer.  Two slots; `start(k, after=event)` waits for `event` (the GPU is done with the slot's
+    previous batch) before it overwrites the slot."""
+
+    def __init__(self, root, ids, batch_size, mel_shape, noise=None, workers=4):
         self.root, self.ids, self.bs = root, ids, batch_size
         pin = torch.cuda.is_available()
-        self.buf = [torch.empty((batch_size,) + mel_shape, dtype=torch.float32, pin_memory=pin) for _ in range(2)]
+        self.buf = [torch.empty((batch_size,) + tuple(mel_shape), dtype=torch.float32, pin_memory=pin) for _ in range(2)]
+        self.noise_spec = noise
+        self.nbuf = [torch.empty((batch_size, noise[1], noise[2]), dtype=torch.float32, pin_memory=pin) for _ in range(2)] if noise else None
+        self.workers = max(1, int(workers))
         self.result = None
+        self.noise = None
         self.error = None
         self.thread = None
 
-    def _load(self, k, slot):
+    def _load(self, k, slot, after):
         try:
+            if after is not None:
+                after.synchronize()
             self._load_batch(k, slot)
         except BaseException as e:      # handed to the consumer: a dead loader thread must not leave the previous batch behind
             self.error = e
@@ -73,19 +91,31 @@ class _Prefetcher:
     def _load_batch(self, k, slot):
         ids = self.ids[k * self.bs:(k + 1) * self.bs]
         mel = self.buf[slot][:len(ids)]
-        gts = []
-        for i, cid in enumerate(ids):
-            m = np.load(pjoin(self.root, cid, "mel.npy"))
-            if m.shape != tuple(mel.shape[1:]):
-                raise ValueError(f"{cid}/mel.npy has shape {m.shape}, expected {tuple(mel.shape[1:])}")
-            mel[i].copy_(torch.from_numpy(np.ascontiguousarray(m, np.float32)))
-            gts.append(np.load(pjoin(self.root, cid, "motion.npy")))
+        gts = [None] * len(ids)
+        nz = self.nbuf[slot][:len(ids)] if self.nbuf else None
+
+        def one(i):
+            _read_npy_into(pjoin(self.root, ids[i], "mel.npy"), mel[i])
+            gts[i] = np.load(pjoin(self.root, ids[i], "motion.npy"))
+            if nz is not None:
+                seed, T, dim_pose = self.noise_spec
+                nz[i].copy_(clip_noise(seed, k * self.bs + i, T, dim_pose))
+
+        if self.workers > 1 and len(ids) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(self.workers) as ex:
+                list(ex.map(one, range(len(ids))))      # (re-raises a worker's exception)
+        else:
+            for i in range(len(ids)):
+                one(i)
+        self.noise = nz
         self.result = (ids, mel, gts)
 
-    def start(self, k):
+    def start(self, k, after=None):
         self.result = None
+        self.noise = None
         self.error = None
-        self.thread = threading.Thread(target=self._load, args=(k, k & 1), daemon=True)
+        self.thread = threading.Thread(target=self._load, args=(k, k & 1, after), daemon=True)
         self.thread.start()
 
     def take(self):
@@ -95,10 +125,69 @@ class _Prefetcher:
         return self.result
 
 
+class _Scorer:
+    """Per-clip MSE of a batch (eval_new.py:124-131) on a background thread, behind the event that says the batch's poses have
+    landed in the pinned buffer - the main thread is enqueueing the next batch meanwhile."""
+
+    def __init__(self, dim_pose):
+        import queue
+        self.dim_pose = dim_pose
+        self.q = queue.Queue()
+        self.done = {}                  # batch -> [(clip id, mse)] | exception
+        self.cv = threading.Condition()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            k, bid, gts, pred_h, event, _keep = job
+            try:
+                if event is not None:
+                    event.synchronize()
+                pred = pred_h.numpy()
+                if not np.isfinite(pred).all():
+                    raise FloatingPointError(f"non-finite poses in batch {k}")
+                res = []
+                for i, cid in enumerate(bid):
+                    pm = pred[i].reshape([pred[i].shape[0], self.dim_pose // 2, 2])          # eval_new.py:124-125
+                    res.append((cid, mse_loss(gts[i], pm)))
+            except BaseException as e:
+                res = e
+            with self.cv:
+                self.done[k] = res
+                self.cv.notify_all()
+
+    def submit(self, k, bid, gts, pred_h, event, keep):
+        self.q.put((k, bid, gts, pred_h, event, keep))
+
+    def wait_for(self, k):
+        """Blocks until batch k has been scored (k < 0: nothing to wait for); returns its [(clip id, mse)] or raises its error."""
+        if k < 0:
+            return None
+        with self.cv:
+            self.cv.wait_for(lambda: k in self.done)
+            res = self.done[k]
+        if isinstance(res, BaseException):
+            raise res
+        return res
+
+    def close(self):
+        self.q.put(None)
+
+
 def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed=0, smooth=False, verbose=True):
     """Samples every clip under `root` and returns {"per_clip": {id: mse}, "total_loss", "final_mse", "clips",
     "seconds", "frames_per_s"}.  Clip i (in sorted order) starts from noise seeded with (seed, i), so the result
-    does not depend on batch_size or on the number of ranks."""
+    does not depend on batch_size or on the number of ranks.
+
+    The host stays out of the GPU's way: batch k + 1's files and noise are prepared, and batch k - 1's MSEs computed, on
+    background threads while batch k is sampled; the poses come back through a pinned double buffer behind an event, not a stream
+    synchronisation; the sampler's per-loop numeric check (a status read that waits for the GPU) is replaced by a finiteness check
+    of the poses on the scoring thread, and a batch that fails it is sampled again the checked way (which is where
+    precision="auto" falls back to the bf16-range mode).  At most two batches are in flight."""
     ids = list_clips(root)
     if limit is not None:
         ids = ids[:int(limit)]
@@ -107,39 +196,90 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
     mel_shape = tuple(np.load(pjoin(root, ids[0], "mel.npy"), mmap_mode="r").shape)
     T = (mel_shape[0] - 1) // 3 + 1
     nb = (len(ids) + batch_size - 1) // batch_size
-    pf = _Prefetcher(root, ids, batch_size, mel_shape)
+    pf = _Prefetcher(root, ids, batch_size, mel_shape, noise=(seed, T, dim_pose))
     pf.start(0)
+    scorer = _Scorer(dim_pose)
+    enc = getattr(trainer, "encoder", None)
+    serial = bool(os.environ.get("DC_EVAL_SERIAL"))      # A/B switch (tools/time_evaluate.py): round 4's behaviour - the status read's stream
+    checked = None if serial else getattr(enc, "check_numerics", None)      # synchronisation and the MSEs between two batches
+    dev = getattr(trainer, "device", None)
+    on_gpu = dev is not None and torch.device(dev).type == "cuda"
+    out_h = [None, None]
+    slot_free = [None, None]             # event: the GPU has consumed the slot's pinned mel / noise buffers
+    results = {}
+    waits = {"loader": 0.0, "enqueue": 0.0, "scorer": 0.0}      # where the main thread spent its time (seconds): waiting for the next
+    t0 = time.perf_counter()                                    # batch's files, inside generate_music_motion, waiting for batch k - 2's scores
+    t_first = None                       # start of the second batch: steady-state rate without the first batch's one-time costs
+    try:
+        if checked:
+            enc.check_numerics = False   # (see above: checked on the scoring thread instead)
+        for k in range(nb):
+            tw = time.perf_counter()
+            bid, mel, gts = pf.take()
+            waits["loader"] += time.perf_counter() - tw
+            noise = pf.noise
+            if k + 1 < nb:
+                pf.start(k + 1, after=slot_free[(k + 1) & 1])
+            if k == 1:
+                t_first = time.perf_counter()
+            if on_gpu:
+                noise = noise.to(dev, non_blocking=True)      # (a blocking copy on the default stream would wait for the previous batch)
+            # [B, T, dim_pose] on the device; smoothing (tools/visualization.py:126) happens in the sampling loop's final write
+            tw = time.perf_counter()
+            pred = trainer.generate_music_motion(mel, dim_pose, noise=noise, smooth=19 if smooth else None)
+            waits["enqueue"] += time.perf_counter() - tw
+            tw = time.perf_counter()
+            scorer.wait_for(k - 2)                            # the pinned pose buffer of this slot has been scored
+            waits["scorer"] += time.perf_counter() - tw
+            s = k & 1
+            if out_h[s] is None or out_h[s].shape[0] < pred.shape[0] or out_h[s].shape[1:] != pred.shape[1:]:
+                out_h[s] = torch.empty((batch_size,) + tuple(pred.shape[1:]), dtype=pred.dtype, pin_memory=pred.is_cuda)     # pageable D2H costs ~3x the copy
+            ph = out_h[s][:pred.shape[0]]
+            ph.copy_(pred, non_blocking=True)
+            ev = None
+            if pred.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+                slot_free[s] = ev
+            scorer.submit(k, bid, gts, ph, ev, pred)
+            if serial:
+                scorer.wait_for(k)
+        for k in range(nb):
+            try:
+                results[k] = scorer.wait_for(k)
+            except FloatingPointError:
+                if not checked:
+                    raise
+                # the checked path (status read, precision="auto" fallback) for this batch alone
+                enc.check_numerics = True
+                pf2 = _Prefetcher(root, ids, batch_size, mel_shape, noise=(seed, T, dim_pose))
+                pf2._load_batch(k, 0)
+                bid, mel, gts = pf2.result
+                pred = trainer.generate_music_motion(mel, dim_pose, noise=pf2.noise, smooth=19 if smooth else None).cpu().numpy()
+                results[k] = [(cid, mse_loss(gts[i], pred[i].reshape([pred[i].shape[0], dim_pose // 2, 2]))) for i, cid in enumerate(bid)]
+                enc.check_numerics = False
+    finally:
+        scorer.close()
+        if checked:
+            enc.check_numerics = checked
+    dt = time.perf_counter() - t0
     per_clip, total_loss = {}, 0.0
-    out_h = None
-    t0 = time.perf_counter()
     for k in range(nb):
-        bid, mel, gts = pf.take()
-        if k + 1 < nb:
-            pf.start(k + 1)
-        noise = torch.stack([clip_noise(seed, k * batch_size + i, T, dim_pose) for i in range(len(bid))])
-        # [B, T, dim_pose] on the device; smoothing (tools/visualization.py:126) happens in the sampling loop's final write
-        pred = trainer.generate_music_motion(mel, dim_pose, noise=noise, smooth=19 if smooth else None)
-        if out_h is None or out_h.shape[0] < pred.shape[0] or out_h.shape[1:] != pred.shape[1:]:
-            out_h = torch.empty(tuple(pred.shape), dtype=pred.dtype, pin_memory=pred.is_cuda)     # pageable D2H costs ~3x the copy
-        out_h[:pred.shape[0]].copy_(pred, non_blocking=True)
-        if pred.is_cuda:
-            torch.cuda.current_stream().synchronize()
-        pred = out_h[:pred.shape[0]].numpy()
-        for i, cid in enumerate(bid):
-            pm = pred[i].reshape([pred[i].shape[0], dim_pose // 2, 2])          # eval_new.py:124-125
-            cur = mse_loss(gts[i], pm)
+        for cid, cur in results[k]:
             per_clip[cid] = float(cur)
             total_loss += cur
             if verbose:
                 print("cur_loss: ", cur)
                 print("total_loss: ", total_loss)
-    dt = time.perf_counter() - t0
     final_mse = total_loss / len(ids)
     if verbose:
         print("final total loss: ", total_loss)
         print("final_mse: ", final_mse)
-    return {"per_clip": per_clip, "total_loss": float(total_loss), "final_mse": float(final_mse), "clips": len(ids),
-            "seconds": dt, "frames_per_s": len(ids) * T / dt}
+    out = {"per_clip": per_clip, "total_loss": float(total_loss), "final_mse": float(final_mse), "clips": len(ids),
+           "seconds": dt, "frames_per_s": len(ids) * T / dt, "main_thread_s": {k: round(v, 4) for k, v in waits.items()}}
+    if t_first is not None and len(ids) > batch_size:
+        out["steady_frames_per_s"] = (len(ids) - batch_size) * T / (t0 + dt - t_first)      # batches 2.. (the first sizes buffers, captures the graph)
+    return out
 
 
 def main(argv=None):

@@ -220,7 +220,9 @@ def algorithmic_work(n_tokens: int) -> dict:
     numerators of bench.py's roofline objects.  k_layer (one decoder layer for all tokens) moves per token the
     residual stream 512 B in + 512 B out, its 24 FiLM tiles x 64 B and the workgroup records 72 B out + 36 B in:
     HBM is its nearer roof.  k_film_gemm is the [6144 x 512] x [512 x tokens] FiLM GEMM: MFMA roof."""
-    return {"k_layer": {"bound": "hbm", "bytes": (512 + 512 + 24 * 64 + 72 + 36) * n_tokens},
+    # k_layer's FLOPs: the step's algorithmic 2 * 4 250 112 per token (SURVEY.md section 8d) minus the FiLM GEMM's, over 8 layers
+    return {"k_layer": {"bound": "hbm", "bytes": (512 + 512 + 24 * 64 + 72 + 36) * n_tokens,
+                        "flops": (2 * 4250112 - 2 * 512 * 6144) // 8 * n_tokens},
             "k_film_gemm": {"bound": "mfma", "flops": 2 * 512 * 6144 * n_tokens}}
 
 

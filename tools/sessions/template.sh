@@ -1,5 +1,5 @@
 #!/bin/bash
-# template of a GPU session (copy to gpurun_out/session.sh, edit, run through tools/gpurun_retry.sh)
+# template of a GPU session (copy to tools/sessions/cur.sh, edit, run through tools/gpurun_retry.sh)
 R="$(pwd)"; O="$R/gpurun_out/rNN_sK"; mkdir -p "$O"
 # same-box A/B of compile-time variants B and C against the default library (ms per loop, per-kernel ms):
 timeout 900 bash tools/ab.sh run B C > "$O/ab.txt" 2>&1; cat "$O/ab.txt"
