@@ -68,13 +68,15 @@ class _Prefetcher:
     clip's x_T into a second pinned buffer.  Two slots; `start(k, after=event)` waits for `event` (the GPU is done with the slot's
     previous batch) before it overwrites the slot."""
 
-    def __init__(self, root, ids, batch_size, mel_shape, noise=None, workers=4):
+    def __init__(self, root, ids, batch_size, mel_shape, noise=None, workers=None):
         self.root, self.ids, self.bs = root, ids, batch_size
         pin = torch.cuda.is_available()
         self.buf = [torch.empty((batch_size,) + tuple(mel_shape), dtype=torch.float32, pin_memory=pin) for _ in range(2)]
         self.noise_spec = noise
         self.nbuf = [torch.empty((batch_size, noise[1], noise[2]), dtype=torch.float32, pin_memory=pin) for _ in range(2)] if noise else None
-        self.workers = max(1, int(workers))
+        # (four threads: with 16 the loaders fight the enqueueing thread for the interpreter lock - 288 clips took 1.35 s instead of 0.40,
+        # profiles/r05_time_evaluate.txt)
+        self.workers = max(1, int(workers)) if workers else 4
         self.result = None
         self.noise = None
         self.error = None
@@ -207,9 +209,10 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
     out_h = [None, None]
     slot_free = [None, None]             # event: the GPU has consumed the slot's pinned mel / noise buffers
     results = {}
+    ev_first = ev_last = None            # completion events of the first and the last batch: the GPU's own steady-state period
+    n_after_first = 0
     waits = {"loader": 0.0, "enqueue": 0.0, "scorer": 0.0}      # where the main thread spent its time (seconds): waiting for the next
     t0 = time.perf_counter()                                    # batch's files, inside generate_music_motion, waiting for batch k - 2's scores
-    t_first = None                       # start of the second batch: steady-state rate without the first batch's one-time costs
     try:
         if checked:
             enc.check_numerics = False   # (see above: checked on the scoring thread instead)
@@ -220,8 +223,6 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
             noise = pf.noise
             if k + 1 < nb:
                 pf.start(k + 1, after=slot_free[(k + 1) & 1])
-            if k == 1:
-                t_first = time.perf_counter()
             if on_gpu:
                 noise = noise.to(dev, non_blocking=True)      # (a blocking copy on the default stream would wait for the previous batch)
             # [B, T, dim_pose] on the device; smoothing (tools/visualization.py:126) happens in the sampling loop's final write
@@ -238,9 +239,11 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
             ph.copy_(pred, non_blocking=True)
             ev = None
             if pred.is_cuda:
-                ev = torch.cuda.Event()
+                ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
                 slot_free[s] = ev
+                ev_first = ev_first or ev
+                ev_last, n_after_first = ev, (n_after_first + len(bid) if ev_first is not ev else 0)
             scorer.submit(k, bid, gts, ph, ev, pred)
             if serial:
                 scorer.wait_for(k)
@@ -277,8 +280,10 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
         print("final_mse: ", final_mse)
     out = {"per_clip": per_clip, "total_loss": float(total_loss), "final_mse": float(final_mse), "clips": len(ids),
            "seconds": dt, "frames_per_s": len(ids) * T / dt, "main_thread_s": {k: round(v, 4) for k, v in waits.items()}}
-    if t_first is not None and len(ids) > batch_size:
-        out["steady_frames_per_s"] = (len(ids) - batch_size) * T / (t0 + dt - t_first)      # batches 2.. (the first sizes buffers, captures the graph)
+    if ev_first is not None and ev_last is not ev_first:
+        # clips of batches 2 .. n over the time between the completion of batch 1 and of batch n ON THE GPU: the pipeline's rate
+        # without the two things nothing can hide (the first batch's load before any GPU work, the last batch's scoring after it)
+        out["steady_frames_per_s"] = n_after_first * T / (ev_first.elapsed_time(ev_last) * 1e-3)
     return out
 
 

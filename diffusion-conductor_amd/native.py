@@ -361,8 +361,6 @@ class NativeSampler:
             elif noise_seed is not None:
                 seed, first = noise_seed if isinstance(noise_seed, (tuple, list)) else (noise_seed, 0)
                 _check(lib().dc_sampler_set_step_noise_seed_at(self._h, C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint64(int(first))))
-            else:
-                assert not np.any(coef[:, 4] != 0), "eta > 0 needs step_noise or noise_seed (a seed serves one loop)"
             _check(lib().dc_sampler_ddim_loop_ex(self._h, noise.data_ptr(), out.data_ptr(), S, _fptr(coef), int(flags), zp, sip,
                                                  len(si), snp, self._stream()))
         return out, snaps
