@@ -173,6 +173,8 @@ struct dc_sampler {
     float* d_recs = nullptr;
     void *d_a_sa = nullptr, *d_a_ca = nullptr;
     void* d_a_ca16 = nullptr;             // cross-attention fragments in the 16-token layer kernel's form (small batches)
+    unsigned long long* d_gran = nullptr; // small batches: granules of the combine the clip's workgroups share inside a launch, [B][1024] (dc_layer16.hip)
+    unsigned l16_seq = 0;                 // eager launches of k_layer16: tag sequence (tags must differ between consecutive launches)
     void *d_kv_sa[2] = {nullptr, nullptr}, *d_kv_ca = nullptr;   // no_eff: key-tile arrays (dc_kernels.hip, full attention)
     int KT = 0;                                                   // key tiles per clip array
     float* d_x = nullptr;
@@ -669,6 +671,8 @@ int ensure_workspace(dc_sampler* s, int B, int Tx) {
         if ((rc = dev_alloc(s, s->d_a_sa, (size_t)B * 16 * 1024))) return rc;
         if ((rc = dev_alloc(s, s->d_a_ca, (size_t)L * B * 16 * 1024))) return rc;
         if ((rc = dev_alloc(s, s->d_a_ca16, (size_t)L * B * 8 * 1024))) return rc;
+        if ((rc = dev_alloc(s, s->d_gran, (size_t)B * 1024 * 8))) return rc;
+        HIP_TRY(hipMemset(s->d_gran, 0, (size_t)B * 1024 * 8));        // tag 0 is never a launch's
         s->cap_B = (size_t)B;
     }
     if ((size_t)M * P > s->cap_MP) {
@@ -691,6 +695,8 @@ int ensure_workspace(dc_sampler* s, int B, int Tx) {
         if ((rc = dev_alloc(s, s->d_snap_cur, 16))) return rc;
         if ((rc = dev_alloc(s, s->d_coef_cur, DC_COEF * 4))) return rc;
     }
+    if ((s->B != B || s->T != T) && s->d_gran)       // another geometry: no granule of the shared combine may carry a tag a launch could expect
+        HIP_TRY(hipMemsetAsync(s->d_gran, 0, s->cap_B * 1024 * 8, s->stream));
     s->B = B;
     s->T = T;
     s->Tx = Tx;
@@ -745,7 +751,7 @@ struct Timed {   // RAII-less helper: wraps a launch with events when profiling
 // that one process can A/B them: a change re-captures) and the update options of the loop.
 unsigned long long form_key(const dc_sampler* s) {
     static const char* sw[] = {"DC_NO_WGREC", "DC_NO_NARROW", "DC_NO_ALIGN", "DC_ALIGN", "DC_NO_FUSE_EMBED", "DC_FILM_STATIC",
-                               "DC_BEGIN_STEP", "DC_NO_PAD", "DC_NO_LAYER16"};
+                               "DC_BEGIN_STEP", "DC_NO_PAD", "DC_NO_LAYER16", "DC_L16_OWN_COMBINE"};
     unsigned long long k = 0;
     for (size_t i = 0; i < sizeof sw / sizeof *sw; ++i) k |= (getenv(sw[i]) ? 1ull : 0ull) << i;
     k |= (unsigned long long)(s->upd_flags & 0xff) << 16;     // (the noise tensor's address is not baked in: the kernels read it from d_zslot)
@@ -812,6 +818,11 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
                          !getenv("DC_NO_LAYER16");
     const int upc = aligned ? (narrow ? upc_narrow : upc_wide) : 0;
     const int nwg = aligned ? B * upc : (narrow ? (G + 3) / 4 : (G + 7) / 8);
+    // k_layer16: the clip's workgroups share the combine of the previous layer's unit records inside the launch (dc_layer16.hip;
+    // DC_L16_OWN_COMBINE=1: every workgroup combines alone, round 4's form).  Tags: captured steps 16 * (graph step + *d_iter) + layer + 1,
+    // eager launches from a sequence of their own above them - consecutive launches never share a tag.
+    const bool l16_shared = layer16 && !getenv("DC_L16_OWN_COMBINE");
+    const unsigned l16_tag = folded ? 16u * (unsigned)graph_step : (0x40000000u | (16u * (s->l16_seq++ & 0x3ffffffu)));
     const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
     // (the kernels write records at recs + rec_stride + wg * 2 * DC_REC_FLOATS: both alternating buffers must lie inside d_recs)
     if ((wgr ? 2 * rec_stride : (size_t)G * 2 * DC_REC_FLOATS) > s->cap_rec_floats)
@@ -873,7 +884,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
             LAUNCH(K_LAYER, dc_launch_layer16(st, fs, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_ca16, s->d_recs, s->d_length, x_src, x_dst,
                                               loop_mode ? 1 : 0, coef_src, snap_src, s->d_snaps, M, T, B, upc16, rec_stride,
                                               l == 0 ? upc_narrow : upc16, l == 0 ? (size_t)2 * DC_REC_FLOATS : (size_t)DC_REC_FLOATS, iter_base, Tx,
-                                              u16));
+                                              u16, l16_shared ? s->d_gran : nullptr, l16_tag));
             continue;
         }
 #ifdef DC_E_CHUNK2
@@ -1075,7 +1086,8 @@ std::vector<float> widen_coef(const float* h_coef, int S) {
 // ======================================================================================
 extern "C" {
 
-static_assert(DC_UPDATE_CLIP_DENOISED == DC_UPD_CLIP && DC_UPDATE_EPSILON == DC_UPD_EPS && DC_STATUS_F16_SATURATED == DC_STATUS_F16_SAT,
+static_assert(DC_UPDATE_CLIP_DENOISED == DC_UPD_CLIP && DC_UPDATE_EPSILON == DC_UPD_EPS && DC_STATUS_F16_SATURATED == DC_STATUS_F16_SAT &&
+                  DC_STATUS_TIMEOUT == DC_STATUS_SYNC_TIMEOUT,
               "include/dc_ddim.h and dc_common.h disagree");
 
 const char* dc_last_error(void) { return g_err.c_str(); }
@@ -1200,7 +1212,7 @@ void dc_sampler_destroy(dc_sampler* s) {
     void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
                     s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t, s->d_coef_of_iter,
-                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status, s->d_smooth_coef, s->d_zslot, s->d_zstep, s->d_a_ca16};
+                    s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status, s->d_smooth_coef, s->d_zslot, s->d_zstep, s->d_a_ca16, s->d_gran};
     for (void* p : ptrs)
         if (p) hipFree(p);
     dc_music_destroy(s->music);

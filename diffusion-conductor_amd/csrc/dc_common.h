@@ -98,6 +98,7 @@ struct DcModel {
 #define DC_UPD_ZSTEP 8       // (internal) *zslot holds ONE iteration's draws [B][Tx][P], refilled by k_step_noise at the head of every step
 #define DC_STATUS_NONFINITE 1    // a predicted x0 was inf / nan
 #define DC_STATUS_F16_SAT 2      // a FiLM modulation value exceeded the fp16 range when stored
+#define DC_STATUS_SYNC_TIMEOUT 4 // a workgroup of the small-batch layer kernel gave up waiting for its clip's combine slices (GPU shared?)
 struct DcUpdate {
     const float* const* zslot;   // DC_UPD_NOISY: device slot holding the base of the per-iteration noise (the reference's th.randn_like(x)
                          // draws, :822): the caller's [S][B][Tx][P] tensor, or (DC_UPD_ZSTEP) the library's one-iteration buffer.  A slot,

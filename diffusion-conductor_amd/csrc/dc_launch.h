@@ -57,7 +57,9 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
 hipError_t dc_launch_layer16(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* E, int NT, const void* a_ca16,
                              float* recs, const int* length, const float* xin, float* xout, int out_mode, const float* coef_cur,
                              const int* snap_cur, float* snaps, int M, int T, int B, int upc, size_t rec_stride, int nu_in, size_t stride_in,
-                             const int* iter_base, int Tx, const DcUpdate& upd);
+                             const int* iter_base, int Tx, const DcUpdate& upd,
+                             unsigned long long* gran /* [B][1024] granules: the clip's workgroups share the combine inside the launch (nullptr: each alone) */,
+                             unsigned tag_base /* the launch's tag = tag_base + 16 * (*iter_base) + l + 1: must differ between consecutive launches */);
 hipError_t dc_launch_cond_af16(hipStream_t st, int fmt, const void* a_ca, void* a_ca16, int n_matrices);
 int dc_layer16_max_units(void);
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);

@@ -13,6 +13,11 @@
 // the batch around it.  One unit record per workgroup (slot 0 of the 32-token kernels' record format, so that layer 0 combines the
 // 128-token unit records k_embed_front's narrow form writes, and later layers the 64-token ones written here).
 //
+// Combine (round 5).  The attention operand of a layer is the clip-wide sum of the previous layer's unit records.  Every workgroup
+// reduces one slice of it, publishes the slice as tagged 8-byte granules and gathers the clip's operand from its neighbours inside the
+// launch, behind LayerNorm, query projection and softmax of the self-attention stage (Slice16, gather16_*): 8 KiB read per workgroup
+// instead of 261, -8 % per layer launch with one clip per call.  DC_L16_OWN_COMBINE=1 keeps round 4's form (wg_combine_attn16).
+//
 // Layout.  Accumulator tile of v_mfma_f32_16x16x32: lane l holds column n = l & 15 (the TOKEN) and rows 4 (l >> 4) + i, i < 4, of a
 // 16-row block.  An activation of 128 features is 8 such blocks: x[rb][i] = feature 16 rb + 4 q4 + i, q4 = l >> 4.  Two consecutive
 // blocks convert in registers into the B operand of a 32-deep k-step: element j of lane (n, q4) is
@@ -186,9 +191,12 @@ DEV Y16 pack_y(const f32x4& x) {
 // q = softmax_heads(Wq LN(h) + bq) ; y = q . A per head (transformer.py:104,109,119 / 147,150,156).  A head = one 16-row block,
 // spread over the four lane groups.  af: [8 heads][64 lanes] fragments of the wave's clip: rows = the head's value features,
 // k-slots of the head PAIR (the other head's slots are zero).
-template <class T16>
+struct NoMid {
+    DEV void operator()() const {}
+};
+template <class T16, class Mid = NoMid>
 DEV void query_attend16(Y16 (&y)[8], float& y_rstd, float& y_shift, const f32x4 (&h)[8], const float* bq, const v8<T16>* w,
-                        const v8<T16>* af, const C16& c) {
+                        const v8<T16>* af, const C16& c, Mid&& mid = Mid() /* runs between the softmax and the first read of af */) {
     f32x4 q[8];
     {
         v8<T16> nb[4];
@@ -211,6 +219,8 @@ DEV void query_attend16(Y16 (&y)[8], float& y_rstd, float& y_shift, const f32x4 
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[rb][i] *= inv;
     }
+    __builtin_amdgcn_sched_barrier(0);
+    mid();
     __builtin_amdgcn_sched_barrier(0);
     Stats16 st;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -397,6 +407,136 @@ DEV void wg_combine_attn16(const float* __restrict__ recs, size_t stride, int nu
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same combine, shared between the clip's workgroups inside the launch (round 5).  With one clip per call the prologue above is
+// bound by ONE CU's read rate for data another CU has just written: 29 records x 9 KiB = 261 KiB at 62 - 70 GB/s is 4 of the
+// prologue's 6.1 us, and every one of the clip's 29 workgroups pays it to build the same 8-KiB operand.  Here every workgroup reduces
+// a 1/32 SLICE of the operand over the clip's records (8 KiB read instead of 261), publishes it as 8-byte {two f16 values, tag}
+// granules with sc1 (write-through) stores, and gathers the clip's 1 024 granules with sc1 loads, re-polling until every tag is
+// this launch's - the data-tagged hand-off of MI355X_MICROARCH.md (persistent kernels, granule / allgather rows): no flag, no
+// counter, no fence, nothing to reset.  A granule that still carries another tag is, within one (B, T) geometry, the previous
+// launch's (every launch overwrites all of them; the buffer is cleared whenever the geometry changes), so tags only have to differ
+// between consecutive launches.  The clip's workgroups are co-resident by construction (B * upc <= CUs is the launch condition of
+// this kernel, one workgroup per CU by its LDS); should the GPU be shared so that they are not, the poll is bounded and raises
+// DC_STATUS_SYNC_TIMEOUT instead of hanging.
+// Slice s (0..31) = the outputs of threads 8 s .. 8 s + 7 of wg_combine_attn16 (oc = s >> 3, ln = 8 (s & 7) + vt): item (vt, jp) =
+// values 2 jp, 2 jp + 1 of virtual thread vt; same products per value as above, summed over the units in a fixed tree (4 per lane in
+// unit order, then an xor tree over 8 lanes): deterministic, a clip's operand does not depend on the batch around it.
+// Granule gi = (hd * 64 + lane64) * 2 + half: the two f16 values half of the non-zero 8 bytes of AF fragment (hd, lane64).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int L16_SLICES = 32;
+constexpr unsigned L16_POLL_LIMIT = 1u << 18;
+
+// One slice of the clip's combine: load() issues the slice's 12 loads per lane, publish() reduces and stores the granule.
+template <class T16>
+struct Slice16 {
+    f32x2 mk[4], sk[4], pk[4];
+    int kq, oc, cc, hh, jp, nu;
+    DEV void load(const float* __restrict__ recs, size_t stride, int nu_, int b, int s, int wave, int lane) {
+        // 32 items per slice = 8 per wave; an item's units are spread over 8 lanes (lane = 8 it + kq: units kq, kq + 8, kq + 16, kq + 24),
+        // so that the whole wave loads and no lane holds more than four units; the lanes' partial results meet in a fixed xor tree
+        nu = nu_;
+        kq = lane & 7;
+        const int it = lane >> 3, item = 4 * it + wave, vt = item >> 2;
+        jp = item & 3;
+        oc = s >> 3;
+        const int ln = 8 * (s & 7) + vt;
+        cc = ln & 31;
+        hh = ln >> 5;
+        const int rowb = 32 * oc + 16 * (cc >> 4) + 4 * hh;
+        const int j = 2 * jp, f = rowb + (j & 3) + 8 * (j >> 2);          // features f, f + 1 (f even)
+        const float* R0 = recs + (size_t)b * nu * stride;
+        const float* pm = R0 + f;
+        const float* pp = R0 + 256 + (size_t)(oc * 64 + ln) * 8 + j;
+        const unsigned st32 = (unsigned)stride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                       // every load up front, indices clamped (ONE memory round trip)
+            const unsigned o = min((unsigned)(kq + 8 * q), (unsigned)(nu - 1)) * st32;
+            mk[q] = *reinterpret_cast<const f32x2*>(pm + o);
+            sk[q] = *reinterpret_cast<const f32x2*>(pm + 128 + o);
+            pk[q] = *reinterpret_cast<const f32x2*>(pp + o);
+        }
+    }
+    DEV void publish(unsigned long long* __restrict__ gran, int b, unsigned tag) {
+        auto xmax = [](float v) {
+            v = fmaxf(v, __shfl_xor(v, 1));
+            v = fmaxf(v, __shfl_xor(v, 2));
+            return fmaxf(v, __shfl_xor(v, 4));
+        };
+        auto xsum = [](float v) {
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            return v + __shfl_xor(v, 4);
+        };
+        float mstar0 = -INFINITY, mstar1 = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (kq + 8 * q >= nu) sk[q] = (f32x2){0.f, 0.f};
+            mstar0 = sk[q].x > 0.f ? fmaxf(mstar0, mk[q].x) : mstar0;
+            mstar1 = sk[q].y > 0.f ? fmaxf(mstar1, mk[q].y) : mstar1;
+        }
+        mstar0 = xmax(mstar0);
+        mstar1 = xmax(mstar1);
+        float z0 = 0.f, z1 = 0.f, a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float w0 = sk[q].x > 0.f ? exp2f_fast(mk[q].x - mstar0) : 0.f;
+            const float w1 = sk[q].y > 0.f ? exp2f_fast(mk[q].y - mstar1) : 0.f;
+            z0 = fmaf(w0, sk[q].x, z0);
+            z1 = fmaf(w1, sk[q].y, z1);
+            a0 = fmaf(w0, pk[q].x, a0);
+            a1 = fmaf(w1, pk[q].y, a1);
+        }
+        z0 = xsum(z0), z1 = xsum(z1), a0 = xsum(a0), a1 = xsum(a1);
+        if (kq == 0) {
+            typedef __attribute__((ext_vector_type(2))) T16 t2;
+            const t2 v = {(T16)(z0 > 0.f ? a0 * fast_rcp(z0) : 0.f), (T16)(z1 > 0.f ? a1 * fast_rcp(z1) : 0.f)};
+            const int hd = 2 * oc + (cc >> 4), l = cc & 15, piece = jp >> 1;
+            const int gi = ((hd * 64 + l + 16 * (2 * piece + hh)) << 1) + (jp & 1);
+            const unsigned long long g = (unsigned long long)__builtin_bit_cast(unsigned, v) | ((unsigned long long)tag << 32);
+            __hip_atomic_store(gran + (size_t)b * 1024 + gi, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_store_dwordx2 ... sc1: one granule, one store
+        }
+    }
+};
+// every thread: granules 4 tid .. 4 tid + 3 = AF fragments 2 tid, 2 tid + 1 of the clip (8 heads x 64 lanes); AF in LDS as above.
+// The four loads are issued right behind the publication (gather16_issue) and looked at only where the operand is needed - behind
+// LayerNorm, the query projection and the softmax of the self-attention stage (gather16_finish): by then every workgroup of the clip
+// has published (they started within a microsecond of each other), and a granule that was read too early is polled again.
+struct Gran16 {
+    unsigned long long g[4];
+};
+DEV Gran16 gather16_issue(const unsigned long long* __restrict__ gran, int b, int tid) {
+    const unsigned long long* G = gran + (size_t)b * 1024 + 4 * tid;
+    Gran16 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.g[i] = __hip_atomic_load(G + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_load_dwordx2 ... sc1
+    return r;
+}
+template <class T16>
+DEV void gather16_finish(Gran16 r, const unsigned long long* __restrict__ gran, int b, unsigned tag, v8<T16>* af, int tid, int* __restrict__ status) {
+    const unsigned long long* G = gran + (size_t)b * 1024 + 4 * tid;
+    unsigned spins = 0;
+    for (;;) {
+        const bool ok = (unsigned)(r.g[0] >> 32) == tag && (unsigned)(r.g[1] >> 32) == tag && (unsigned)(r.g[2] >> 32) == tag &&
+                        (unsigned)(r.g[3] >> 32) == tag;
+        if (ok || ++spins > L16_POLL_LIMIT) break;
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.g[i] = __hip_atomic_load(G + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (spins > L16_POLL_LIMIT && status) atomicOr(status, DC_STATUS_SYNC_TIMEOUT);
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int fi = 2 * tid + q, hd = fi >> 6, e = hd & 1;
+        u4 w = {0u, 0u, 0u, 0u};
+        w[2 * e] = (unsigned)r.g[2 * q];
+        w[2 * e + 1] = (unsigned)r.g[2 * q + 1];
+        reinterpret_cast<u4*>(af)[fi] = w;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -413,7 +553,9 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
                const int* __restrict__ snap_cur, float* __restrict__ snaps, int M, int T, int B, int upc,
                size_t rec_stride /* floats between the two alternating record buffers */,
                int nu_in, size_t stride_in /* unit records per clip / floats per unit of the records this layer combines */,
-               const int* __restrict__ iter_base, int Tx, const DcUpdate upd) {
+               const int* __restrict__ iter_base, int Tx, const DcUpdate upd,
+               unsigned long long* __restrict__ gran /* [B][1024] granules of the shared combine, or nullptr: every workgroup combines alone */,
+               unsigned tag_base /* + 16 * (*iter_base) + l + 1 = this launch's tag */) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using W = v8<T16>;
     constexpr int NW = L16_NW;
@@ -461,11 +603,23 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
 
     f32x4 h[8];
     LSTAMP(0);
+    const unsigned tag = tag_base + (iter_base ? 16u * (unsigned)*iter_base : 0u) + (unsigned)l + 1u;
     load_h16(h, hbuf, c);
     stage_frags<NW>(L.sa_q, buf0, 33, wave, lane);
     E16 e[4];
-    wg_combine_attn16<T16>(recs_in, stride_in, nu_in, c.b, reinterpret_cast<W*>(lds + L16_OFF_AF), reinterpret_cast<float*>(buf1),
-                           reinterpret_cast<float*>(lds + L16_OFF_PST) /* the tail's 36 KiB: free until then */, tid);
+    Gran16 gr{};
+    if (gran) {       // (wave-uniform) this workgroup's slices of the clip's combine, published now, gathered where the operand is needed (stage 1)
+        // (the slice's loads in FRONT of the residual-stream loads measured no better: profiles/r05_small_batch_shared_combine.txt)
+        Slice16<T16> sl;
+        for (int s2 = u; s2 < L16_SLICES; s2 += upc) {      // (one slice; a second for the first few workgroups at T = 1800; more for short clips)
+            sl.load(recs_in, stride_in, nu_in, c.b, s2, wave, lane);
+            sl.publish(gran, c.b, tag);
+        }
+        LSTAMP(20);
+        gr = gather16_issue(gran, c.b, tid);
+    } else
+        wg_combine_attn16<T16>(recs_in, stride_in, nu_in, c.b, reinterpret_cast<W*>(lds + L16_OFF_AF), reinterpret_cast<float*>(buf1),
+                               reinterpret_cast<float*>(lds + L16_OFF_PST) /* the tail's 36 KiB: free until then */, tid);
     e16_load(e, Eg, c);                          // (behind the combine, whose record batches need the registers; first used in stage 2)
     LSTAMP(1);
     // closer that leaves the 16 FiLM-tile loads just issued in flight (they are the wave's youngest vector-memory operations; the
@@ -480,7 +634,14 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
     stage_frags<NW>(L.sa_o, buf1, 33, wave, lane);
     Y16 y[8];
     float y_rstd, y_shift;
-    query_attend16<T16>(y, y_rstd, y_shift, h, c0, w0, af, c);
+    query_attend16<T16>(y, y_rstd, y_shift, h, c0, w0, af, c, [&]() {
+        if (gran) {
+            LSTAMP(21);
+            gather16_finish<T16>(gr, gran, c.b, tag, reinterpret_cast<W*>(lds + L16_OFF_AF), tid, upd.status);
+            __syncthreads();          // the operand is written by all four waves
+            LSTAMP(22);
+        }
+    });
     LSTAMP(3);
     stage_sync();
     LSTAMP(4);
@@ -776,7 +937,7 @@ int dc_layer16_max_units(void) { return L16_MAXU; }
 hipError_t dc_launch_layer16(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* E, int NT, const void* a_ca16,
                              float* recs, const int* length, const float* xin, float* xout, int out_mode, const float* coef_cur,
                              const int* snap_cur, float* snaps, int M, int T, int B, int upc, size_t rec_stride, int nu_in, size_t stride_in,
-                             const int* iter_base, int Tx, const DcUpdate& upd) {
+                             const int* iter_base, int Tx, const DcUpdate& upd, unsigned long long* gran, unsigned tag_base) {
     if (nu_in < 1 || nu_in > L16_MAXU || upc < 1 || (T & 31)) return hipErrorInvalidValue;
     static unsigned long long done[2] = {0, 0};      // > 64 KiB of dynamic LDS needs the opt-in, per device
     int dev = 0;
@@ -789,10 +950,10 @@ hipError_t dc_launch_layer16(hipStream_t st, int fmt, const DcModel* dm, int l, 
     const dim3 grid(B * upc), block(256);
     if (fmt == 1)
         k_layer16<_Float16><<<grid, block, L16_LDS, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const f16x8*)a_ca16, recs, length, xin, xout, out_mode,
-                                                          coef_cur, snap_cur, snaps, M, T, B, upc, rec_stride, nu_in, stride_in, iter_base, Tx, upd);
+                                                          coef_cur, snap_cur, snaps, M, T, B, upc, rec_stride, nu_in, stride_in, iter_base, Tx, upd, gran, tag_base);
     else
         k_layer16<__bf16><<<grid, block, L16_LDS, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const bf16x8*)a_ca16, recs, length, xin, xout, out_mode,
-                                                        coef_cur, snap_cur, snaps, M, T, B, upc, rec_stride, nu_in, stride_in, iter_base, Tx, upd);
+                                                        coef_cur, snap_cur, snaps, M, T, B, upc, rec_stride, nu_in, stride_in, iter_base, Tx, upd, gran, tag_base);
     return hipGetLastError();
 }
 hipError_t dc_launch_cond_af16(hipStream_t st, int fmt, const void* a_ca, void* a_ca16, int n_matrices) {

@@ -209,6 +209,7 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
     out_h = [None, None]
     slot_free = [None, None]             # event: the GPU has consumed the slot's pinned mel / noise buffers
     results = {}
+    own_before = None
     ev_first = ev_last = None            # completion events of the first and the last batch: the GPU's own steady-state period
     n_after_first = 0
     waits = {"loader": 0.0, "enqueue": 0.0, "scorer": 0.0}      # where the main thread spent its time (seconds): waiting for the next
@@ -216,6 +217,10 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
     try:
         if checked:
             enc.check_numerics = False   # (see above: checked on the scoring thread instead)
+            # ... which cannot see the one failure that leaves finite poses: a timed-out combine exchange of the small-batch layer kernel
+            # (dc_ddim.h, DC_STATUS_TIMEOUT; possible only on a GPU shared with other work).  Unchecked loops run the form without it.
+            own_before = os.environ.get("DC_L16_OWN_COMBINE")
+            os.environ["DC_L16_OWN_COMBINE"] = "1"
         for k in range(nb):
             tw = time.perf_counter()
             bid, mel, gts = pf.take()
@@ -265,6 +270,10 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
         scorer.close()
         if checked:
             enc.check_numerics = checked
+            if own_before is None:
+                os.environ.pop("DC_L16_OWN_COMBINE", None)
+            else:
+                os.environ["DC_L16_OWN_COMBINE"] = own_before
     dt = time.perf_counter() - t0
     per_clip, total_loss = {}, 0.0
     for k in range(nb):

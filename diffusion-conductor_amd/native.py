@@ -28,7 +28,7 @@ EXPORTS = [
 ]
 
 UPDATE_CLIP_DENOISED, UPDATE_EPSILON = 1, 2          # flags of dc_sampler_ddim_loop_ex
-STATUS_NONFINITE, STATUS_F16_SATURATED = 1, 2        # bits of dc_sampler_status
+STATUS_NONFINITE, STATUS_F16_SATURATED, STATUS_TIMEOUT = 1, 2, 4        # bits of dc_sampler_status
 
 
 class DcConfig(C.Structure):
@@ -212,6 +212,9 @@ def describe_status(st: int, precision: str) -> str:
     if st & STATUS_F16_SATURATED:
         msg.append("a FiLM modulation value left the fp16 range in which every precision mode stores it: this checkpoint is "
                    "outside what the library supports")
+    if st & STATUS_TIMEOUT:
+        msg.append("a workgroup of the small-batch layer kernel gave up waiting for its clip's combine slices (is the GPU shared with other "
+                   "work?): the loop's results are invalid; DC_L16_OWN_COMBINE=1 selects the form without the in-launch exchange")
     return "; ".join(msg) or "ok"
 
 

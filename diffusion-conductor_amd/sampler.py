@@ -19,6 +19,8 @@ scope for this path and are not provided.
 """
 from __future__ import annotations
 
+import os
+
 import enum
 import math
 
@@ -203,6 +205,14 @@ class GaussianDiffusion:
             st = nat.status()
             if st == 0:
                 return out, snaps
+            if st == native.STATUS_TIMEOUT and not os.environ.get("DC_L16_OWN_COMBINE"):
+                # small batches: the clip's workgroups exchange their combine slices inside a layer launch and one of them gave up
+                # waiting (the GPU is shared with other work, so they were not co-resident): switch this process to the form
+                # without the exchange and run the loop again
+                import warnings
+                warnings.warn("libdc_ddim: in-launch combine exchange timed out (GPU shared?); continuing with DC_L16_OWN_COMBINE=1")
+                os.environ["DC_L16_OWN_COMBINE"] = "1"
+                continue
             if not model.numerics_fallback(st):
                 raise FloatingPointError(native.describe_status(st, model.active_precision))
 

@@ -209,9 +209,14 @@ DC_EXPORT int dc_step_noise_fill(float* d_out, int64_t n, uint64_t seed, int32_t
  *                          FiLM tiles of every timestep of the last loop (the GEMM is re-run per timestep on this failure path).
  *                          NONFINITE without this bit in the fp16 mode means an fp16 OPERAND overflowed: use precision "mixed"
  *                          (bf16-range operands; Python: MotionTransformer(precision="auto") switches and re-runs by itself).
+ *   DC_STATUS_TIMEOUT      small batches only (B * ceil(T / 64) <= CUs): a workgroup gave up waiting for the slices of its clip's attention
+ *                          combine, which the clip's workgroups exchange inside a layer launch - they are co-resident by construction unless
+ *                          the GPU is shared with other work; the wait is bounded (~0.1 s) and the loop's results are then invalid.
+ *                          DC_L16_OWN_COMBINE=1 in the environment selects the form without the exchange.
  * clear != 0 resets the word. */
 #define DC_STATUS_NONFINITE 1
 #define DC_STATUS_F16_SATURATED 2
+#define DC_STATUS_TIMEOUT 4
 DC_EXPORT int dc_sampler_status(dc_sampler* s, int32_t* h_status, int32_t clear);
 
 /* Timing hook for bench.py: device time (ms, HIP events on the library's own stream)

@@ -235,6 +235,39 @@ def test_layer16_small_batches(models, B, T, length):
         assert torch.equal(alone, a[S][k:k + 1])
 
 
+@pytest.mark.parametrize("B,T,length", [(1, 1800, [1800]), (3, 1800, [1800, 640, 1]), (8, 1800, None), (2, 900, [900, 333]), (7, 257, None)])
+def test_layer16_shared_combine_inside_the_launch(models, B, T, length):
+    """k_layer16's prologue: the clip's workgroups reduce one slice each of the previous layer's unit records, publish it as tagged
+    8-byte granules and gather the clip's operand from each other inside the launch (dc_layer16.hip, round 5) instead of every
+    workgroup reading all records.  Against the form in which every workgroup combines alone (DC_L16_OWN_COMBINE=1; another
+    summation tree: fp32 rounding level), graph == eager, re-runs identical (tags advance, nothing stale is ever accepted), loops of
+    another batch size in between (the granule buffer is cleared when the geometry changes), and the status word stays clean."""
+    S = 25
+    length = length or [T - 29 * i for i in range(B)]
+    xfp, xfo = xf_pair(B, T, first=81)
+    noise = torch.from_numpy(batch_noise(B, T, first=81))
+    m = models["fp16"]
+    a = _ddim(m, S, noise, xfp, xfo, length, idxs=(3,))
+    # another geometry in between, then the same loop again
+    _ddim(m, S, noise[:1], xfp[:1], xfo[:1], length[:1])
+    a2 = _ddim(m, S, noise, xfp, xfo, length, idxs=(3,))
+    os.environ["DC_DISABLE_GRAPH"] = "1"
+    try:
+        c = _ddim(m, S, noise, xfp, xfo, length, idxs=(3,))
+    finally:
+        del os.environ["DC_DISABLE_GRAPH"]
+    os.environ["DC_L16_OWN_COMBINE"] = "1"
+    try:
+        b = _ddim(m, S, noise, xfp, xfo, length, idxs=(3,))
+    finally:
+        del os.environ["DC_L16_OWN_COMBINE"]
+    d = rel_l2(a[S], b[S].cpu().numpy())
+    print(f"shared vs own combine B={B} T={T}: {d:.3e}")
+    assert torch.isfinite(a[S]).all() and torch.equal(a[S], a2[S]) and torch.equal(a[3], a2[3]) and torch.equal(a[S], c[S])
+    assert d <= TOL_PARITY          # (another summation tree in front of the f16 operand rounding: the same noise level as 16- vs 32-token waves)
+    assert m._native.status() == 0
+
+
 @pytest.mark.parametrize("B,T,length", [(1, 1800, [1800]), (3, 1800, [1800, 77, 1500]), (4, 1800, [1800, 1, 911, 1799]), (12, 1800, None), (6, 512, None)])
 def test_small_batch_embedding_rides_in_the_film_launch(models, B, T, length):
     """Small batches (narrow clip-aligned units): the embedding's units are extra workgroups of the FiLM launch - beside the GEMM's

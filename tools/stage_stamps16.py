@@ -22,3 +22,10 @@ print(f"k_layer16, bs={B}, T={T}, workgroup 3 of layer 3 (us):   wave " + "".joi
 for k in range(1, 20):
     print(f"{k:2d} {names[k - 1]:32s}" + "".join(f"{(st[w, k] - st[w, k - 1]) / 100.0:8.2f}" for w in range(4)))
 print(f"   {'total':32s}" + "".join(f"{(st[w, 19] - st[w, 0]) / 100.0:8.2f}" for w in range(4)))
+if st[0, 20] > st[0, 0]:      # shared combine (round 5): stamp 20 sits between the slice's publication and the gather
+    print(f"   {'prologue: loads + slice published':32s}" + "".join(f"{(st[w, 20] - st[w, 0]) / 100.0:8.2f}" for w in range(4)))
+    print(f"   {'prologue: FiLM loads issued':32s}" + "".join(f"{(st[w, 1] - st[w, 20]) / 100.0:8.2f}" for w in range(4)))
+    if st[0, 21] > st[0, 0]:
+        print(f"   {'stage 1: LN + Q + softmax':32s}" + "".join(f"{(st[w, 21] - st[w, 2]) / 100.0:8.2f}" for w in range(4)))
+        print(f"   {'stage 1: gather + barrier':32s}" + "".join(f"{(st[w, 22] - st[w, 21]) / 100.0:8.2f}" for w in range(4)))
+        print(f"   {'stage 1: attend':32s}" + "".join(f"{(st[w, 3] - st[w, 22]) / 100.0:8.2f}" for w in range(4)))
