@@ -751,7 +751,7 @@ struct Timed {   // RAII-less helper: wraps a launch with events when profiling
 // that one process can A/B them: a change re-captures) and the update options of the loop.
 unsigned long long form_key(const dc_sampler* s) {
     static const char* sw[] = {"DC_NO_WGREC", "DC_NO_NARROW", "DC_NO_ALIGN", "DC_ALIGN", "DC_NO_FUSE_EMBED", "DC_FILM_STATIC",
-                               "DC_BEGIN_STEP", "DC_NO_PAD", "DC_NO_LAYER16", "DC_L16_OWN_COMBINE"};
+                               "DC_BEGIN_STEP", "DC_NO_PAD", "DC_NO_LAYER16", "DC_L16_OWN_COMBINE", "DC_L16_TEST_DROP_SLICE"};
     unsigned long long k = 0;
     for (size_t i = 0; i < sizeof sw / sizeof *sw; ++i) k |= (getenv(sw[i]) ? 1ull : 0ull) << i;
     k |= (unsigned long long)(s->upd_flags & 0xff) << 16;     // (the noise tensor's address is not baked in: the kernels read it from d_zslot)
@@ -842,7 +842,8 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     DcEmbedArgs ea{};
     if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, aligned ? upc : 0, ss ? 1 : 0, 0};
     if (fuse_extra) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, upc, 0, 1};
-    const DcUpdate upd{s->d_zslot, s->d_status, loop_mode ? s->upd_flags : 0, folded ? graph_step : -1, nullptr};
+    const DcUpdate upd{s->d_zslot, s->d_status, (loop_mode ? s->upd_flags : 0) | (getenv("DC_L16_TEST_DROP_SLICE") ? DC_UPD_TEST_DROP_SLICE : 0),
+                       folded ? graph_step : -1, nullptr};
 #ifdef DC_E_CHUNK2
     const int film_rounds = 3;           // experiment: 2 layers' FiLM tiles per launch, in front of their consumers (layer loop below)
 #else

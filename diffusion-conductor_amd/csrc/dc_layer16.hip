@@ -611,7 +611,8 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
     if (gran) {       // (wave-uniform) this workgroup's slices of the clip's combine, published now, gathered where the operand is needed (stage 1)
         // (the slice's loads in FRONT of the residual-stream loads measured no better: profiles/r05_small_batch_shared_combine.txt)
         Slice16<T16> sl;
-        for (int s2 = u; s2 < L16_SLICES; s2 += upc) {      // (one slice; a second for the first few workgroups at T = 1800; more for short clips)
+        const bool drop = (upd.flags & DC_UPD_TEST_DROP_SLICE) && wg == 0;      // (test hook: the timeout path)
+        for (int s2 = u; s2 < L16_SLICES && !drop; s2 += upc) {      // (one slice; a second for the first few workgroups at T = 1800; more for short clips)
             sl.load(recs_in, stride_in, nu_in, c.b, s2, wave, lane);
             sl.publish(gran, c.b, tag);
         }

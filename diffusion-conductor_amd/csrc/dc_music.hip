@@ -607,54 +607,70 @@ __global__ __launch_bounds__(512, 1) void k_me_mid(const bf16x8* __restrict__ in
 // Sliding window along time: a thread owns (clip, output column, 8 channels) and walks NY consecutive output rows,
 // keeping the last KH row maxima (each the maximum over the KW taps of one input row) in registers; an output row
 // costs SH new input rows instead of KH (5x5 stride 1: 5x fewer loads than one thread per output).
-template <int KH, int KW, int SH, int SW, int PH, int PW>
+// XO adjacent output columns per thread: their windows overlap ((XO - 1) SW + KW input columns instead of XO KW) - two columns need 7
+// loads per plane and input row instead of 10, but 173 VGPRs instead of 48 cost the occupancy that hides the loads: no faster (round 5).
+template <int KH, int KW, int SH, int SW, int PH, int PW, int XO>
 __global__ __launch_bounds__(256) void k_me_pool(const bf16x8* __restrict__ in_hi, const bf16x8* __restrict__ in_lo,
                                                  bf16x8* __restrict__ out_hi, bf16x8* __restrict__ out_lo, int Bc, int H, int W,
                                                  int C8, int Ho, int Wo, int NY) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int strips = (Ho + NY - 1) / NY;
-    const long long total = (long long)Bc * strips * Wo * C8;
+    const int Wq = (Wo + XO - 1) / XO;
+    const long long total = (long long)Bc * strips * Wq * C8;
     if (idx >= total) return;
     const int c8 = (int)(idx % C8);
-    const int xo = (int)((idx / C8) % Wo);
-    const int sy = (int)((idx / ((long long)C8 * Wo)) % strips);
-    const int b = (int)(idx / ((long long)C8 * Wo * strips));
-    float ring[KH][8];                   // ring[k] = row maximum of input row (next_row - KH + k), oldest first
-    auto row_max = [&](int yy, float (&m)[8]) {
+    const int xo0 = (int)((idx / C8) % Wq) * XO;
+    const int sy = (int)((idx / ((long long)C8 * Wq)) % strips);
+    const int b = (int)(idx / ((long long)C8 * Wq * strips));
+    constexpr int NC = (XO - 1) * SW + KW;      // input columns the thread's XO windows cover
+    float ring[KH][XO][8];                      // ring[k][i] = row maximum of input row (next_row - KH + k) over output i's window, oldest first
+    auto row_max = [&](int yy, float (&m)[XO][8]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+        for (int i = 0; i < XO; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[i][j] = -INFINITY;
         if (yy < 0 || yy >= H) return;
 #pragma unroll
-        for (int kx = 0; kx < KW; ++kx) {
-            const int xx = xo * SW - PW + kx;
+        for (int c = 0; c < NC; ++c) {
+            const int xx = xo0 * SW - PW + c;
             if (xx < 0 || xx >= W) continue;
             const size_t o = (((size_t)b * H + yy) * W + xx) * C8 + c8;
             const bf16x8 h = in_hi[o], l = in_lo[o];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)h[j] + (float)l[j]);
+            for (int i = 0; i < XO; ++i)
+                if (c >= i * SW && c < i * SW + KW) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m[i][j] = fmaxf(m[i][j], (float)h[j] + (float)l[j]);
+                }
         }
     };
     const int yo0 = sy * NY, yo1 = min(yo0 + NY, Ho);
 #pragma unroll
     for (int k = 0; k < KH; ++k) row_max(yo0 * SH - PH + k, ring[k]);
     for (int yo = yo0; yo < yo1; ++yo) {
-        float m[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            m[j] = ring[0][j];
+        for (int i = 0; i < XO; ++i) {
+            if (xo0 + i >= Wo) continue;
+            float m[8];
 #pragma unroll
-            for (int k = 1; k < KH; ++k) m[j] = fmaxf(m[j], ring[k][j]);
+            for (int j = 0; j < 8; ++j) {
+                m[j] = ring[0][i][j];
+#pragma unroll
+                for (int k = 1; k < KH; ++k) m[j] = fmaxf(m[j], ring[k][i][j]);
+            }
+            bf16x8 oh, ol;
+            split8(m, oh, ol);
+            const size_t oidx = (((size_t)b * Ho + yo) * Wo + xo0 + i) * C8 + c8;
+            out_hi[oidx] = oh;
+            out_lo[oidx] = ol;
         }
-        bf16x8 oh, ol;
-        split8(m, oh, ol);
-        const size_t oidx = (((size_t)b * Ho + yo) * Wo + xo) * C8 + c8;
-        out_hi[oidx] = oh;
-        out_lo[oidx] = ol;
         if (yo + 1 < yo1) {              // advance the window by SH input rows
 #pragma unroll
             for (int k = 0; k + SH < KH; ++k)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ring[k][j] = ring[k + SH][j];
+                for (int i = 0; i < XO; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ring[k][i][j] = ring[k + SH][i][j];
 #pragma unroll
             for (int k = (KH > SH ? KH - SH : 0); k < KH; ++k) row_max((yo + 1) * SH - PH + k, ring[k]);
         }
@@ -1080,8 +1096,12 @@ template <int KH, int KW, int SH, int SW, int PH, int PW>
 hipError_t launch_pool(hipStream_t st, const bf16x8* ih, const bf16x8* il, bf16x8* oh, bf16x8* ol, int Bc, int H, int W, int C,
                        int Ho, int Wo) {
     constexpr int NY = 24;                 // output rows per thread: (NY + KH - 1) / NY of the minimum input traffic (3 ... 24: same time)
-    const long long total = (long long)Bc * ((Ho + NY - 1) / NY) * Wo * (C / 8);
-    k_me_pool<KH, KW, SH, SW, PH, PW><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(ih, il, oh, ol, Bc, H, W, C / 8, Ho, Wo, NY);
+#ifndef DC_ME_POOL_XO
+#define DC_ME_POOL_XO 1                    // adjacent output columns per thread (2 measured 4.43 vs 4.37 ms per encode_music: 173 VGPRs, profiles/r05_ab_pool.txt)
+#endif
+    constexpr int XO = DC_ME_POOL_XO;
+    const long long total = (long long)Bc * ((Ho + NY - 1) / NY) * ((Wo + XO - 1) / XO) * (C / 8);
+    k_me_pool<KH, KW, SH, SW, PH, PW, XO><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(ih, il, oh, ol, Bc, H, W, C / 8, Ho, Wo, NY);
     return hipGetLastError();
 }
 

@@ -268,6 +268,36 @@ def test_layer16_shared_combine_inside_the_launch(models, B, T, length):
     assert m._native.status() == 0
 
 
+def test_layer16_combine_exchange_timeout_is_bounded_and_reported(models):
+    """A workgroup that never publishes its slice (test hook DC_L16_TEST_DROP_SLICE=1; in production: a GPU shared with other work, so
+    that the clip's workgroups are not co-resident): the neighbours' wait ends after the poll limit, one forward (eight layer launches)
+    returns, dc_sampler_status carries DC_STATUS_TIMEOUT, and the next call without the hook is healthy again."""
+    import time
+    from diffusion_conductor_amd import native
+    B, T = 1, 1800
+    xfp, xfo = xf_pair(B, T, first=83)
+    x = torch.from_numpy(batch_noise(B, T, first=83)).cuda()
+    m = models["fp16"]
+    nat = m.set_conditioning(xfp.cuda(), xfo.cuda(), [T])
+    good = nat.denoise(x, np.array([7], np.int32))
+    torch.cuda.synchronize()
+    assert nat.status() == 0
+    os.environ["DC_L16_TEST_DROP_SLICE"] = "1"
+    try:
+        t0 = time.perf_counter()
+        nat.denoise(x, np.array([7], np.int32))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = nat.status()
+    finally:
+        del os.environ["DC_L16_TEST_DROP_SLICE"]
+    print(f"forward with a dropped slice: {dt:.2f} s, status {st}")
+    assert st & native.STATUS_TIMEOUT and dt < 60
+    again = nat.denoise(x, np.array([7], np.int32))
+    torch.cuda.synchronize()
+    assert nat.status() == 0 and torch.equal(again, good)
+
+
 @pytest.mark.parametrize("B,T,length", [(1, 1800, [1800]), (3, 1800, [1800, 77, 1500]), (4, 1800, [1800, 1, 911, 1799]), (12, 1800, None), (6, 512, None)])
 def test_small_batch_embedding_rides_in_the_film_launch(models, B, T, length):
     """Small batches (narrow clip-aligned units): the embedding's units are extra workgroups of the FiLM launch - beside the GEMM's

@@ -1,18 +1,26 @@
 #!/bin/bash
-# GPU box: the round's evidence in one call - full gpu suite, rocprofv3 passes, stage stamps, the bench lines of every configuration.
-# usage: bash tools/final_evidence.sh r04
-TAG="${1:-r04}"
+# GPU box: the round's evidence in one call - full gpu suite, rocprofv3 passes (kernel trace, SQ / issue / LDS / FETCH / WRITE and the
+# instruction-class census), stage stamps, the bench lines of every configuration, the batch-size curve, the evaluation driver.
+# usage: bash tools/final_evidence.sh r05      (results under gpurun_out/; copy what is to be judged into profiles/)
+TAG="${1:-r05}"
 cd "$(dirname "$0")/.."
+R="$(pwd)"
 O=gpurun_out
 mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/${TAG}_pytest_gpu.txt
-bash tools/collect_profiles.sh $TAG > $O/${TAG}_collect.log 2>&1
-DC_STAMPS=1 DC_DISABLE_GRAPH=1 python tools/stage_stamps.py > $O/${TAG}_stage_stamps.txt 2>&1
-DC_STAMP_PREC=mixed DC_STAMPS=1 DC_DISABLE_GRAPH=1 python tools/stage_stamps.py > $O/${TAG}_stage_stamps_mixed.txt 2>&1
-python bench.py 2> $O/${TAG}_bench_default.err | tail -1 > $O/${TAG}_bench_default.json
-python bench.py --ddim 1000 --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${TAG}_bench_ddim1000.json
-python bench.py --bs 128 --frames 900 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${TAG}_bench_t900.json
-python bench.py --no-eff --steps 5 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${TAG}_bench_noeff.json
-python bench.py --precision mixed --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${TAG}_bench_mixed.json
-timeout 600 python tools/time_small_batch.py 1 2 3 4 8 2>/dev/null > $O/${TAG}_small_batch.txt
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/${TAG}_pytest_gpu.txt
+timeout 1500 bash tools/collect_profiles.sh $TAG > $O/${TAG}_collect.log 2>&1
+( export TMPDIR=/tmp; cd /tmp
+  BENCH="/usr/bin/python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_SALU \
+      --kernel-trace --output-format csv -d "$R/$O/profiles_$TAG/pmc_census" -- $BENCH > "$R/$O/profiles_$TAG/pmc_census.log" 2>&1 )
+python3 tools/pmc_summary.py "$O/profiles_$TAG/pmc_census" > "$O/profiles_$TAG/summary_pmc_census.txt" 2>&1; rm -rf "$O/profiles_$TAG/pmc_census"
+DC_STAMPS=1 DC_DISABLE_GRAPH=1 timeout 600 python tools/stage_stamps.py > $O/${TAG}_stage_stamps.txt 2>&1
+timeout 900 python bench.py 2> $O/${TAG}_bench_default.err | tail -1 > $O/${TAG}_bench_default.json
+timeout 900 python bench.py --ddim 1000 --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${TAG}_bench_ddim1000.json
+timeout 900 python bench.py --bs 128 --frames 900 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${TAG}_bench_t900.json
+timeout 900 python bench.py --no-eff --steps 5 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${TAG}_bench_noeff.json
+timeout 900 python bench.py --precision mixed --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${TAG}_bench_mixed.json
+timeout 900 python tools/batch_curve.py 2>/dev/null > $O/${TAG}_batch_curve.md
+timeout 600 python tools/time_evaluate.py --clips 294 2>/dev/null > $O/${TAG}_time_evaluate_294.json
+timeout 600 python tools/time_evaluate.py --clips 96 --ddim 1000 --repeat 1 2>/dev/null > $O/${TAG}_time_evaluate_ddim1000.json
 cat $O/${TAG}_pytest_gpu.txt; for f in default ddim1000 t900 noeff mixed; do echo -n "$f: "; grep -o "ms_per_step\": [0-9.]*" $O/${TAG}_bench_$f.json; done
