@@ -1384,17 +1384,10 @@ DEV void ering_issue(const f16x8* __restrict__ Eg /*wave-uniform: the block's 8 
 #else
     constexpr bool nt = true;
 #endif
-#ifdef DC_DMA_NO_IMM          // (A/B hedge: no immediate offsets)
-    lds_dma16_s<0, nt>(gsrc, voff, d);
-    lds_dma16_s<0, nt>(gsrc + 64, voff, d + 1024);
-    lds_dma16_s<0, nt>(hsrc, voff, d + 2048);
-    lds_dma16_s<0, nt>(hsrc + 64, voff, d + 3072);
-#else
     lds_dma16_s<0, nt>(gsrc, voff, d);            // (the immediate offset moves the global AND the LDS address: the second half of a
     lds_dma16_s<1024, nt>(gsrc, voff, d);         // tile lands 1 KiB behind the first without a second LDS base)
     lds_dma16_s<0, nt>(hsrc, voff, d + 2048);
     lds_dma16_s<1024, nt>(hsrc, voff, d + 2048);
-#endif
 }
 // same StylizationBlock with the FiLM tiles of k-tiles 0,1 arriving through the ring (issued a stage ago) and those of
 // k-tiles 2,3 prefetched into registers at the start of the preceding stage (EPre; they landed with that stage's closing
