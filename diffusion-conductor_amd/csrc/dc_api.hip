@@ -844,11 +844,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     if (fuse_extra) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, upc, 0, 1};
     const DcUpdate upd{s->d_zslot, s->d_status, (loop_mode ? s->upd_flags : 0) | (getenv("DC_L16_TEST_DROP_SLICE") ? DC_UPD_TEST_DROP_SLICE : 0),
                        folded ? graph_step : -1, nullptr};
-#ifdef DC_E_CHUNK2
-    const int film_rounds = 3;           // experiment: 2 layers' FiLM tiles per launch, in front of their consumers (layer loop below)
-#else
     const int film_rounds = s->NT / 16;
-#endif
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
                                        film_rounds, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
                                        want_stamps_film ? s->d_stamps + 252 : nullptr,
@@ -888,16 +884,6 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
                                               u16, l16_shared ? s->d_gran : nullptr, l16_tag));
             continue;
         }
-#ifdef DC_E_CHUNK2
-        if (l > 0 && (l & 1) == 0) {
-            LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 3 * (l / 2),
-                                               3, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B, nullptr,
-                                               adapt ? s->d_film_rate + 1024 * s->film_rate_parity : nullptr,
-                                               adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr, iter_base,
-                                               s->h_model.film_w16, s->h_model.film_b16, nullptr, s->d_status));
-            s->film_rate_parity ^= 1;
-        }
-#endif
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src,

@@ -774,11 +774,7 @@ DEV void film_gemm3_body(const v8<T16>* __restrict__ W, const float* __restrict_
                         o[4 * fb + h2] = r[0];            // registers 8 fb + 2 h2, +1     (block rows 0..3 | 8..11 of this lane half)
                         o[4 * fb + 2 + h2] = r[1];        // registers 8 fb + 4 + 2 h2, +1 (block rows 4..7 | 12..15)
                     }
-#ifdef DC_E_CHUNK2
-                store_etile(E, (size_t)(g0 + g) * 48 + (blk - 2 * round0) * 8 + 4 * ti + t, lane, __builtin_bit_cast(f16x16, o));
-#else
                 store_etile(E, (size_t)(g0 + g) * NT + blk * 8 + 4 * ti + t, lane, __builtin_bit_cast(f16x16, o));
-#endif
             }
         }
         my = nxt;
@@ -1152,13 +1148,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     const W* af = reinterpret_cast<const W*>(lds + OFF_AF);
     const DcLayer& L = dm->layer[l];
     const bool last = l + 1 >= nl;
-#ifdef DC_E_CHUNK2
-    // experiment (EXPERIMENTS.md, round 5): the FiLM GEMM runs in four 2-layer chunks in front of their consumers into ONE aliased
-    // [G][48 tiles] buffer (177 MB at bs=32)
-    const f16x8* Eg = reinterpret_cast<const f16x8*>(E) + ((size_t)g * 48 + (size_t)(l & 1) * 24) * 128;
-#else
     const f16x8* Eg = reinterpret_cast<const f16x8*>(E) + ((size_t)g * NT + (size_t)l * 24) * 128;   // 3 blocks x 8 tiles
-#endif
     const W* acl = a_ca + (size_t)l * B * 16 * 64;
     const float* recs_in = recs + (size_t)(l & 1) * rec_stride;
     float* recs_out = recs + (size_t)((l + 1) & 1) * rec_stride;
