@@ -622,6 +622,10 @@ int clip_stride(const dc_sampler* s, int B, int Tx) {
     const int Tp = (Tx + 31) / 32 * 32;
     if (s->split_small) return Tp;         // split formats: workgroup records exist on clip-aligned units only (one clip per workgroup)
     const bool small_batch = (long long)B * ((Tp + 127) / 128) <= s->num_cu;       // narrow, clip-aligned workgroups
+    // ... unless the padding frames cost the layer launches a whole extra round of workgroups (256 tokens each, one per CU): 36 clips of
+    // 1800 frames are 254 workgroups, of 1824 frames 257 - 38 vs 51 ms per loop (profiles/r05_big_batches.md)
+    const auto rounds = [&](int T) { return (((long long)B * T + 255) / 256 + s->num_cu - 1) / s->num_cu; };
+    if (!small_batch && rounds(Tp) > rounds(Tx)) return Tx;
     return (small_batch || (Tp - Tx) * 50 <= Tx) ? Tp : Tx;
 }
 int ensure_workspace(dc_sampler* s, int B, int Tx) {
