@@ -488,6 +488,29 @@ def test_bs32_interior_clips_vs_oracle(models):
     assert worst["fp16"] <= TOL_PARITY and worst["mixed"] <= TOL_PARITY, worst
 
 
+def test_clip_stride_avoids_an_extra_round_of_layer_workgroups(models):
+    """The clip stride is padded to whole 32-frame groups (1800 -> 1824) only while the padding frames do not tip the layer launches
+    into another round of 256-token workgroups on the 256 CUs: 36 clips are 254 workgroups unpadded, 257 padded (51 vs 37 ms per
+    loop).  The unpadded batch runs flat units whose groups straddle clip edges: two interior clips against the oracle (DDIM-25)."""
+    T = 1800
+    m = models["fp16"]
+    strides = {}
+    for B in (32, 36):
+        xfp, xfo = xf_pair(B, T, first=90)
+        nat = m.set_conditioning(xfp.cuda(), xfo.cuda(), [T] * B)
+        strides[B] = nat.clip_stride()
+    assert strides == {32: 1824, 36: 1800}, strides
+    B, clips = 36, (17, 35)
+    xfp, xfo = xf_pair(B, T, first=90)
+    noise = torch.from_numpy(batch_noise(B, T, first=90))
+    with torch.no_grad():
+        ref = O.ddim_sample_loop(oracle_params(), noise[list(clips)], xfp[list(clips)], xfo[list(clips)], [T] * len(clips), 25)
+    a = _ddim(m, 25, noise, xfp, xfo, [T] * B)
+    errs = [rel_l2(a[c:c + 1], ref[i:i + 1]) for i, c in enumerate(clips)]
+    print("bs36 (unpadded stride) clips 17 / 35 vs oracle: " + "  ".join(f"{e:.3e}" for e in errs))
+    assert max(errs) <= TOL_PARITY
+
+
 def test_bs32_every_clip_vs_oracle(models):
     """All 32 clips of the headline batch (bs=32 x 1800, DDIM-50, flat 256-token units: 28 of the 32 clips share a unit with a
     neighbour at one end or both) against the CPU oracle's DDIM-50 of the same batch (the oracle has no cross-clip operation), per
