@@ -225,6 +225,7 @@ struct dc_sampler {
     float* d_smooth_coef = nullptr;
 
     dc_music* music = nullptr;   // MusicEncoder (built when its parameters were supplied)
+    int me_format = -1;          // dc_sampler_set_encoder_format (-1: by precision)
     bool host_only = false;      // -DDC_HOST_SANITIZE builds without a device: the host half only (tests/test_host_sanitize.py)
 
     Prof prof;
@@ -1260,6 +1261,8 @@ int dc_sampler_finalize_params(dc_sampler* s) {
         std::string err;
         s->music = dc_music_build(s->params, DC_C, &err);
         if (!s->music) return fail(DC_ERR_PARAM, "music encoder: %s", err.c_str());
+        // one fp16 plane where the denoiser rounds the features to 16-bit operands anyway, split planes for the split-operand precisions
+        dc_music_set_format(s->music, s->me_format >= 0 ? s->me_format : (s->split_small ? DC_ME_SPLIT : DC_ME_FP16));
     }
     s->finalized = true;
     s->cond_set = false;
@@ -1315,6 +1318,14 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
     }
     s->cond_set = true;
     return sync_out(s, user);
+}
+
+int dc_sampler_set_encoder_format(dc_sampler* s, int32_t format) {
+    if (!s) return fail(DC_ERR_INVALID, "null sampler");
+    if (format != DC_ME_SPLIT && format != DC_ME_FP16) return fail(DC_ERR_INVALID, "encoder format %d (DC_ME_SPLIT = 0, DC_ME_FP16 = 1)", format);
+    s->me_format = format;                                  // (kept across dc_sampler_finalize)
+    if (s->music) dc_music_set_format(s->music, format);
+    return DC_OK;
 }
 
 int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t B, int32_t Tm, int32_t n_mels, float* d_xf_proj,

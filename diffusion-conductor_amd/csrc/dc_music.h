@@ -21,5 +21,9 @@ std::vector<std::pair<std::string, size_t>> dc_music_required(int music_dim);
 // Work is enqueued on `st`; clips are processed in chunks so the activation planes stay bounded.
 hipError_t dc_music_encode(dc_music* m, const float* d_mel, int B, int Tm, float* d_xf_proj, float* d_xf_out, hipStream_t st,
                            std::string* err);
+// plane format of this encoder's activations: 0 = two bf16 planes (hi + lo, three MFMAs per product: ~6e-6 at the output), 1 = one
+// fp16 plane (one MFMA per product, half the bytes: ~4e-4 at the output, 1.3e-4 of x0 after DDIM-50).  DC_ME_PREC=f16|split overrides.
+void dc_music_set_format(dc_music* m, int single_fp16);
+int dc_music_format(const dc_music* m);
 int dc_music_frames(int Tm);
 long long dc_music_workspace_bytes(const dc_music* m);

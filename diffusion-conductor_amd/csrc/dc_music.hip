@@ -55,6 +55,53 @@ DEV f32x16 zero16() {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Plane formats.  SP = true: the split form above (two bf16 planes, three MFMAs per k-step: ~6e-6 at the encoder's output).
+// SP = false: ONE fp16 plane and fp16 weights, one MFMA per k-step, half the LDS reads and half the HBM bytes: every activation is
+// rounded to 11 bits once per layer - 3.7e-4 relative at the encoder's output, 1.3e-4 of x0 after DDIM-50 (tests/study_encoder_fp16.py
+// reproduces both on the CPU), i.e. the order of the fp16 operand rounding the fp16 sampler applies to these features anyway.
+// dc_music_encode picks the format per call (dc_music_set_format / DC_ME_PREC); the kernels are the same templates.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+template <bool SP> struct PL;
+template <> struct PL<true> {
+    using e = __bf16;
+    using v8 = bf16x8;
+    using v4 = bf16x4;
+    static constexpr int N = 2;
+};
+template <> struct PL<false> {
+    using e = _Float16;
+    using v8 = f16x8;
+    using v4 = f16x4;
+    static constexpr int N = 1;
+};
+DEV f32x16 mfma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+// one k-step: split planes hi*hi + lo*hi + hi*lo; single plane one product (al, bl are then dead values and their loads disappear)
+DEV f32x16 mma(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 acc) { return mma3(ah, al, bh, bl, acc); }
+DEV f32x16 mma(f16x8 ah, f16x8, f16x8 bh, f16x8, f32x16 acc) { return mfma(ah, bh, acc); }
+// four values -> one 8-byte piece per plane
+DEV void put4(const float (&v)[4], __bf16* hi, __bf16* lo) {
+    bf16x4 oh, ol;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        oh[e] = h;
+        ol[e] = (__bf16)(v[e] - (float)h);
+    }
+    *reinterpret_cast<bf16x4*>(hi) = oh;
+    *reinterpret_cast<bf16x4*>(lo) = ol;
+}
+DEV void put4(const float (&v)[4], _Float16* hi, _Float16*) {
+    f16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+    *reinterpret_cast<f16x4*>(hi) = o;
+}
+// value of element e of an 8-byte piece (pair)
+DEV float val4(const bf16x4& h, const bf16x4& l, int e) { return (float)h[e] + (float)l[e]; }
+DEV float val4(const f16x4& h, const f16x4&, int e) { return (float)h[e]; }
+
+// ---------------------------------------------------------------------------------------------------------
 // 3x3 reflect-padded convolution + folded BatchNorm + ReLU (+ residual).  RES: 0 none, 1 identity, 2 1x1 conv + BN.
 // Weight fragments (A operand, natural k = tap*CIN + ci): [hi: NKS][lo: NKS] then for RES == 2 [hi: KC][lo: KC].
 // CIN == 1 reads the fp32 mel directly: its single k-step holds the 9 taps (k = tap), split in registers.
@@ -172,21 +219,24 @@ DEV void me_dma16(const void* gsrc /*per-lane*/, const char* lds_dst /*wave-unif
                  : "v"(gsrc), "s"(dst)
                  : "memory");
 }
-template <int CIN, int COUT, int RES, int ROWS, int NXS>
-__global__ __launch_bounds__(256, 2) void k_me_conv_t(const bf16x8* __restrict__ in_hi, const bf16x8* __restrict__ in_lo,
-                                                      __bf16* __restrict__ out_hi, __bf16* __restrict__ out_lo,
-                                                      const bf16x8* __restrict__ w, const float* __restrict__ bias_ft,
+template <int CIN, int COUT, int RES, int ROWS, int NXS, bool SP>
+__global__ __launch_bounds__(256, 2) void k_me_conv_t(const typename PL<SP>::v8* __restrict__ in_hi, const typename PL<SP>::v8* __restrict__ in_lo,
+                                                      typename PL<SP>::e* __restrict__ out_hi, typename PL<SP>::e* __restrict__ out_lo,
+                                                      const typename PL<SP>::v8* __restrict__ w, const float* __restrict__ bias_ft,
                                                       const float* __restrict__ rbias_ft, int H, int W, int ntiles) {
-    constexpr int KC = CIN / 16, NKS = 9 * KC, NF = 2 * NKS + (RES == 2 ? 2 * KC : 0);
+    using V8 = typename PL<SP>::v8;
+    using V4 = typename PL<SP>::v4;
+    constexpr int NPL = PL<SP>::N;                  // planes (weights: [hi: NKS][lo: NKS][res hi: KC][res lo: KC], single plane: [NKS][res: KC])
+    constexpr int KC = CIN / 16, NKS = 9 * KC, NF = NPL * NKS + (RES == 2 ? NPL * KC : 0);
     constexpr int TX = 32 * NXS, PXW = TX + 2, RH = ROWS + 2;
     constexpr int SEL = RH * PXW;                    // pieces per (plane, chunk, half)
-    constexpr int NP = 2 * KC * 2 * SEL;
+    constexpr int NP = NPL * KC * 2 * SEL;
     constexpr int NDMA = (NP + 63) / 64;
     constexpr int TPW = ROWS * NXS / 4;
     static_assert(ROWS * NXS % 4 == 0, "wave tiles divide over 4 waves");
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    bf16x8* wl = reinterpret_cast<bf16x8*>(lds);
-    bf16x8* tl = wl + NF * 64;
+    V8* wl = reinterpret_cast<V8*>(lds);
+    V8* tl = wl + NF * 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = lane & 31, kh = lane >> 5;
     for (int f = wave; f < NF; f += 4) wl[f * 64 + lane] = w[f * 64 + lane];
@@ -205,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void k_me_conv_t(const bf16x8* __restrict__
             if (p < NP) {
                 const int px = p % PXW, row = (p / PXW) % RH, sel = p / SEL;
                 const int yy = reflect(y0 - 1 + row, H), xx = reflect(x0 - 1 + px, W);
-                const bf16x8* src = ((sel >= 2 * KC) ? in_lo : in_hi) + (((size_t)b * H + yy) * W + xx) * (CIN / 8) + (sel % (2 * KC));
+                const V8* src = ((sel >= 2 * KC) ? in_lo : in_hi) + (((size_t)b * H + yy) * W + xx) * (CIN / 8) + (sel % (2 * KC));
                 me_dma16(src, reinterpret_cast<const char*>(tl + 64 * j));
             }
         }
@@ -218,16 +268,17 @@ __global__ __launch_bounds__(256, 2) void k_me_conv_t(const bf16x8* __restrict__
         auto piece = [&](int plane, int kc, int r, int seg, int dy, int dx) {
             return tl[((plane * KC + kc) * 2 + kh) * SEL + (r + dy) * PXW + seg * 32 + n + dx];
         };
+        constexpr int LO = NPL - 1;                  // the second plane (single plane: the same piece, a dead value)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
                 const int ks = tap * KC + kc;
-                const bf16x8 ah = wl[ks * 64 + lane], al = wl[(NKS + ks) * 64 + lane];
+                const V8 ah = wl[ks * 64 + lane], al = wl[(LO * NKS + ks) * 64 + lane];
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
                     const int wt = wave * TPW + i, r = wt / NXS, seg = wt % NXS;
-                    acc[i] = mma3(ah, al, piece(0, kc, r, seg, tap / 3, tap % 3), piece(1, kc, r, seg, tap / 3, tap % 3), acc[i]);
+                    acc[i] = mma(ah, al, piece(0, kc, r, seg, tap / 3, tap % 3), piece(LO, kc, r, seg, tap / 3, tap % 3), acc[i]);
                 }
             }
 #pragma unroll
@@ -238,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void k_me_conv_t(const bf16x8* __restrict__
             if constexpr (RES == 2) {
 #pragma unroll
                 for (int kc = 0; kc < KC; ++kc)
-                    res = mma3(wl[(2 * NKS + kc) * 64 + lane], wl[(2 * NKS + KC + kc) * 64 + lane], piece(0, kc, r, seg, 1, 1),
-                               piece(1, kc, r, seg, 1, 1), res);
+                    res = mma(wl[(NPL * NKS + kc) * 64 + lane], wl[(NPL * NKS + LO * KC + kc) * 64 + lane], piece(0, kc, r, seg, 1, 1),
+                              piece(LO, kc, r, seg, 1, 1), res);
             }
             if (y >= H) continue;
             const size_t pix = ((size_t)b * H + y) * W + x;
@@ -251,24 +302,16 @@ __global__ __launch_bounds__(256, 2) void k_me_conv_t(const bf16x8* __restrict__
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][4 * q + e] + bias[4 * q + e], 0.f);
                 if constexpr (RES == 1) {               // input channels c0 .. c0+3 of the centre pixel: half kh of piece (q >> 1, q & 1)
                     const int pc = ((q >> 1) * 2 + (q & 1)) * SEL + (r + 1) * PXW + seg * 32 + n + 1;
-                    const bf16x4 xh = reinterpret_cast<const bf16x4*>(tl + pc)[kh];
-                    const bf16x4 xl = reinterpret_cast<const bf16x4*>(tl + 2 * KC * SEL + pc)[kh];
+                    const V4 xh = reinterpret_cast<const V4*>(tl + pc)[kh];
+                    const V4 xl = reinterpret_cast<const V4*>(tl + LO * 2 * KC * SEL + pc)[kh];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)xh[e] + (float)xl[e];
+                    for (int e = 0; e < 4; ++e) v[e] += val4(xh, xl, e);
                 }
                 if constexpr (RES == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += res[4 * q + e] + rbias[4 * q + e];
                 }
-                bf16x4 oh, ol;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const __bf16 h = (__bf16)v[e];
-                    oh[e] = h;
-                    ol[e] = (__bf16)(v[e] - (float)h);
-                }
-                *reinterpret_cast<bf16x4*>(out_hi + pix * COUT + c0) = oh;
-                *reinterpret_cast<bf16x4*>(out_lo + pix * COUT + c0) = ol;
+                put4(v, out_hi + pix * COUT + c0, out_lo + pix * COUT + c0);
             }
         }
         __syncthreads();          // everyone is done with the tile before the next fill lands
@@ -290,15 +333,24 @@ __global__ __launch_bounds__(256, 2) void k_me_conv_t(const bf16x8* __restrict__
 // lane groups complete a pixel's 32 bytes in one store instruction.
 // ---------------------------------------------------------------------------------------------------------
 DEV f32x4 mfma16b(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-DEV f32x4 mma3_16(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4 acc) {
+DEV f32x4 mfma16b(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+DEV f32x4 mma_16(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4 acc) {
     acc = mfma16b(ah, bh, acc);
     acc = mfma16b(al, bh, acc);
     return mfma16b(ah, bl, acc);
 }
-template <int ROWS, int TX>
-__global__ __launch_bounds__(512, 1) void k_me_stem(const float* __restrict__ mel, __bf16* __restrict__ out_hi, __bf16* __restrict__ out_lo,
-                                                    const bf16x8* __restrict__ w /* 22 fragments */, const float* __restrict__ bias /*[3][16]*/,
+DEV f32x4 mma_16(f16x8 ah, f16x8, f16x8 bh, f16x8, f32x4 acc) { return mfma16b(ah, bh, acc); }
+// SP = false (one fp16 plane): 51 KiB of LDS and two workgroups per CU - one's phase A (vector ALU) beside the other's MFMA phases.
+template <int ROWS, int TX, bool SP>
+__global__ __launch_bounds__(512, SP ? 2 : 4) void k_me_stem(const float* __restrict__ mel, typename PL<SP>::e* __restrict__ out_hi,
+                                                               typename PL<SP>::e* __restrict__ out_lo,
+                                                    const typename PL<SP>::v8* __restrict__ w /* split: 22 fragments (conv1.0: hi, lo; conv1.1: 5 hi, 5 lo; conv1.2: 5 hi, 5 lo); single plane: 10 (conv1.1: 5, conv1.2: 5) */,
+                                                    const float* __restrict__ bias /*[3][16]*/,
                                                     const float* __restrict__ wa32 /* conv1.0 folded weights [16][9] */, int H, int W, int ntiles) {
+    using E = typename PL<SP>::e;
+    using V8 = typename PL<SP>::v8;
+    using V4 = typename PL<SP>::v4;
+    constexpr int NPL = PL<SP>::N, LO = NPL - 1;
     constexpr int RAH = ROWS + 4, RAW = TX + 4, NA = RAH * RAW;       // conv1.0 region
     constexpr int RBH = ROWS + 2, RBW = TX + 2, NB = RBH * RBW;       // conv1.1 region
     constexpr int NBP = (NB + 15) / 16 * 16;                          // plane stride of TB: a multiple of 256 B keeps the reads conflict-free
@@ -309,37 +361,39 @@ __global__ __launch_bounds__(512, 1) void k_me_stem(const float* __restrict__ me
     static_assert(TX == 64 && NC % 128 == 0, "phase C walks two rows per step");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* TA = lds;                                // pieces [plane][half][NA] x 16 B
-    char* TB = TA + 4 * NA * 16;                   // pieces [plane][half][NBP] x 16 B
-    float* MT = reinterpret_cast<float*>(TB + 4 * NBP * 16);
+    char* TB = TA + 2 * NPL * NA * 16;             // pieces [plane][half][NBP] x 16 B
+    float* MT = reinterpret_cast<float*>(TB + 2 * NPL * NBP * 16);
+    float* WA = MT + NM;                           // single plane: conv1.0's 144 weights (two workgroups per CU leave 128 registers per lane)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = lane & 15, q4 = lane >> 4;
     // conv1.1 / conv1.2 weight fragments stay in registers (the B operands are the only LDS reads of the MFMA phases)
-    bf16x8 wb_h[5], wb_l[5], wc_h[5], wc_l[5];
+    V8 wb_h[5], wb_l[5], wc_h[5], wc_l[5];
 #pragma unroll
     for (int ks = 0; ks < 5; ++ks) {
-        wb_h[ks] = w[(2 + ks) * 64 + lane];
-        wb_l[ks] = w[(7 + ks) * 64 + lane];
-        wc_h[ks] = w[(12 + ks) * 64 + lane];
-        wc_l[ks] = w[(17 + ks) * 64 + lane];
+        if constexpr (SP) {
+            wb_h[ks] = w[(2 + ks) * 64 + lane];
+            wb_l[ks] = w[(7 + ks) * 64 + lane];
+            wc_h[ks] = w[(12 + ks) * 64 + lane];
+            wc_l[ks] = w[(17 + ks) * 64 + lane];
+        } else {
+            wb_h[ks] = wb_l[ks] = w[ks * 64 + lane];
+            wc_h[ks] = wc_l[ks] = w[(5 + ks) * 64 + lane];
+        }
     }
     const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + 16 + 4 * q4), bc = *reinterpret_cast<const f32x4*>(bias + 32 + 4 * q4);
     // phase A runs on the vector ALU in fp32: thread = (pixel, channel quad); its quad's 36 weights in registers
     const int quad = tid & 3;
     float wa[4][9];
+    if constexpr (SP) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wa[c][k] = wa32[(4 * quad + c) * 9 + k];
+            for (int k = 0; k < 9; ++k) wa[c][k] = wa32[(4 * quad + c) * 9 + k];
+    } else if (tid < 144) {
+        WA[tid] = wa32[tid];
+    }
     const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + 4 * quad);
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    auto split4 = [](const f32x4& v, bf16x4& oh, bf16x4& ol) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const __bf16 h = (__bf16)v[e];
-            oh[e] = h;
-            ol[e] = (__bf16)(v[e] - (float)h);
-        }
-    };
     // k-step ks of this lane: tap 2 ks + (q4 >> 1) (the ninth tap's partner slot has zero weights: it re-reads tap 8), channel half q4 & 1
     int ckA[5], ckB[5];          // piece offsets relative to the centre piece (TA: centre = the position itself; TB: centre = tile origin)
 #pragma unroll
@@ -377,6 +431,12 @@ __global__ __launch_bounds__(512, 1) void k_me_stem(const float* __restrict__ me
         };
         // ---- A: conv1.0 at the reflected positions of the 2-pixel-grown tile (fp32 FMAs; taps are plain neighbours in MT)
         {
+            if constexpr (!SP) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) wa[c][k] = WA[(4 * quad + c) * 9 + k];
+            }
             int row = (tid >> 2) / RAW, px = (tid >> 2) % RAW;
             for (int p = tid >> 2; p < NA; p += 128) {
                 const int cy = local(row, y0, 2, 3, H, MH), cx = local(px, x0, 2, 3, W, MW);
@@ -388,13 +448,11 @@ __global__ __launch_bounds__(512, 1) void k_me_stem(const float* __restrict__ me
 #pragma unroll
                     for (int c = 0; c < 4; ++c) acc[c] = fmaf(wa[c][k], mval, acc[c]);
                 }
+                float v[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = fmaxf(acc[c], 0.f);
-                bf16x4 oh, ol;
-                split4(acc, oh, ol);
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[c], 0.f);
                 char* dst = TA + (size_t)(((quad >> 1) * NA + p) * 16 + (quad & 1) * 8);
-                *reinterpret_cast<bf16x4*>(dst) = oh;
-                *reinterpret_cast<bf16x4*>(dst + 2 * NA * 16) = ol;
+                put4(v, reinterpret_cast<E*>(dst), reinterpret_cast<E*>(dst + 2 * NA * 16));
                 px += 128 - RAW;
                 row += 1;
                 if (px >= RAW) {
@@ -414,20 +472,18 @@ __global__ __launch_bounds__(512, 1) void k_me_stem(const float* __restrict__ me
                 f32x4 acc = z4;
 #pragma unroll
                 for (int ks = 0; ks < 5; ++ks) {
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(ctr + ckA[ks]);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(ctr + ckA[ks] + 2 * NA * 16);
-                    acc = mma3_16(wb_h[ks], wb_l[ks], bh, bl, acc);
+                    const V8 bh = *reinterpret_cast<const V8*>(ctr + ckA[ks]);
+                    const V8 bl = *reinterpret_cast<const V8*>(ctr + ckA[ks] + LO * 2 * NA * 16);
+                    acc = mma_16(wb_h[ks], wb_l[ks], bh, bl, acc);
                 }
-                const bf16x4 rh = *reinterpret_cast<const bf16x4*>(ctr + hp * NA * 16 + ho);
-                const bf16x4 rl = *reinterpret_cast<const bf16x4*>(ctr + (2 + hp) * NA * 16 + ho);
+                const V4 rh = *reinterpret_cast<const V4*>(ctr + hp * NA * 16 + ho);
+                const V4 rl = *reinterpret_cast<const V4*>(ctr + (LO * 2 + hp) * NA * 16 + ho);
+                float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e] + bb[e], 0.f) + ((float)rh[e] + (float)rl[e]);
-                bf16x4 oh, ol;
-                split4(acc, oh, ol);
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[e] + bb[e], 0.f) + val4(rh, rl, e);
                 if (f < NB) {
                     char* dst = TB + (size_t)((hp * NBP + f) * 16 + ho);
-                    *reinterpret_cast<bf16x4*>(dst) = oh;
-                    *reinterpret_cast<bf16x4*>(dst + 2 * NBP * 16) = ol;
+                    put4(v, reinterpret_cast<E*>(dst), reinterpret_cast<E*>(dst + 2 * NBP * 16));
                 }
                 px += 128 - RBW;
                 row += 1;
@@ -443,26 +499,23 @@ __global__ __launch_bounds__(512, 1) void k_me_stem(const float* __restrict__ me
             const int row0 = wave >> 2, px = (wave & 3) * 16 + n;
             const char* org = TB + (size_t)(row0 * RBW + px) * 16;
             size_t pix = ((size_t)b * H + y0 + row0) * W + x0 + px;
-#pragma unroll
+            constexpr int UNR = SP ? ROWS / 2 : 1;          // (single plane: 128 registers per lane)
+#pragma unroll(UNR)
             for (int k = 0; k < ROWS / 2; ++k) {
                 f32x4 acc = z4;
 #pragma unroll
                 for (int ks = 0; ks < 5; ++ks) {
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(org + ckB[ks]);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(org + ckB[ks] + 2 * NBP * 16);
-                    acc = mma3_16(wc_h[ks], wc_l[ks], bh, bl, acc);
+                    const V8 bh = *reinterpret_cast<const V8*>(org + ckB[ks]);
+                    const V8 bl = *reinterpret_cast<const V8*>(org + ckB[ks] + LO * 2 * NBP * 16);
+                    acc = mma_16(wc_h[ks], wc_l[ks], bh, bl, acc);
                 }
                 const char* ctr = org + (RBW + 1) * 16;
-                const bf16x4 rh = *reinterpret_cast<const bf16x4*>(ctr + hp * NBP * 16 + ho);
-                const bf16x4 rl = *reinterpret_cast<const bf16x4*>(ctr + (2 + hp) * NBP * 16 + ho);
+                const V4 rh = *reinterpret_cast<const V4*>(ctr + hp * NBP * 16 + ho);
+                const V4 rl = *reinterpret_cast<const V4*>(ctr + (LO * 2 + hp) * NBP * 16 + ho);
+                float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e] + bc[e], 0.f) + ((float)rh[e] + (float)rl[e]);
-                bf16x4 oh, ol;
-                split4(acc, oh, ol);
-                if (y0 + row0 + 2 * k < H) {
-                    *reinterpret_cast<bf16x4*>(out_hi + pix * 16 + 4 * q4) = oh;
-                    *reinterpret_cast<bf16x4*>(out_lo + pix * 16 + 4 * q4) = ol;
-                }
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[e] + bc[e], 0.f) + val4(rh, rl, e);
+                if (y0 + row0 + 2 * k < H) put4(v, out_hi + pix * 16 + 4 * q4, out_lo + pix * 16 + 4 * q4);
                 org += 2 * RBW * 16;
                 pix += 2 * (size_t)W;
             }
@@ -479,36 +532,57 @@ __global__ __launch_bounds__(512, 1) void k_me_stem(const float* __restrict__ me
 //   C:    conv2.1 + identity residual on the tile, taps from TB; the next tile's fill is in flight meanwhile     -> HBM
 // v_mfma_f32_32x32x16_bf16 (32 output channels = the tile's rows), weights of both layers in LDS (56 KiB).
 // ---------------------------------------------------------------------------------------------------------
-template <int ROWS, int TX>
-__global__ __launch_bounds__(512, 1) void k_me_mid(const bf16x8* __restrict__ in_hi, const bf16x8* __restrict__ in_lo,
-                                                   __bf16* __restrict__ out_hi, __bf16* __restrict__ out_lo,
-                                                   const bf16x8* __restrict__ w0 /* conv2.0: 9 hi, 9 lo, residual hi, lo */,
+// SP = false (one fp16 plane): 64 KiB of LDS, two workgroups per CU.
+template <int ROWS, int TX, bool SP>
+__global__ __launch_bounds__(512, SP ? 2 : 4) void k_me_mid(const typename PL<SP>::v8* __restrict__ in_hi, const typename PL<SP>::v8* __restrict__ in_lo,
+                                                   typename PL<SP>::e* __restrict__ out_hi, typename PL<SP>::e* __restrict__ out_lo,
+                                                   const typename PL<SP>::v8* __restrict__ w0 /* conv2.0: 9 hi, 9 lo, residual hi, lo (single plane: 9, residual) */,
                                                    const float* __restrict__ bias0_ft, const float* __restrict__ rbias0_ft,
-                                                   const bf16x8* __restrict__ w1 /* conv2.1: 18 hi, 18 lo */,
+                                                   const typename PL<SP>::v8* __restrict__ w1 /* conv2.1: 18 hi, 18 lo (single plane: 18) */,
                                                    const float* __restrict__ bias1_ft, int H, int W, int ntiles) {
+    using V8 = typename PL<SP>::v8;
+    using V4 = typename PL<SP>::v4;
+    using E = typename PL<SP>::e;
+    constexpr int NPL = PL<SP>::N, LO = NPL - 1;
     static_assert(TX == 32 && ROWS == 8, "phase C: one tile row per wave");
     constexpr int RAH = ROWS + 4, RAW = TX + 4, NA = RAH * RAW;           // input region (16 channels: halves kh)
     constexpr int RBH = ROWS + 2, RBW = TX + 2, NB = RBH * RBW;           // conv2.0 region (32 channels: chunks kc, halves kh)
     constexpr int NBP = (NB + 15) / 16 * 16;
-    constexpr int NPA = 4 * NA;                                            // 16-byte pieces of TA: [plane][kh][NA]
+    constexpr int NPA = 2 * NPL * NA;                                      // 16-byte pieces of TA: [plane][kh][NA]
     constexpr int NDMA = (NPA + 63) / 64;
+    constexpr int NW0 = 10 * NPL, NW1 = 18 * NPL;
     static_assert(NA % 16 == 0, "plane stride of TA");
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    bf16x8* wl0 = reinterpret_cast<bf16x8*>(lds);                          // 20 fragments
-    bf16x8* wl1 = wl0 + 20 * 64;                                           // 36 fragments
-    bf16x8* TA = wl1 + 36 * 64;                                            // pieces [plane][kh][NA]
-    bf16x8* TB = TA + NDMA * 64;                                           // pieces [plane][kc][kh][NBP]
+    V8* wl0 = reinterpret_cast<V8*>(lds);                                  // 20 (10) fragments
+    V8* wl1 = wl0 + NW0 * 64;                                              // 36 (18) fragments
+    V8* TA = wl1 + NW1 * 64;                                               // pieces [plane][kh][NA]
+    V8* TB = TA + NDMA * 64;                                               // pieces [plane][kc][kh][NBP]
+    float* BL = reinterpret_cast<float*>(TB + NPL * 4 * NBP);              // single plane: the three bias vectors (128 registers per lane)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = lane & 31, kh = lane >> 5;
-    for (int f = wave; f < 20; f += 8) wl0[f * 64 + lane] = w0[f * 64 + lane];
-    for (int f = wave; f < 36; f += 8) wl1[f * 64 + lane] = w1[f * 64 + lane];      // (in registers instead: 4.36 vs 4.25 ms per 32 clips)
+    for (int f = wave; f < NW0; f += 8) wl0[f * 64 + lane] = w0[f * 64 + lane];
+    for (int f = wave; f < NW1; f += 8) wl1[f * 64 + lane] = w1[f * 64 + lane];      // (in registers instead: 4.36 vs 4.25 ms per 32 clips)
     f32x16 bias0, rbias0, bias1;
+    if constexpr (SP) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        bias0[r] = bias0_ft[kh * 16 + r];
-        rbias0[r] = rbias0_ft[kh * 16 + r];
-        bias1[r] = bias1_ft[kh * 16 + r];
+        for (int r = 0; r < 16; ++r) {
+            bias0[r] = bias0_ft[kh * 16 + r];
+            rbias0[r] = rbias0_ft[kh * 16 + r];
+            bias1[r] = bias1_ft[kh * 16 + r];
+        }
+    } else if (tid < 96) {
+        BL[tid] = tid < 32 ? bias0_ft[tid] : tid < 64 ? rbias0_ft[tid - 32] : bias1_ft[tid - 64];
     }
+    auto ld16 = [&](int which) {                                           // one bias vector of this lane's half from LDS
+        f32x16 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(BL + which * 32 + kh * 16 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = t4[e];
+        }
+        return v;
+    };
     const int txn = W / TX, tyn = (H + ROWS - 1) / ROWS;
     auto fill = [&](int t) {
         const int tx = t % txn, ty = (t / txn) % tyn, b = t / (txn * tyn);
@@ -517,7 +591,7 @@ __global__ __launch_bounds__(512, 1) void k_me_mid(const bf16x8* __restrict__ in
             if (p < NPA) {
                 const int idx = p % NA, sel = p / NA;                      // sel = plane * 2 + kh
                 const int yy = reflect(ty * ROWS - 2 + idx / RAW, H), xx = reflect(tx * TX - 2 + idx % RAW, W);
-                const bf16x8* src = ((sel >> 1) ? in_lo : in_hi) + (((size_t)b * H + yy) * W + xx) * 2 + (sel & 1);
+                const V8* src = ((sel >> 1) ? in_lo : in_hi) + (((size_t)b * H + yy) * W + xx) * 2 + (sel & 1);
                 me_dma16(src, reinterpret_cast<const char*>(TA + 64 * j));
             }
         }
@@ -537,28 +611,26 @@ __global__ __launch_bounds__(512, 1) void k_me_mid(const bf16x8* __restrict__ in
             const int f = f0 + n, fr = min(f, NB - 1);
             const int row = fr / RBW, px = fr % RBW;
             const int ly = local(row, y0, 1, 2, H, RAH), lx = local(px, x0, 1, 2, W, RAW);
-            const bf16x8* ctr = TA + kh * NA + ly * RAW + lx;
+            const V8* ctr = TA + kh * NA + ly * RAW + lx;
             f32x16 acc = zero16();
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int o = (tap / 3 - 1) * RAW + tap % 3 - 1;
-                acc = mma3(wl0[tap * 64 + lane], wl0[(9 + tap) * 64 + lane], ctr[o], ctr[2 * NA + o], acc);
+                acc = mma(wl0[tap * 64 + lane], wl0[(LO * 9 + tap) * 64 + lane], ctr[o], ctr[LO * 2 * NA + o], acc);
             }
-            const f32x16 res = mma3(wl0[18 * 64 + lane], wl0[19 * 64 + lane], ctr[0], ctr[2 * NA], zero16());
+            const f32x16 res = mma(wl0[NPL * 9 * 64 + lane], wl0[(NPL * 9 + LO) * 64 + lane], ctr[0], ctr[LO * 2 * NA], zero16());
+            if constexpr (!SP) {
+                bias0 = ld16(0);
+                rbias0 = ld16(1);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {           // output channels 8 q + 4 kh .. + 3: chunk q >> 1, half q & 1, byte offset 8 kh
-                bf16x4 oh, ol;
+                float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = fmaxf(acc[4 * q + e] + bias0[4 * q + e], 0.f) + res[4 * q + e] + rbias0[4 * q + e];
-                    const __bf16 h = (__bf16)v;
-                    oh[e] = h;
-                    ol[e] = (__bf16)(v - (float)h);
-                }
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[4 * q + e] + bias0[4 * q + e], 0.f) + res[4 * q + e] + rbias0[4 * q + e];
                 if (f < NB) {
-                    bf16x8* dst = TB + ((q >> 1) * 2 + (q & 1)) * NBP + f;
-                    reinterpret_cast<bf16x4*>(dst)[kh] = oh;
-                    reinterpret_cast<bf16x4*>(dst + 4 * NBP)[kh] = ol;
+                    V8* dst = TB + ((q >> 1) * 2 + (q & 1)) * NBP + f;
+                    put4(v, reinterpret_cast<E*>(dst) + 4 * kh, reinterpret_cast<E*>(dst + 4 * NBP) + 4 * kh);
                 }
             }
         }
@@ -567,33 +639,28 @@ __global__ __launch_bounds__(512, 1) void k_me_mid(const bf16x8* __restrict__ in
         // ---- C: conv2.1 + identity residual: wave = tile row
         {
             const int row = wave;
-            const bf16x8* org = TB + kh * NBP + row * RBW + n;      // piece of (kc 0, this half, halo row `row`, halo column n)
+            const V8* org = TB + kh * NBP + row * RBW + n;          // piece of (kc 0, this half, halo row `row`, halo column n)
             f32x16 acc = zero16();
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
                     const int ks = tap * 2 + kc, o = kc * 2 * NBP + (tap / 3) * RBW + tap % 3;
-                    acc = mma3(wl1[ks * 64 + lane], wl1[(18 + ks) * 64 + lane], org[o], org[4 * NBP + o], acc);
+                    acc = mma(wl1[ks * 64 + lane], wl1[(LO * 18 + ks) * 64 + lane], org[o], org[LO * 4 * NBP + o], acc);
                 }
             const int y = y0 + row;
+            if constexpr (!SP) bias1 = ld16(2);
             if (y < H) {
                 const size_t pix = ((size_t)b * H + y) * W + x0 + n;
-                const bf16x8* ctr = TB + (row + 1) * RBW + n + 1;
+                const V8* ctr = TB + (row + 1) * RBW + n + 1;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const bf16x4 xh = reinterpret_cast<const bf16x4*>(ctr + ((q >> 1) * 2 + (q & 1)) * NBP)[kh];
-                    const bf16x4 xl = reinterpret_cast<const bf16x4*>(ctr + (4 + (q >> 1) * 2 + (q & 1)) * NBP)[kh];
-                    bf16x4 oh, ol;
+                    const V4 xh = reinterpret_cast<const V4*>(ctr + ((q >> 1) * 2 + (q & 1)) * NBP)[kh];
+                    const V4 xl = reinterpret_cast<const V4*>(ctr + (LO * 4 + (q >> 1) * 2 + (q & 1)) * NBP)[kh];
+                    float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = fmaxf(acc[4 * q + e] + bias1[4 * q + e], 0.f) + (float)xh[e] + (float)xl[e];
-                        const __bf16 h = (__bf16)v;
-                        oh[e] = h;
-                        ol[e] = (__bf16)(v - (float)h);
-                    }
-                    *reinterpret_cast<bf16x4*>(out_hi + pix * 32 + 8 * q + 4 * kh) = oh;
-                    *reinterpret_cast<bf16x4*>(out_lo + pix * 32 + 8 * q + 4 * kh) = ol;
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[4 * q + e] + bias1[4 * q + e], 0.f) + val4(xh, xl, e);
+                    put4(v, out_hi + pix * 32 + 8 * q + 4 * kh, out_lo + pix * 32 + 8 * q + 4 * kh);
                 }
             }
         }
@@ -676,15 +743,62 @@ __global__ __launch_bounds__(256) void k_me_pool(const bf16x8* __restrict__ in_h
         }
     }
 }
+// The same sliding window on ONE fp16 plane: the maximum of fp16 values is one of them, so the window works on the packed values
+// (v_pk_max_f16: 4 instructions per 8 channels and tap, 4 registers per row maximum) and the output is exact.
+template <int KH, int KW, int SH, int SW, int PH, int PW>
+__global__ __launch_bounds__(256) void k_me_pool16(const f16x8* __restrict__ in, f16x8* __restrict__ out, int Bc, int H, int W, int C8, int Ho,
+                                                   int Wo, int NY) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int strips = (Ho + NY - 1) / NY;
+    const long long total = (long long)Bc * strips * Wo * C8;
+    if (idx >= total) return;
+    const int c8 = (int)(idx % C8);
+    const int xo = (int)((idx / C8) % Wo);
+    const int sy = (int)((idx / ((long long)C8 * Wo)) % strips);
+    const int b = (int)(idx / ((long long)C8 * Wo * strips));
+    f16x8 ninf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ninf[j] = (_Float16)(-INFINITY);
+    f16x8 ring[KH];
+    auto row_max = [&](int yy) {
+        f16x8 m = ninf;
+        if (yy < 0 || yy >= H) return m;
+#pragma unroll
+        for (int c = 0; c < KW; ++c) {
+            const int xx = xo * SW - PW + c;
+            if (xx < 0 || xx >= W) continue;
+            m = __builtin_elementwise_max(m, in[(((size_t)b * H + yy) * W + xx) * C8 + c8]);
+        }
+        return m;
+    };
+    const int yo0 = sy * NY, yo1 = min(yo0 + NY, Ho);
+#pragma unroll
+    for (int k = 0; k < KH; ++k) ring[k] = row_max(yo0 * SH - PH + k);
+    for (int yo = yo0; yo < yo1; ++yo) {
+        f16x8 m = ring[0];
+#pragma unroll
+        for (int k = 1; k < KH; ++k) m = __builtin_elementwise_max(m, ring[k]);
+        out[(((size_t)b * Ho + yo) * Wo + xo) * C8 + c8] = m;
+        if (yo + 1 < yo1) {
+#pragma unroll
+            for (int k = 0; k + SH < KH; ++k) ring[k] = ring[k + SH];
+#pragma unroll
+            for (int k = (KH > SH ? KH - SH : 0); k < KH; ++k) ring[k] = row_max((yo + 1) * SH - PH + k);
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // conv4: Conv1d(512 -> 64, k=1) + BatchNorm1d over the flattened (channel, bin) axis.  The planes hold a frame's 512
 // features in (bin, channel) order, so the host permutes the weight columns instead of moving data.
 // One wave = 32 frames; weights (natural-k fragments [ot][ks], hi then lo) stream from L2.
+// Single fp16 plane: the weights stay split (fp16 hi + lo, two products per k-step) - the layer is 1 % of the encoder.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_me_head(const bf16x8* __restrict__ in_hi, const bf16x8* __restrict__ in_lo,
-                                                 const bf16x8* __restrict__ w4, const float* __restrict__ bias_ft,
+template <bool SP>
+__global__ __launch_bounds__(256) void k_me_head(const typename PL<SP>::v8* __restrict__ in_hi, const typename PL<SP>::v8* __restrict__ in_lo,
+                                                 const typename PL<SP>::v8* __restrict__ w4, const float* __restrict__ bias_ft,
                                                  float* __restrict__ xf_out, int M) {
+    using V8 = typename PL<SP>::v8;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = lane & 31, kh = lane >> 5;
     const int tok = (blockIdx.x * 4 + wave) * 32 + n;
@@ -692,10 +806,17 @@ __global__ __launch_bounds__(256) void k_me_head(const bf16x8* __restrict__ in_h
     f32x16 acc[2] = {zero16(), zero16()};
 #pragma unroll 4
     for (int ks = 0; ks < 32; ++ks) {
-        const bf16x8 bh = in_hi[t * 64 + 2 * ks + kh], bl = in_lo[t * 64 + 2 * ks + kh];
+        const V8 bh = in_hi[t * 64 + 2 * ks + kh];
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot)
-            acc[ot] = mma3(w4[(ot * 32 + ks) * 64 + lane], w4[(64 + ot * 32 + ks) * 64 + lane], bh, bl, acc[ot]);
+        for (int ot = 0; ot < 2; ++ot) {
+            const V8 ah = w4[(ot * 32 + ks) * 64 + lane], al = w4[(64 + ot * 32 + ks) * 64 + lane];
+            if constexpr (SP) {
+                acc[ot] = mma3(ah, al, bh, in_lo[t * 64 + 2 * ks + kh], acc[ot]);
+            } else {
+                acc[ot] = mfma(ah, bh, acc[ot]);
+                acc[ot] = mfma(al, bh, acc[ot]);
+            }
+        }
     }
     if (tok >= M) return;
 #pragma unroll
@@ -760,12 +881,23 @@ inline float bf2f(uint16_t h) {
     return f;
 }
 inline int tile_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+inline uint16_t f2h(float f) {   // fp32 -> fp16 bits, round to nearest even (the compiler's conversion)
+    const _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+inline float h2f(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
+}
 
 // natural-k A fragments of Wm [n_out][k_in] (row-major): frag (ot, ks), lane (i = l & 31, hh = l >> 5), element j
-//   = Wm[32 ot + i][16 ks + 8 hh + j]; order [hi: ot][ks] then [lo: ot][ks]
-std::vector<uint16_t> pack_nat(const std::vector<float>& Wm, int n_out, int k_in, int OT, int KS) {
+//   = Wm[32 ot + i][16 ks + 8 hh + j]; order [hi: ot][ks] then [lo: ot][ks]; fmt 0: bf16 hi + lo, 1: fp16 hi only, 2: fp16 hi + lo
+std::vector<uint16_t> pack_nat(const std::vector<float>& Wm, int n_out, int k_in, int OT, int KS, int fmt = 0) {
     const size_t ne = (size_t)OT * KS * 512;
-    std::vector<uint16_t> out(2 * ne, 0);
+    std::vector<uint16_t> out((fmt == 1 ? 1 : 2) * ne, 0);
     for (int ot = 0; ot < OT; ++ot)
         for (int ks = 0; ks < KS; ++ks)
             for (int l = 0; l < 64; ++l)
@@ -773,9 +905,9 @@ std::vector<uint16_t> pack_nat(const std::vector<float>& Wm, int n_out, int k_in
                     const int row = 32 * ot + (l & 31), col = 16 * ks + 8 * (l >> 5) + j;
                     const float v = (row < n_out && col < k_in) ? Wm[(size_t)row * k_in + col] : 0.f;
                     const size_t o = (((size_t)ot * KS + ks) * 64 + l) * 8 + j;
-                    const uint16_t h = f2bf(v);
+                    const uint16_t h = fmt ? f2h(v) : f2bf(v);
                     out[o] = h;
-                    out[ne + o] = f2bf(v - bf2f(h));
+                    if (fmt != 1) out[ne + o] = fmt ? f2h(v - h2f(h)) : f2bf(v - bf2f(h));
                 }
     return out;
 }
@@ -791,7 +923,8 @@ std::vector<float> ftvec(const std::vector<float>& v, int NT) {
 }
 
 struct ConvDev {
-    const bf16x8* w = nullptr;
+    const bf16x8* w = nullptr;            // split planes: bf16 hi + lo fragments
+    const f16x8* w16 = nullptr;           // single plane: fp16 fragments (conv1.1 ... conv3.1)
     const float *bias = nullptr, *rbias = nullptr;
 };
 
@@ -801,14 +934,17 @@ struct dc_music {
     uint8_t* arena = nullptr;
     ConvDev conv[7];
     const bf16x8 *w4 = nullptr, *wp = nullptr;
+    const f16x8* w4_16 = nullptr;         // conv4 as fp16 hi + lo fragments (single-plane format)
     const float *b4 = nullptr, *bp = nullptr;
     const bf16x8* stem_w = nullptr;       // k_me_stem: 22 fragments (conv1.0: hi, lo; conv1.1: 5 hi, 5 lo; conv1.2: 5 hi, 5 lo)
+    const f16x8* stem_w16 = nullptr;      // single-plane format: 10 fp16 fragments (conv1.1: 5, conv1.2: 5)
     const float* stem_b = nullptr;        // [3][16] folded biases
     const float* stem_wa = nullptr;       // conv1.0 folded weights [16][9] fp32 (that layer runs on the vector ALU)
     // ping-pong plane pairs, sized for `cap` clips of `cap_tm` mel frames
     bf16x8 *a_hi = nullptr, *a_lo = nullptr, *b_hi = nullptr, *b_lo = nullptr;
     int cap = 0, cap_tm = 0;
     long long ws_bytes = 0;
+    int format = 0;                       // 0: split bf16 planes, 1: one fp16 plane (dc_music_set_format)
 };
 
 namespace {
@@ -883,10 +1019,10 @@ dc_music* dc_music_build(const std::map<std::string, std::vector<float>>& params
         }
     };
     struct Off {
-        size_t w, bias, rbias;
+        size_t w, w16, bias, rbias;
     } off[7];
     // v_mfma_f32_16x16x32 A fragments of the fused conv1 kernel: lane (co = l & 15, q4 = l >> 4), element j
-    std::vector<uint16_t> stem_hi[3], stem_lo[3];
+    std::vector<uint16_t> stem_hi[3], stem_lo[3], stem_16;
     std::vector<float> stem_bias, stem_wa32;
     auto stem_pack = [&](int layer, const std::vector<float>& Wm, int K, int cin) {
         const int nks = cin == 1 ? 1 : 5;
@@ -907,6 +1043,7 @@ dc_music* dc_music_build(const std::map<std::string, std::vector<float>>& params
                     const uint16_t h = f2bf(v);
                     stem_hi[layer][((size_t)ks * 64 + l) * 8 + j] = h;
                     stem_lo[layer][((size_t)ks * 64 + l) * 8 + j] = f2bf(v - bf2f(h));
+                    if (cin != 1) stem_16.push_back(f2h(v));          // (layers 1, 2 in order: [layer][ks][lane][j])
                 }
     };
     const std::string me = "music_encoder.";
@@ -923,6 +1060,7 @@ dc_music* dc_music_build(const std::map<std::string, std::vector<float>>& params
                 for (int tap = 0; tap < 9; ++tap)
                     Wm[(size_t)co * K + tap * c.cin + ci] = w[((size_t)co * c.cin + ci) * 9 + tap] * sc[co];
         std::vector<uint16_t> frags = pack_nat(Wm, c.cout, K, 1, KS);
+        std::vector<uint16_t> frags16 = pack_nat(Wm, c.cout, K, 1, KS, 1);
         if (i == 0) {
             stem_wa32.resize(16 * 9);
             for (int co = 0; co < 16; ++co)
@@ -943,9 +1081,12 @@ dc_music* dc_music_build(const std::map<std::string, std::vector<float>>& params
                 for (int ci = 0; ci < c.cin; ++ci) Rm[(size_t)co * c.cin + ci] = rw[(size_t)co * c.cin + ci] * rs[co];
             const std::vector<uint16_t> rf = pack_nat(Rm, c.cout, c.cin, 1, c.cin / 16);
             frags.insert(frags.end(), rf.begin(), rf.end());
+            const std::vector<uint16_t> rf16 = pack_nat(Rm, c.cout, c.cin, 1, c.cin / 16, 1);
+            frags16.insert(frags16.end(), rf16.begin(), rf16.end());
             rb_ft = ftvec(rb, 1);
         }
         off[i].w = add(frags.data(), frags.size() * 2);
+        off[i].w16 = add(frags16.data(), frags16.size() * 2);
         const std::vector<float> b_ft = ftvec(bi, 1);
         off[i].bias = add(b_ft.data(), b_ft.size() * 4);
         if (c.res_conv) off[i].rbias = add(rb_ft.data(), rb_ft.size() * 4);
@@ -960,6 +1101,8 @@ dc_music* dc_music_build(const std::map<std::string, std::vector<float>>& params
             for (int bin = 0; bin < 16; ++bin) W4[(size_t)o * 512 + bin * 32 + c] = w4[(size_t)o * 512 + c * 16 + bin] * s4[o];
     const std::vector<uint16_t> f4 = pack_nat(W4, 64, 512, 2, 32);
     const size_t o_w4 = add(f4.data(), f4.size() * 2);
+    const std::vector<uint16_t> f4h = pack_nat(W4, 64, 512, 2, 32, 2);
+    const size_t o_w4h = add(f4h.data(), f4h.size() * 2);
     const std::vector<float> b4_ft = ftvec(b4, 2);
     const size_t o_b4 = add(b4_ft.data(), b4_ft.size() * 4);
     std::vector<uint16_t> stem_frags;
@@ -968,6 +1111,7 @@ dc_music* dc_music_build(const std::map<std::string, std::vector<float>>& params
         stem_frags.insert(stem_frags.end(), stem_lo[i].begin(), stem_lo[i].end());
     }
     const size_t o_stem_w = add(stem_frags.data(), stem_frags.size() * 2);
+    const size_t o_stem_w16 = add(stem_16.data(), stem_16.size() * 2);
     const size_t o_stem_b = add(stem_bias.data(), stem_bias.size() * 4);
     const size_t o_stem_wa = add(stem_wa32.data(), stem_wa32.size() * 4);
     const std::vector<uint16_t> fp = pack_nat(P("proj.weight"), 64, 64, 2, 4);
@@ -985,10 +1129,13 @@ dc_music* dc_music_build(const std::map<std::string, std::vector<float>>& params
     m->ws_bytes = (long long)host.size();
     for (int i = 0; i < 7; ++i) {
         m->conv[i].w = reinterpret_cast<const bf16x8*>(m->arena + off[i].w);
+        m->conv[i].w16 = reinterpret_cast<const f16x8*>(m->arena + off[i].w16);
         m->conv[i].bias = reinterpret_cast<const float*>(m->arena + off[i].bias);
         m->conv[i].rbias = off[i].rbias == (size_t)-1 ? nullptr : reinterpret_cast<const float*>(m->arena + off[i].rbias);
     }
     m->stem_w = reinterpret_cast<const bf16x8*>(m->arena + o_stem_w);
+    m->stem_w16 = reinterpret_cast<const f16x8*>(m->arena + o_stem_w16);
+    m->w4_16 = reinterpret_cast<const f16x8*>(m->arena + o_w4h);
     m->stem_b = reinterpret_cast<const float*>(m->arena + o_stem_b);
     m->stem_wa = reinterpret_cast<const float*>(m->arena + o_stem_wa);
     m->w4 = reinterpret_cast<const bf16x8*>(m->arena + o_w4);
@@ -1053,7 +1200,7 @@ hipError_t launch_conv_t(hipStream_t st, const ConvDev& c, const bf16x8* ih, con
     MeDev d;
     if (hipError_t e = me_device(d)) return e;
     const int ncu = d.ncu;
-    const auto fn = k_me_conv_t<CIN, COUT, RES, ROWS, NXS>;
+    const auto fn = k_me_conv_t<CIN, COUT, RES, ROWS, NXS, true>;
     if (hipError_t e = me_optin((const void*)fn, SHM, optin, d.dev)) return e;
     const long long ntiles = (long long)Bc * ((H + ROWS - 1) / ROWS) * (W / (32 * NXS));
     const unsigned grid = (unsigned)std::min<long long>(ntiles, 2LL * ncu);
@@ -1061,41 +1208,69 @@ hipError_t launch_conv_t(hipStream_t st, const ConvDev& c, const bf16x8* ih, con
                                            (int)ntiles);
     return hipGetLastError();
 }
-// conv1.0 -> conv1.1 -> conv1.2 fused (W a multiple of 64); DC_ME_NO_STEM=1 keeps the three separate launches
-hipError_t launch_stem(hipStream_t st, const dc_music* m, const float* mel, bf16x8* oh, bf16x8* ol, int Bc, int H, int W) {
-    constexpr int ROWS = 8, TX = 64;
+// ... on one fp16 plane (W a multiple of the tile width: the mel has 128 bins)
+template <int CIN, int COUT, int RES, int ROWS, int NXS>
+hipError_t launch_conv_t16(hipStream_t st, const ConvDev& c, const f16x8* in, f16x8* out, int Bc, int H, int W) {
+    constexpr int KC = CIN / 16, NKS = 9 * KC, NF = NKS + (RES == 2 ? KC : 0);
+    constexpr int NP = KC * 2 * (ROWS + 2) * (32 * NXS + 2), NDMA = (NP + 63) / 64;
+    constexpr int SHM = (NF + NDMA) * 1024;
+    if (W % (32 * NXS) != 0) return hipErrorInvalidValue;
+    static unsigned long long optin = 0;
+    MeDev d;
+    if (hipError_t e = me_device(d)) return e;
+    const auto fn = k_me_conv_t<CIN, COUT, RES, ROWS, NXS, false>;
+    if (hipError_t e = me_optin((const void*)fn, SHM, optin, d.dev)) return e;
+    const long long ntiles = (long long)Bc * ((H + ROWS - 1) / ROWS) * (W / (32 * NXS));
+    const unsigned grid = (unsigned)std::min<long long>(ntiles, 2LL * d.ncu);
+    fn<<<dim3(grid), dim3(256), SHM, st>>>(in, nullptr, reinterpret_cast<_Float16*>(out), nullptr, c.w16, c.bias, c.rbias, H, W, (int)ntiles);
+    return hipGetLastError();
+}
+// conv1.0 -> conv1.1 -> conv1.2 fused (W a multiple of 64); DC_ME_NO_STEM=1 keeps the three separate launches (split planes only)
+template <bool SP>
+hipError_t launch_stem(hipStream_t st, const dc_music* m, const float* mel, typename PL<SP>::v8* oh, typename PL<SP>::v8* ol, int Bc, int H, int W) {
+    constexpr int ROWS = 8, TX = 64, NPL = PL<SP>::N;
     constexpr int NBP = ((ROWS + 2) * (TX + 2) + 15) / 16 * 16;
-    constexpr int SHM = 4 * (ROWS + 4) * (TX + 4) * 16 + 4 * NBP * 16 + (ROWS + 6) * (TX + 6) * 4;
+    constexpr int SHM = 2 * NPL * (ROWS + 4) * (TX + 4) * 16 + 2 * NPL * NBP * 16 + (ROWS + 6) * (TX + 6) * 4 + (SP ? 0 : 144 * 4);
     static unsigned long long optin = 0;
     MeDev d;
     if (hipError_t e = me_device(d)) return e;
-    const int ncu = d.ncu;
-    if (hipError_t e = me_optin((const void*)k_me_stem<ROWS, TX>, SHM, optin, d.dev)) return e;
+    if (W % TX != 0) return hipErrorInvalidValue;
+    if (hipError_t e = me_optin((const void*)k_me_stem<ROWS, TX, SP>, SHM, optin, d.dev)) return e;
     const long long ntiles = (long long)Bc * ((H + ROWS - 1) / ROWS) * (W / TX);
-    const unsigned grid = (unsigned)std::min<long long>(ntiles, ncu);
-    k_me_stem<ROWS, TX><<<dim3(grid), dim3(512), SHM, st>>>(mel, reinterpret_cast<__bf16*>(oh), reinterpret_cast<__bf16*>(ol), m->stem_w,
-                                                            m->stem_b, m->stem_wa, H, W, (int)ntiles);
+    const unsigned grid = (unsigned)std::min<long long>(ntiles, (SP ? 1 : 2) * (long long)d.ncu);
+    using E = typename PL<SP>::e;
+    const typename PL<SP>::v8* w;
+    if constexpr (SP) w = m->stem_w; else w = m->stem_w16;
+    k_me_stem<ROWS, TX, SP><<<dim3(grid), dim3(512), SHM, st>>>(mel, reinterpret_cast<E*>(oh), reinterpret_cast<E*>(ol), w, m->stem_b, m->stem_wa, H,
+                                                                W, (int)ntiles);
     return hipGetLastError();
 }
-// conv2.0 -> conv2.1 fused (W a multiple of 32); DC_ME_NO_MID=1 keeps the two separate launches
-hipError_t launch_mid(hipStream_t st, const dc_music* m, const bf16x8* ih, const bf16x8* il, bf16x8* oh, bf16x8* ol, int Bc, int H, int W) {
-    constexpr int ROWS = 8, TX = 32;
-    constexpr int NPA = 4 * (ROWS + 4) * (TX + 4), NDMA = (NPA + 63) / 64, NBP = ((ROWS + 2) * (TX + 2) + 15) / 16 * 16;
-    constexpr int SHM = 56 * 1024 + NDMA * 1024 + 8 * NBP * 16;
+// conv2.0 -> conv2.1 fused (W a multiple of 32); DC_ME_NO_MID=1 keeps the two separate launches (split planes only)
+template <bool SP>
+hipError_t launch_mid(hipStream_t st, const dc_music* m, const typename PL<SP>::v8* ih, const typename PL<SP>::v8* il, typename PL<SP>::v8* oh,
+                      typename PL<SP>::v8* ol, int Bc, int H, int W) {
+    constexpr int ROWS = 8, TX = 32, NPL = PL<SP>::N;
+    constexpr int NPA = 2 * NPL * (ROWS + 4) * (TX + 4), NDMA = (NPA + 63) / 64, NBP = ((ROWS + 2) * (TX + 2) + 15) / 16 * 16;
+    constexpr int SHM = 28 * NPL * 1024 + NDMA * 1024 + 4 * NPL * NBP * 16 + (SP ? 0 : 96 * 4);
     static unsigned long long optin = 0;
     MeDev d;
     if (hipError_t e = me_device(d)) return e;
-    if (hipError_t e = me_optin((const void*)k_me_mid<ROWS, TX>, SHM, optin, d.dev)) return e;
+    if (W % TX != 0) return hipErrorInvalidValue;
+    if (hipError_t e = me_optin((const void*)k_me_mid<ROWS, TX, SP>, SHM, optin, d.dev)) return e;
     const long long ntiles = (long long)Bc * ((H + ROWS - 1) / ROWS) * (W / TX);
-    const unsigned grid = (unsigned)std::min<long long>(ntiles, d.ncu);
-    k_me_mid<ROWS, TX><<<dim3(grid), dim3(512), SHM, st>>>(ih, il, reinterpret_cast<__bf16*>(oh), reinterpret_cast<__bf16*>(ol), m->conv[3].w,
-                                                           m->conv[3].bias, m->conv[3].rbias, m->conv[4].w, m->conv[4].bias, H, W, (int)ntiles);
+    const unsigned grid = (unsigned)std::min<long long>(ntiles, (SP ? 1 : 2) * (long long)d.ncu);
+    using E = typename PL<SP>::e;
+    const typename PL<SP>::v8 *w0, *w1;
+    if constexpr (SP) { w0 = m->conv[3].w; w1 = m->conv[4].w; } else { w0 = m->conv[3].w16; w1 = m->conv[4].w16; }
+    k_me_mid<ROWS, TX, SP><<<dim3(grid), dim3(512), SHM, st>>>(ih, il, reinterpret_cast<E*>(oh), reinterpret_cast<E*>(ol), w0, m->conv[3].bias,
+                                                               m->conv[3].rbias, w1, m->conv[4].bias, H, W, (int)ntiles);
     return hipGetLastError();
 }
+constexpr int kPoolNY = 24;                // output rows per thread: (NY + KH - 1) / NY of the minimum input traffic (3 ... 24: same time)
 template <int KH, int KW, int SH, int SW, int PH, int PW>
 hipError_t launch_pool(hipStream_t st, const bf16x8* ih, const bf16x8* il, bf16x8* oh, bf16x8* ol, int Bc, int H, int W, int C,
                        int Ho, int Wo) {
-    constexpr int NY = 24;                 // output rows per thread: (NY + KH - 1) / NY of the minimum input traffic (3 ... 24: same time)
+    constexpr int NY = kPoolNY;
 #ifndef DC_ME_POOL_XO
 #define DC_ME_POOL_XO 1                    // adjacent output columns per thread (2 measured 4.43 vs 4.37 ms per encode_music: 173 VGPRs, profiles/r05_ab_pool.txt)
 #endif
@@ -1104,8 +1279,25 @@ hipError_t launch_pool(hipStream_t st, const bf16x8* ih, const bf16x8* il, bf16x
     k_me_pool<KH, KW, SH, SW, PH, PW, XO><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(ih, il, oh, ol, Bc, H, W, C / 8, Ho, Wo, NY);
     return hipGetLastError();
 }
+template <int KH, int KW, int SH, int SW, int PH, int PW>
+hipError_t launch_pool16(hipStream_t st, const f16x8* in, f16x8* out, int Bc, int H, int W, int C, int Ho, int Wo) {
+    constexpr int NY = kPoolNY;
+    const long long total = (long long)Bc * ((Ho + NY - 1) / NY) * Wo * (C / 8);
+    k_me_pool16<KH, KW, SH, SW, PH, PW><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(in, out, Bc, H, W, C / 8, Ho, Wo, NY);
+    return hipGetLastError();
+}
 
 }  // namespace
+
+// plane format of this encoder's next dc_music_encode calls: 0 = split bf16 planes (~6e-6), 1 = one fp16 plane (~4e-4, about half the
+// time); DC_ME_PREC=f16 | split (read per call) overrides it
+void dc_music_set_format(dc_music* m, int single_fp16) {
+    if (m) m->format = single_fp16 ? 1 : 0;
+}
+int dc_music_format(const dc_music* m) {
+    if (const char* e = getenv("DC_ME_PREC")) return (!strcmp(e, "f16") || !strcmp(e, "fp16")) ? 1 : 0;
+    return m ? m->format : 0;
+}
 
 hipError_t dc_music_encode(dc_music* m, const float* d_mel, int B, int Tm, float* d_xf_proj, float* d_xf_out, hipStream_t st,
                            std::string* err) {
@@ -1137,11 +1329,34 @@ hipError_t dc_music_encode(dc_music* m, const float* d_mel, int B, int Tm, float
         hipError_t e_ = (x);              \
         if (e_ != hipSuccess) return e_;  \
     } while (0)
+    if (dc_music_format(m)) {              // one fp16 plane per activation (the hi buffers; half of each is used)
+        f16x8 *pa = reinterpret_cast<f16x8*>(m->a_hi), *pb = reinterpret_cast<f16x8*>(m->b_hi);
+        for (int b0 = 0; b0 < B; b0 += chunk) {
+            const int Bc = std::min(chunk, B - b0);
+            const float* mel = d_mel + (size_t)b0 * Tm * 128;
+            ME_TRY(launch_stem<false>(st, m, mel, pa, nullptr, Bc, Tm, 128));
+            ME_TRY((launch_pool16<5, 5, 1, 2, 2, 2>(st, pa, pb, Bc, Tm, 128, 16, Tm, 64)));
+            ME_TRY(launch_mid<false>(st, m, pb, nullptr, pa, nullptr, Bc, Tm, 64));
+            ME_TRY((launch_pool16<5, 5, 3, 2, 2, 2>(st, pa, pb, Bc, Tm, 64, 32, T, 32)));
+            ME_TRY((launch_conv_t16<32, 32, 1, 8, 1>(st, m->conv[5], pb, pa, Bc, T, 32)));
+            ME_TRY((launch_conv_t16<32, 32, 1, 8, 1>(st, m->conv[6], pa, pb, Bc, T, 32)));
+            ME_TRY((launch_pool16<3, 3, 1, 2, 1, 1>(st, pb, pa, Bc, T, 32, 32, T, 16)));
+            const int M = Bc * T;
+            const unsigned grid = (unsigned)((M + 127) / 128);
+            float* xo = d_xf_out + (size_t)b0 * T * 64;
+            float* xp = d_xf_proj + (size_t)b0 * T * 64;
+            k_me_head<false><<<dim3(grid), dim3(256), 0, st>>>(pa, nullptr, m->w4_16, m->b4, xo, M);
+            ME_TRY(hipGetLastError());
+            k_me_proj<<<dim3(grid), dim3(256), 0, st>>>(xo, m->wp, m->bp, xp, M);
+            ME_TRY(hipGetLastError());
+        }
+        return hipSuccess;
+    }
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = std::min(chunk, B - b0);
         const float* mel = d_mel + (size_t)b0 * Tm * 128;
         if (!getenv("DC_ME_NO_STEM")) {
-            ME_TRY(launch_stem(st, m, mel, ah, al, Bc, Tm, 128));
+            ME_TRY(launch_stem<true>(st, m, mel, ah, al, Bc, Tm, 128));
         } else {
             ME_TRY((launch_conv<1, 16, 0>(st, m->conv[0], mel, nullptr, nullptr, ah, al, Bc, Tm, 128)));
             ME_TRY((launch_conv_t<16, 16, 1, 8, 2>(st, m->conv[1], ah, al, bh, bl, Bc, Tm, 128)));
@@ -1149,7 +1364,7 @@ hipError_t dc_music_encode(dc_music* m, const float* d_mel, int B, int Tm, float
         }
         ME_TRY((launch_pool<5, 5, 1, 2, 2, 2>(st, ah, al, bh, bl, Bc, Tm, 128, 16, Tm, 64)));
         if (!getenv("DC_ME_NO_MID")) {
-            ME_TRY(launch_mid(st, m, bh, bl, ah, al, Bc, Tm, 64));
+            ME_TRY(launch_mid<true>(st, m, bh, bl, ah, al, Bc, Tm, 64));
             std::swap(ah, bh);      // (the two-launch form leaves conv2.1's output in b)
             std::swap(al, bl);
         } else {
@@ -1164,7 +1379,7 @@ hipError_t dc_music_encode(dc_music* m, const float* d_mel, int B, int Tm, float
         const unsigned grid = (unsigned)((M + 127) / 128);
         float* xo = d_xf_out + (size_t)b0 * T * 64;
         float* xp = d_xf_proj + (size_t)b0 * T * 64;
-        k_me_head<<<dim3(grid), dim3(256), 0, st>>>(bh, bl, m->w4, m->b4, xo, M);
+        k_me_head<true><<<dim3(grid), dim3(256), 0, st>>>(bh, bl, m->w4, m->b4, xo, M);
         ME_TRY(hipGetLastError());
         k_me_proj<<<dim3(grid), dim3(256), 0, st>>>(xo, m->wp, m->bp, xp, M);
         ME_TRY(hipGetLastError());

@@ -90,6 +90,8 @@ class MotionTransformer(nn.Module):
             if self._native is not None:
                 self._native.close()
             self._native = NativeSampler(self.cfg, self.active_precision, self.max_timesteps, idx)
+            if self.encoder_format is not None:
+                self._native.set_encoder_format(self.encoder_format)
             self._native_dirty = True
         if self._native_dirty:
             self._native.load_state_dict(self.state_dict())
@@ -132,7 +134,13 @@ class MotionTransformer(nn.Module):
         mel = text.to(device=device, dtype=torch.float32).contiguous()
         return nat.encode_music(mel)
 
-    h2d_chunk = 8        # clips of the FIRST host-to-device copy when a pinned host batch is encoded (the rest follows beside the encode of these)
+    # MusicEncoder activation format: None = the library's choice by precision ("f16": one fp16 plane beside an fp16 / bf16 denoiser,
+    # 3.7e-4 at the encoder's output and half the time; "split": two bf16 planes, 6e-6, beside the split-operand precisions); set before
+    # the first forward / encode_music.  DC_ME_PREC=f16|split in the environment overrides it.
+    encoder_format = None
+
+    h2d_chunk = 8        # a pinned host batch of at least 2 x this many clips is copied in chunks beside the encoder
+    h2d_schedule = (8, 8, 4)     # ... of B/8, B/8, B/4 clips and the rest: the first copy is the only one the encoder waits for
 
     @staticmethod
     def _h2d_bounds(B, sizes):
@@ -150,7 +158,7 @@ class MotionTransformer(nn.Module):
 
     def _encode_music_pipelined(self, nat, mel_host, device):
         """A pinned host batch: the mel spectrograms cross PCIe in chunks on a copy stream while the MusicEncoder works on the
-        chunks that have landed - the 88 MB of a 32-clip batch (1.8 ms) hide behind the 4 ms of convolutions."""
+        chunks that have landed - most of the 1.8 ms the 88 MB of a 32-clip batch take hide behind the convolutions."""
         B, Tm, _ = mel_host.shape
         T = (Tm - 1) // 3 + 1
         if device.index is None:              # "cuda" never equals a tensor's "cuda:0": the buffer and the stream would be re-made per call
@@ -173,9 +181,10 @@ class MotionTransformer(nn.Module):
             cs.wait_event(self._mel_done)         # the previous call's encodes (possibly on another stream) have read the staging buffer
         events = []
         sched = os.environ.get("DC_H2D_CHUNKS")          # diagnostic: explicit chunk sizes, e.g. "4,12,16"
-        # default: a first chunk of h2d_chunk clips (its copy is the only one the encoder waits for), then the rest in one piece -
-        # 32 clips: median 5.1 ms against 6.0 for four chunks of 8 and 5.9 for two of 16 (profiles/r03_ab_h2d_chunks.txt)
-        sizes = [int(v) for v in sched.split(",")] if sched else [self.h2d_chunk, max(1, B - self.h2d_chunk)]
+        # default: growing chunks (32 clips: 4, 4, 8, 16) - the first copy is the only one the encoder waits for and every later one
+        # is shorter than the encode it runs beside.  With the 2.1-ms fp16-plane encoder, end to end at bs=32: 38.3 ms against 38.7 for
+        # round 3's "8, then the rest" (then the best for a 4.4-ms encoder) and 38.5 for four of 8 (profiles/r05_ab_h2d_chunks.txt)
+        sizes = [int(v) for v in sched.split(",")] if sched else [max(1, B // d) for d in self.h2d_schedule] + [B]
         with torch.cuda.stream(cs):
             for lo, hi in self._h2d_bounds(B, sizes):
                 mel[lo:hi].copy_(mel_host[lo:hi], non_blocking=True)

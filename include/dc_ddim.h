@@ -144,6 +144,16 @@ DC_EXPORT int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj,
 DC_EXPORT int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t B, int32_t Tm, int32_t n_mels,
                             float* d_xf_proj, float* d_xf_out, void* stream);
 
+/* Activation format of the MusicEncoder kernels (no counterpart in the reference, whose encoder is fp32 PyTorch):
+ *   DC_ME_SPLIT (0): two bf16 planes per activation and three MFMAs per product - 6e-6 relative at the encoder's output;
+ *   DC_ME_FP16  (1): one fp16 plane, one MFMA per product, half the bytes - 3.7e-4 at the encoder's output (every activation is
+ *                    rounded to 11 bits once per layer), 1.3e-4 of x0 after DDIM-50, about half the time (2.1 vs 4.2 ms per 32 clips).
+ * Default: DC_ME_FP16 for the precisions whose denoiser rounds these features to 16-bit operands anyway (DC_PREC_FP16, DC_PREC_BF16),
+ * DC_ME_SPLIT for the split-operand precisions.  The environment variable DC_ME_PREC=f16|split (read per call) overrides both. */
+#define DC_ME_SPLIT 0
+#define DC_ME_FP16 1
+DC_EXPORT int dc_sampler_set_encoder_format(dc_sampler* s, int32_t format);
+
 /* One MotionTransformer.forward (models/transformer.py:469-497) on the conditioning set
  * above: d_x fp32 [B, T, input_feats], h_timesteps int32 [B] -> d_out fp32 [B, T, input_feats]. */
 DC_EXPORT int dc_sampler_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timesteps,

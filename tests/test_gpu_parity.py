@@ -546,41 +546,98 @@ def test_harness_generate_music_motion_golden(models):
     assert err <= TOL_PARITY
 
 
+TOL_ENC_SPLIT = 1e-4      # two bf16 planes, three MFMAs per product (~16 mantissa bits): measured 6 - 7e-6
+TOL_ENC_F16 = 6e-4        # one fp16 plane: every activation rounded to 11 bits once per layer: measured 3.6 - 3.9e-4
+
+
+def _enc_env(fmt, extra=None):
+    env = {"DC_ME_PREC": fmt}
+    env.update(extra or {})
+    return env
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
 def test_encode_music_golden(models):
-    """G4: MusicEncoder + proj through dc_sampler_encode_music (bf16x3 MFMA conv stack) vs the reference's own
-    outputs.  Tolerance 1e-4 rel-L2 (fp32 reference; the split-bf16 products carry ~16 mantissa bits)."""
+    """G4: MusicEncoder + proj through dc_sampler_encode_music vs the reference's own outputs, in both activation formats
+    (include/dc_ddim.h, dc_sampler_set_encoder_format): split bf16 planes 1e-4 rel-L2, one fp16 plane 6e-4."""
     g = golden("g4_encode_music.npz")
     m = models["fp16"]
-    xp, x = m.encode_music(torch.from_numpy(batch_mel(1, 270)).cuda(), "cuda:0")
-    assert rel_l2(xp, g["small_x_proj"]) <= 1e-4 and rel_l2(x, g["small_x"]) <= 1e-4
-    xp, x = m.encode_music(torch.from_numpy(batch_mel(1, 5400)).cuda(), "cuda:0")
-    assert rel_l2(xp.cpu()[:, ::25], g["full_x_proj_sub"]) <= 1e-4
+    for fmt, tol in (("split", TOL_ENC_SPLIT), ("f16", TOL_ENC_F16)):
+        xp, x = _with_env(_enc_env(fmt), lambda: m.encode_music(torch.from_numpy(batch_mel(1, 270)).cuda(), "cuda:0"))
+        e1, e2 = rel_l2(xp, g["small_x_proj"]), rel_l2(x, g["small_x"])
+        xp, x = _with_env(_enc_env(fmt), lambda: m.encode_music(torch.from_numpy(batch_mel(1, 5400)).cuda(), "cuda:0"))
+        e3 = rel_l2(xp.cpu()[:, ::25], g["full_x_proj_sub"])
+        print(f"encode_music golden, {fmt}: {e1:.2e} {e2:.2e} {e3:.2e}")
+        assert max(e1, e2, e3) <= tol
+        if fmt == "f16":
+            assert min(e1, e2, e3) > 1e-5          # (the single-plane kernels did run)
 
 
 def test_encode_music_batched_vs_oracle(models):
     """Clips are encoded in chunks (32 at full length; DC_ME_CHUNK=4 makes a batch of 9 cross two chunk edges).  30-s clips
     (Tm = 2700 -> T = 900) and an odd frame count (271 = 33 x 8 + 7: partial row tiles of the LDS-tiled convolutions, the
-    stride-3 pool's floor) against the oracle; the fused conv1 / conv2 kernels and their separate launches (DC_ME_NO_STEM=1,
-    DC_ME_NO_MID=1) both."""
+    stride-3 pool's floor) against the oracle, in both activation formats; for the split format the fused conv1 / conv2 kernels and
+    their separate launches (DC_ME_NO_STEM=1, DC_ME_NO_MID=1) both."""
     from oracle import ddim_oracle as O
     m = models["fp16"]
     p = oracle_params()
-    for B, Tm, env in ((9, 5400, {"DC_ME_CHUNK": "4"}), (3, 2700, {}), (2, 271, {}), (2, 271, {"DC_ME_NO_STEM": "1", "DC_ME_NO_MID": "1"}),
-                       (2, 2700, {"DC_ME_NO_STEM": "1"}), (2, 2700, {"DC_ME_NO_MID": "1"})):
+    cases = [(9, 5400, {"DC_ME_CHUNK": "4"}, "split"), (3, 2700, {}, "split"), (2, 271, {}, "split"),
+             (2, 271, {"DC_ME_NO_STEM": "1", "DC_ME_NO_MID": "1"}, "split"), (2, 2700, {"DC_ME_NO_STEM": "1"}, "split"),
+             (2, 2700, {"DC_ME_NO_MID": "1"}, "split"),
+             (9, 5400, {"DC_ME_CHUNK": "4"}, "f16"), (3, 2700, {}, "f16"), (2, 271, {}, "f16"), (1, 33, {}, "f16"), (1, 33, {}, "split")]
+    for B, Tm, env, fmt in cases:
         mel = torch.from_numpy(batch_mel(B, Tm))
-        os.environ.update(env)
-        try:
-            xp, x = m.encode_music(mel.cuda(), "cuda:0")
+
+        def run():
+            out = m.encode_music(mel.cuda(), "cuda:0")
             torch.cuda.synchronize()
-        finally:
-            for k in env:
-                del os.environ[k]
+            return out
+        xp, x = _with_env(_enc_env(fmt, env), run)
         with torch.no_grad():
             rxp, rx = O.encode_music(p, mel)
         assert tuple(x.shape) == tuple(rx.shape)
         e1, e2 = rel_l2(xp, rxp), rel_l2(x, rx)
-        print(f"encode_music B={B} Tm={Tm} {env}: rel-L2 x_proj {e1:.2e} x {e2:.2e}")
-        assert e1 <= 1e-4 and e2 <= 1e-4
+        print(f"encode_music B={B} Tm={Tm} {env} {fmt}: rel-L2 x_proj {e1:.2e} x {e2:.2e}")
+        tol = TOL_ENC_SPLIT if fmt == "split" else TOL_ENC_F16
+        assert e1 <= tol and e2 <= tol
+
+
+def test_encoder_format_follows_the_precision_and_can_be_set(models):
+    """Default format: one fp16 plane beside the fp16 denoiser (whose conditioning pre-pass rounds the features to fp16 operands anyway),
+    split planes beside the split-operand precisions; dc_sampler_set_encoder_format overrides it, DC_ME_PREC overrides both; an
+    unknown format is refused."""
+    from diffusion_conductor_amd import native
+    from oracle import ddim_oracle as O
+    assert "DC_ME_PREC" not in os.environ
+    mel = torch.from_numpy(batch_mel(1, 540))
+    with torch.no_grad():
+        _, rx = O.encode_music(oracle_params(), mel)
+    err = lambda m: rel_l2(m.encode_music(mel.cuda(), "cuda:0")[1], rx)
+    e16, esp = err(models["fp16"]), err(models["mixed"])
+    print(f"default formats: fp16 model {e16:.2e}, mixed model {esp:.2e}")
+    assert 1e-5 < e16 <= TOL_ENC_F16 and esp <= TOL_ENC_SPLIT
+    nat = models["fp16"]._ensure_native("cuda:0")
+    try:
+        nat.set_encoder_format("split")
+        assert err(models["fp16"]) <= TOL_ENC_SPLIT
+        assert 1e-5 < _with_env({"DC_ME_PREC": "f16"}, lambda: err(models["fp16"])) <= TOL_ENC_F16
+        with pytest.raises(native.DcError, match="encoder format"):
+            native._check(native.lib().dc_sampler_set_encoder_format(nat._h, 7))
+    finally:
+        nat.set_encoder_format("f16")
+    assert 1e-5 < err(models["fp16"]) <= TOL_ENC_F16
 
 
 def test_error_behaviour(models):

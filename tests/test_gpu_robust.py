@@ -371,7 +371,7 @@ def test_encode_music_from_a_pinned_host_batch_is_pipelined_and_identical():
     p = O.to_torch_params(sd)
     with torch.no_grad():
         rxp, rx = O.encode_music(p, mel[16:19])
-    assert rel_l2(x_h[16:19], rx) <= 1e-4 and rel_l2(xp_h[16:19], rxp) <= 1e-4
+    assert rel_l2(x_h[16:19], rx) <= 6e-4 and rel_l2(xp_h[16:19], rxp) <= 6e-4      # (fp16 model: one fp16 plane per activation, measured 3.7e-4)
 
 
 @pytest.mark.parametrize("B,T", [(1, 257), (3, 1000), (2, 1799), (4, 1800), (33, 300), (5, 77)])

@@ -454,6 +454,8 @@ def test_pinned_host_encode_chunk_boundaries():
     assert f(32, [8, 24]) == [(0, 8), (8, 32)] and f(16, [8, 8]) == [(0, 8), (8, 16)] and f(5, [8, 1]) == [(0, 5)]
     assert f(9, [8, 1]) == [(0, 8), (8, 9)] and f(19, [4, 12, 16]) == [(0, 4), (4, 16), (16, 19)]
     assert f(40, [8, 8, 8]) == [(0, 8), (8, 16), (16, 40)] and f(1, [8, 1]) == [(0, 1)]
+    sched = lambda B: f(B, [max(1, B // d) for d in MotionTransformer.h2d_schedule] + [B])      # the default: growing chunks
+    assert sched(32) == [(0, 4), (4, 8), (8, 16), (16, 32)] and sched(17) == [(0, 2), (2, 4), (4, 8), (8, 17)]
     for B in range(1, 70):
-        r = f(B, [8, max(1, B - 8)])
-        assert r[0][0] == 0 and r[-1][1] == B and all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(lo < hi for lo, hi in r)
+        for r in (f(B, [8, max(1, B - 8)]), sched(B)):
+            assert r[0][0] == 0 and r[-1][1] == B and all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(lo < hi for lo, hi in r)

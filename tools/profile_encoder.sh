@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/enc -- python3 $R/tools/profile_encoder.py 2>&1 | grep encode_music
+rm -rf $R/gpurun_out/enc; rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/enc -- python3 $R/tools/profile_encoder.py 2>&1 | grep encode_music
 python3 - <<'PY'
 import csv, glob, os, collections
 R=os.environ["GRAFT_REPO_ROOT"]
