@@ -430,7 +430,10 @@ __global__ __launch_bounds__(512, SP ? 2 : 4) void k_me_stem(const float* __rest
             return min(max(r, 1), lim - 2);
         };
         // ---- A: conv1.0 at the reflected positions of the 2-pixel-grown tile (fp32 FMAs; taps are plain neighbours in MT)
-        {
+#ifndef DC_DIAG_STEM_SKIP
+#define DC_DIAG_STEM_SKIP 0          // diagnostic builds (timing only, results invalid): bit 0 / 1 / 2 = phase A / B / C does not run
+#endif
+        if (!(DC_DIAG_STEM_SKIP & 1)) {
             if constexpr (!SP) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(512, SP ? 2 : 4) void k_me_stem(const float* __rest
         }
         __syncthreads();
         // ---- B: conv1.1 at the reflected positions of the 1-pixel-grown tile, from TA
-        {
+        if (!(DC_DIAG_STEM_SKIP & 2)) {
             int row = (wave * 16 + n) / RBW, px = (wave * 16 + n) % RBW;
             for (int f = wave * 16 + n; f < NBP; f += 128) {
                 const int rr = min(row, RBH - 1);
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(512, SP ? 2 : 4) void k_me_stem(const float* __rest
         }
         __syncthreads();
         // ---- C: conv1.2 on the tile, from TB (its halo already holds the reflected values); two tile rows per step
-        {
+        if (!(DC_DIAG_STEM_SKIP & 4)) {
             const int row0 = wave >> 2, px = (wave & 3) * 16 + n;
             const char* org = TB + (size_t)(row0 * RBW + px) * 16;
             size_t pix = ((size_t)b * H + y0 + row0) * W + x0 + px;
@@ -1281,7 +1284,8 @@ hipError_t launch_pool(hipStream_t st, const bf16x8* ih, const bf16x8* il, bf16x
 }
 template <int KH, int KW, int SH, int SW, int PH, int PW>
 hipError_t launch_pool16(hipStream_t st, const f16x8* in, f16x8* out, int Bc, int H, int W, int C, int Ho, int Wo) {
-    constexpr int NY = kPoolNY;
+    // (DC_ME_POOL_NY: diagnostic.  Rows per thread 6 / 12 / 24 / 48 / 96: the three pools together 719 / 730 / 682 / 805 / 1 116 us per 32 clips)
+    static const int NY = getenv("DC_ME_POOL_NY") ? std::max(1, atoi(getenv("DC_ME_POOL_NY"))) : kPoolNY;
     const long long total = (long long)Bc * ((Ho + NY - 1) / NY) * Wo * (C / 8);
     k_me_pool16<KH, KW, SH, SW, PH, PW><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(in, out, Bc, H, W, C / 8, Ho, Wo, NY);
     return hipGetLastError();
