@@ -43,11 +43,23 @@ class DDPMTrainer(object):
     def _sample_local(self, mel, noise, dim_pose, idxs, smooth=None):
         xf_proj, xf_out = self.encoder.encode_music(mel, self.device)
         B, T = mel.shape[0], xf_proj.shape[1]
-        return self.diffusion.ddim_sample_loop(
-            self.encoder, (B, T, dim_pose), noise=noise, clip_denoised=False, progress=False,
-            model_kwargs={"xf_proj": xf_proj, "xf_out": xf_out,
-                          "length": torch.LongTensor([T] * B)},
-            idxs=idxs, smooth=smooth)
+        try:
+            return self.diffusion.ddim_sample_loop(
+                self.encoder, (B, T, dim_pose), noise=noise, clip_denoised=False, progress=False,
+                model_kwargs={"xf_proj": xf_proj, "xf_out": xf_out,
+                              "length": torch.LongTensor([T] * B)},
+                idxs=idxs, smooth=smooth)
+        except FloatingPointError:
+            # The loop's numeric check failed.  If the music features themselves are not finite, the fp16-plane MusicEncoder
+            # overflowed (an activation beyond 65504; the reference's mel is normalised to [0, 1], so this takes unusual input):
+            # encode once more on the split bf16 planes (fp32 range) and sample again.  Anything else is the caller's to see.
+            if getattr(self.encoder, "encoder_format", "split") == "split" or bool(torch.isfinite(xf_out).all()):
+                raise
+            self.encoder.encoder_format = "split"
+            nat = getattr(self.encoder, "_native", None)
+            if nat is not None:
+                nat.set_encoder_format("split")
+            return self._sample_local(mel, noise, dim_pose, idxs, smooth)
 
     def generate_music_motion(self, music_mel, dim_pose, batch_size=1024, idxs=[], noise=None, seed=None, smooth=None):
         """music_mel: np.ndarray/tensor [5400,128] (reference) or [B,5400,128] -> tensor [B,1800,dim_pose].
