@@ -407,20 +407,26 @@ def test_mixed_mode_clip_aligned_units_edge_shapes(B, T):
 
 
 def test_fp16_plane_encoder_overflow_is_resampled_on_split_planes():
-    """The fp16-plane MusicEncoder holds activations up to 65504.  A mel far outside the reference's [0, 1] normalisation
-    (tools/visualization.py:163-165) overflows it; the loop's numeric check fires, the harness finds the music features non-finite,
-    encodes again on the split bf16 planes (fp32 range) and samples again - the caller gets the result the oracle computes."""
+    """The fp16-plane MusicEncoder holds activations up to 65504.  A checkpoint whose encoder runs at 3e5 times the usual scale
+    inside (conv1.0 scaled up, conv4 scaled down by the same factor: ReLU and the max-pools are positively homogeneous, so its output
+    stays of order one) overflows the planes; the loop's numeric check fires, the harness finds the music features non-finite,
+    encodes again on the split bf16 planes (fp32 range) and samples again - the caller gets what the oracle computes for that
+    checkpoint."""
     import types
     from helpers import batch_mel
     from diffusion_conductor_amd import DDPMTrainer
-    sd = synthetic_state_dict(DenoiserConfig(), seed=0)
+    sd = dict(synthetic_state_dict(DenoiserConfig(), seed=0))
+    k = np.float32(3e5)
+    for n in ("music_encoder.conv1.0.conv2d_layer.0.weight", "music_encoder.conv1.0.conv2d_layer.0.bias"):
+        sd[n] = sd[n] * k
+    sd["music_encoder.conv4.0.weight"] = sd["music_encoder.conv4.0.weight"] / k
     m = _model(sd, "fp16")
     S = 25
     tr = DDPMTrainer(types.SimpleNamespace(device=torch.device("cuda:0"), diffusion_steps=S, is_train=False), m)
     tr.eval_mode()
-    mel = batch_mel(1, 540) * np.float32(3e5)
+    mel = batch_mel(1, 540)
     xo = m.encode_music(torch.from_numpy(mel).cuda(), "cuda:0")[1]
-    assert not bool(torch.isfinite(xo).all()), "the input was meant to overflow the fp16 planes"
+    assert not bool(torch.isfinite(xo).all()), "the checkpoint was meant to overflow the fp16 planes"
     noise = torch.from_numpy(batch_noise(1, 180, first=7))
     out = tr.generate_music_motion(mel[0], 26, noise=noise)
     torch.cuda.synchronize()
@@ -428,5 +434,5 @@ def test_fp16_plane_encoder_overflow_is_resampled_on_split_planes():
     with torch.no_grad():
         ref = O.generate_music_motion(O.to_torch_params(sd), torch.from_numpy(mel), 26, S, noise)
     err = rel_l2(out, ref)
-    print(f"overflowing mel, re-encoded on split planes: rel-L2 {err:.3e}")
+    print(f"overflowing encoder, re-encoded on split planes: rel-L2 {err:.3e}")
     assert err <= TOL
