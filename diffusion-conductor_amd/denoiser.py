@@ -167,18 +167,27 @@ class MotionTransformer(nn.Module):
         if getattr(self, "_copy_stream", None) is None or self._copy_stream.device != device:
             self._copy_stream = torch.cuda.Stream(device)
         cs = self._copy_stream
-        # the device-side staging buffer is the module's own and is reused call after call: a fresh 88-MB tensor per call goes through
-        # the caching allocator's cross-stream bookkeeping (record_stream) and, whenever that ends in a hipMalloc, costs the call 6 ms
-        st = getattr(self, "_mel_stage", None)
+        # Two device-side staging buffers of the module's own, used alternately and reused call after call (a fresh 88-MB tensor per call
+        # goes through the caching allocator's cross-stream bookkeeping and, whenever that ends in a hipMalloc, costs the call 6 ms).
+        # The copy stream waits only for the encode that last READ the slot (two calls ago), not for whatever the compute stream is
+        # doing: a caller that enqueues batch k + 1 while batch k's loop runs (evaluate.py) gets its mel across PCIe beside that loop.
+        slots = getattr(self, "_mel_slots", None)
         n = mel_host.numel()
-        if st is None or st.device != device or st.numel() < n:
-            st = self._mel_stage = torch.empty(n, dtype=torch.float32, device=device)
-        mel = st[:n].view(tuple(mel_host.shape))
+        if slots is None or slots[0][0].device != device:
+            slots = self._mel_slots = [[None, None], [None, None]]      # [staging tensor, event: its last reader is done]
+            for sl in slots:
+                sl[0] = torch.empty(0, dtype=torch.float32, device=device)
+            self._mel_turn = 0
+        self._mel_turn ^= 1
+        sl = slots[self._mel_turn]
+        if sl[0].numel() < n:
+            sl[0] = torch.empty(n, dtype=torch.float32, device=device)
+            cs.wait_stream(cur)                   # (a fresh allocation is ordered on `cur`)
+        mel = sl[0][:n].view(tuple(mel_host.shape))
         xf_proj = torch.empty((B, T, 64), dtype=torch.float32, device=device)
         xf_out = torch.empty_like(xf_proj)
-        cs.wait_stream(cur)                       # the allocations above are ordered on `cur`
-        if getattr(self, "_mel_done", None) is not None:
-            cs.wait_event(self._mel_done)         # the previous call's encodes (possibly on another stream) have read the staging buffer
+        if sl[1] is not None:
+            cs.wait_event(sl[1])                  # the encode that read this slot (possibly on another stream) is done with it
         events = []
         sched = os.environ.get("DC_H2D_CHUNKS")          # diagnostic: explicit chunk sizes, e.g. "4,12,16"
         # default: growing chunks (32 clips: 4, 4, 8, 16) - the first copy is the only one the encoder waits for and every later one
@@ -194,8 +203,8 @@ class MotionTransformer(nn.Module):
         for lo, hi, ev in events:
             cur.wait_event(ev)
             nat.encode_music(mel[lo:hi], out=(xf_proj[lo:hi], xf_out[lo:hi]))
-        self._mel_done = torch.cuda.Event()
-        self._mel_done.record(cur)
+        sl[1] = torch.cuda.Event()
+        sl[1].record(cur)
         return xf_proj, xf_out
 
     def set_conditioning(self, xf_proj, xf_out, length=None):

@@ -47,10 +47,12 @@ def smooth_motion(kp_pred, kernel=11, order=5):
     return out[0] if single else out
 
 
-def clip_noise(seed, index, T, dim_pose):
-    """x_T of clip `index` (position in sorted order): its own generator, independent of batching."""
+def clip_noise(seed, index, T, dim_pose, out=None):
+    """x_T of clip `index` (position in sorted order): its own generator, independent of batching.  `out`: a [T, dim_pose] fp32 CPU
+    tensor to draw into (a row of the pinned batch buffer: a `copy_` between two CPU tensors goes through torch's thread pool and
+    costs milliseconds per clip - it was what bound the evaluation driver's loader)."""
     g = torch.Generator().manual_seed((int(seed) * 1000003 + int(index)) & 0x7fffffffffff)
-    return torch.randn(T, dim_pose, generator=g)
+    return torch.randn(T, dim_pose, generator=g) if out is None else torch.randn(T, dim_pose, generator=g, out=out)
 
 
 def _read_npy_into(path, dst):
@@ -101,7 +103,7 @@ class _Prefetcher:
             gts[i] = np.load(pjoin(self.root, ids[i], "motion.npy"))
             if nz is not None:
                 seed, T, dim_pose = self.noise_spec
-                nz[i].copy_(clip_noise(seed, k * self.bs + i, T, dim_pose))
+                clip_noise(seed, k * self.bs + i, T, dim_pose, out=nz[i])
 
         if self.workers > 1 and len(ids) > 1:
             from concurrent.futures import ThreadPoolExecutor
