@@ -638,6 +638,9 @@ def test_encoder_format_follows_the_precision_and_can_be_set(models):
     finally:
         nat.set_encoder_format("f16")
     assert 1e-5 < err(models["fp16"]) <= TOL_ENC_F16
+    fresh = make_model("fp16")                      # the attribute, set before the module's sampler exists: applied when the parameters are finalized
+    fresh.encoder_format = "split"
+    assert err(fresh) <= TOL_ENC_SPLIT
 
 
 def test_error_behaviour(models):
