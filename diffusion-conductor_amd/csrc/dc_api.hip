@@ -420,6 +420,37 @@ int build_model(dc_sampler* s) {
             cf[o] = (float)(acc * scale);
         }
     };
+    // `linear` with the mean over its 512 outputs taken off (the LayerNorm in front of the cross-attention K / V projections sees
+    // linear(x) - mean = Wc x + bc), and that LayerNorm's variance as a quadratic form of the 64 inputs
+    std::vector<double> lin_wc((size_t)512 * 64), lin_bc(512);
+    std::vector<float> lin_gram(64 * 64 + 64 + 1);
+    {
+        const float* w = P_("linear.weight");   // [512][64]
+        const float* b = P_("linear.bias");
+        double bm = 0.0;
+        for (int k = 0; k < 512; ++k) bm += b[k];
+        bm /= 512.0;
+        for (int k = 0; k < 512; ++k) lin_bc[k] = (double)b[k] - bm;
+        for (int i = 0; i < 64; ++i) {
+            double wm = 0.0;
+            for (int k = 0; k < 512; ++k) wm += w[(size_t)k * 64 + i];
+            wm /= 512.0;
+            for (int k = 0; k < 512; ++k) lin_wc[(size_t)k * 64 + i] = (double)w[(size_t)k * 64 + i] - wm;
+        }
+        for (int i = 0; i < 64; ++i) {
+            for (int j = 0; j < 64; ++j) {
+                double acc = 0.0;
+                for (int k = 0; k < 512; ++k) acc += lin_wc[(size_t)k * 64 + i] * lin_wc[(size_t)k * 64 + j];
+                lin_gram[i * 64 + j] = (float)(acc / 512.0);
+            }
+            double acc = 0.0;
+            for (int k = 0; k < 512; ++k) acc += lin_wc[(size_t)k * 64 + i] * lin_bc[k];
+            lin_gram[64 * 64 + i] = (float)(acc / 512.0);
+        }
+        double cc = 0.0;
+        for (int k = 0; k < 512; ++k) cc += lin_bc[k] * lin_bc[k];
+        lin_gram[64 * 64 + 64] = (float)(cc / 512.0);
+    }
     const double LOG2E = 1.4426950408889634;
     // softmax inputs: the linear-attention kernels use exp2 on log2(e)-scaled queries/keys; the full-attention
     // (no_eff) kernels keep keys unscaled and fold log2(e) / sqrt(head_dim) into the queries (scores arrive as exp2 exponents)
@@ -481,6 +512,23 @@ int build_model(dc_sampler* s) {
                 }
                 add_packed(kv ? &y.ca_wv : &y.ca_wk, wf.data(), D, DC_E, false, false);   // conditioning pre-pass is always split-bf16
                 add_raw(kv ? &y.ca_bv : &y.ca_bk, bf.data(), D);
+                // The same projection composed with `linear` (transformer.py:479-480; 64 -> 512, shared by all layers): with y = W x + b,
+                // n-hat = (y - mean(y)) rstd = rstd (Wc x + bc), Wc / bc = W / b with their mean over the 512 outputs taken off, so
+                //   W' n-hat + b' = rstd (A x + d) + b',   A = W' Wc [128][64],  d = W' bc
+                // - an eighth of the pre-pass GEMM's products (k_cond_ca_partials64), and no [tokens][512] image in between.
+                std::vector<float> af((size_t)D * 64), df(D);
+                for (int o = 0; o < D; ++o) {
+                    double dacc = 0.0;
+                    for (int k = 0; k < DC_E; ++k) dacc += (double)wf[(size_t)o * DC_E + k] * lin_bc[k];
+                    df[o] = (float)dacc;
+                    for (int i = 0; i < 64; ++i) {
+                        double acc = 0.0;
+                        for (int k = 0; k < DC_E; ++k) acc += (double)wf[(size_t)o * DC_E + k] * lin_wc[(size_t)k * 64 + i];
+                        af[(size_t)o * 64 + i] = (float)acc;
+                    }
+                }
+                add_packed(kv ? &y.ca_av : &y.ca_ak, af.data(), D, 64, false, false);
+                add_raw(kv ? &y.ca_dv : &y.ca_dk, df.data(), D);
             }
         }
         {
@@ -567,6 +615,7 @@ int build_model(dc_sampler* s) {
             for (int i = 0; i < 64; ++i) wt[(size_t)i * 512 + k] = w[(size_t)k * 64 + i];
         add_raw(&m.lin_wt, wt.data(), wt.size());
         add_raw(&m.lin_b, P_("linear.bias"), 512);
+        add_raw(&m.lin_gram, lin_gram.data(), lin_gram.size());
     }
     // timestep table storage + MLP operands (transposed for coalesced reads)
     const int nt = c.max_timesteps;
@@ -1302,13 +1351,20 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
     }
     // emb's step-invariant term: linear(xf_proj) as fp32 operand image
     HIP_TRY(dc_launch_cond_embed(st, 0, d_xf_proj, s->h_model.lin_wt, s->h_model.lin_b, s->d_pp, nullptr, nullptr, M, G, T, Tx));
-    // cross-attention: linear(xf_out) -> text_norm (affine folded into K/V) as bf16 hi / lo operand images -> per-layer K,V -> A_ca
-    HIP_TRY(dc_launch_cond_embed(st, 1, d_xf_out, s->h_model.lin_wt, s->h_model.lin_b, nullptr, s->d_nh_hi, s->d_nh_lo, M, G, T, Tx));
-    // one-time cost: always split precision (plain bf16 here alone costs ~2e-3 on A_cross)
+    // cross-attention: linear(xf_out) -> text_norm (affine folded into K/V) -> per-layer K,V -> A_ca; one-time cost: always split
+    // precision (plain bf16 here alone costs ~2e-3 on A_cross).  The linear-attention records come straight from the 64 music
+    // features (`linear` composed into the projections on the host, k_cond_ca_partials64: an eighth of the products, no [tokens][512]
+    // image in between); DC_COND_512=1 and the full-attention keys / values take the image (k_cond_embed<1>).
+    const bool cond64 = !s->cfg.no_eff && !getenv("DC_COND_512");
+    if (!cond64)
+        HIP_TRY(dc_launch_cond_embed(st, 1, d_xf_out, s->h_model.lin_wt, s->h_model.lin_b, nullptr, s->d_nh_hi, s->d_nh_lo, M, G, T, Tx));
     if (s->cfg.no_eff) {
         HIP_TRY(dc_launch_ca_kv(st, s->small_fmt, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_kv_ca, M, T, G, B, s->KT, L));
     } else {
-        HIP_TRY(dc_launch_ca_partials(st, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_recs_ca, M, T, G, L, Tx));
+        if (cond64)      // (1 / std per token goes through the unused image buffer)
+            HIP_TRY(dc_launch_ca_partials64(st, s->d_model, d_xf_out, s->h_model.lin_gram, reinterpret_cast<float*>(s->d_nh_hi), s->d_recs_ca, M, T, G, L, Tx));
+        else
+            HIP_TRY(dc_launch_ca_partials(st, s->d_model, s->d_nh_hi, s->d_nh_lo, s->d_recs_ca, M, T, G, L, Tx));
         HIP_TRY(dc_launch_attn_combine(st, s->small_fmt, s->d_recs_ca, s->d_a_ca, T, G, B, L, 32));
         if (!s->split_small) HIP_TRY(dc_launch_cond_af16(st, s->small_fmt, s->d_a_ca, s->d_a_ca16, L * B));      // (small batches: dc_layer16.hip)
     }

@@ -53,6 +53,9 @@ struct DcLayer {
     const bf16x8 *img_ffn_w1, *img_ffn_w2;     // 16 frags/half each; consts (b1 | b2) follow img_ffn_w2
     const bf16x8 *ca_wk, *ca_wv;               // conditioning pre-pass: natural-k pack [ot][ks], bf16 hi+lo (text_norm folded in)
     const float *ca_bk, *ca_bv;                // plain [128]
+    // ... and the same projections composed with `linear` (k_cond_ca_partials64): K = rstd (A x + d) + b on the 64 music features x
+    const bf16x8 *ca_ak, *ca_av;               // A = W' Wc  [128][64], natural-k pack [ot 4][ks 4], bf16 hi + lo
+    const float *ca_dk, *ca_dv;                // d = W' bc  [128]
 };
 
 // Stage images of the 16-token layer kernel for small batches (dc_layer16.hip; non-split formats, linear attention): fragments
@@ -81,6 +84,7 @@ struct DcModel {
     const bf16x8* film_w16;
     const float* film_b16;
     const float* lin_wt;     // `linear` weight transposed [64][512]
+    const float* lin_gram;   // LayerNorm variance of linear(x) as a quadratic form of x: [64][64] Gc = Wc^T Wc / 512, then gv[64] = Wc^T bc / 512, then c = |bc|^2 / 512
     const float* lin_b;      // [512]
     const float* temb;       // [max_timesteps][512]
     int num_layers;

@@ -306,6 +306,128 @@ __global__ __launch_bounds__(512, 1) void k_cond_ca_partials(const DcModel* __re
     }
 }
 
+// The same records from the 64 music features themselves (round 5).  `linear` (64 -> 512) is shared by all layers and the
+// LayerNorm behind it is affine in its input up to the per-token 1 / std, so
+//   K = W' n-hat + b' = rstd (A x + d) + b',   A = W' Wc [128][64], d = W' bc        (host: dc_api.hip, build_model)
+// - 4 k-steps of 16 per layer instead of 32, no [tokens][512] image written and read back: the pre-pass GEMM does an eighth of the
+// products.  rstd comes from k_cond_rstd: the variance of linear(x) over its 512 outputs as a quadratic form of x,
+//   var = x^T Gc x + 2 gv^T x + c      (Gc = Wc^T Wc / 512 is positive semi-definite: no cancellation beyond the sum's own)
+// Same record format and masking as above; grid (ceil(G/8), L), one wave per (group, layer); the layer's 64 weight fragments
+// (K hi, K lo, V hi, V lo x 4 tiles x 4 k-steps, 64 KiB) are copied to LDS once per workgroup.
+__global__ __launch_bounds__(256) void k_cond_rstd(const float* __restrict__ xf /*[B][Tx][64]*/, const float* __restrict__ gram, float* __restrict__ rstd /*[G * 32]*/,
+                                                   int M, int T, int Tx, int ntok) {
+    __shared__ __attribute__((aligned(16))) float gs[64 * 64 + 64 + 4];
+    for (int i = threadIdx.x; i < 64 * 64 + 64 + 1; i += 256) gs[i] = gram[i];
+    __syncthreads();
+    const int tok = blockIdx.x * 256 + threadIdx.x;
+    if (tok >= ntok) return;
+    const int bb = tok / T, nn = tok - bb * T;
+    float r = 0.f;                                      // rows of the padding and past M: K = b', masked by the records' row ranges anyway
+    if (tok < M && nn < Tx) {
+        f32x4 x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = reinterpret_cast<const f32x4*>(xf)[((size_t)bb * Tx + nn) * 16 + i];
+        float var = gs[64 * 64 + 64];
+#pragma unroll 4
+        for (int i = 0; i < 64; ++i) {
+            float u = 2.f * gs[64 * 64 + i];            // 2 gv_i + sum_j Gc[i][j] x_j
+#pragma unroll
+            for (int j4 = 0; j4 < 16; ++j4) {
+                const f32x4 g4 = reinterpret_cast<const f32x4*>(gs)[i * 16 + j4];      // broadcast
+                u = fmaf(g4[0], x[j4][0], u);
+                u = fmaf(g4[1], x[j4][1], u);
+                u = fmaf(g4[2], x[j4][2], u);
+                u = fmaf(g4[3], x[j4][3], u);
+            }
+            var = fmaf(u, x[i >> 2][i & 3], var);
+        }
+        r = rsqrtf(fmaxf(var, 0.f) + 1e-5f);
+    }
+    rstd[tok] = r;
+}
+__global__ __launch_bounds__(512, 1) void k_cond_ca_partials64(const DcModel* __restrict__ dm, const float* __restrict__ xf /*[B][Tx][64]*/,
+                                                               const float* __restrict__ rstd, float* __restrict__ recs, int M, int T, int G,
+                                                               int Tx /* frames per clip (<= the clip stride T) */) {
+    extern __shared__ __attribute__((aligned(16))) char wbuf[];          // 64 fragments: [which: K hi, K lo, V hi, V lo][oc 4][ks 4]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int g = blockIdx.x * 8 + wave;
+    const bool active = g < G;
+    if (!active) g = G - 1;
+    const int l = blockIdx.y;
+    const DcLayer& L = dm->layer[l];
+    const GroupCtx cx = make_ctx(g, lane, M, T);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = 8 * wave + i, which = f >> 4, rest = f & 15;                    // natural pack: [hi: oc 4][ks 4][lo: ...]
+        const bf16x8* src = ((which & 2) ? L.ca_av : L.ca_ak) + (size_t)(((which & 1) ? 16 : 0) + rest) * 64 + lane;
+        lds_dma16(src, wbuf + f * 1024);
+    }
+    // this lane's token (c) as the A operand of the four k-steps: features 16 ks + 8 hh .. + 7, split in registers
+    const int tok = 32 * g + cx.c;
+    const int bb = tok / T, nn = tok - bb * T;
+    const bool live = tok < M && nn < Tx;
+    bf16x8 ah[4], al[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (live) {
+            const f32x4* px = reinterpret_cast<const f32x4*>(xf) + ((size_t)bb * Tx + nn) * 16 + 4 * ks + 2 * cx.hh;
+            v0 = px[0];
+            v1 = px[1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = j < 4 ? v0[j] : v1[j - 4];
+            const __bf16 h = (__bf16)v;
+            ah[ks][j] = h;
+            al[ks][j] = (__bf16)(v - (float)h);
+        }
+    }
+    // 1 / std of this lane's 16 token rows (tile_row(r, hh) = 4 consecutive rows per register quad)
+    f32x16 rs;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rstd + (size_t)32 * g + 8 * q + 4 * cx.hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rs[4 * q + i] = v[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) return;
+    const bf16x8* w = reinterpret_cast<const bf16x8*>(wbuf) + lane;
+    f32x16 K[4], V[4];
+#pragma unroll
+    for (int oc = 0; oc < 4; ++oc) {
+        K[oc] = splat(0.f);
+        V[oc] = splat(0.f);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 bk = w[(0 * 16 + oc * 4 + ks) * 64], bkl = w[(1 * 16 + oc * 4 + ks) * 64], bv = w[(2 * 16 + oc * 4 + ks) * 64],
+                         bvl = w[(3 * 16 + oc * 4 + ks) * 64];
+            K[oc] = mfma(ah[ks], bk, K[oc]);
+            V[oc] = mfma(ah[ks], bv, V[oc]);
+            K[oc] = mfma(al[ks], bk, K[oc]);
+            V[oc] = mfma(al[ks], bv, V[oc]);
+            K[oc] = mfma(ah[ks], bkl, K[oc]);
+            V[oc] = mfma(ah[ks], bvl, V[oc]);
+        }
+        const float dk = L.ca_dk[32 * oc + cx.c], dv = L.ca_dv[32 * oc + cx.c], bk = L.ca_bk[32 * oc + cx.c], bv = L.ca_bv[32 * oc + cx.c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            K[oc][r] = fmaf(rs[r], K[oc][r] + dk, bk);
+            V[oc][r] = fmaf(rs[r], V[oc][r] + dv, bv);
+        }
+    }
+    float* rec = recs + ((size_t)l * G + g) * 2 * DC_REC_FLOATS;
+    const int nslot = cx.straddle ? 2 : 1;
+    for (int slot = 0; slot < nslot; ++slot) {
+        const RowRange valid = valid_rows(cx, slot, M, T, nullptr, Tx);
+        float* R = rec + (size_t)slot * DC_REC_FLOATS;
+#pragma unroll
+        for (int oc = 0; oc < 4; ++oc) emit_partial<__bf16, true>(K[oc], V[oc], oc, valid, R, cx);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // combine partial records of one (set, clip, 32-feature tile) into attention operand frags
 //   A[d][l] = sum_g w_g[d] P_g[d][l] / sum_g w_g[d] ssum_g[d],   w_g = exp(m_g - max_g m_g)
@@ -2268,6 +2390,17 @@ hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* 
                                  float* recs, int M, int T, int G, int L, int Tx) {
     hipLaunchKernelGGL(k_cond_ca_partials, dim3((G + 7) / 8, L), dim3(512), 0, st, dm, (const bf16x8*)nh_hi,
                        (const bf16x8*)nh_lo, recs, M, T, G, Tx);
+    return LAUNCH_CHECK();
+}
+
+hipError_t dc_launch_ca_partials64(hipStream_t st, const DcModel* dm, const float* xf, const float* gram, float* rstd, float* recs, int M, int T, int G,
+                                   int L, int Tx) {
+    const int ntok = G * 32;
+    hipLaunchKernelGGL(k_cond_rstd, dim3((ntok + 255) / 256), dim3(256), 0, st, xf, gram, rstd, M, T, Tx, ntok);
+    if (hipError_t e = hipGetLastError()) return e;
+    static unsigned long long optin_done = 0;
+    if (hipError_t e = lds_optin((const void*)k_cond_ca_partials64, 65536, optin_done)) return e;
+    hipLaunchKernelGGL(k_cond_ca_partials64, dim3((G + 7) / 8, L), dim3(512), 65536, st, dm, xf, rstd, recs, M, T, G, Tx);
     return LAUNCH_CHECK();
 }
 

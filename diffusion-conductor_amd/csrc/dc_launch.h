@@ -14,6 +14,9 @@ hipError_t dc_launch_cond_embed(hipStream_t st, int mode, const float* xf, const
                                 int Tx /* frames per clip of xf (<= T; the rest of a clip's stride is padding) */);
 hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* nh_hi, const void* nh_lo,
                                  float* recs, int M, int T, int G, int L, int Tx /* frames per clip (<= the clip stride T) */);
+// the same records from the 64 music features (K = rstd (A x + d) + b'): k_cond_rstd -> rstd [G * 32], then k_cond_ca_partials64
+hipError_t dc_launch_ca_partials64(hipStream_t st, const DcModel* dm, const float* xf /*[B][Tx][64]*/, const float* gram, float* rstd, float* recs,
+                                   int M, int T, int G, int L, int Tx);
 hipError_t dc_launch_attn_combine(hipStream_t st, int fmt, const float* recs, void* afrag, int T, int NU, int B, int nset,
                                   int gran);
 hipError_t dc_launch_silu_emb(hipStream_t st, int fmt, bool split, const float* pp, const float* temb, const int* t_clip,
