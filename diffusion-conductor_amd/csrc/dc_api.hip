@@ -616,6 +616,7 @@ int build_model(dc_sampler* s) {
         add_raw(&m.lin_wt, wt.data(), wt.size());
         add_raw(&m.lin_b, P_("linear.bias"), 512);
         add_raw(&m.lin_gram, lin_gram.data(), lin_gram.size());
+        add_packed(&m.lin_pack, w, 512, 64, false, false);
     }
     // timestep table storage + MLP operands (transposed for coalesced reads)
     const int nt = c.max_timesteps;
@@ -1350,7 +1351,11 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
         HIP_TRY(hipMemcpyAsync(s->d_length, s->len_dev.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     }
     // emb's step-invariant term: linear(xf_proj) as fp32 operand image
-    HIP_TRY(dc_launch_cond_embed(st, 0, d_xf_proj, s->h_model.lin_wt, s->h_model.lin_b, s->d_pp, nullptr, nullptr, M, G, T, Tx));
+    // (split-bf16 MFMAs, k_cond_pp64; DC_COND_512=1: the fp32 FMA form)
+    if (!getenv("DC_COND_512"))
+        HIP_TRY(dc_launch_cond_pp64(st, d_xf_proj, s->h_model.lin_pack, s->h_model.lin_b, s->d_pp, M, G, T, Tx));
+    else
+        HIP_TRY(dc_launch_cond_embed(st, 0, d_xf_proj, s->h_model.lin_wt, s->h_model.lin_b, s->d_pp, nullptr, nullptr, M, G, T, Tx));
     // cross-attention: linear(xf_out) -> text_norm (affine folded into K/V) -> per-layer K,V -> A_ca; one-time cost: always split
     // precision (plain bf16 here alone costs ~2e-3 on A_cross).  The linear-attention records come straight from the 64 music
     // features (`linear` composed into the projections on the host, k_cond_ca_partials64: an eighth of the products, no [tokens][512]

@@ -84,6 +84,7 @@ struct DcModel {
     const bf16x8* film_w16;
     const float* film_b16;
     const float* lin_wt;     // `linear` weight transposed [64][512]
+    const bf16x8* lin_pack;  // `linear` weight [512][64] as natural-k fragments [ot 16][ks 4], bf16 hi + lo (k_cond_pp64)
     const float* lin_gram;   // LayerNorm variance of linear(x) as a quadratic form of x: [64][64] Gc = Wc^T Wc / 512, then gv[64] = Wc^T bc / 512, then c = |bc|^2 / 512
     const float* lin_b;      // [512]
     const float* temb;       // [max_timesteps][512]

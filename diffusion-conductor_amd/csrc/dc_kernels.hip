@@ -306,6 +306,74 @@ __global__ __launch_bounds__(512, 1) void k_cond_ca_partials(const DcModel* __re
     }
 }
 
+// MODE 0 of k_cond_embed on the matrix pipe (round 5): pp = linear(xf_proj) for one 32-token group per wave as 16 tiles x 4 k-steps of
+// split-bf16 products (weights on the rows: the accumulator has the token on the lane), the image's [token][8 features] pieces
+// assembled by a swap between the lane halves; 128 KiB of weight fragments per 8-wave workgroup in LDS.  ~16 mantissa bits: the image
+// feeds SiLU(temb + pp), which is rounded to 11.
+__global__ __launch_bounds__(512, 1) void k_cond_pp64(const float* __restrict__ xf /*[B][Tx][64]*/, const bf16x8* __restrict__ wp, const float* __restrict__ b,
+                                                      float* __restrict__ out_f32, int M, int T, int G, int Tx) {
+    extern __shared__ __attribute__((aligned(16))) char wbuf[];          // [hi: ot 16][ks 4][lo: ...] x 1 KiB
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int g = blockIdx.x * 8 + wave;
+    const bool active = g < G;
+    if (!active) g = G - 1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lds_dma16(wp + (size_t)(16 * wave + i) * 64 + lane, wbuf + (16 * wave + i) * 1024);
+    const int c = lane & 31, hh = lane >> 5;
+    const int tok = 32 * g + c;
+    const int bb = tok / T, nn = tok - bb * T;
+    const bool live = tok < M && nn < Tx;
+    bf16x8 xh[4], xl[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (live) {
+            const f32x4* px = reinterpret_cast<const f32x4*>(xf) + ((size_t)bb * Tx + nn) * 16 + 4 * ks + 2 * hh;
+            v0 = px[0];
+            v1 = px[1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = j < 4 ? v0[j] : v1[j - 4];
+            const __bf16 h = (__bf16)v;
+            xh[ks][j] = h;
+            xl[ks][j] = (__bf16)(v - (float)h);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) return;
+    const bf16x8* w = reinterpret_cast<const bf16x8*>(wbuf) + lane;
+    f32x4* out = reinterpret_cast<f32x4*>(out_f32) + (size_t)g * 32 * 128 + lane;
+#pragma unroll 2
+    for (int ot = 0; ot < 16; ++ot) {
+        f32x16 acc = splat(0.f);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 ah = w[(ot * 4 + ks) * 64], al = w[(64 + ot * 4 + ks) * 64];
+            acc = mfma(ah, xh[ks], acc);
+            acc = mfma(al, xh[ks], acc);
+            acc = mfma(ah, xl[ks], acc);
+        }
+        // rows (r & 3) + 8 (r >> 2) + 4 hh of the tile -> this lane's 8 consecutive features 16 ks + 8 hh .. of k-steps 2 ot, 2 ot + 1
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 lo4, hi4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * q + i]), __float_as_uint(acc[8 * q + 4 + i]), false, false);
+                lo4[i] = __uint_as_float(r[0]);
+                hi4[i] = __uint_as_float(r[1]);
+            }
+            const int ks = 2 * ot + q;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + 16 * ks + 8 * hh), b1 = *reinterpret_cast<const f32x4*>(b + 16 * ks + 8 * hh + 4);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            out[(size_t)ks * 128] = live ? lo4 + b0 : z;              // rows of the padding and past M: zeros
+            out[(size_t)ks * 128 + 64] = live ? hi4 + b1 : z;
+        }
+    }
+}
+
 // The same records from the 64 music features themselves (round 5).  `linear` (64 -> 512) is shared by all layers and the
 // LayerNorm behind it is affine in its input up to the per-token 1 / std, so
 //   K = W' n-hat + b' = rstd (A x + d) + b',   A = W' Wc [128][64], d = W' bc        (host: dc_api.hip, build_model)
@@ -2390,6 +2458,13 @@ hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* 
                                  float* recs, int M, int T, int G, int L, int Tx) {
     hipLaunchKernelGGL(k_cond_ca_partials, dim3((G + 7) / 8, L), dim3(512), 0, st, dm, (const bf16x8*)nh_hi,
                        (const bf16x8*)nh_lo, recs, M, T, G, Tx);
+    return LAUNCH_CHECK();
+}
+
+hipError_t dc_launch_cond_pp64(hipStream_t st, const float* xf, const void* wpack, const float* b, float* out_f32, int M, int G, int T, int Tx) {
+    static unsigned long long optin_done = 0;
+    if (hipError_t e = lds_optin((const void*)k_cond_pp64, 131072, optin_done)) return e;
+    hipLaunchKernelGGL(k_cond_pp64, dim3((G + 7) / 8), dim3(512), 131072, st, xf, (const bf16x8*)wpack, b, out_f32, M, T, G, Tx);
     return LAUNCH_CHECK();
 }
 

@@ -14,6 +14,8 @@ hipError_t dc_launch_cond_embed(hipStream_t st, int mode, const float* xf, const
                                 int Tx /* frames per clip of xf (<= T; the rest of a clip's stride is padding) */);
 hipError_t dc_launch_ca_partials(hipStream_t st, const DcModel* dm, const void* nh_hi, const void* nh_lo,
                                  float* recs, int M, int T, int G, int L, int Tx /* frames per clip (<= the clip stride T) */);
+// MODE 0 of dc_launch_cond_embed (the fp32 image of linear(xf_proj)) on split-bf16 MFMAs
+hipError_t dc_launch_cond_pp64(hipStream_t st, const float* xf /*[B][Tx][64]*/, const void* wpack, const float* b, float* out_f32, int M, int G, int T, int Tx);
 // the same records from the 64 music features (K = rstd (A x + d) + b'): k_cond_rstd -> rstd [G * 32], then k_cond_ca_partials64
 hipError_t dc_launch_ca_partials64(hipStream_t st, const DcModel* dm, const float* xf /*[B][Tx][64]*/, const float* gram, float* rstd, float* recs,
                                    int M, int T, int G, int L, int Tx);
