@@ -312,7 +312,10 @@ def main():
         "config": {"workload": f"{'configs[1]: ' if headline else ''}DDIM-{S} sampling loop, bs={B} clips/GPU x {T} frames "
                                f"({T // 30} s), {'full T x T attention (no_eff)' if args.no_eff else 'linear attention'}, "
                                f"precision={args.precision}, conditioning + x_T resident in HBM (loop-only)",
-                   "clips_per_gpu": B, "frames_per_clip": T, "ddim_steps": S, "parallelism": f"clip-dp{world}"},
+                   "clips_per_gpu": B, "frames_per_clip": T, "ddim_steps": S, "parallelism": f"clip-dp{world}",
+                   # fp16 precision: the loop's last evaluation(s) run on split fp16 operands (dc_sampler_set_precise_tail, default 1;
+                   # DC_PRECISE_TAIL overrides) - inside the timed loop, like everything else the product path does
+                   "precise_tail_steps": (int(os.environ.get("DC_PRECISE_TAIL", "1")) if args.precision == "fp16" and not args.no_eff else 0)},
         # no_eff: 7.56 G + 13.27 G (T/1800) MAC per clip-step of 1800 tokens
         "mfma_roofline_frac_whole_loop": round(value / world * S * (2 * (7.56e9 + 13.27e9 * T / 1800) / 1800 if args.no_eff
                                                                       else FLOP_PER_TOKEN_STEP) / PEAK_BF16_FLOPS, 4),

@@ -224,8 +224,11 @@ struct dc_sampler {
     int smooth_window = 0, smooth_order = 0, smooth_table_window = 0;     // (table_window: the hat matrix d_smooth_coef holds)
     float* d_smooth_coef = nullptr;
 
+    DcModel h_model_split{};     // fp16 precision: the same model with the layer stage images in their split form ([hi][lo][consts]): the loop's precise tail
+    DcModel* d_model_split = nullptr;
     dc_music* music = nullptr;   // MusicEncoder (built when its parameters were supplied)
     int me_format = -1;          // dc_sampler_set_encoder_format (-1: by precision)
+    int tail_split = 1;          // dc_sampler_set_precise_tail: the loop's last evaluations with split operands (fp16 precision only)
     bool host_only = false;      // -DDC_HOST_SANITIZE builds without a device: the host half only (tests/test_host_sanitize.py)
 
     Prof prof;
@@ -362,16 +365,30 @@ int build_model(dc_sampler* s) {
         O.fix.push_back({(const void**)dst, A.add(v, n * 4)});
     };
     // stage image: [hi frags][lo frags if `with_lo`][1 KiB of fp32 constants if `consts`] (dc_common.h)
+    // fp16 precision: every layer stage image is also kept in its split form (the fp16 lo halves exist anyway): the loop's last
+    // evaluations can then run on split operands (dc_sampler_set_precise_tail) through h_model_split, a copy of the model record
+    // whose image pointers are these twins
+    const bool want_twins = c.precision == DC_PREC_FP16 && !c.no_eff && !s->split_small;
+    std::vector<std::pair<size_t, size_t>> twins;          // (offset of the pointer inside DcModel, arena offset of the split image)
     auto add_image = [&](const bf16x8** dst, const float* w, int n_out, int k_in, bool with_lo, const float* consts,
                          size_t n_consts) {
         const size_t ne = packed_elems(n_out, k_in);
         std::vector<uint16_t> hi(ne), lo(ne);
         pack_weight(w, n_out, k_in, true, hi.data(), lo.data(), sf16);
-        std::vector<uint8_t> blob(ne * 2 * (with_lo ? 2 : 1) + (consts ? 1024 : 0), 0);
-        memcpy(blob.data(), hi.data(), ne * 2);
-        if (with_lo) memcpy(blob.data() + ne * 2, lo.data(), ne * 2);
-        if (consts) memcpy(blob.data() + ne * 2 * (with_lo ? 2 : 1), consts, n_consts * 4);
+        auto blob_of = [&](bool lo_too) {
+            std::vector<uint8_t> blob(ne * 2 * (lo_too ? 2 : 1) + (consts ? 1024 : 0), 0);
+            memcpy(blob.data(), hi.data(), ne * 2);
+            if (lo_too) memcpy(blob.data() + ne * 2, lo.data(), ne * 2);
+            if (consts) memcpy(blob.data() + ne * 2 * (lo_too ? 2 : 1), consts, n_consts * 4);
+            return blob;
+        };
+        const std::vector<uint8_t> blob = blob_of(with_lo);
         O.fix.push_back({(const void**)dst, A.add(blob.data(), blob.size())});
+        const size_t off = (size_t)((const char*)dst - (const char*)&m);
+        if (want_twins && !with_lo && off < sizeof(DcModel)) {
+            const std::vector<uint8_t> b2 = blob_of(true);
+            twins.push_back({off, A.add(b2.data(), b2.size())});
+        }
     };
     auto ftvec = [&](const float* v, int n, int NT_) {
         std::vector<float> buf((size_t)NT_ * 32);
@@ -460,7 +477,7 @@ int build_model(dc_sampler* s) {
     // 32-row tiles are interleaved (scale0, shift0, scale1, shift1, ...) so one wave holds matching pairs
     const int NT = 3 * L * DC_FILM_TILES_PER_BLOCK;
     s->NT = NT;
-    std::vector<float> film_w((size_t)NT * 32 * DC_E), film_b((size_t)NT * 32);
+    std::vector<float> film_w((size_t)NT * 32 * DC_E), film_b((size_t)NT * 32), film_b_g1((size_t)NT * 32);
     for (int i = 0; i < L; ++i) {
         const std::string p = "temporal_decoder_blocks." + std::to_string(i);
         DcLayer& y = m.layer[i];
@@ -574,11 +591,17 @@ int build_model(dc_sampler* s) {
                     }
                     film_b[row0 + (size_t)(2 * t) * 32 + f] = (float)((double)ng[o] * (1.0 + bb[o]) - 1.0);
                     film_b[row0 + (size_t)(2 * t + 1) * 32 + f] = (float)(((double)nb[o] * (1.0 + bb[o]) + bb[128 + o]) * LOG2E);
+                    film_b_g1[row0 + (size_t)(2 * t) * 32 + f] = (float)((double)ng[o] * (1.0 + bb[o]));          // (G' itself: see below)
+                    film_b_g1[row0 + (size_t)(2 * t + 1) * 32 + f] = film_b[row0 + (size_t)(2 * t + 1) * 32 + f];
                 }
         }
     }
     add_packed(&m.film_w, film_w.data(), NT * 32, DC_E, false, s->film_fmt == 1);
     add_ft(&m.film_b, film_b.data(), NT * 32, NT);
+    // ... and with the scale tiles holding G' itself: the plain-operand layer kernels then form n-hat G' + H' in ONE mixed-precision FMA
+    // instead of two (-192 vector instructions per wave and layer).  fp16 keeps 11 bits of a number near 1 there instead of 11 bits of
+    // its small part - affordable where the loop's last evaluations run on split operands and G' - 1 tiles (precise tail, dc_ddim.h)
+    add_ft(&m.film_b_g1, film_b_g1.data(), NT * 32, NT);
     {   // 16x16x32 operand order (dc_common.h)
         static const int pi[16] = {0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15};
         const bool f16 = s->film_fmt == 1;
@@ -597,6 +620,10 @@ int build_model(dc_sampler* s) {
                 for (int r = 0; r < 16; ++r) b16[((size_t)ot * 2 + fb) * 16 + r] = film_b[(size_t)32 * ot + 16 * fb + pi[r]];
         O.fix.push_back({(const void**)&m.film_w16, A.add(w16.data(), w16.size() * 2)});
         add_raw(&m.film_b16, b16.data(), b16.size());
+        for (int ot = 0; ot < NT; ++ot)
+            for (int fb = 0; fb < 2; ++fb)
+                for (int r = 0; r < 16; ++r) b16[((size_t)ot * 2 + fb) * 16 + r] = film_b_g1[(size_t)32 * ot + 16 * fb + pi[r]];
+        add_raw(&m.film_b16_g1, b16.data(), b16.size());
     }
     {   // the two pose projections always run split: [hi][lo][bias]
         const std::vector<float> jb = ftvec(P_("joint_embed.bias"), D, 4);
@@ -650,6 +677,8 @@ int build_model(dc_sampler* s) {
         s->d_arena = (uint8_t*)malloc(s->arena_bytes);
         memcpy(s->d_arena, A.host.data(), s->arena_bytes);
         for (auto& f : O.fix) *f.first = s->d_arena + f.second;
+        s->h_model_split = m;
+        for (auto& tw : twins) *(const void**)((char*)&s->h_model_split + tw.first) = s->d_arena + tw.second;
         return DC_OK;
     }
     if (s->d_arena) hipFree(s->d_arena);
@@ -659,6 +688,10 @@ int build_model(dc_sampler* s) {
     for (auto& f : O.fix) *f.first = s->d_arena + f.second;
     if (!s->d_model) HIP_TRY(hipMalloc((void**)&s->d_model, sizeof(DcModel)));
     HIP_TRY(hipMemcpy(s->d_model, &m, sizeof(DcModel), hipMemcpyHostToDevice));
+    s->h_model_split = m;
+    for (auto& tw : twins) *(const void**)((char*)&s->h_model_split + tw.first) = s->d_arena + tw.second;
+    if (!s->d_model_split) HIP_TRY(hipMalloc((void**)&s->d_model_split, sizeof(DcModel)));
+    HIP_TRY(hipMemcpy(s->d_model_split, &s->h_model_split, sizeof(DcModel), hipMemcpyHostToDevice));
     HIP_TRY(dc_launch_temb_table(s->stream, d_freqs, d_w0t, d_b0, d_w2t, d_b2, (float*)m.temb, nt));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return DC_OK;
@@ -818,9 +851,11 @@ unsigned long long form_key(const dc_sampler* s) {
 // step's kernels then look the timestep / DDIM scalars up themselves - this step's slot of the per-iteration tables, offset by
 // the iteration at which the replay began (*d_iter, advanced once per replay) - and the per-step bookkeeping launch
 // (k_begin_step, 5 us + a launch gap) is dropped.
-int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_src, float* x_dst, int graph_step = -1) {
+int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_src, float* x_dst, int graph_step = -1,
+                 bool split_step = false /* this evaluation's 128-wide GEMMs on split operands (the fp16 images' hi + lo halves) */) {
     const int B = s->B, T = s->T, M = s->M, G = s->G, L = s->cfg.num_layers;
-    const bool ss = s->split_small, sf = s->split_film;
+    const bool ss = s->split_small || split_step, sf = s->split_film;
+    const DcModel* dmod = (split_step && !s->split_small) ? s->d_model_split : s->d_model;      // (the precise tail's split stage images)
     const int fs = s->small_fmt, ff = s->film_fmt;
     // non-split formats: the FiLM GEMM produces its own operand from pp + temb (no k_silu_emb pass); the separate pass
     // remains for the split formats, for the v1 kernel, and under the test hooks that read the operand image back
@@ -900,12 +935,20 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const DcUpdate upd{s->d_zslot, s->d_status, (loop_mode ? s->upd_flags : 0) | (getenv("DC_L16_TEST_DROP_SLICE") ? DC_UPD_TEST_DROP_SLICE : 0),
                        folded ? graph_step : -1, nullptr};
     const int film_rounds = s->NT / 16;
-    LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, s->h_model.film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
+    // scale tiles: G' for the plain-operand consumers of this step, G' - 1 for the split-operand ones (dc_dev.h, film_affine)
+#ifdef DC_NO_FILM_G1
+    const bool g1_tiles = false;
+#else
+    const bool g1_tiles = !ss;
+#endif
+    const float* film_b = g1_tiles ? s->h_model.film_b_g1 : s->h_model.film_b;
+    const float* film_b16 = g1_tiles ? s->h_model.film_b16_g1 : s->h_model.film_b16;
+    LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
                                        film_rounds, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
                                        want_stamps_film ? s->d_stamps + 252 : nullptr,
                                        adapt ? s->d_film_rate + 1024 * s->film_rate_parity : nullptr,
                                        adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr, iter_base,
-                                       s->h_model.film_w16, s->h_model.film_b16, (fuse_embed || fuse_extra) ? &ea : nullptr, s->d_status));
+                                       s->h_model.film_w16, film_b16, (fuse_embed || fuse_extra) ? &ea : nullptr, s->d_status));
     s->film_rate_parity ^= 1;
     const int nl_run = (s->dbg_layers >= 0 && s->dbg_layers < L) ? s->dbg_layers : L;
     if (s->cfg.no_eff) {
@@ -923,9 +966,9 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     if (fuse_embed || fuse_extra) {
         // (embedded by the FiLM launch)
     } else if (s->dbg_first >= 0)
-        LAUNCH(K_EMBED, dc_launch_front_from_h(st, fs, ss, s->d_model, s->d_h, s->d_recs, s->d_length, M, T, G, B, s->dbg_first));
+        LAUNCH(K_EMBED, dc_launch_front_from_h(st, fs, ss, dmod, s->d_h, s->d_recs, s->d_length, M, T, G, B, s->dbg_first));
     else
-        LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
+        LAUNCH(K_EMBED, dc_launch_embed_front(st, fs, ss, wgr, dmod, x_src, s->d_h, s->d_recs, s->d_length, M, T, G, B,
                                               want_stamps_film ? s->d_stamps + 256 : nullptr, narrow, Tx, upc));
     for (int l = s->dbg_first >= 0 ? s->dbg_first : 0; l < nl_run; ++l) {
         const int dbg = (l == nl_run - 1) ? s->dbg_stage : 0;
@@ -940,7 +983,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
             continue;
         }
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
-        LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
+        LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, dmod, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src,
                                         s->d_snaps, M, T, G, B, dbg, ((l == 3 || l == 4) && want_stamps) ? s->d_stamps : nullptr, rec_stride,
                                         iter_base, narrow, Tx, upc, upd));
@@ -1038,17 +1081,30 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     HIP_TRY(hipMemsetAsync(s->d_iter, 0, 16, st));
     HIP_TRY(hipMemcpyAsync(s->d_x, d_noise, MP * 4, hipMemcpyDeviceToDevice, st));
     const bool no_graph = getenv("DC_DISABLE_GRAPH") != nullptr;
+    // precise tail: the loop's last `tail` model evaluations on split operands (dc_sampler_set_precise_tail; DC_PRECISE_TAIL=k overrides):
+    // fp16 precision, linear attention, a clip stride of whole 32-frame groups (the split kernels' clip-aligned units), no test hooks
+    int tail = s->tail_split;
+    if (const char* e = getenv("DC_PRECISE_TAIL")) tail = atoi(e);
+    if (s->cfg.precision != DC_PREC_FP16 || s->cfg.no_eff || s->T % 32 != 0 || s->T < 256 || s->dbg_layers >= 0 || s->dbg_first >= 0 || s->dbg_stage != 0 ||
+        !s->d_model_split)
+        tail = 0;
+    tail = std::max(0, std::min(tail, std::min(S, steps_per_graph(S))));
     if (profile || no_graph) {
         s->prof.on = profile;
         for (int i = 0; i < S; ++i)
-            if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x))) {
+            if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, -1, i >= S - tail))) {
                 s->prof.on = false;
                 return rc;
             }
         s->prof.on = false;
     } else {
         const int K = steps_per_graph(S);
-        const unsigned long long fk = form_key(s);
+        const int replays = S / K;
+      // (with a precise tail and several replays per loop - S > 64 - the LAST replay runs a second graph whose final steps are split)
+      for (int part = 0; part < ((tail && replays > 1) ? 2 : 1); ++part) {
+        const int tail_here = (part == 1 || replays == 1) ? tail : 0;
+        const int launches = (tail && replays > 1) ? (part == 0 ? replays - 1 : 1) : replays;
+        const unsigned long long fk = form_key(s) | ((unsigned long long)tail_here << 40);
         auto current = [&]() {
             return s->graph && s->graph_B == s->B && s->graph_T == s->T && s->graph_Tx == s->Tx && s->graph_K == K && s->graph_form == fk;
         };
@@ -1075,7 +1131,7 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             for (int i = 0; i < K; ++i)
-                if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, i))) {
+                if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, i, i >= K - tail_here))) {
                     hipStreamEndCapture(st, &g);
                     if (g) hipGraphDestroy(g);
                     return rc;
@@ -1099,7 +1155,8 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
             s->graph_K = K;
             s->graph_form = fk;
         }
-        for (int i = 0; i < S / K; ++i) HIP_TRY(hipGraphLaunch(s->graph, st));
+        for (int i = 0; i < launches; ++i) HIP_TRY(hipGraphLaunch(s->graph, st));
+      }
     }
     // the final write x0 -> the caller's tensor: a copy, or (dc_sampler_set_smoothing) the Savitzky-Golay filter along time
     // (tools/visualization.py:20-26,126) reading the loop's x0 and writing the caller's tensor directly - no pass of its own
@@ -1251,7 +1308,7 @@ void dc_sampler_destroy(dc_sampler* s) {
     hipSetDevice(s->cfg.device);
     hipDeviceSynchronize();
     drop_graph(s);
-    void* ptrs[] = {s->d_arena, s->d_model, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
+    void* ptrs[] = {s->d_arena, s->d_model, s->d_model_split, s->d_length, s->d_pp, s->d_s_hi, s->d_s_lo, s->d_E, s->d_h, s->d_recs, s->d_a_sa,
                     s->d_a_ca, s->d_x, s->d_snaps, s->d_recs_ca, s->d_nh_hi, s->d_nh_lo, s->d_iter,
                     s->d_t_clip, s->d_snap_cur, s->d_t_of_iter, s->d_snap_of_iter, s->d_coef_cur, s->d_coef_of_t, s->d_coef_of_iter,
                     s->d_kv_sa[0], s->d_kv_sa[1], s->d_kv_ca, s->d_stamps, s->d_film_rate, s->d_status, s->d_smooth_coef, s->d_zslot, s->d_zstep, s->d_a_ca16, s->d_gran};
@@ -1379,6 +1436,13 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
     }
     s->cond_set = true;
     return sync_out(s, user);
+}
+
+int dc_sampler_set_precise_tail(dc_sampler* s, int32_t steps) {
+    if (!s) return fail(DC_ERR_INVALID, "null sampler");
+    if (steps < 0) return fail(DC_ERR_INVALID, "precise tail: steps >= 0");
+    s->tail_split = steps;
+    return DC_OK;
 }
 
 int dc_sampler_set_encoder_format(dc_sampler* s, int32_t format) {

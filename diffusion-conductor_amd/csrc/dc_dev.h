@@ -1240,7 +1240,33 @@ DEV float add_mix_h(uint32_t h2, float c) {        // (float)half + c
     return d;
 }
 
-// one k-tile of the FiLM-modulated, SiLU'ed operand: z = SiLU(nhat*G' + H'), gp = G' - 1; everything in the log2(e)
+// d = ga * n + hb with ga and hb read as fp16 halves of two packed registers
+template <int HI>
+DEV float fma_mix_hh(uint32_t g2, float n, uint32_t h2) {
+    float d;
+    if constexpr (HI)
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(g2), "v"(n), "v"(h2));
+    else
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(g2), "v"(n), "v"(h2));
+    return d;
+}
+// n-hat G' + H' from a tile pair's packed halves.  G1 (the plain-operand kernels): the scale tile holds G' itself - one FMA; else it
+// holds G' - 1 (fp16's 11 bits on the small part): (G' - 1) n + n, then + H'.  The FiLM GEMM is launched with the matching constants
+// (dc_api.hip, enqueue_step).
+template <int HI, bool G1>
+DEV float film_affine(uint32_t g2, float n, uint32_t h2) {
+#ifdef DC_NO_FILM_G1          // (A/B build: G' - 1 tiles everywhere, round 4's form)
+    constexpr bool g1 = false;
+#else
+    constexpr bool g1 = G1;
+#endif
+    if constexpr (g1)
+        return fma_mix_hh<HI>(g2, n, h2);
+    else
+        return add_mix_h<HI>(h2, fma_mix_h<HI>(g2, n, n));
+}
+
+// one k-tile of the FiLM-modulated, SiLU'ed operand: z = SiLU(nhat*G' + H'), gp = G' - 1 (split operands) or G'; everything in the log2(e)
 // scaling of silu_l2_pair: rstd / shift arrive multiplied by log2(e), hp = log2(e) H', z = log2(e) SiLU(.)
 template <class T16, bool SPLIT, class YTile>
 DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shift, const f16x16& gp, const f16x16& hp) {
@@ -1250,7 +1276,7 @@ DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shif
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float n0 = fma_mix_h<0>(yw[k], rstd, shift), n1 = fma_mix_h<1>(yw[k], rstd, shift);
-            const f32x2 zz = silu_l2_pair(add_mix_h<0>(hw[k], fma_mix_h<0>(gw[k], n0, n0)), add_mix_h<1>(hw[k], fma_mix_h<1>(gw[k], n1, n1)));
+            const f32x2 zz = silu_l2_pair(film_affine<0, !SPLIT>(gw[k], n0, hw[k]), film_affine<1, !SPLIT>(gw[k], n1, hw[k]));
             z[2 * k] = zz.x;
             z[2 * k + 1] = zz.y;
         }
@@ -1259,7 +1285,7 @@ DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shif
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float n0 = fmaf((float)y[2 * k], rstd, shift), n1 = fmaf((float)y[2 * k + 1], rstd, shift);
-            const f32x2 zz = silu_l2_pair(add_mix_h<0>(hw[k], fma_mix_h<0>(gw[k], n0, n0)), add_mix_h<1>(hw[k], fma_mix_h<1>(gw[k], n1, n1)));
+            const f32x2 zz = silu_l2_pair(film_affine<0, !SPLIT>(gw[k], n0, hw[k]), film_affine<1, !SPLIT>(gw[k], n1, hw[k]));
             z[2 * k] = zz.x;
             z[2 * k + 1] = zz.y;
         }

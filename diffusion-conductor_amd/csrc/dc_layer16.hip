@@ -267,8 +267,7 @@ DEV v8<T16> styl16(const Y16& ya, const Y16& yb, float rstd, float shift, const 
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const float n0 = fma_mix_h<0>(y.p[p], rstd, shift), n1 = fma_mix_h<1>(y.p[p], rstd, shift);
-            const f32x2 zz = silu_l2_pair(add_mix_h<0>(e.h[fb][p], fma_mix_h<0>(e.g[fb][p], n0, n0)),
-                                          add_mix_h<1>(e.h[fb][p], fma_mix_h<1>(e.g[fb][p], n1, n1)));
+            const f32x2 zz = silu_l2_pair(film_affine<0, true>(e.g[fb][p], n0, e.h[fb][p]), film_affine<1, true>(e.g[fb][p], n1, e.h[fb][p]));
             z[fb][2 * p] = zz.x;
             z[fb][2 * p + 1] = zz.y;
         }

@@ -150,6 +150,16 @@ DC_EXPORT int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t
  *                    rounded to 11 bits once per layer), 1.3e-4 of x0 after DDIM-50, about half the time (2.1 vs 4.2 ms per 32 clips).
  * Default: DC_ME_FP16 for the precisions whose denoiser rounds these features to 16-bit operands anyway (DC_PREC_FP16, DC_PREC_BF16),
  * DC_ME_SPLIT for the split-operand precisions.  The environment variable DC_ME_PREC=f16|split (read per call) overrides both. */
+/* Precise tail of the sampling loops (DC_PREC_FP16 only; no counterpart in the reference, which computes in fp32): the last `steps` model
+ * evaluations of a loop run their 128-wide GEMMs on split fp16 operands (hi + lo halves of the same weight images, three MFMAs per
+ * product) instead of plain fp16 ones.  What the fp16 mode loses against the reference is almost entirely the WEIGHTS' rounding in the
+ * final evaluations (DDIM's last step returns the model's own prediction of x0): golden DDIM-50 5.0e-4 with steps = 0, 2.3e-4 with 1,
+ * 1.6e-4 with 2, 1.2e-4 with 4, at +0.6 % of the loop per step at bs = 32.  Ignored (0) for the other precisions,
+ * for `no_eff`, and when the clip stride is not a whole number of 32-frame groups.  Default: 1.  DC_PRECISE_TAIL=k in the environment
+ * overrides it.  (The plain-fp16 evaluations read FiLM scale tiles that hold G' itself - one mixed-precision FMA per element instead of two -,
+ * the split ones G' - 1; with steps = 0 the golden DDIM-50 measures 5.7e-4.) */
+DC_EXPORT int dc_sampler_set_precise_tail(dc_sampler* s, int32_t steps);
+
 #define DC_ME_SPLIT 0
 #define DC_ME_FP16 1
 DC_EXPORT int dc_sampler_set_encoder_format(dc_sampler* s, int32_t format);

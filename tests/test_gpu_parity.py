@@ -128,6 +128,33 @@ def test_ddim50_config1_golden(models, prec, tol):
     assert err <= tol and e0 <= tol and e24 <= tol
 
 
+def test_precise_tail_halves_the_fp16_error(models):
+    """fp16 precision: the loop's last model evaluation(s) run on split fp16 operands (include/dc_ddim.h, dc_sampler_set_precise_tail;
+    default 1).  DDIM's last step returns the model's own prediction of x0, and what the fp16 mode loses is mostly the weights' rounding
+    there: golden DDIM-50 (G5) with 0 / 1 / 2 split evaluations, eager and captured loops alike."""
+    g = golden("g5_ddim50_b1.npz")
+    xfp, xfo = xf_pair(1, 1800)
+    noise = torch.from_numpy(batch_noise(1, 1800))
+    assert "DC_PRECISE_TAIL" not in os.environ
+    errs = {}
+    for k in (0, 1, 2):
+        errs[k] = rel_l2(_with_env({"DC_PRECISE_TAIL": str(k)}, lambda: _ddim(models["fp16"], 50, noise, xfp, xfo, [1800])), g["x0"])
+    default = _ddim(models["fp16"], 50, noise, xfp, xfo, [1800])
+    eager = _with_env({"DC_DISABLE_GRAPH": "1"}, lambda: _ddim(models["fp16"], 50, noise, xfp, xfo, [1800]))
+    print("precise tail 0 / 1 / 2: " + " ".join(f"{errs[k]:.3e}" for k in (0, 1, 2)) + f"; default {rel_l2(default, g['x0']):.3e}")
+    assert errs[0] <= TOL_PARITY and errs[1] <= 0.6 * errs[0] and errs[2] <= 0.8 * errs[1]
+    assert rel_l2(default, g["x0"]) == errs[1] and torch.equal(default, eager)          # the default is one evaluation; graph == eager
+    nat = models["fp16"]._ensure_native("cuda:0")
+    try:
+        nat.set_precise_tail(2)
+        assert rel_l2(_ddim(models["fp16"], 50, noise, xfp, xfo, [1800]), g["x0"]) == errs[2]
+        from diffusion_conductor_amd import native
+        with pytest.raises(native.DcError, match="precise tail"):
+            native._check(native.lib().dc_sampler_set_precise_tail(nat._h, -1))
+    finally:
+        nat.set_precise_tail(1)
+
+
 def test_ddim50_t900_ragged_golden(models):
     """G6: 30 s clips (T=900), B=2, ragged lengths."""
     g = golden("g6_variants.npz")
@@ -148,6 +175,9 @@ def test_ddim1000_graph_replay_golden(models):
     err = rel_l2(out, g["ddim1000_x0"])
     print(f"ddim1000 rel-L2 {err:.3e}")
     assert err <= TOL_PARITY
+    # (the precise tail lives in the LAST replay's graph only - a second captured graph: 2.3e-4 with it, 5.1e-4 without)
+    if "DC_PRECISE_TAIL" not in os.environ:
+        assert err <= 3.5e-4
 
 
 def test_graph_equals_eager(models):
