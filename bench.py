@@ -428,21 +428,33 @@ def main():
             if cpu_x0 is not None:
                 line["bs1"]["rel_l2_vs_oracle"] = float(f"{rel_l2(o1, cpu_x0):.3e}")
             log(f"bs=1: {line['bs1']}")
-            if args.precision != "mixed":
+            if args.precision == "fp16":
+                # the bf16-operand mode: plain bf16 MFMA operands in every GEMM (FiLM GEMM included), the loop's last 8 of 50 model
+                # evaluations on split bf16 (three MFMAs per product; dc_sampler_set_precise_tail) - what carries its precision
                 del nat1, nat
-                m2 = build_model("mixed", False, dev)
+                m2 = build_model("bf16", False, dev)
                 n2 = m2.set_conditioning(xfp, xf, [T] * B)
                 t2, o2 = time_loops(n2, noise, coef, 3)
-                line["bf16_mode"] = {"precision": "mixed", "ms_per_step": round(1e3 * t2, 3), "frames_per_s": round(B * T / t2, 1),
+                line["bf16_mode"] = {"precision": "bf16", "ms_per_step": round(1e3 * t2, 3), "frames_per_s": round(B * T / t2, 1),
                                      "rel_l2": float(f"{rel_l2(o2[:1], cpu_x0):.3e}") if cpu_x0 is not None else None,
-                                     "operands": "128-wide GEMMs as three bf16 MFMAs (hi*hi + lo*hi + hi*lo), FiLM GEMM f16; no "
-                                                 "bf16-everywhere mode meets the 1e-3 bound (plain_bf16_rel_l2)"}
-                if cpu_x0 is not None:      # the plain-bf16 error beside the gated modes (one clip, one loop)
-                    del n2, m2
-                    m3 = build_model("bf16", False, dev)
-                    o3, _ = m3.set_conditioning(xfp[:1].contiguous(), xf[:1].contiguous(), [T]).ddim_loop(noise[:1].contiguous(), coef)
+                                     "precise_tail_steps": int(os.environ.get("DC_PRECISE_TAIL", "8")),
+                                     "operands": "every GEMM on plain bf16 MFMA operands; the last 8 of the loop's 50 model evaluations on "
+                                                 "split bf16 (hi*hi + lo*hi + hi*lo).  plain_bf16_rel_l2: the same mode without that tail"}
+                if cpu_x0 is not None:      # the plain-bf16 error (one clip, one loop)
+                    os.environ["DC_PRECISE_TAIL"] = "0"
+                    try:
+                        o3, _ = m2.set_conditioning(xfp[:1].contiguous(), xf[:1].contiguous(), [T]).ddim_loop(noise[:1].contiguous(), coef)
+                    finally:
+                        del os.environ["DC_PRECISE_TAIL"]
                     line["bf16_mode"]["plain_bf16_rel_l2"] = float(f"{rel_l2(o3, cpu_x0):.3e}")
-                log(f"bf16 mode: {line['bf16_mode']}")
+                del n2, m2
+                # ... and the split-operand mode (`mixed`: split bf16 in every 128-wide GEMM of every evaluation, f16 FiLM GEMM)
+                m4 = build_model("mixed", False, dev)
+                n4 = m4.set_conditioning(xfp, xf, [T] * B)
+                t4, o4 = time_loops(n4, noise, coef, 3)
+                line["split_mode"] = {"precision": "mixed", "ms_per_step": round(1e3 * t4, 3), "frames_per_s": round(B * T / t4, 1),
+                                      "rel_l2": float(f"{rel_l2(o4[:1], cpu_x0):.3e}") if cpu_x0 is not None else None}
+                log(f"bf16 mode: {line['bf16_mode']}; split mode: {line['split_mode']}")
         print(json.dumps(line), file=result_out, flush=True)
     if world > 1 or selftest_multi:
         dist.barrier()

@@ -228,7 +228,7 @@ struct dc_sampler {
     DcModel* d_model_split = nullptr;
     dc_music* music = nullptr;   // MusicEncoder (built when its parameters were supplied)
     int me_format = -1;          // dc_sampler_set_encoder_format (-1: by precision)
-    int tail_split = 1;          // dc_sampler_set_precise_tail: the loop's last evaluations with split operands (fp16 precision only)
+    int tail_split = -1;         // dc_sampler_set_precise_tail: the loop's last evaluations with split operands (-1: by precision - fp16 1, bf16 8)
     bool host_only = false;      // -DDC_HOST_SANITIZE builds without a device: the host half only (tests/test_host_sanitize.py)
 
     Prof prof;
@@ -368,7 +368,7 @@ int build_model(dc_sampler* s) {
     // fp16 precision: every layer stage image is also kept in its split form (the fp16 lo halves exist anyway): the loop's last
     // evaluations can then run on split operands (dc_sampler_set_precise_tail) through h_model_split, a copy of the model record
     // whose image pointers are these twins
-    const bool want_twins = c.precision == DC_PREC_FP16 && !c.no_eff && !s->split_small;
+    const bool want_twins = (c.precision == DC_PREC_FP16 || c.precision == DC_PREC_BF16) && !c.no_eff && !s->split_small;
     std::vector<std::pair<size_t, size_t>> twins;          // (offset of the pointer inside DcModel, arena offset of the split image)
     auto add_image = [&](const bf16x8** dst, const float* w, int n_out, int k_in, bool with_lo, const float* consts,
                          size_t n_consts) {
@@ -1083,9 +1083,9 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     const bool no_graph = getenv("DC_DISABLE_GRAPH") != nullptr;
     // precise tail: the loop's last `tail` model evaluations on split operands (dc_sampler_set_precise_tail; DC_PRECISE_TAIL=k overrides):
     // fp16 precision, linear attention, a clip stride of whole 32-frame groups (the split kernels' clip-aligned units), no test hooks
-    int tail = s->tail_split;
+    int tail = s->tail_split >= 0 ? s->tail_split : (s->cfg.precision == DC_PREC_BF16 ? 8 : 1);
     if (const char* e = getenv("DC_PRECISE_TAIL")) tail = atoi(e);
-    if (s->cfg.precision != DC_PREC_FP16 || s->cfg.no_eff || s->T % 32 != 0 || s->T < 256 || s->dbg_layers >= 0 || s->dbg_first >= 0 || s->dbg_stage != 0 ||
+    if ((s->cfg.precision != DC_PREC_FP16 && s->cfg.precision != DC_PREC_BF16) || s->cfg.no_eff || s->T % 32 != 0 || s->T < 256 || s->dbg_layers >= 0 || s->dbg_first >= 0 || s->dbg_stage != 0 ||
         !s->d_model_split)
         tail = 0;
     tail = std::max(0, std::min(tail, std::min(S, steps_per_graph(S))));

@@ -92,7 +92,7 @@ class MotionTransformer(nn.Module):
             self._native = NativeSampler(self.cfg, self.active_precision, self.max_timesteps, idx)
             if self.encoder_format is not None:
                 self._native.set_encoder_format(self.encoder_format)
-            if self.precise_tail:
+            if self.precise_tail is not None:
                 self._native.set_precise_tail(self.precise_tail)
             self._native_dirty = True
         if self._native_dirty:
@@ -142,7 +142,7 @@ class MotionTransformer(nn.Module):
     encoder_format = None
     # fp16 precision: the sampling loops' last `precise_tail` model evaluations on split fp16 operands (include/dc_ddim.h,
     # dc_sampler_set_precise_tail); set before the first forward.  DC_PRECISE_TAIL=k in the environment overrides it.
-    precise_tail = 0
+    precise_tail = None       # None: the library's default (1 for fp16, 8 for bf16)
 
     h2d_chunk = 8        # a pinned host batch of at least 2 x this many clips is copied in chunks beside the encoder
     h2d_schedule = (8, 8, 4)     # ... of B/8, B/8, B/4 clips and the rest: the first copy is the only one the encoder waits for

@@ -150,14 +150,16 @@ DC_EXPORT int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t
  *                    rounded to 11 bits once per layer), 1.3e-4 of x0 after DDIM-50, about half the time (2.1 vs 4.2 ms per 32 clips).
  * Default: DC_ME_FP16 for the precisions whose denoiser rounds these features to 16-bit operands anyway (DC_PREC_FP16, DC_PREC_BF16),
  * DC_ME_SPLIT for the split-operand precisions.  The environment variable DC_ME_PREC=f16|split (read per call) overrides both. */
-/* Precise tail of the sampling loops (DC_PREC_FP16 only; no counterpart in the reference, which computes in fp32): the last `steps` model
- * evaluations of a loop run their 128-wide GEMMs on split fp16 operands (hi + lo halves of the same weight images, three MFMAs per
- * product) instead of plain fp16 ones.  What the fp16 mode loses against the reference is almost entirely the WEIGHTS' rounding in the
- * final evaluations (DDIM's last step returns the model's own prediction of x0): golden DDIM-50 5.0e-4 with steps = 0, 2.3e-4 with 1,
- * 1.6e-4 with 2, 1.2e-4 with 4, at +0.6 % of the loop per step at bs = 32.  Ignored (0) for the other precisions,
- * for `no_eff`, and when the clip stride is not a whole number of 32-frame groups.  Default: 1.  DC_PRECISE_TAIL=k in the environment
- * overrides it.  (The plain-fp16 evaluations read FiLM scale tiles that hold G' itself - one mixed-precision FMA per element instead of two -,
- * the split ones G' - 1; with steps = 0 the golden DDIM-50 measures 5.7e-4.) */
+/* Precise tail of the sampling loops (DC_PREC_FP16, DC_PREC_BF16; no counterpart in the reference, which computes in fp32): the last
+ * `steps` model evaluations of a loop run their 128-wide GEMMs on SPLIT operands (hi + lo halves of the same 16-bit weight images, three
+ * MFMAs per product) instead of plain ones.  What a 16-bit mode loses against the reference is almost entirely the WEIGHTS' rounding
+ * in the final evaluations (DDIM's last step returns the model's own prediction of x0).  Golden DDIM-50, rel-L2 of x0:
+ *   fp16:  5.0e-4 with steps = 0,  2.3e-4 with 1,  1.6e-4 with 2,  1.2e-4 with 4   (+0.45 % of the loop per step at bs = 32)
+ *   bf16:  3.1e-3 with steps = 0,  9.5e-4 with 2,  6.8e-4 with 4,  5.4e-4 with 8   - the bf16-operand mode that meets the 1e-3 bound
+ * Default (steps never set): 1 for fp16, 8 for bf16.  Ignored (0) for the split precisions, for `no_eff`, and when the clip stride is
+ * not a whole number of 32-frame groups.  DC_PRECISE_TAIL=k in the environment overrides it.  (The plain evaluations read FiLM scale
+ * tiles that hold G' itself - one mixed-precision FMA per element instead of two -, the split ones G' - 1; fp16 with steps = 0 then
+ * measures 5.6e-4.) */
 DC_EXPORT int dc_sampler_set_precise_tail(dc_sampler* s, int32_t steps);
 
 #define DC_ME_SPLIT 0
