@@ -852,7 +852,8 @@ unsigned long long form_key(const dc_sampler* s) {
 // the iteration at which the replay began (*d_iter, advanced once per replay) - and the per-step bookkeeping launch
 // (k_begin_step, 5 us + a launch gap) is dropped.
 int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_src, float* x_dst, int graph_step = -1,
-                 bool split_step = false /* this evaluation's 128-wide GEMMs on split operands (the fp16 images' hi + lo halves) */) {
+                 bool split_step = false /* this evaluation's 128-wide GEMMs on split operands (the fp16 images' hi + lo halves) */,
+                 bool g1_loop = false /* a loop with a precise tail: its plain-operand evaluations read G' scale tiles */) {
     const int B = s->B, T = s->T, M = s->M, G = s->G, L = s->cfg.num_layers;
     const bool ss = s->split_small || split_step, sf = s->split_film;
     const DcModel* dmod = (split_step && !s->split_small) ? s->d_model_split : s->d_model;      // (the precise tail's split stage images)
@@ -936,10 +937,11 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
                        folded ? graph_step : -1, nullptr};
     const int film_rounds = s->NT / 16;
     // scale tiles: G' for the plain-operand consumers of this step, G' - 1 for the split-operand ones (dc_dev.h, film_affine)
+    // (the production forms of the plain-operand kernels only: test hooks, stamps and the per-group record form keep G' - 1)
 #ifdef DC_NO_FILM_G1
     const bool g1_tiles = false;
 #else
-    const bool g1_tiles = !ss;
+    const bool g1_tiles = g1_loop && !ss && wgr && !s->cfg.no_eff && s->dbg_stage == 0 && s->dbg_layers < 0 && s->dbg_first < 0 && !want_stamps;
 #endif
     const float* film_b = g1_tiles ? s->h_model.film_b_g1 : s->h_model.film_b;
     const float* film_b16 = g1_tiles ? s->h_model.film_b16_g1 : s->h_model.film_b16;
@@ -979,14 +981,14 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
             LAUNCH(K_LAYER, dc_launch_layer16(st, fs, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_a_ca16, s->d_recs, s->d_length, x_src, x_dst,
                                               loop_mode ? 1 : 0, coef_src, snap_src, s->d_snaps, M, T, B, upc16, rec_stride,
                                               l == 0 ? upc_narrow : upc16, l == 0 ? (size_t)2 * DC_REC_FLOATS : (size_t)DC_REC_FLOATS, iter_base, Tx,
-                                              u16, l16_shared ? s->d_gran : nullptr, l16_tag));
+                                              u16, l16_shared ? s->d_gran : nullptr, l16_tag, g1_tiles));
             continue;
         }
         if (!wgr) LAUNCH(K_COMBINE, dc_launch_attn_combine(st, fs, s->d_recs, s->d_a_sa, T, (M + s->gran - 1) / s->gran, B, 1, s->gran));
         LAUNCH(K_LAYER, dc_launch_layer(st, fs, ss, wgr, dmod, l, s->d_h, s->d_E, s->NT, s->d_a_sa, s->d_a_ca, s->d_recs,
                                         s->d_length, x_src, x_dst, loop_mode ? 1 : 0, coef_src, snap_src,
                                         s->d_snaps, M, T, G, B, dbg, ((l == 3 || l == 4) && want_stamps) ? s->d_stamps : nullptr, rec_stride,
-                                        iter_base, narrow, Tx, upc, upd));
+                                        iter_base, narrow, Tx, upc, upd, g1_tiles));
     }
     return DC_OK;
 }
@@ -1092,7 +1094,7 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     if (profile || no_graph) {
         s->prof.on = profile;
         for (int i = 0; i < S; ++i)
-            if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, -1, i >= S - tail))) {
+            if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, -1, i >= S - tail, tail > 0))) {
                 s->prof.on = false;
                 return rc;
             }
@@ -1131,7 +1133,7 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             for (int i = 0; i < K; ++i)
-                if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, i, i >= K - tail_here))) {
+                if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, i, i >= K - tail_here, tail > 0))) {
                     hipStreamEndCapture(st, &g);
                     if (g) hipGraphDestroy(g);
                     return rc;

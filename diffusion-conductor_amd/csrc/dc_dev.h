@@ -1250,7 +1250,7 @@ DEV float fma_mix_hh(uint32_t g2, float n, uint32_t h2) {
         asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(g2), "v"(n), "v"(h2));
     return d;
 }
-// n-hat G' + H' from a tile pair's packed halves.  G1 (the plain-operand kernels): the scale tile holds G' itself - one FMA; else it
+// n-hat G' + H' from a tile pair's packed halves.  G1 (plain-operand kernels of a loop with a precise tail): the scale tile holds G' itself - one FMA; else it
 // holds G' - 1 (fp16's 11 bits on the small part): (G' - 1) n + n, then + H'.  The FiLM GEMM is launched with the matching constants
 // (dc_api.hip, enqueue_step).
 template <int HI, bool G1>
@@ -1268,7 +1268,7 @@ DEV float film_affine(uint32_t g2, float n, uint32_t h2) {
 
 // one k-tile of the FiLM-modulated, SiLU'ed operand: z = SiLU(nhat*G' + H'), gp = G' - 1 (split operands) or G'; everything in the log2(e)
 // scaling of silu_l2_pair: rstd / shift arrive multiplied by log2(e), hp = log2(e) H', z = log2(e) SiLU(.)
-template <class T16, bool SPLIT, class YTile>
+template <class T16, bool SPLIT, class YTile, bool G1 = false>
 DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shift, const f16x16& gp, const f16x16& hp) {
     f32x16 z;
     if constexpr (std::is_same<YTile, f16x16>::value) {      // packed y (non-split formats): three mixed-precision FMAs per element
@@ -1276,7 +1276,7 @@ DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shif
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float n0 = fma_mix_h<0>(yw[k], rstd, shift), n1 = fma_mix_h<1>(yw[k], rstd, shift);
-            const f32x2 zz = silu_l2_pair(film_affine<0, !SPLIT>(gw[k], n0, hw[k]), film_affine<1, !SPLIT>(gw[k], n1, hw[k]));
+            const f32x2 zz = silu_l2_pair(film_affine<0, G1 && !SPLIT>(gw[k], n0, hw[k]), film_affine<1, G1 && !SPLIT>(gw[k], n1, hw[k]));
             z[2 * k] = zz.x;
             z[2 * k + 1] = zz.y;
         }
@@ -1285,7 +1285,7 @@ DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shif
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float n0 = fmaf((float)y[2 * k], rstd, shift), n1 = fmaf((float)y[2 * k + 1], rstd, shift);
-            const f32x2 zz = silu_l2_pair(film_affine<0, !SPLIT>(gw[k], n0, hw[k]), film_affine<1, !SPLIT>(gw[k], n1, hw[k]));
+            const f32x2 zz = silu_l2_pair(film_affine<0, G1 && !SPLIT>(gw[k], n0, hw[k]), film_affine<1, G1 && !SPLIT>(gw[k], n1, hw[k]));
             z[2 * k] = zz.x;
             z[2 * k + 1] = zz.y;
         }
@@ -1297,7 +1297,7 @@ DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shif
 //   h += W_o * SiLU( LN(y) * (1 + scale) + shift ) + b_o          (weights image `w` in LDS, b_o behind it)
 // with LN(y)*(1+scale)+shift = nhat*G' + H', nhat = (y-mean)*rstd; the FiLM GEMM delivers G'-1 and H' tiles.
 // E tiles come straight from global memory (Eg: this block's 8 tiles for this group).
-template <class T16, bool SPLIT>
+template <class T16, bool SPLIT, bool G1 = false>
 DEV void styl_accumulate(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd, float shift, const f16x8* __restrict__ Eg,
                          const float* bo, const v8<T16>* w, int lane, int hh) {
     XFrag<T16, SPLIT> zf[4];
@@ -1307,7 +1307,7 @@ DEV void styl_accumulate(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd,
             f16x16 gp, hp;
             gp = load_etile(Eg + kt * 128 + lane);
             hp = load_etile(Eg + (4 + kt) * 128 + lane);
-            styl_tile<T16, SPLIT, ytile<SPLIT>>(zf[kt], y[kt], rstd, shift, gp, hp);
+            styl_tile<T16, SPLIT, ytile<SPLIT>, G1>(zf[kt], y[kt], rstd, shift, gp, hp);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1457,7 +1457,7 @@ DEV void epre_landed(EPre& e) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(e.glo[i]), "+v"(e.ghi[i]), "+v"(e.hlo[i]), "+v"(e.hhi[i]));
 }
-template <class T16, bool SPLIT, class F>
+template <class T16, bool SPLIT, bool G1 = false, class F>
 DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float rstd, float shift, const EPre& ep,
                               char* ring, const float* bo, const v8<T16>* w, int lane, int hh, F&& prefetch_next) {
 #pragma unroll
@@ -1487,7 +1487,7 @@ DEV void styl_accumulate_ring(f32x16 (&h)[4], const ytile<SPLIT> (&y)[4], float 
             hp = join16(ep.hlo[kt - 2], ep.hhi[kt - 2]);
         }
         XFrag<T16, SPLIT> zf;
-        styl_tile<T16, SPLIT, ytile<SPLIT>>(zf, y[kt], rstd, shift, gp, hp);
+        styl_tile<T16, SPLIT, ytile<SPLIT>, G1>(zf, y[kt], rstd, shift, gp, hp);
         mma_kt<4, 4, T16, SPLIT>(h, w, kt, zf, lane);
         __builtin_amdgcn_sched_barrier(0);
         if (kt == 0) sprio<2>();

@@ -1251,7 +1251,7 @@ __global__ __launch_bounds__(512, 2) void k_film_embed(const v8<T16>* __restrict
 #ifndef DC_SPLIT_NW
 #define DC_SPLIT_NW 8      // waves per k_layer workgroup in the split modes (4: one wave per SIMD, round 1-2's form)
 #endif
-template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR, bool NARROW = false>
+template <class T16, bool SPLIT, bool DBG, bool STAMP, bool WGR, bool NARROW = false, bool G1 = false /* FiLM scale tiles hold G' (film_affine) */>
 __global__ __launch_bounds__((NARROW || (SPLIT && DC_SPLIT_NW == 4)) ? 256 : 512, (SPLIT && DC_SPLIT_NW == 4) ? 1 : 2)      // (NARROW runs one wave per SIMD by its LDS; bounds of 2 keep hipcc off the AGPR half: 247 VGPRs instead of 247 + 112 and 1 400 accvgpr moves)
 void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
              const v8<T16>* __restrict__ a_sa /*[B][16][64]*/, const v8<T16>* __restrict__ a_ca /*[L][B][16][64]*/,
@@ -1420,7 +1420,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
         if (wg_lds) stage_attn(acl);
-        if (!(DBG && skip_blocks >= 1)) { if constexpr (split_pf) styl_accumulate_pf<T16, SPLIT, DC_SPLIT_STYL_PF == 2>(h, y, y_rstd, y_shift, Eg, epf, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh); }
+        if (!(DBG && skip_blocks >= 1)) { if constexpr (split_pf) styl_accumulate_pf<T16, SPLIT, DC_SPLIT_STYL_PF == 2>(h, y, y_rstd, y_shift, Eg, epf, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT, G1>(h, y, y_rstd, y_shift, Eg, c1, w1, lane, cx.hh); }
     } else {
         auto next2 = [&]() {
             stage_frags<NW>(L.img_ca_q, buf0, NFW + 1, wave, lane);
@@ -1431,7 +1431,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         if (DBG && skip_blocks >= 1)
             next2();
         else
-            styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, next2);
+            styl_accumulate_ring<T16, SPLIT, G1>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, next2);
     }
     if constexpr (DBG) if ((dbg & 0xff) == 1) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after self-attention
     DC_STAMP(4);
@@ -1460,7 +1460,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if constexpr (!use_ring) {
         stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
         stage_frags<NW>(L.img_ffn_w2, buf0 + 16 * WM * 1024, 16 * WM + 1, wave, lane);
-        if (!(DBG && skip_blocks >= 2)) { if constexpr (split_pf) styl_accumulate_pf<T16, SPLIT, DC_SPLIT_STYL_PF == 2>(h, y, y_rstd, y_shift, Eg + 8 * 128, epf, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh); }
+        if (!(DBG && skip_blocks >= 2)) { if constexpr (split_pf) styl_accumulate_pf<T16, SPLIT, DC_SPLIT_STYL_PF == 2>(h, y, y_rstd, y_shift, Eg + 8 * 128, epf, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT, G1>(h, y, y_rstd, y_shift, Eg + 8 * 128, c1, w1, lane, cx.hh); }
     } else {
         auto next4 = [&]() {
             stage_frags<NW>(L.img_ffn_w1, buf0, 16 * WM, wave, lane);
@@ -1471,7 +1471,7 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         if (DBG && skip_blocks >= 2)
             next4();
         else
-            styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, next4);
+            styl_accumulate_ring<T16, SPLIT, G1>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, next4);
     }
     if constexpr (DBG) if ((dbg & 0xff) == 2) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after cross-attention
     DC_STAMP(7);
@@ -1533,9 +1533,9 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         };
         if constexpr (!use_ring) {
             next_w();
-            { if constexpr (split_pf) styl_accumulate_pf<T16, SPLIT, DC_SPLIT_STYL_PF == 2>(h, y, y_rstd, y_shift, Eg + 16 * 128, epf, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, c1, w1, lane, cx.hh); }
+            { if constexpr (split_pf) styl_accumulate_pf<T16, SPLIT, DC_SPLIT_STYL_PF == 2>(h, y, y_rstd, y_shift, Eg + 16 * 128, epf, c1, w1, lane, cx.hh); else styl_accumulate<T16, SPLIT, G1>(h, y, y_rstd, y_shift, Eg + 16 * 128, c1, w1, lane, cx.hh); }
         } else {
-            styl_accumulate_ring<T16, SPLIT>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, next_w);
+            styl_accumulate_ring<T16, SPLIT, G1>(h, y, y_rstd, y_shift, ep, ring, c1, w1, lane, cx.hh, next_w);
         }
     }
     if constexpr (DBG) if ((dbg & 0xff) == 3) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
@@ -2636,7 +2636,7 @@ hipError_t dc_launch_embed_front(hipStream_t st, int fmt, bool split, bool wgr, 
     return e;
 }
 
-template <class T16, bool SP, bool DBG, bool STAMP, bool WGR, bool NARROW = false>
+template <class T16, bool SP, bool DBG, bool STAMP, bool WGR, bool NARROW = false, bool G1 = false>
 static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                  const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                                  float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
@@ -2646,8 +2646,8 @@ static hipError_t launch_layer_t(hipStream_t st, const DcModel* dm, int l, float
     // two stage images (+1 KiB constants each); non-split adds the attention-frag region and the FiLM rings
     const size_t shm = SP ? 2 * 65 * 1024 + (WGR ? 16384 + 6144 : 0) : 2 * 33 * 1024 + 16384 + 8 * 8192 + 6144;
     static unsigned long long optin_done = 0;   // > 64 KiB of dynamic LDS needs the opt-in
-    if (hipError_t e = lds_optin((const void*)k_layer<T16, SP, DBG, STAMP, WGR, NARROW>, (int)shm, optin_done)) return e;
-    k_layer<T16, SP, DBG, STAMP, WGR, NARROW><<<dim3((WGR && upc) ? B * upc : (G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(
+    if (hipError_t e = lds_optin((const void*)k_layer<T16, SP, DBG, STAMP, WGR, NARROW, G1>, (int)shm, optin_done)) return e;
+    k_layer<T16, SP, DBG, STAMP, WGR, NARROW, G1><<<dim3((WGR && upc) ? B * upc : (G + NW - 1) / NW), dim3(NW * 64), shm, st>>>(
         dm, l, hbuf, (const f16x16*)E, NT, (const v8<T16>*)a_sa, (const v8<T16>*)a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur,
         snaps, M, T, G, B, dbg, stamps, rec_stride, iter_base, Tx, WGR ? upc : 0, upd);
     return hipGetLastError();
@@ -2657,13 +2657,22 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                            const void* a_sa, const void* a_ca, float* recs, const int* length, const float* xin,
                            float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps,
                            int M, int T, int G, int B, int dbg, unsigned long long* stamps, size_t rec_stride, const int* iter_base,
-                           bool narrow, int Tx, int upc, const DcUpdate& upd) {
+                           bool narrow, int Tx, int upc, const DcUpdate& upd, bool g1) {
     hipError_t e = hipSuccess;
 #define LAYER_ARGS st, dm, l, hbuf, E, NT, a_sa, a_ca, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, G, B, dbg, stamps, \
                    rec_stride, iter_base, Tx, upc, upd
-    if (wgr && !split && narrow && dbg == 0 && stamps == nullptr)      // narrow workgroups: production build only
+    // (g1: the FiLM scale tiles of this evaluation hold G' - the two production forms of the plain-operand kernel only)
+    if (g1 && !(wgr && !split && dbg == 0 && stamps == nullptr)) return hipErrorInvalidValue;
+    if (wgr && !split && narrow && dbg == 0 && stamps == nullptr) {      // narrow workgroups: production build only
+        if (g1)
+            return fmt == 1 ? launch_layer_t<_Float16, false, false, false, true, true, true>(LAYER_ARGS)
+                            : launch_layer_t<__bf16, false, false, false, true, true, true>(LAYER_ARGS);
         return fmt == 1 ? launch_layer_t<_Float16, false, false, false, true, true>(LAYER_ARGS)
                         : launch_layer_t<__bf16, false, false, false, true, true>(LAYER_ARGS);
+    }
+    if (wgr && !split && g1)
+        return fmt == 1 ? launch_layer_t<_Float16, false, false, false, true, false, true>(LAYER_ARGS)
+                        : launch_layer_t<__bf16, false, false, false, true, false, true>(LAYER_ARGS);
     if (wgr && !split) {        // workgroup-level records + in-kernel combine (non-split formats, T >= 256)
         if (dbg != 0)
             e = fmt == 1 ? launch_layer_t<_Float16, false, true, false, true>(LAYER_ARGS) : launch_layer_t<__bf16, false, true, false, true>(LAYER_ARGS);

@@ -53,7 +53,8 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
                                                    indexed by *iter_base; else nullptr (scalars prepared by k_begin_step) */,
                            bool narrow /* wgr, non-split, dbg == 0: 4-wave workgroups; recs / rec_stride then count 128-token units */,
                            int Tx /* frames per clip of xin / xout / snaps */, int upc /* as dc_launch_embed_front */,
-                           const DcUpdate& upd /* options of the fused DDIM update + the status word (dc_common.h) */);
+                           const DcUpdate& upd /* options of the fused DDIM update + the status word (dc_common.h) */,
+                           bool g1 = false /* the FiLM scale tiles hold G' (film_affine in dc_dev.h; plain-operand production forms only) */);
 // The same layer for SMALL batches on 16-token waves (dc_layer16.hip): non-split formats, clip-aligned 64-token units (grid = B * upc,
 // upc = ceil(T / 64), T = clip stride, a multiple of 32), one unit record per workgroup.  a_ca16 = the cross-attention fragments in
 // that kernel's form (dc_launch_cond_af16, once per conditioning).  nu_in / stride_in: unit records per clip and floats per unit of
@@ -64,7 +65,8 @@ hipError_t dc_launch_layer16(hipStream_t st, int fmt, const DcModel* dm, int l, 
                              const int* snap_cur, float* snaps, int M, int T, int B, int upc, size_t rec_stride, int nu_in, size_t stride_in,
                              const int* iter_base, int Tx, const DcUpdate& upd,
                              unsigned long long* gran /* [B][1024] granules: the clip's workgroups share the combine inside the launch (nullptr: each alone) */,
-                             unsigned tag_base /* the launch's tag = tag_base + 16 * (*iter_base) + l + 1: must differ between consecutive launches */);
+                             unsigned tag_base /* the launch's tag = tag_base + 16 * (*iter_base) + l + 1: must differ between consecutive launches */,
+                             bool g1 = false /* the FiLM scale tiles hold G' */);
 hipError_t dc_launch_cond_af16(hipStream_t st, int fmt, const void* a_ca, void* a_ca16, int n_matrices);
 int dc_layer16_max_units(void);
 hipError_t dc_launch_advance_iter(hipStream_t st, int* iter, int k);

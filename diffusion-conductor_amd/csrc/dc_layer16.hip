@@ -258,7 +258,7 @@ DEV void e16_load(E16 (&e)[4], const f16x8* __restrict__ Eg /* block's 8 tiles *
         }
 }
 // one k-tile of the FiLM-modulated, SiLU'ed operand (see styl_tile in dc_dev.h): blocks 2 kt, 2 kt + 1
-template <class T16>
+template <class T16, bool G1 = false>
 DEV v8<T16> styl16(const Y16& ya, const Y16& yb, float rstd, float shift, const E16& e) {
     f32x4 z[2];
 #pragma unroll
@@ -267,7 +267,7 @@ DEV v8<T16> styl16(const Y16& ya, const Y16& yb, float rstd, float shift, const 
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const float n0 = fma_mix_h<0>(y.p[p], rstd, shift), n1 = fma_mix_h<1>(y.p[p], rstd, shift);
-            const f32x2 zz = silu_l2_pair(film_affine<0, true>(e.g[fb][p], n0, e.h[fb][p]), film_affine<1, true>(e.g[fb][p], n1, e.h[fb][p]));
+            const f32x2 zz = silu_l2_pair(film_affine<0, G1>(e.g[fb][p], n0, e.h[fb][p]), film_affine<1, G1>(e.g[fb][p], n1, e.h[fb][p]));
             z[fb][2 * p] = zz.x;
             z[fb][2 * p + 1] = zz.y;
         }
@@ -275,21 +275,21 @@ DEV v8<T16> styl16(const Y16& ya, const Y16& yb, float rstd, float shift, const 
     return frag2<T16>(z[0], z[1]);
 }
 // StylizationBlock (transformer.py:68-81) accumulated into the residual stream: h += W_o SiLU(nhat G' + H') + b_o
-template <class T16>
+template <class T16, bool G1 = false>
 DEV void styl_accumulate16(f32x4 (&h)[8], const Y16 (&y)[8], float rstd, float shift, const E16 (&e)[4], const float* bo,
                            const v8<T16>* w, const C16& c) {
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb) h[rb] += *reinterpret_cast<const f32x4*>(bo + 16 * rb + 4 * c.q4);
     v8<T16> cur[8], nxt[8];
     wfrags<8, T16>(cur, w, 0, c.lane);
-    v8<T16> zb = styl16<T16>(y[0], y[1], rstd, shift, e[0]);
+    v8<T16> zb = styl16<T16, G1>(y[0], y[1], rstd, shift, e[0]);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
         if (kt + 1 < 4) wfrags<8, T16>(nxt, w, (kt + 1) * 8, c.lane);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rb = 0; rb < 8; ++rb) h[rb] = mfma16(cur[rb], zb, h[rb]);
-        if (kt + 1 < 4) zb = styl16<T16>(y[2 * kt + 2], y[2 * kt + 3], rstd, shift, e[kt + 1]);     // (vector work beside the matrix pipe)
+        if (kt + 1 < 4) zb = styl16<T16, G1>(y[2 * kt + 2], y[2 * kt + 3], rstd, shift, e[kt + 1]);     // (vector work beside the matrix pipe)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rb = 0; rb < 8; ++rb) cur[rb] = nxt[rb];
@@ -544,7 +544,7 @@ DEV void gather16_finish(Gran16 r, const unsigned long long* __restrict__ gran, 
 // projection fused with the DDIM update (gaussian_diffusion.py:812-830).  The FiLM tiles of a StylizationBlock are requested at
 // the head of the stage in front of it (registers are plentiful at one wave per SIMD).
 // ------------------------------------------------------------------------------------------------------------------
-template <class T16>
+template <class T16, bool G1 = false /* FiLM scale tiles hold G' (film_affine, dc_dev.h) */>
 __global__ __launch_bounds__(256, 2)      // (one workgroup per CU by its LDS; "2" keeps the compiler off the AGPR half: 250 VGPRs, no accvgpr moves)
 void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, const f16x16* __restrict__ E, int NT,
                const v8<T16>* __restrict__ a_ca /*[L][B][8 heads][64] 16-token form*/, float* __restrict__ recs, const int* __restrict__ length,
@@ -649,7 +649,7 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
         stage_frags<NW>(L.ca_q, buf0, 33, wave, lane);
         stage_frags<NW>(a_ca + ((size_t)l * B + c.b) * 8 * 64, lds + L16_OFF_AF, 8, wave, lane);
     }
-    styl_accumulate16<T16>(h, y, y_rstd, y_shift, e, c1, w1, c);
+    styl_accumulate16<T16, G1>(h, y, y_rstd, y_shift, e, c1, w1, c);
     LSTAMP(5);
     stage_sync();
     LSTAMP(6);
@@ -661,7 +661,7 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
     stage_sync();
     LSTAMP(8);
     stage_frags<NW>(L.ffn_w, buf0, 33, wave, lane);          // W1 (16 fragments) | W2 (16) | b1[64], b2[128]
-    styl_accumulate16<T16>(h, y, y_rstd, y_shift, e, c1, w1, c);
+    styl_accumulate16<T16, G1>(h, y, y_rstd, y_shift, e, c1, w1, c);
     LSTAMP(9);
     stage_sync();
     LSTAMP(10);
@@ -711,7 +711,7 @@ void k_layer16(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, 
         stage_frags<NW>(dm->l16[l + 1].sa_k, buf0, 33, wave, lane);
     else
         stage_frags<NW>(dm->out16, buf0, 17, wave, lane);        // 8 hi + 8 lo fragments + bias: always runs split
-    styl_accumulate16<T16>(h, y, y_rstd, y_shift, e, c1, w1, c);
+    styl_accumulate16<T16, G1>(h, y, y_rstd, y_shift, e, c1, w1, c);
     LSTAMP(13);
     stage_sync();
     LSTAMP(14);
@@ -946,27 +946,36 @@ __global__ void k_cond_af16(const v8<T16>* __restrict__ src, v8<T16>* __restrict
 
 int dc_layer16_max_units(void) { return L16_MAXU; }
 
+namespace {
+template <class T16, bool G1>
+hipError_t launch_layer16_t(hipStream_t st, const DcModel* dm, int l, float* hbuf, const void* E, int NT, const void* a_ca16,
+                            float* recs, const int* length, const float* xin, float* xout, int out_mode, const float* coef_cur,
+                            const int* snap_cur, float* snaps, int M, int T, int B, int upc, size_t rec_stride, int nu_in, size_t stride_in,
+                            const int* iter_base, int Tx, const DcUpdate& upd, unsigned long long* gran, unsigned tag_base) {
+    static unsigned long long done = 0;      // > 64 KiB of dynamic LDS needs the opt-in, per device
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev)) return e;
+    if (dev >= 64 || !((done >> dev) & 1ull)) {
+        if (hipError_t e = hipFuncSetAttribute((const void*)k_layer16<T16, G1>, hipFuncAttributeMaxDynamicSharedMemorySize, L16_LDS)) return e;
+        if (dev < 64) done |= 1ull << dev;
+    }
+    k_layer16<T16, G1><<<dim3(B * upc), dim3(256), L16_LDS, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const v8<T16>*)a_ca16, recs, length, xin, xout,
+                                                                  out_mode, coef_cur, snap_cur, snaps, M, T, B, upc, rec_stride, nu_in, stride_in,
+                                                                  iter_base, Tx, upd, gran, tag_base);
+    return hipGetLastError();
+}
+}  // namespace
+
 hipError_t dc_launch_layer16(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* E, int NT, const void* a_ca16,
                              float* recs, const int* length, const float* xin, float* xout, int out_mode, const float* coef_cur,
                              const int* snap_cur, float* snaps, int M, int T, int B, int upc, size_t rec_stride, int nu_in, size_t stride_in,
-                             const int* iter_base, int Tx, const DcUpdate& upd, unsigned long long* gran, unsigned tag_base) {
+                             const int* iter_base, int Tx, const DcUpdate& upd, unsigned long long* gran, unsigned tag_base, bool g1) {
     if (nu_in < 1 || nu_in > L16_MAXU || upc < 1 || (T & 31)) return hipErrorInvalidValue;
-    static unsigned long long done[2] = {0, 0};      // > 64 KiB of dynamic LDS needs the opt-in, per device
-    int dev = 0;
-    if (hipError_t e = hipGetDevice(&dev)) return e;
-    const void* fn = fmt == 1 ? (const void*)k_layer16<_Float16> : (const void*)k_layer16<__bf16>;
-    if (dev >= 64 || !((done[fmt == 1] >> dev) & 1ull)) {
-        if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, L16_LDS)) return e;
-        if (dev < 64) done[fmt == 1] |= 1ull << dev;
-    }
-    const dim3 grid(B * upc), block(256);
-    if (fmt == 1)
-        k_layer16<_Float16><<<grid, block, L16_LDS, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const f16x8*)a_ca16, recs, length, xin, xout, out_mode,
-                                                          coef_cur, snap_cur, snaps, M, T, B, upc, rec_stride, nu_in, stride_in, iter_base, Tx, upd, gran, tag_base);
-    else
-        k_layer16<__bf16><<<grid, block, L16_LDS, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const bf16x8*)a_ca16, recs, length, xin, xout, out_mode,
-                                                        coef_cur, snap_cur, snaps, M, T, B, upc, rec_stride, nu_in, stride_in, iter_base, Tx, upd, gran, tag_base);
-    return hipGetLastError();
+#define L16_ARGS st, dm, l, hbuf, E, NT, a_ca16, recs, length, xin, xout, out_mode, coef_cur, snap_cur, snaps, M, T, B, upc, rec_stride, nu_in, stride_in, \
+                 iter_base, Tx, upd, gran, tag_base
+    if (fmt == 1) return g1 ? launch_layer16_t<_Float16, true>(L16_ARGS) : launch_layer16_t<_Float16, false>(L16_ARGS);
+    return g1 ? launch_layer16_t<__bf16, true>(L16_ARGS) : launch_layer16_t<__bf16, false>(L16_ARGS);
+#undef L16_ARGS
 }
 hipError_t dc_launch_cond_af16(hipStream_t st, int fmt, const void* a_ca, void* a_ca16, int n_matrices) {
     const int n = n_matrices * 8 * 64;
