@@ -1084,15 +1084,11 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     HIP_TRY(hipMemcpyAsync(s->d_x, d_noise, MP * 4, hipMemcpyDeviceToDevice, st));
     const bool no_graph = getenv("DC_DISABLE_GRAPH") != nullptr;
     // precise tail: the loop's last `tail` model evaluations on split operands (dc_sampler_set_precise_tail; DC_PRECISE_TAIL=k overrides):
-    // fp16 / bf16 precision, linear attention, no test hooks (clip strides that are not whole 32-frame groups and short clips run the
-    // split evaluations in the per-group record form with its combine launches)
+    // fp16 / bf16 precision, linear attention, no test hooks
     int tail = s->tail_split >= 0 ? s->tail_split : (s->cfg.precision == DC_PREC_BF16 ? 8 : 1);
-    bool tail_asked = s->tail_split >= 0;        // (set by the caller: honoured wherever the split kernels can run)
-    if (const char* e = getenv("DC_PRECISE_TAIL")) tail = atoi(e), tail_asked = true;
-    // the default applies where a split evaluation is cheap - the workgroup-record form on clip-aligned units (clip stride of whole
-    // 32-frame groups, T >= 256: +0.45 % of the loop per evaluation at bs = 32 x 1800).  Elsewhere (T = 900 x 128 unpadded, short clips)
-    // it would run in the per-group record form with its combine launches (+3 % per evaluation at bs = 128 x 900): only when asked for
-    if (!tail_asked && (s->T % 32 != 0 || s->T < 256)) tail = 0;
+    if (const char* e = getenv("DC_PRECISE_TAIL")) tail = atoi(e);
+    // (clip strides that are not whole 32-frame groups - T = 900 x 128 unpadded - and short clips run the split evaluations in the
+    // per-group record form with its combine launches: no measurable cost at one evaluation per loop, 70.6 vs 70.6 ms at bs = 128 x 900)
     if ((s->cfg.precision != DC_PREC_FP16 && s->cfg.precision != DC_PREC_BF16) || s->cfg.no_eff || s->dbg_layers >= 0 || s->dbg_first >= 0 || s->dbg_stage != 0 ||
         !s->d_model_split)
         tail = 0;

@@ -156,10 +156,10 @@ DC_EXPORT int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t
  * in the final evaluations (DDIM's last step returns the model's own prediction of x0).  Golden DDIM-50, rel-L2 of x0:
  *   fp16:  5.0e-4 with steps = 0,  2.3e-4 with 1,  1.6e-4 with 2,  1.2e-4 with 4   (+0.45 % of the loop per step at bs = 32)
  *   bf16:  3.1e-3 with steps = 0,  9.5e-4 with 2,  6.8e-4 with 4,  5.4e-4 with 8   - the bf16-operand mode that meets the 1e-3 bound
- * Default (steps never set): 1 for fp16, 8 for bf16 where a split evaluation is cheap (clip stride of whole 32-frame groups, T >= 256:
- * the workgroup-record form), else 0 - an explicit value is honoured there too, through the per-group record form (+3 % of the loop per
- * evaluation at bs = 128 x 900, 5.2e-4 -> 2.6e-4).  Ignored for the split precisions and for `no_eff`.  DC_PRECISE_TAIL=k in the
- * environment overrides it.  (In a loop that has a tail the plain
+ * Default (steps never set): 1 for fp16, 8 for bf16.  (Clip strides of whole 32-frame groups run the split evaluations in the
+ * workgroup-record form on clip-aligned units, others - T = 900 x 128 unpadded, short clips - in the per-group record form: 5.2e-4 ->
+ * 2.6e-4 there at no measurable cost.)  Ignored for the split precisions and for `no_eff`.  DC_PRECISE_TAIL=k in the environment
+ * overrides it.  (In a loop that has a tail the plain
  * evaluations read FiLM scale tiles that hold G' itself - one mixed-precision FMA per element instead of two -, the split ones G' - 1;
  * loops without a tail keep G' - 1 everywhere.) */
 DC_EXPORT int dc_sampler_set_precise_tail(dc_sampler* s, int32_t steps);

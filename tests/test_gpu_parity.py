@@ -153,6 +153,15 @@ def test_precise_tail_halves_the_fp16_error(models):
             native._check(native.lib().dc_sampler_set_precise_tail(nat._h, -1))
     finally:
         nat.set_precise_tail(1)
+    # a clip stride that is not a whole number of 32-frame groups (here forced: DC_NO_PAD) has no clip-aligned units: the split evaluation
+    # runs in the per-group record form with its combine launches
+    g6 = golden("g6_variants.npz")
+    xfp9, xfo9 = xf_pair(2, 900, first=10)
+    noise9 = torch.from_numpy(batch_noise(2, 900, first=10))
+    e9 = {k: rel_l2(_with_env({"DC_NO_PAD": "1", "DC_PRECISE_TAIL": k}, lambda: _ddim(models["fp16"], 50, noise9, xfp9, xfo9, [900, 700])),
+                    g6["t900_x0"]) for k in ("0", "1")}
+    print(f"T = 900 unpadded: precise tail 0 / 1: {e9['0']:.3e} {e9['1']:.3e}")
+    assert e9["0"] <= TOL_PARITY and e9["1"] <= 0.7 * e9["0"]
     # the bf16 precision: plain bf16 operands cannot meet the bound (8 mantissa bits), the last 8 of 50 evaluations on split bf16 can
     eb = {k: rel_l2(_with_env({"DC_PRECISE_TAIL": str(k)}, lambda: _ddim(models["bf16"], 50, noise, xfp, xfo, [1800])), g["x0"]) for k in (0, 2, 8)}
     print("bf16, precise tail 0 / 2 / 8: " + " ".join(f"{eb[k]:.3e}" for k in (0, 2, 8)))
