@@ -169,6 +169,30 @@ def test_precise_tail_halves_the_fp16_error(models):
     assert rel_l2(_ddim(models["bf16"], 50, noise, xfp, xfo, [1800]), g["x0"]) == eb[8]          # its default
 
 
+@pytest.mark.parametrize("S", [1, 25])
+def test_precise_tail_in_short_loops(models, S):
+    """A loop of fewer steps than the tail asks for runs every evaluation on split operands (the tail is clipped to the loop: S = 1 - the only
+    length below bf16's default of 8 that the reference's linear schedule admits, betas <= 1 -; S = 25: seventeen plain evaluations in front
+    of eight split ones), on a short ragged batch (T = 96: the per-group record form) and on clip-aligned units (T = 320), against the
+    oracle.  One all-split evaluation: fp16 6 - 7e-5; bf16 3.6 - 4.0e-4, the floor of that mode's tail (its FiLM GEMM keeps plain bf16
+    operands in the tail's evaluations too)."""
+    for B, T, length in ((2, 96, [96, 61]), (2, 320, [320, 1])):
+        xfp, xfo = xf_pair(B, T, first=40)
+        noise = torch.from_numpy(batch_noise(B, T, first=40))
+        with torch.no_grad():
+            ref = O.ddim_sample_loop(oracle_params(), noise, xfp, xfo, length, S)
+        for mode in ("fp16", "bf16"):
+            plain = rel_l2(_with_env({"DC_PRECISE_TAIL": "0"}, lambda: _ddim(models[mode], S, noise, xfp, xfo, length)), ref)
+            a = _ddim(models[mode], S, noise, xfp, xfo, length)
+            asked = rel_l2(_with_env({"DC_PRECISE_TAIL": "50"}, lambda: _ddim(models[mode], S, noise, xfp, xfo, length)), ref)
+            err = rel_l2(a, ref)
+            print(f"S={S} T={T} ({mode}): plain {plain:.3e}, default tail {err:.3e}, tail 50 {asked:.3e}")
+            assert torch.isfinite(a).all() and err <= TOL_PARITY and asked <= TOL_PARITY
+            assert err < plain
+            if S == 1:
+                assert err == asked and err <= (1e-4 if mode == "fp16" else 5e-4)        # every evaluation split
+
+
 def test_ddim50_t900_ragged_golden(models):
     """G6: 30 s clips (T=900), B=2, ragged lengths."""
     g = golden("g6_variants.npz")
