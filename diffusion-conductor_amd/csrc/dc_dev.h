@@ -380,11 +380,16 @@ DEV float gelu_erf(float x) {
     const float erfa = 1.f - poly * t * __expf(-a * a);
     return 0.5f * x * (1.f + copysignf(erfa, x));
 }
-// the same on two elements with packed-fp32 arithmetic: gelu(x) = x/2 + |x|/2 * erf(|x| / sqrt 2)  (x sign(x) = |x|),
-// exp(-a^2) = 2^(-x^2 log2(e) / 2)
+// the same on two elements with packed-fp32 arithmetic: gelu(x) = x/2 + |x|/2 * erf(|x| / sqrt 2)  (x sign(x) = |x|).
+// erf by Abramowitz-Stegun 7.1.28: 1 - erf(a) = (1 + a1 a + ... + a6 a^6)^-16 (|error| <= 3e-7), the 1/sqrt 2 of a = |x| / sqrt 2 folded
+// into the coefficients: one v_rcp_f32 per element and no v_exp_f32 (transcendentals issue at a quarter of the packed-fp32 rate; 7.1.26
+// - one rcp AND one exp - stays for the scalar form and under -DDC_GELU_AS26).  Against fp64 over |x| <= 12: max |error| of the GELU
+// 8.8e-7 (7.1.26: 4.7e-7); beyond |x| ~ 19 the sixteenth power overflows to +inf and its reciprocal is the exact limit 0.
 DEV f32x2 gelu_erf_pair(float x0, float x1) {
     const f32x2 x = {x0, x1};
     const f32x2 ax = {fabsf(x0), fabsf(x1)};
+    const f32x2 half_ax = ax * 0.5f;
+#ifdef DC_GELU_AS26
     const f32x2 den = fma2(ax, (f32x2){0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f},
                                                 (f32x2){1.f, 1.f});
     const f32x2 t = {fast_rcp(den.x), fast_rcp(den.y)};
@@ -392,10 +397,24 @@ DEV f32x2 gelu_erf_pair(float x0, float x1) {
     poly = fma2(poly, t, (f32x2){1.421413741f, 1.421413741f});
     poly = fma2(poly, t, (f32x2){-0.284496736f, -0.284496736f});
     poly = fma2(poly, t, (f32x2){0.254829592f, 0.254829592f});
-    const f32x2 xx = x * x * (-0.5f * 1.4426950408889634f);
+    const f32x2 xx = x * x * (-0.5f * 1.4426950408889634f);              // exp(-a^2) = 2^(-x^2 log2(e) / 2)
     const f32x2 ex = {exp2f_fast(xx.x), exp2f_fast(xx.y)};
     const f32x2 pe = poly * t * ex;                                    // 1 - erf(a)
-    const f32x2 half_ax = ax * 0.5f;
+#else
+    constexpr float c1 = 0.0705230784f * 0.70710678118654752440f, c2 = 0.0422820123f * 0.5f, c3 = 0.0092705272f * 0.35355339059327376220f,
+                    c4 = 0.0001520143f * 0.25f, c5 = 0.0002765672f * 0.17677669529663688110f, c6 = 0.0000430638f * 0.125f;
+    f32x2 p = fma2(ax, (f32x2){c6, c6}, (f32x2){c5, c5});
+    p = fma2(p, ax, (f32x2){c4, c4});
+    p = fma2(p, ax, (f32x2){c3, c3});
+    p = fma2(p, ax, (f32x2){c2, c2});
+    p = fma2(p, ax, (f32x2){c1, c1});
+    p = fma2(p, ax, (f32x2){1.f, 1.f});
+    f32x2 pe = {fast_rcp(p.x), fast_rcp(p.y)};
+    pe = pe * pe;
+    pe = pe * pe;
+    pe = pe * pe;
+    pe = pe * pe;                                                       // 1 - erf(a)
+#endif
     // x/2 + |x|/2 (1 - pe)
     return fma2(half_ax, (f32x2){1.f, 1.f} - pe, x * 0.5f);
 }
