@@ -702,6 +702,8 @@ int build_model(dc_sampler* s) {
 // frames past `length`).  Measured (same box): bs=32 x 1800 (+1.3 % tokens) -1.6 % per loop; bs=128 x 900
 // (+3.1 %) +0.2 %; small batches, which then also run clip-aligned units (enqueue_step), -9 % at bs=4 x 1800.
 int clip_stride(const dc_sampler* s, int B, int Tx) {
+    // clips shorter than one 32-token group: one group per clip (a group's records name at most two clips)
+    if (Tx < 32 && !s->cfg.no_eff && !getenv("DC_NO_PAD")) return 32;
     if (s->cfg.no_eff || Tx < 256 || Tx % 32 == 0 || getenv("DC_NO_PAD")) return Tx;
     const int Tp = (Tx + 31) / 32 * 32;
     if (s->split_small) return Tp;         // split formats: workgroup records exist on clip-aligned units only (one clip per workgroup)
@@ -1383,7 +1385,9 @@ int dc_sampler_finalize_params(dc_sampler* s) {
 int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const float* d_xf_out, const int32_t* h_length,
                                 int32_t B, int32_t T, void* stream) {
     if (!s || !s->finalized) return fail(DC_ERR_INVALID, "sampler not finalized");
-    if (!d_xf_proj || !d_xf_out || B < 1 || T < 32) return fail(DC_ERR_INVALID, "bad conditioning arguments (need B >= 1, T >= 32)");
+    if (!d_xf_proj || !d_xf_out || B < 1 || T < 1) return fail(DC_ERR_INVALID, "bad conditioning arguments (need B >= 1, T >= 1)");
+    if (T < 32 && clip_stride(s, B, T) < 32)
+        return fail(DC_ERR_UNSUPPORTED, "T=%d: clips shorter than 32 frames need the padded clip stride (linear attention, DC_NO_PAD unset)", T);
     if (clip_stride(s, B, T) / 32 + 2 > 128) return fail(DC_ERR_UNSUPPORTED, "T=%d: the attention combine holds at most 128 token groups per clip (T <= 4032)", T);
     if (T > s->cfg.num_frames) return fail(DC_ERR_INVALID, "T=%d exceeds num_frames=%d rows of sequence_embedding", T, s->cfg.num_frames);
     if (s->host_only) return fail(DC_ERR_NO_DEVICE, "host-only sampler (sanitizer build without a device)");

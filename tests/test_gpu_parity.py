@@ -193,6 +193,31 @@ def test_precise_tail_in_short_loops(models, S):
                 assert err == asked and err <= (1e-4 if mode == "fp16" else 5e-4)        # every evaluation split
 
 
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (40, 7), (5, 31), (2, 33)])
+def test_clips_shorter_than_one_token_group(models, B, T):
+    """The reference takes any T; the token space works in 32-frame groups whose records name at most two clips, so clips of fewer than
+    32 frames get a clip stride of one group (padding frames behave like frames past `length`).  Forward and a DDIM-25 loop against the
+    oracle, ragged lengths; full attention (`no_eff`) refuses such clips loudly."""
+    S = 25
+    xfp, xfo = xf_pair(B, T, first=7)
+    noise = torch.from_numpy(batch_noise(B, T, first=7))
+    length = [max(1, T - (b % 3) * (T // 3)) for b in range(B)]
+    t = torch.tensor([(37 * b + 11) % 1000 for b in range(B)], dtype=torch.long)
+    with torch.no_grad():
+        ref_f = O.denoiser_forward(oracle_params(), noise, t, length, xfp, xfo)
+        ref = O.ddim_sample_loop(oracle_params(), noise, xfp, xfo, length, S)
+    for mode in ("fp16", "mixed", "bf16"):
+        f = models[mode](noise.cuda(), t, length=torch.LongTensor(length), xf_proj=xfp.cuda(), xf_out=xfo.cuda())
+        a = _ddim(models[mode], S, noise, xfp, xfo, length)
+        ef, ea = rel_l2(f, ref_f), max(rel_l2(a[c:c + 1], ref[c:c + 1]) for c in range(B))
+        print(f"B={B} T={T} ({mode}): forward {ef:.3e}, ddim25 worst clip {ea:.3e}")
+        assert torch.isfinite(a).all() and ea <= TOL_PARITY and ef <= (TOL_BF16 if mode == "bf16" else TOL_PARITY)
+    if T < 32:
+        from diffusion_conductor_amd import native
+        with pytest.raises(native.DcError, match="shorter than 32 frames"):
+            _with_env({"DC_NO_PAD": "1"}, lambda: _ddim(models["fp16"], S, noise, xfp, xfo, length))
+
+
 def test_ddim50_t900_ragged_golden(models):
     """G6: 30 s clips (T=900), B=2, ragged lengths."""
     g = golden("g6_variants.npz")
