@@ -1467,7 +1467,8 @@ int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t B, int32_
     if (!s->music) return fail(DC_ERR_PARAM, "music encoder parameters (music_encoder.*, proj.*) were not supplied");
     if (!d_mel || !d_xf_proj || !d_xf_out || B < 1) return fail(DC_ERR_INVALID, "bad encode_music arguments");
     if (n_mels != 128) return fail(DC_ERR_UNSUPPORTED, "mel spectrograms must have 128 bins (conv4 takes 32 channels x 16 bins), got %d", n_mels);
-    if (Tm < 2) return fail(DC_ERR_INVALID, "need at least 2 mel frames (reflect padding)");
+    // (conv3 / conv4 run on (Tm - 1) / 3 + 1 rows, and reflection padding needs two: the reference's ReflectionPad2d raises below 4 frames)
+    if (Tm < 4) return fail(DC_ERR_INVALID, "need at least 4 mel frames (reflection padding of the (Tm - 1) / 3 + 1 rows behind the stride-3 pool), got %d", Tm);
     HIP_TRY(hipSetDevice(s->cfg.device));
     hipStream_t user = (hipStream_t)stream, st = s->stream;
     int rc;

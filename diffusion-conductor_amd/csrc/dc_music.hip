@@ -37,7 +37,9 @@ DEV f32x16 mma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 acc) {
 }
 DEV int reflect(int i, int n) {        // torch 'reflect' padding of width 1 (no edge repeat)
     i = i < 0 ? -i : i;
-    return i >= n ? 2 * n - 2 - i : i;
+    // (callers also ask for halo rows of tiles that reach past the image - up to ROWS + 2 beyond it, values nobody uses: with fewer rows
+    // than that in the image the single reflection would leave it on the other side, hence the clamp)
+    return max(i >= n ? 2 * n - 2 - i : i, 0);
 }
 DEV void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll

@@ -707,6 +707,28 @@ def test_encode_music_batched_vs_oracle(models):
         assert e1 <= tol and e2 <= tol
 
 
+@pytest.mark.parametrize("Tm", [4, 5, 7, 10, 13])
+def test_encode_music_of_a_few_mel_frames(models, Tm):
+    """Mel spectrograms shorter than the convolutions' row tiles (found by tools/fuzz_encoder.py: the halo rows of a tile that reaches past
+    the image were reflected only once and left an image of fewer rows than the tile on the other side - a memory fault at Tm = 4).  Both
+    activation formats against the oracle; below 4 frames the reference's reflection padding raises, and so does the library."""
+    p = oracle_params()
+    mel = torch.from_numpy(batch_mel(3, Tm, first=5))
+    with torch.no_grad():
+        rp, rx = O.encode_music(p, mel)
+    for fmt, tol in (("split", TOL_ENC_SPLIT), ("f16", TOL_ENC_F16)):
+        xp, x = _with_env(_enc_env(fmt), lambda: models["fp16"].encode_music(mel.cuda(), "cuda:0"))
+        torch.cuda.synchronize()
+        e = max(rel_l2(xp, rp), rel_l2(x, rx))
+        print(f"encode_music Tm={Tm} ({fmt}): {e:.2e}")
+        assert tuple(x.shape) == tuple(rx.shape) and e <= tol
+    from diffusion_conductor_amd import native
+    with pytest.raises(native.DcError, match="at least 4 mel frames"):
+        models["fp16"].encode_music(torch.from_numpy(batch_mel(1, 3)).cuda(), "cuda:0")
+    with pytest.raises(RuntimeError):
+        O.encode_music(p, torch.from_numpy(batch_mel(1, 3)))
+
+
 def test_encoder_format_follows_the_precision_and_can_be_set(models):
     """Default format: one fp16 plane beside the fp16 denoiser (whose conditioning pre-pass rounds the features to fp16 operands anyway),
     split planes beside the split-operand precisions; dc_sampler_set_encoder_format overrides it, DC_ME_PREC overrides both; an
