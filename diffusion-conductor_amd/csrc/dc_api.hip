@@ -1088,17 +1088,24 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     // precise tail: the loop's last `tail` model evaluations on split operands (dc_sampler_set_precise_tail; DC_PRECISE_TAIL=k overrides):
     // fp16 / bf16 precision, linear attention, no test hooks
     int tail = s->tail_split >= 0 ? s->tail_split : (s->cfg.precision == DC_PREC_BF16 ? 8 : 1);
-    if (const char* e = getenv("DC_PRECISE_TAIL")) tail = atoi(e);
+    bool tail_asked = s->tail_split >= 0;
+    if (const char* e = getenv("DC_PRECISE_TAIL")) tail = atoi(e), tail_asked = true;
+    // An EPSILON model's final sample is sqrt(1 / abar) x_t - sqrt(1 / abar - 1) eps, not the last evaluations' prediction: what the plain
+    // 16-bit evaluations left in x_t stays (eta = 0: fp16 1.4 - 1.8e-3 whatever the tail, tools/fuzz_sampler.py).  Parity first: unless a
+    // tail was asked for, such a loop runs EVERY evaluation on split operands (2.1e-4, at the split precisions' speed).
+    if (!tail_asked && (flags & DC_UPD_EPS)) tail = S;
     // (clip strides that are not whole 32-frame groups - T = 900 x 128 unpadded - and short clips run the split evaluations in the
     // per-group record form with its combine launches: no measurable cost at one evaluation per loop, 70.6 vs 70.6 ms at bs = 128 x 900)
     if ((s->cfg.precision != DC_PREC_FP16 && s->cfg.precision != DC_PREC_BF16) || s->cfg.no_eff || s->dbg_layers >= 0 || s->dbg_first >= 0 || s->dbg_stage != 0 ||
         !s->d_model_split)
         tail = 0;
+    // (a tail of the whole loop splits every replay's graph; any shorter one lives in the last replay and is clipped to its steps)
+    const bool tail_all = tail >= S;
     tail = std::max(0, std::min(tail, std::min(S, steps_per_graph(S))));
     if (profile || no_graph) {
         s->prof.on = profile;
         for (int i = 0; i < S; ++i)
-            if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, -1, i >= S - tail, tail > 0))) {
+            if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, -1, tail_all || i >= S - tail, tail > 0))) {
                 s->prof.on = false;
                 return rc;
             }
@@ -1108,7 +1115,7 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
         const int replays = S / K;
       // (with a precise tail and several replays per loop - S > 64 - the LAST replay runs a second graph whose final steps are split)
       for (int part = 0; part < ((tail && replays > 1) ? 2 : 1); ++part) {
-        const int tail_here = (part == 1 || replays == 1) ? tail : 0;
+        const int tail_here = (part == 1 || replays == 1) ? tail : (tail_all ? K : 0);
         const int launches = (tail && replays > 1) ? (part == 0 ? replays - 1 : 1) : replays;
         const unsigned long long fk = form_key(s) | ((unsigned long long)tail_here << 40);
         auto current = [&]() {

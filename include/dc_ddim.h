@@ -158,7 +158,9 @@ DC_EXPORT int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t
  *   bf16:  3.1e-3 with steps = 0,  9.5e-4 with 2,  6.8e-4 with 4,  5.4e-4 with 8   - the bf16-operand mode that meets the 1e-3 bound
  * Default (steps never set): 1 for fp16, 8 for bf16.  (Clip strides of whole 32-frame groups run the split evaluations in the
  * workgroup-record form on clip-aligned units, others - T = 900 x 128 unpadded, short clips - in the per-group record form: 5.2e-4 ->
- * 2.6e-4 there at no measurable cost.)  Ignored for the split precisions and for `no_eff`.  DC_PRECISE_TAIL=k in the environment
+ * 2.6e-4 there at no measurable cost.)  Loops of an EPSILON model (DC_UPDATE_EPSILON) run EVERY evaluation on split operands unless a
+ * number was set here: their final sample carries what the plain evaluations left in x_t (fp16, eta = 0: 1.4 - 1.8e-3 with any shorter
+ * tail, 2.1e-4 all split).  Ignored for the split precisions and for `no_eff`.  DC_PRECISE_TAIL=k in the environment
  * overrides it.  (In a loop that has a tail the plain
  * evaluations read FiLM scale tiles that hold G' itself - one mixed-precision FMA per element instead of two -, the split ones G' - 1;
  * loops without a tail keep G' - 1 everywhere.) */

@@ -1,0 +1,22 @@
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+import torch
+from helpers import O, batch_noise, make_model, oracle_params, rel_l2, xf_pair
+from diffusion_conductor_amd.sampler import GaussianDiffusion, LossType, ModelMeanType, ModelVarType, get_named_beta_schedule
+torch.set_num_threads(16)
+B, T, S = 2, 256, 25
+xfp, xfo = xf_pair(B, T, first=3)
+noise = torch.from_numpy(batch_noise(B, T, first=3))
+length = [256, 200]
+with torch.no_grad():
+    ref = O.ddim_sample_loop(oracle_params(), noise, xfp, xfo, length, S, clip_denoised=True, eps_model=True)
+gd = GaussianDiffusion(betas=get_named_beta_schedule("linear", S), model_mean_type=ModelMeanType.EPSILON, model_var_type=ModelVarType.FIXED_SMALL, loss_type=LossType.MSE)
+for prec in ("fp16", "mixed", "bf16x3"):
+    m = make_model(prec)
+    for tail in ("0", "1", "4", "25"):
+        os.environ["DC_PRECISE_TAIL"] = tail
+        out = gd.ddim_sample_loop(m, (B, T, 26), noise=noise.cuda(), clip_denoised=True, progress=False,
+                                  model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor(length)})
+        torch.cuda.synchronize()
+        print(prec, "tail", tail, f"{rel_l2(out, ref):.3e}", flush=True)
+        if prec != "fp16": break
