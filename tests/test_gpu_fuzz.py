@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("tool,cases,seed", [("fuzz_shapes.py", 10, 11), ("fuzz_encoder.py", 24, 12), ("fuzz_sampler.py", 14, 13),
-                                             ("fuzz_harness.py", 8, 14)])
+                                             ("fuzz_harness.py", 8, 14), ("fuzz_evaluate.py", 10, 15)])
 def test_fuzz_tool_short_run(tool, cases, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(cases), str(seed)], capture_output=True, text=True, timeout=900)
     print(r.stdout[-3000:])
