@@ -20,6 +20,7 @@ scope for this path and are not provided.
 from __future__ import annotations
 
 import os
+import warnings
 
 import enum
 import math
@@ -195,6 +196,16 @@ class GaussianDiffusion:
                 # torch alike must pass step_noise_seed=(seed, lo*T*P) instead, or every shard would add the same draws.
                 zseed = int(th.randint(0, 2 ** 62, (1,)).item())
         plain = flags == 0 and eta == 0.0
+        if (flags & native.UPDATE_EPSILON) and eta == 0.0:
+            # An EPSILON model's final sample carries what the 16-bit evaluations left in x_t; fp16 / linear attention answers by running
+            # every evaluation on split operands (dc_ddim.h, dc_sampler_set_precise_tail).  Where no split kernels exist the result is
+            # outside the 1e-3 parity bound: say so instead of returning it silently.
+            prec = getattr(model, "active_precision", None)
+            full = bool(getattr(getattr(model, "cfg", None), "no_eff", False))
+            if (full and prec in ("fp16", "bf16")) or prec == "bf16":
+                warnings.warn(f"libdc_ddim: EPSILON model at eta = 0 in precision '{prec}'"
+                              f"{' with full attention (no_eff)' if full else ''}: 1 - 2e-3 from the fp32 reference "
+                              "(outside the 1e-3 bound); use precision='mixed' (linear attention) or 'fp16'", stacklevel=3)
         coef = self.native_coefficients(None if plain else eta)
         while True:
             nat = model.set_conditioning(mk["xf_proj"], mk["xf_out"], mk.get("length"))
@@ -209,7 +220,6 @@ class GaussianDiffusion:
                 # small batches: the clip's workgroups exchange their combine slices inside a layer launch and one of them gave up
                 # waiting (the GPU is shared with other work, so they were not co-resident): switch this process to the form
                 # without the exchange and run the loop again
-                import warnings
                 warnings.warn("libdc_ddim: in-launch combine exchange timed out (GPU shared?); continuing with DC_L16_OWN_COMBINE=1")
                 os.environ["DC_L16_OWN_COMBINE"] = "1"
                 continue
