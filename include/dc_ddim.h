@@ -130,7 +130,8 @@ DC_EXPORT int dc_sampler_finalize_params(dc_sampler* s);
  * the K/V/attention half of LinearTemporalCrossAttention.forward :149-155): applies
  * `linear` to xf_proj / xf_out, and builds the per-clip cross-attention matrices for
  * all layers.  d_xf_proj, d_xf_out: fp32 [B, T, 64] (the pair encode_music returns);
- * h_length: int32 [B] (model_kwargs['length']), NULL = all T.
+ * h_length: int32 [B] (model_kwargs['length'], 1 <= length <= T), NULL = all T.  1 <= T <= min(num_frames, 4032); full attention
+ * (`no_eff`) needs T >= 32 (DC_ERR_UNSUPPORTED below that).
  * Must be called before dc_sampler_denoise / dc_sampler_ddim_loop; (re)allocates the
  * workspace for (B, T). */
 DC_EXPORT int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const float* d_xf_out,
@@ -139,7 +140,7 @@ DC_EXPORT int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj,
 /* MotionTransformer.encode_music in eval mode (models/transformer.py:447-459) with the MusicEncoder conv stack
  * (:289-340) as MFMA kernels: d_mel fp32 [B, Tm, n_mels=128] (the tensor generate_music_motion builds at
  * trainers/ddpm_trainer.py:186-189) -> d_xf_out = music_encoder(mel) and d_xf_proj = proj(d_xf_out), both fp32
- * [B, (Tm-1)/3+1, 64], caller-allocated.  Needs the `music_encoder.*` and `proj.*` state_dict entries
+ * [B, (Tm-1)/3+1, 64], caller-allocated; Tm >= 4 (the reference's reflection padding raises below that).  Needs the `music_encoder.*` and `proj.*` state_dict entries
  * (optional as a group in dc_sampler_set_param; DC_ERR_PARAM here when they were not supplied). */
 DC_EXPORT int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t B, int32_t Tm, int32_t n_mels,
                             float* d_xf_proj, float* d_xf_out, void* stream);
