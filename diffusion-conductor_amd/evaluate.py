@@ -167,15 +167,19 @@ class _Scorer:
     def submit(self, k, bid, gts, pred_h, event, keep):
         self.q.put((k, bid, gts, pred_h, event, keep))
 
-    def wait_for(self, k):
-        """Blocks until batch k has been scored (k < 0: nothing to wait for); returns its [(clip id, mse)] or raises its error."""
+    def wait_for(self, k, reraise=True):
+        """Blocks until batch k has been scored (k < 0: nothing to wait for); returns its [(clip id, mse)] or raises its error.
+        reraise=False only waits (the sampling loop frees a pinned slot with it: a failed batch is dealt with when the results are
+        collected, where a non-finite one is sampled again the checked way)."""
         if k < 0:
             return None
         with self.cv:
             self.cv.wait_for(lambda: k in self.done)
             res = self.done[k]
         if isinstance(res, BaseException):
-            raise res
+            if reraise:
+                raise res
+            return None
         return res
 
     def close(self):
@@ -237,7 +241,7 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
             pred = trainer.generate_music_motion(mel, dim_pose, noise=noise, smooth=19 if smooth else None)
             waits["enqueue"] += time.perf_counter() - tw
             tw = time.perf_counter()
-            scorer.wait_for(k - 2)                            # the pinned pose buffer of this slot has been scored
+            scorer.wait_for(k - 2, reraise=False)             # the pinned pose buffer of this slot has been scored (errors: collected below)
             waits["scorer"] += time.perf_counter() - tw
             s = k & 1
             if out_h[s] is None or out_h[s].shape[0] < pred.shape[0] or out_h[s].shape[1:] != pred.shape[1:]:
@@ -253,7 +257,7 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
                 ev_last, n_after_first = ev, (n_after_first + len(bid) if ev_first is not ev else 0)
             scorer.submit(k, bid, gts, ph, ev, pred)
             if serial:
-                scorer.wait_for(k)
+                scorer.wait_for(k, reraise=False)
         for k in range(nb):
             try:
                 results[k] = scorer.wait_for(k)

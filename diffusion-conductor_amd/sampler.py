@@ -10,9 +10,11 @@ Fast path: when ``model`` is this package's MotionTransformer and no host callba
 hipGraph - for ``model_mean_type`` START_X (how DDPMTrainer.generate_music_motion calls it) or
 EPSILON, with or without ``clip_denoised`` (the reference's default is True) and for any ``eta``
 (the per-iteration noise the reference draws with ``th.randn_like`` is drawn up front, or taken
-from the extension keyword ``step_noise=`` so that runs can be reproduced).  A host callback, or
-the progressive generator, runs the same update rule step by step with the model call still
-going through the native denoiser.
+from the extension keyword ``step_noise=`` so that runs can be reproduced).  A host callback
+(``denoised_fn``, ``cond_fn`` with the reference's ``condition_score``, :581-603), the
+``PREVIOUS_X`` parameterisation (:510-514), a learned-variance model (2C output channels,
+:472-486) or the progressive generator run the same update rule step by step with the model
+call still going through the native denoiser; ``p_mean_variance`` (:442-536) is provided whole.
 
 Training-time members (losses, VLB terms, ancestral p_sample, schedule samplers) are out of
 scope for this path and are not provided.
@@ -105,6 +107,13 @@ class GaussianDiffusion:
         self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
         self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
         self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        # posterior q(x_{t-1} | x_t, x_0) (gaussian_diffusion.py:363-379): read by the PREVIOUS_X parameterisation, the learned-range
+        # variance and p_mean_variance's "mean" - never by the captured loop
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:])) \
+            if self.num_timesteps > 1 else np.log(np.maximum(self.posterior_variance, 1e-20))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
         self._native_coef = None
 
     # ---- helpers ------------------------------------------------------------------------
@@ -121,15 +130,36 @@ class GaussianDiffusion:
         return _extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - \
             _extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * eps
 
-    def _pred_xstart(self, model, x, t, clip_denoised, denoised_fn, model_kwargs):
-        """The part of p_mean_variance (gaussian_diffusion.py:442-536) DDIM reads: pred_xstart."""
+    def _predict_xstart_from_xprev(self, x_t, t, xprev):
+        """gaussian_diffusion.py:545-553: (xprev - coef2 * x_t) / coef1."""
+        assert x_t.shape == xprev.shape
+        return _extract(1.0 / self.posterior_mean_coef1, t, x_t.shape) * xprev - \
+            _extract(self.posterior_mean_coef2 / self.posterior_mean_coef1, t, x_t.shape) * x_t
+
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        """gaussian_diffusion.py:418-440."""
+        assert x_start.shape == x_t.shape
+        mean = _extract(self.posterior_mean_coef1, t, x_t.shape) * x_start + _extract(self.posterior_mean_coef2, t, x_t.shape) * x_t
+        return mean, _extract(self.posterior_variance, t, x_t.shape), _extract(self.posterior_log_variance_clipped, t, x_t.shape)
+
+    def _model_output(self, model, x, t, model_kwargs):
+        """The model call of p_mean_variance (gaussian_diffusion.py:466-476): returns (mean-parameter output, variance values or None).
+        A learned-variance model emits 2C channels along dim 1, split as th.split(model_output, C, dim=1) (:474)."""
         if model_kwargs is None:
             model_kwargs = {}
-        assert t.shape == (x.shape[0],)
+        B, C = x.shape[:2]
+        assert t.shape == (B,)
         model_output = model(x, self._scale_timesteps(t), **model_kwargs)
         if self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE):
-            raise NotImplementedError("learned variance is not used by Diffusion-Conductor (ddpm_trainer.py:93)")
-        if self.model_mean_type == ModelMeanType.START_X:
+            assert model_output.shape == (B, 2 * C, *x.shape[2:])
+            return th.split(model_output, C, dim=1)
+        return model_output, None
+
+    def _xstart_of(self, model_output, x, t, clip_denoised, denoised_fn):
+        """pred_xstart of p_mean_variance (gaussian_diffusion.py:497-521) for the three parameterisations."""
+        if self.model_mean_type == ModelMeanType.PREVIOUS_X:
+            pred = self._predict_xstart_from_xprev(x_t=x, t=t, xprev=model_output)
+        elif self.model_mean_type == ModelMeanType.START_X:
             pred = model_output
         elif self.model_mean_type == ModelMeanType.EPSILON:
             pred = self._predict_xstart_from_eps(x_t=x, t=t, eps=model_output)
@@ -142,13 +172,58 @@ class GaussianDiffusion:
         assert pred.shape == x.shape
         return pred
 
+    def _pred_xstart(self, model, x, t, clip_denoised, denoised_fn, model_kwargs):
+        """The part of p_mean_variance (gaussian_diffusion.py:442-536) DDIM reads: pred_xstart."""
+        model_output, _ = self._model_output(model, x, t, model_kwargs)
+        return self._xstart_of(model_output, x, t, clip_denoised, denoised_fn)
+
+    def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+        """gaussian_diffusion.py:442-536, whole: {"mean", "variance", "log_variance", "pred_xstart"}.  (DDIM reads pred_xstart only:
+        ddim_sample takes the short way through _pred_xstart.)"""
+        model_output, var_values = self._model_output(model, x, t, model_kwargs)
+        if self.model_var_type == ModelVarType.LEARNED:
+            log_variance = var_values
+            variance = th.exp(log_variance)
+        elif self.model_var_type == ModelVarType.LEARNED_RANGE:
+            min_log = _extract(self.posterior_log_variance_clipped, t, x.shape)
+            max_log = _extract(np.log(self.betas), t, x.shape)
+            frac = (var_values + 1) / 2                       # the model's [-1, 1] covers [min_var, max_var]
+            log_variance = frac * max_log + (1 - frac) * min_log
+            variance = th.exp(log_variance)
+        else:
+            var, logvar = {
+                ModelVarType.FIXED_LARGE: (np.append(self.posterior_variance[1], self.betas[1:]),
+                                           np.log(np.append(self.posterior_variance[1], self.betas[1:]))),
+                ModelVarType.FIXED_SMALL: (self.posterior_variance, self.posterior_log_variance_clipped),
+            }[self.model_var_type]
+            variance, log_variance = _extract(var, t, x.shape), _extract(logvar, t, x.shape)
+        pred_xstart = self._xstart_of(model_output, x, t, clip_denoised, denoised_fn)
+        if self.model_mean_type == ModelMeanType.PREVIOUS_X:
+            mean = model_output
+        else:
+            mean, _, _ = self.q_posterior_mean_variance(x_start=pred_xstart, x_t=x, t=t)
+        assert mean.shape == log_variance.shape == pred_xstart.shape == x.shape
+        return {"mean": mean, "variance": variance, "log_variance": log_variance, "pred_xstart": pred_xstart}
+
+    def condition_score(self, cond_fn, p_mean_var, x, t, model_kwargs=None):
+        """gaussian_diffusion.py:581-603 (Song et al. 2020): the prediction the model would have made had its score been conditioned
+        by cond_fn = grad log p(y | x).  "mean" is recomputed only when the input carries one (DDIM does not read it)."""
+        alpha_bar = _extract(self.alphas_cumprod, t, x.shape)
+        eps = self._predict_eps_from_xstart(x, t, p_mean_var["pred_xstart"])
+        eps = eps - (1 - alpha_bar).sqrt() * cond_fn(x, self._scale_timesteps(t), **(model_kwargs or {}))
+        out = dict(p_mean_var)
+        out["pred_xstart"] = self._predict_xstart_from_eps(x, t, eps)
+        if "mean" in out:
+            out["mean"], _, _ = self.q_posterior_mean_variance(x_start=out["pred_xstart"], x_t=x, t=t)
+        return out
+
     # ---- DDIM ---------------------------------------------------------------------------
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                     eta=0.0, noise=None):
         """gaussian_diffusion.py:783-831.  `noise` (extension): the draw to use in place of th.randn_like(x)."""
-        if cond_fn is not None:
-            raise NotImplementedError("cond_fn (classifier guidance) is not on the Diffusion-Conductor path")
         pred_xstart = self._pred_xstart(model, x, t, clip_denoised, denoised_fn, model_kwargs)
+        if cond_fn is not None:
+            pred_xstart = self.condition_score(cond_fn, {"pred_xstart": pred_xstart}, x, t, model_kwargs=model_kwargs)["pred_xstart"]
         eps = self._predict_eps_from_xstart(x, t, pred_xstart)
         alpha_bar = _extract(self.alphas_cumprod, t, x.shape)
         alpha_bar_prev = _extract(self.alphas_cumprod_prev, t, x.shape)

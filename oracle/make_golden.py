@@ -436,8 +436,91 @@ def main():
         g10["stress_t900_length"] = np.asarray(length, np.int64)
         np.savez_compressed(os.path.join(OUT, "g10_no_eff_long.npz"), **g10)
 
+    def make_g11():
+        # ---- G11: the sampler's off-path branches - ModelMeanType.PREVIOUS_X (gaussian_diffusion.py:510-514, 545), the learned-variance
+        # output split (:472-486) and cond_fn / condition_score (:581-603, 806-808).  (a) host arithmetic on weight-free callables
+        # (oracle/toy_models.py), every (mean type x variance type x cond_fn x clip x eta) branch, plus p_mean_variance's whole
+        # dict; (b) the same three branches around the reference MotionTransformer at B=2, T=96 (ragged), DDIM-50, for the GPU
+        # test whose model call runs in the HIP library.  Here the fixture IS the reference's output (the oracle module has no
+        # counterpart of these branches: the package's sampler.py is compared with the fixture directly).
+        from oracle import toy_models as TM
+        g11 = {}
+        real_randn_like = torch.randn_like
+        S = 50
+        gen = torch.Generator().manual_seed(1234)
+        x_T = torch.randn(TM.SHAPE, generator=gen)
+        z = torch.randn((S,) + TM.SHAPE, generator=gen)
+        g11["toy_x_T"], g11["toy_z"] = x_T.numpy(), z.numpy()
+
+        def gd_of(mean, var):
+            return rgd.GaussianDiffusion(betas=rgd.get_named_beta_schedule("linear", S), model_mean_type=getattr(rgd.ModelMeanType, mean),
+                                         model_var_type=getattr(rgd.ModelVarType, var), loss_type=rgd.LossType.MSE)
+
+        def patched(draws, fn):
+            calls = [0]
+
+            def fake(x, *a, **k):
+                calls[0] += 1
+                return draws[calls[0] - 1].clone()
+            torch.randn_like = fake
+            try:
+                return fn()
+            finally:
+                torch.randn_like = real_randn_like
+
+        cases = [("prevx_small_clip", "PREVIOUS_X", "FIXED_SMALL", False, True, 0.0),
+                 ("prevx_large_eta", "PREVIOUS_X", "FIXED_LARGE", False, True, 0.4),
+                 ("startx_learned_clip", "START_X", "LEARNED", False, True, 0.0),
+                 ("eps_range_eta", "EPSILON", "LEARNED_RANGE", False, False, 0.3),
+                 ("startx_cond", "START_X", "FIXED_SMALL", True, False, 0.0),
+                 ("eps_cond_clip_eta", "EPSILON", "FIXED_SMALL", True, True, 0.2),
+                 ("prevx_range_cond", "PREVIOUS_X", "LEARNED_RANGE", True, True, 0.1)]
+        for tag, mean, var, cond, clip, eta in cases:
+            gd = gd_of(mean, var)
+            mdl = TM.toy_model_learned if var.startswith("LEARNED") else TM.toy_model
+            outs = patched(z, lambda: list(gd.ddim_sample_loop_progressive(
+                mdl, TM.SHAPE, noise=x_T, clip_denoised=clip, cond_fn=TM.toy_cond_fn if cond else None, progress=False, eta=eta,
+                device="cpu", model_kwargs={"scale": 0.8})))
+            assert len(outs) == S and all(torch.isfinite(o["sample"]).all() for o in outs), tag
+            g11[f"toy_{tag}_final"] = outs[-1]["sample"].numpy()
+            for it in (0, 24, 49):
+                g11[f"toy_{tag}_sample{it}"] = outs[it]["sample"].numpy()
+                g11[f"toy_{tag}_pred{it}"] = outs[it]["pred_xstart"].numpy()
+            tt = torch.tensor([49, 7, 0])
+            with torch.no_grad():
+                pmv = gd.p_mean_variance(mdl, x_T, tt, clip_denoised=clip, model_kwargs={"scale": 0.8})
+            for k in ("mean", "variance", "log_variance", "pred_xstart"):
+                g11[f"toy_{tag}_pmv_{k}"] = pmv[k].expand(TM.SHAPE).numpy().copy()
+        # (b) around the reference denoiser
+        B, T = 2, 96
+        length = [96, 70]
+        xfp_, xf_ = features(B, T, first=60)
+        nz = torch.from_numpy(batch_noise(B, T, first=60))
+        mk = {"xf_proj": xfp_, "xf_out": xf_, "length": torch.as_tensor(length)}
+
+        def learned_wrap(x, t, **kw):          # a 2C-channel model whose first half is the denoiser (the variance half is not read by DDIM)
+            y = model(x, t, **kw)
+            return torch.cat([y, torch.zeros_like(y)], dim=1)
+
+        for tag, mean, var, cond, clip in (("mt_cond", "START_X", "FIXED_SMALL", True, False),
+                                           ("mt_prevx", "PREVIOUS_X", "FIXED_SMALL", False, True),
+                                           ("mt_learned", "START_X", "LEARNED_RANGE", False, False)):
+            gd = gd_of(mean, var)
+            mdl = learned_wrap if var.startswith("LEARNED") else model
+            outs = list(gd.ddim_sample_loop_progressive(mdl, (B, T, 26), noise=nz, clip_denoised=clip, progress=False, eta=0.0, device="cpu",
+                                                        cond_fn=TM.pose_cond_fn if cond else None, model_kwargs=mk))
+            g11[f"{tag}_final"] = outs[-1]["sample"].numpy()
+            g11[f"{tag}_pred24"] = outs[24]["pred_xstart"].numpy()
+            log[f"g11_{tag}_final_rms"] = float(outs[-1]["sample"].pow(2).mean().sqrt())
+        plain = ref_ddim(model, S, nz, xfp_, xf_, length)
+        assert torch.equal(plain, torch.from_numpy(g11["mt_learned_final"]))          # DDIM never reads the variance half
+        log["g11_mt_cond_vs_plain"] = rel_l2(g11["mt_cond_final"], plain.numpy())     # (the guidance term must matter for the fixture to test it)
+        assert log["g11_mt_cond_vs_plain"] > 1e-2
+        g11["mt_length"] = np.asarray(length, np.int64)
+        np.savez_compressed(os.path.join(OUT, "g11_offpath_branches.npz"), **g11)
+
     for name, fn in (("g1", make_g1), ("g2", make_g2), ("g3", make_g3), ("g4", make_g4), ("g5", make_g5), ("g6", make_g6),
-                     ("g6b", make_g6b), ("g7", make_g7), ("g8", make_g8), ("g9", make_g9), ("g10", make_g10)):
+                     ("g6b", make_g6b), ("g7", make_g7), ("g8", make_g8), ("g9", make_g9), ("g10", make_g10), ("g11", make_g11)):
         if want(name):
             t0 = time.time()
             fn()

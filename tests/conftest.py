@@ -17,6 +17,21 @@ def pytest_configure(config):
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
+_ORDER = ("test_gpu_parity", "test_gpu_stages", "test_gpu_robust")
+
+
+def pytest_collection_modifyitems(config, items):
+    """The driver runs `pytest -m gpu -x`: parity tests first, then stage and robustness tests, the subprocess fuzz runs last, so
+    that one slow or failing fuzz case cannot hide the parity results behind it (stable sort: order inside a file is kept)."""
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        for i, stem in enumerate(_ORDER):
+            if name.startswith(stem):
+                return i
+        return len(_ORDER) + (1 if "fuzz" in name else 0)
+    items.sort(key=rank)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

@@ -474,3 +474,36 @@ def test_fp16_plane_encoder_overflow_is_resampled_on_split_planes():
     err = rel_l2(out, ref)
     print(f"overflowing encoder, re-encoded on split planes: rel-L2 {err:.3e}")
     assert err <= TOL
+
+
+@pytest.mark.parametrize("prec", ["fp16", "mixed"])
+@pytest.mark.parametrize("tag,mean,var,cond,clip", [("mt_cond", "START_X", "FIXED_SMALL", True, False),
+                                                    ("mt_prevx", "PREVIOUS_X", "FIXED_SMALL", False, True),
+                                                    ("mt_learned", "START_X", "LEARNED_RANGE", False, False)])
+def test_sampler_off_path_branches_around_the_native_denoiser_g11(tag, mean, var, cond, clip, prec):
+    """cond_fn / condition_score (gaussian_diffusion.py:581-603, 806-808), ModelMeanType.PREVIOUS_X (:510-514, 545) and a learned-variance
+    (2C-channel) model (:472-486) through the step-through path: the host arithmetic of sampler.py around the HIP denoiser's model call,
+    against the imported reference's DDIM-50 output with the reference denoiser (fixture G11, B=2, T=96, ragged)."""
+    from diffusion_conductor_amd.sampler import GaussianDiffusion, LossType, ModelMeanType, ModelVarType, get_named_beta_schedule
+    from oracle import toy_models as TM
+    g = golden("g11_offpath_branches.npz")
+    sd = synthetic_state_dict(DenoiserConfig(), seed=0)
+    B, T, S = 2, 96, 50
+    xfp, xfo = (t.cuda() for t in _features(sd, B, T, 60))
+    noise = torch.from_numpy(batch_noise(B, T, first=60)).cuda()
+    m = _model(sd, prec)
+    gd = GaussianDiffusion(betas=get_named_beta_schedule("linear", S), model_mean_type=getattr(ModelMeanType, mean),
+                           model_var_type=getattr(ModelVarType, var), loss_type=LossType.MSE)
+
+    def learned_wrap(x, t, **kw):
+        y = m(x, t, **kw)
+        return torch.cat([y, torch.zeros_like(y)], dim=1)
+
+    mdl = learned_wrap if var.startswith("LEARNED") else m
+    outs = list(gd.ddim_sample_loop_progressive(mdl, (B, T, 26), noise=noise, clip_denoised=clip, progress=False, eta=0.0, device="cuda",
+                                                cond_fn=TM.pose_cond_fn if cond else None,
+                                                model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.LongTensor(g["mt_length"])}))
+    torch.cuda.synchronize()
+    e_final, e_mid = rel_l2(outs[-1]["sample"], g[f"{tag}_final"]), rel_l2(outs[24]["pred_xstart"], g[f"{tag}_pred24"])
+    print(f"g11[{tag}][{prec}] rel-L2 final {e_final:.3e}  pred_xstart@24 {e_mid:.3e}")
+    assert len(outs) == S and torch.isfinite(outs[-1]["sample"]).all() and max(e_final, e_mid) <= TOL
