@@ -162,13 +162,20 @@ def launch_ranks(n, argv):
     return worst
 
 
-def multi_gpu_evidence(dist, dev, local, rank, world, B, s_per_step, gathered, nat, noise, coef, model, args):
-    """What proves an N-rank run (module docstring).  Collectives outside the timed region; every rank takes part."""
+def device_identity(local):
+    """One string per physical device: PCI bus / device id + uuid + name (what the ranks all-gather to prove they are N devices)."""
     import torch
-    from diffusion_conductor_amd.synthetic import batch_music_features, batch_noise
     pr = torch.cuda.get_device_properties(local)
-    ident = f"{getattr(pr, 'pci_bus_id', '?'):02x}:{getattr(pr, 'pci_device_id', '?'):02x} {getattr(pr, 'uuid', '')} {pr.name}" \
+    return f"{getattr(pr, 'pci_bus_id', '?'):02x}:{getattr(pr, 'pci_device_id', '?'):02x} {getattr(pr, 'uuid', '')} {pr.name}" \
         if isinstance(getattr(pr, "pci_bus_id", None), int) else f"{getattr(pr, 'uuid', '')} {pr.name} #{local}"
+
+
+def multi_gpu_evidence(dist, dev, ident, rank, world, B, s_per_step, gathered, resample_own, resample_shard):
+    """What proves an N-rank run (module docstring).  Collectives outside the timed region; every rank takes part.
+    `ident`: this rank's device identity; `gathered`: the all-gathered poses [world * B, T, P] of the last timed step;
+    `resample_own()`: this rank's shard sampled again; `resample_shard(r)`: rank r's shard sampled alone on THIS device (inputs
+    regenerated from their seeds).  Host logic only - tests/test_sharding_gloo.py runs it on two gloo ranks with stub samplers."""
+    import torch
     idents = [None] * world
     dist.all_gather_object(idents, ident)
     assert len(set(idents)) == world, f"ranks share a device: {idents}"
@@ -177,17 +184,13 @@ def multi_gpu_evidence(dist, dev, local, rank, world, B, s_per_step, gathered, n
     dist.all_gather(ts, t)
     ms = [float(x.item()) for x in ts]
     # the gathered tensor is [world * B, T, P] in rank order: my block must be my own result, bit for bit
-    mine, _ = nat.ddim_loop(noise, coef)
+    mine = resample_own()
     ok = torch.tensor([int(torch.equal(gathered[rank * B:(rank + 1) * B], mine))], device=dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     same_single = None
-    if rank == 0:        # rank 0 samples the LAST rank's shard alone (inputs regenerated from their seeds) and compares
+    if rank == 0:        # rank 0 samples the LAST rank's shard alone and compares
         r = world - 1
-        xf = torch.from_numpy(batch_music_features(B, args.frames, first=r * B)).to(dev)
-        xfp = torch.nn.functional.linear(xf, model.proj.weight, model.proj.bias).contiguous()
-        nz = torch.from_numpy(batch_noise(B, args.frames, first=r * B)).to(dev)
-        solo, _ = model.set_conditioning(xfp, xf, [args.frames] * B).ddim_loop(nz, coef)
-        same_single = bool(torch.equal(solo, gathered[r * B:(r + 1) * B]))
+        same_single = bool(torch.equal(resample_shard(r), gathered[r * B:(r + 1) * B]))
     return {"rccl_ranks": int(dist.get_world_size()), "backend": dist.get_backend(), "devices": idents,
             "ms_per_step_by_rank": {"min": round(min(ms), 3), "max": round(max(ms), 3)},
             "gather_block_equals_local": bool(ok.item()), "sharded_equals_single_gpu": same_single,
@@ -253,6 +256,7 @@ def main():
 
     from diffusion_conductor_amd.sampler import (GaussianDiffusion, LossType, ModelMeanType, ModelVarType,
                                                  get_named_beta_schedule)
+    from diffusion_conductor_amd.native import precise_tail_default
     from diffusion_conductor_amd.sharding import gather_poses
     from diffusion_conductor_amd.synthetic import batch_music_features, batch_noise
 
@@ -299,7 +303,13 @@ def main():
     log(f"timed region: {dt:.3f} s for {args.steps} steps")
     multi = None
     if world > 1 or selftest_multi:
-        multi = multi_gpu_evidence(dist, dev, local, rank, world, B, dt_local / args.steps, out, nat, noise, coef, model, args)
+        def resample_shard(r):
+            xf_r = torch.from_numpy(batch_music_features(B, T, first=r * B)).to(dev)
+            xfp_r = torch.nn.functional.linear(xf_r, model.proj.weight, model.proj.bias).contiguous()
+            nz_r = torch.from_numpy(batch_noise(B, T, first=r * B)).to(dev)
+            return model.set_conditioning(xfp_r, xf_r, [T] * B).ddim_loop(nz_r, coef)[0]
+        multi = multi_gpu_evidence(dist, dev, device_identity(local), rank, world, B, dt_local / args.steps, out,
+                                   lambda: nat.ddim_loop(noise, coef)[0], resample_shard)
 
     frames = world * B * T * args.steps
     value = frames / dt
@@ -315,7 +325,7 @@ def main():
                    "clips_per_gpu": B, "frames_per_clip": T, "ddim_steps": S, "parallelism": f"clip-dp{world}",
                    # fp16 precision: the loop's last evaluation(s) run on split fp16 operands (dc_sampler_set_precise_tail, default 1;
                    # DC_PRECISE_TAIL overrides) - inside the timed loop, like everything else the product path does
-                   "precise_tail_steps": (int(os.environ.get("DC_PRECISE_TAIL", "1")) if args.precision == "fp16" and not args.no_eff else 0)},
+                   "precise_tail_steps": int(os.environ.get("DC_PRECISE_TAIL", precise_tail_default(args.precision)))},
         # no_eff: 7.56 G + 13.27 G (T/1800) MAC per clip-step of 1800 tokens
         "mfma_roofline_frac_whole_loop": round(value / world * S * (2 * (7.56e9 + 13.27e9 * T / 1800) / 1800 if args.no_eff
                                                                       else FLOP_PER_TOKEN_STEP) / PEAK_BF16_FLOPS, 4),
@@ -383,21 +393,21 @@ def main():
             tj = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
         alg = native.algorithmic_work(B * T)       # per-launch algorithmic bytes / FLOPs of the build's kernels
 
-        def roof(name):
+        def roof(name, prof=prof, tj=tj):
             ms, cnt = prof[name]
             per = ms / cnt * 1e-3
             w = dict(alg[name])
-            if w["bound"] == "mfma":
-                ach, peak, unit = w["flops"] / per / 1e12, PEAK_BF16_FLOPS / 1e12, "TFLOP/s"
-            else:
-                ach, peak, unit = w["bytes"] / per / 1e9, PEAK_HBM_BYTES / 1e9, "GB/s"
-            r = {"bound": w["bound"], "kernel": name, "achieved": round(ach, 1), "peak": peak, "unit": unit,
+            ach, peak, unit = w["flops"] / per / 1e12, PEAK_BF16_FLOPS / 1e12, "TFLOP/s"      # the MFMA roof: the path's primary bound
+            r = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": peak, "unit": unit,
                  "frac": round(ach / peak, 4), "traffic": tj.get(name, {}).get("traffic_bytes"),
                  "traffic_source": TRAFFIC_FILE if name in tj else None,
                  "avg_launch_us": round(per * 1e6, 1), "launches": cnt, "layers_per_launch": w.get("layers_per_launch", 1)}
-            # the OTHER roof of the same kernel, so that the line says how far both are (k_layer: 15.9 GFLOP per launch at bs=32)
-            if w["bound"] == "hbm" and "flops" in w:
-                r["mfma_frac"] = round(w["flops"] / per / PEAK_BF16_FLOPS, 4)
+            r["mfma_frac"] = r["frac"]
+            if "design_bytes" in w:
+                # beside it: the HBM bytes THIS decomposition moves per launch (fp32 residual stream in / out + the FiLM tiles the GEMM
+                # wrote one launch earlier + unit records) over the launch time - design bytes, not section 8d's compulsory bytes
+                r["hbm_design_bytes"] = int(w["design_bytes"])
+                r["hbm_design_frac"] = round(w["design_bytes"] / per / PEAK_HBM_BYTES, 4)
             if name == "k_film_gemm":
                 r["graph_kernel"] = "k_film_embed: the captured loop runs this GEMM and k_embed_front as ONE launch; this eager pass times them apart"
             return r
@@ -428,24 +438,54 @@ def main():
             if cpu_x0 is not None:
                 line["bs1"]["rel_l2_vs_oracle"] = float(f"{rel_l2(o1, cpu_x0):.3e}")
             log(f"bs=1: {line['bs1']}")
+            # the throughput option: flat 256-token units (228 workgroups instead of the 256 clip-aligned ones; a clip then depends on its
+            # neighbours at the rounding level) - dc_sampler_set_clip_aligned(0)
+            nat = model.set_conditioning(xfp, xf, [T] * B)      # (the one-clip run above re-conditioned the same sampler object)
+            nat.set_clip_aligned(False)
+            tf, of = time_loops(nat, noise, coef, 3)
+            nat.set_clip_aligned(None)
+            oa, _ = nat.ddim_loop(noise, coef)
+            line["flat_units"] = {"ms_per_step": round(1e3 * tf, 3), "frames_per_s": round(B * T / tf, 1),
+                                  "worst_clip_rel_l2_vs_clip_aligned": float(f"{max(rel_l2(of[c:c + 1], oa[c:c + 1]) for c in range(B)):.3e}"),
+                                  "note": "value / ms_per_step above are the batch-invariant default (clip-aligned units)"}
+            del of, oa
             if args.precision == "fp16":
                 # the bf16-operand mode: plain bf16 MFMA operands in every GEMM (FiLM GEMM included), the loop's last 8 of 50 model
                 # evaluations on split bf16 (three MFMAs per product; dc_sampler_set_precise_tail) - what carries its precision
                 del nat1, nat
                 m2 = build_model("bf16", False, dev)
                 n2 = m2.set_conditioning(xfp, xf, [T] * B)
+                tail2 = native.precise_tail_default("bf16")
                 t2, o2 = time_loops(n2, noise, coef, 3)
                 line["bf16_mode"] = {"precision": "bf16", "ms_per_step": round(1e3 * t2, 3), "frames_per_s": round(B * T / t2, 1),
                                      "rel_l2": float(f"{rel_l2(o2[:1], cpu_x0):.3e}") if cpu_x0 is not None else None,
-                                     "precise_tail_steps": int(os.environ.get("DC_PRECISE_TAIL", "8")),
-                                     "operands": "every GEMM on plain bf16 MFMA operands; the last 8 of the loop's 50 model evaluations on "
-                                                 "split bf16 (hi*hi + lo*hi + hi*lo).  plain_bf16_rel_l2: the same mode without that tail"}
+                                     "precise_tail_steps": tail2,
+                                     "operands": f"every GEMM on plain bf16 MFMA operands; the last {tail2} of the loop's {S} model evaluations in the "
+                                                 "'mixed' form: 128-wide GEMMs on split bf16 (hi*hi + lo*hi + hi*lo), FiLM GEMM on f16 operands.  "
+                                                 "plain_bf16_rel_l2: the same mode without that tail"}
+                # the mode's own kernel-level evidence: one eager pass with per-launch events over the loop as it runs (tail included) and
+                # one with the tail off - k_layer's plain launches from the second, the split ones from the difference
+                prof_t, _ = n2.profile_loop(noise, coef)
+                n2.set_precise_tail(0)
+                prof_p, _ = n2.profile_loop(noise, coef)
+                n2.set_precise_tail(-1)
+                lp_ms, lp_n = prof_p["k_layer"]
+                lt_ms, lt_n = prof_t["k_layer"]
+                n_split = tail2 * model.num_layers
+                split_us = (lt_ms - lp_ms * (lt_n - n_split) / max(lp_n, 1)) / max(n_split, 1) * 1e3
+                tot_t, tot_p = sum(v[0] for v in prof_t.values()), sum(v[0] for v in prof_p.values())
+                line["bf16_mode"]["roofline"] = {
+                    "k_film_gemm": roof("k_film_gemm", prof_p, {}), "k_layer_plain": roof("k_layer", prof_p, {}),
+                    "k_layer_split_launch_us": round(split_us, 1), "k_layer_split_launches": n_split,
+                    "tail_share_of_loop": round(1.0 - tot_p / tot_t * (S - tail2) / S, 4) if tot_t > 0 else None,
+                    "eager_kernel_ms": {"with_tail": {k: round(v[0], 3) for k, v in prof_t.items() if v[1]},
+                                        "tail_off": {k: round(v[0], 3) for k, v in prof_p.items() if v[1]}},
+                    "note": "eager passes (per-launch HIP events on the library's stream); the captured loop fuses k_embed_front into the FiLM launch"}
                 if cpu_x0 is not None:      # the plain-bf16 error (one clip, one loop)
-                    os.environ["DC_PRECISE_TAIL"] = "0"
-                    try:
-                        o3, _ = m2.set_conditioning(xfp[:1].contiguous(), xf[:1].contiguous(), [T]).ddim_loop(noise[:1].contiguous(), coef)
-                    finally:
-                        del os.environ["DC_PRECISE_TAIL"]
+                    n1b = m2.set_conditioning(xfp[:1].contiguous(), xf[:1].contiguous(), [T])
+                    n1b.set_precise_tail(0)
+                    o3, _ = n1b.ddim_loop(noise[:1].contiguous(), coef)
+                    n1b.set_precise_tail(-1)
                     line["bf16_mode"]["plain_bf16_rel_l2"] = float(f"{rel_l2(o3, cpu_x0):.3e}")
                 del n2, m2
                 # ... and the split-operand mode (`mixed`: split bf16 in every 128-wide GEMM of every evaluation, f16 FiLM GEMM)

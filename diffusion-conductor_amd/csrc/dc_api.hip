@@ -175,6 +175,8 @@ struct dc_sampler {
     void* d_a_ca16 = nullptr;             // cross-attention fragments in the 16-token layer kernel's form (small batches)
     unsigned long long* d_gran = nullptr; // small batches: granules of the combine the clip's workgroups share inside a launch, [B][1024] (dc_layer16.hip)
     unsigned l16_seq = 0;                 // eager launches of k_layer16: tag sequence (tags must differ between consecutive launches)
+    bool l16_own = false;                 // every workgroup of k_layer16 combines alone (no in-launch exchange): dc_sampler_set_combine_exchange(s, 0),
+                                          // or latched by dc_sampler_status after a DC_STATUS_TIMEOUT (the GPU is shared: co-residency cannot be assumed)
     void *d_kv_sa[2] = {nullptr, nullptr}, *d_kv_ca = nullptr;   // no_eff: key-tile arrays (dc_kernels.hip, full attention)
     int KT = 0;                                                   // key tiles per clip array
     float* d_x = nullptr;
@@ -228,6 +230,8 @@ struct dc_sampler {
     DcModel* d_model_split = nullptr;
     dc_music* music = nullptr;   // MusicEncoder (built when its parameters were supplied)
     int me_format = -1;          // dc_sampler_set_encoder_format (-1: by precision)
+    int clip_aligned = -1;         // dc_sampler_set_clip_aligned: 1 clip-aligned units in the wide form too, 0 flat units, -1 the library's rule
+    bool precise_forward = false;  // dc_sampler_set_precise_forward: dc_sampler_denoise on split operands (the precise tail's evaluation form)
     int tail_split = -1;         // dc_sampler_set_precise_tail: the loop's last evaluations with split operands (-1: by precision - fp16 1, bf16 8)
     bool host_only = false;      // -DDC_HOST_SANITIZE builds without a device: the host half only (tests/test_host_sanitize.py)
 
@@ -368,7 +372,7 @@ int build_model(dc_sampler* s) {
     // fp16 precision: every layer stage image is also kept in its split form (the fp16 lo halves exist anyway): the loop's last
     // evaluations can then run on split operands (dc_sampler_set_precise_tail) through h_model_split, a copy of the model record
     // whose image pointers are these twins
-    const bool want_twins = (c.precision == DC_PREC_FP16 || c.precision == DC_PREC_BF16) && !c.no_eff && !s->split_small;
+    const bool want_twins = (c.precision == DC_PREC_FP16 || c.precision == DC_PREC_BF16) && !s->split_small;
     std::vector<std::pair<size_t, size_t>> twins;          // (offset of the pointer inside DcModel, arena offset of the split image)
     auto add_image = [&](const bf16x8** dst, const float* w, int n_out, int k_in, bool with_lo, const float* consts,
                          size_t n_consts) {
@@ -620,6 +624,21 @@ int build_model(dc_sampler* s) {
                 for (int r = 0; r < 16; ++r) b16[((size_t)ot * 2 + fb) * 16 + r] = film_b[(size_t)32 * ot + 16 * fb + pi[r]];
         O.fix.push_back({(const void**)&m.film_w16, A.add(w16.data(), w16.size() * 2)});
         add_raw(&m.film_b16, b16.data(), b16.size());
+        m.film_w16_tail = nullptr;
+        if (want_twins && c.precision == DC_PREC_BF16) {
+            // bf16 precision: the evaluations of the precise tail run the "mixed" form - split-bf16 128-wide GEMMs AND an f16 FiLM GEMM
+            // (8 mantissa bits on the K = 512 operands were the tail's floor: 3.6 - 4.1e-4 with every evaluation split)
+            for (size_t i = 0; i < w16.size(); ++i) w16[i] = 0;
+            for (int ot = 0; ot < NT; ++ot)
+                for (int ks = 0; ks < DC_E / 32; ++ks)
+                    for (int fb = 0; fb < 2; ++fb)
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 8; ++j) {
+                                const float v = film_w[(size_t)(32 * ot + 16 * fb + pi[l & 15]) * DC_E + 32 * ks + 8 * (l >> 4) + j];
+                                w16[((((size_t)ot * (DC_E / 32) + ks) * 2 + fb) * 64 + l) * 8 + j] = f2h(v);
+                            }
+            O.fix.push_back({(const void**)&m.film_w16_tail, A.add(w16.data(), w16.size() * 2)});
+        }
         for (int ot = 0; ot < NT; ++ot)
             for (int fb = 0; fb < 2; ++fb)
                 for (int r = 0; r < 16; ++r) b16[((size_t)ot * 2 + fb) * 16 + r] = film_b_g1[(size_t)32 * ot + 16 * fb + pi[r]];
@@ -841,10 +860,12 @@ struct Timed {   // RAII-less helper: wraps a launch with events when profiling
 // that one process can A/B them: a change re-captures) and the update options of the loop.
 unsigned long long form_key(const dc_sampler* s) {
     static const char* sw[] = {"DC_NO_WGREC", "DC_NO_NARROW", "DC_NO_ALIGN", "DC_ALIGN", "DC_NO_FUSE_EMBED", "DC_FILM_STATIC",
-                               "DC_BEGIN_STEP", "DC_NO_PAD", "DC_NO_LAYER16", "DC_L16_OWN_COMBINE", "DC_L16_TEST_DROP_SLICE"};
+                               "DC_BEGIN_STEP", "DC_NO_PAD", "DC_NO_LAYER16", "DC_L16_OWN_COMBINE", "DC_L16_TEST_DROP_SLICE", "DC_TAIL_FILM_BF16", "DC_FLAT_UNITS"};
     unsigned long long k = 0;
     for (size_t i = 0; i < sizeof sw / sizeof *sw; ++i) k |= (getenv(sw[i]) ? 1ull : 0ull) << i;
     k |= (unsigned long long)(s->upd_flags & 0xff) << 16;     // (the noise tensor's address is not baked in: the kernels read it from d_zslot)
+    k |= (s->l16_own ? 1ull : 0ull) << 24;
+    k |= (unsigned long long)((s->clip_aligned + 1) & 3) << 25;
     return k;
 }
 
@@ -859,7 +880,9 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const int B = s->B, T = s->T, M = s->M, G = s->G, L = s->cfg.num_layers;
     const bool ss = s->split_small || split_step, sf = s->split_film;
     const DcModel* dmod = (split_step && !s->split_small) ? s->d_model_split : s->d_model;      // (the precise tail's split stage images)
-    const int fs = s->small_fmt, ff = s->film_fmt;
+    // (bf16 precision, split evaluations: the f16 FiLM image - the step is then exactly a "mixed" evaluation)
+    const bool film_tail = split_step && !s->split_small && s->h_model.film_w16_tail != nullptr && !getenv("DC_TAIL_FILM_BF16");
+    const int fs = s->small_fmt, ff = film_tail ? 1 : s->film_fmt;
     // non-split formats: the FiLM GEMM produces its own operand from pp + temb (no k_silu_emb pass); the separate pass
     // remains for the split formats, for the v1 kernel, and under the test hooks that read the operand image back
     const bool fuse_silu = !sf && s->dbg_layers < 0;
@@ -902,7 +925,16 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const int nwg_narrow = can_align ? B * upc_narrow : (G + 3) / 4;
     const bool narrow = wgr && !ss && nwg_narrow <= s->num_cu && T <= 3840 && s->dbg_layers < 0 && s->dbg_stage == 0 &&
                         !getenv("DC_NO_NARROW") && !want_stamps;
-    const bool aligned = can_align && (narrow || ss || aligned_env);
+    // ... and for the wide (chip-full) form whenever the clip-aligned launch needs no more rounds of workgroups over the chip than the flat
+    // one (bs = 32 x 1800: 256 workgroups instead of 228, one round either way): a clip's result is then bit-identical whatever the
+    // batch around it - the reference's semantics (transformer.py:111: the key softmax is per clip) - for +1.6 ... +2.1 % per loop
+    // (profiles/r06_ab_align.txt).  Where it would cost a round (bs = 35 x 1800: 280 against 250 workgroups on 256 CUs) flat units stay -
+    // a clip then depends on its neighbours at the rounding level (4e-4).  dc_sampler_set_clip_aligned: 1 forces
+    // aligned units, 0 flat ones; DC_ALIGN=1 / DC_FLAT_UNITS=1 in the environment do the same per process.
+    const int nwg_flat = (G + 7) / 8, ncu = s->num_cu > 0 ? s->num_cu : 256;
+    const bool same_rounds = ((long long)B * upc_wide + ncu - 1) / ncu == ((long long)nwg_flat + ncu - 1) / ncu;
+    const bool aligned_wide = s->clip_aligned > 0 || aligned_env || (s->clip_aligned < 0 && same_rounds && !getenv("DC_FLAT_UNITS"));
+    const bool aligned = can_align && (narrow || ss || aligned_wide);
     // 16-token waves (dc_layer16.hip) while every clip-aligned 64-token unit still gets a CU of its own (bs <= 8 at T = 1800): in that
     // regime the layer is bound by the LENGTH of one wave's dependency chain, and a 16-token wave's is about half as long.  The
     // embedding stays the narrow 32-token form (its 128-token unit records feed layer 0).  DC_NO_LAYER16=1 keeps the 32-token form.
@@ -914,7 +946,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     // k_layer16: the clip's workgroups share the combine of the previous layer's unit records inside the launch (dc_layer16.hip;
     // DC_L16_OWN_COMBINE=1: every workgroup combines alone, round 4's form).  Tags: captured steps 16 * (graph step + *d_iter) + layer + 1,
     // eager launches from a sequence of their own above them - consecutive launches never share a tag.
-    const bool l16_shared = layer16 && !getenv("DC_L16_OWN_COMBINE");
+    const bool l16_shared = layer16 && !s->l16_own && !getenv("DC_L16_OWN_COMBINE");
     const unsigned l16_tag = folded ? 16u * (unsigned)graph_step : (0x40000000u | (16u * (s->l16_seq++ & 0x3ffffffu)));
     const size_t rec_stride = wgr ? (size_t)nwg * 2 * DC_REC_FLOATS : 0;
     // (the kernels write records at recs + rec_stride + wg * 2 * DC_REC_FLOATS: both alternating buffers must lie inside d_recs)
@@ -933,7 +965,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     const bool fuse_extra = narrow && aligned && !ss && ff == fs && fuse_silu && s->h_model.film_w16 && s->dbg_first < 0 && !s->prof.on &&
                             !getenv("DC_NO_FUSE_EMBED");
     DcEmbedArgs ea{};
-    if (fuse_embed) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, aligned ? upc : 0, ss ? 1 : 0, 0};
+    if (fuse_embed) ea = DcEmbedArgs{dmod, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, aligned ? upc : 0, ss ? 1 : 0, 0};
     if (fuse_extra) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, upc, 0, 1};
     const DcUpdate upd{s->d_zslot, s->d_status, (loop_mode ? s->upd_flags : 0) | (getenv("DC_L16_TEST_DROP_SLICE") ? DC_UPD_TEST_DROP_SLICE : 0),
                        folded ? graph_step : -1, nullptr};
@@ -952,15 +984,16 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
                                        want_stamps_film ? s->d_stamps + 252 : nullptr,
                                        adapt ? s->d_film_rate + 1024 * s->film_rate_parity : nullptr,
                                        adapt ? s->d_film_rate + 1024 * (s->film_rate_parity ^ 1) : nullptr, iter_base,
-                                       s->h_model.film_w16, film_b16, (fuse_embed || fuse_extra) ? &ea : nullptr, s->d_status));
+                                       film_tail ? s->h_model.film_w16_tail : s->h_model.film_w16, film_b16,
+                                       (fuse_embed || fuse_extra) ? &ea : nullptr, s->d_status));
     s->film_rate_parity ^= 1;
     const int nl_run = (s->dbg_layers >= 0 && s->dbg_layers < L) ? s->dbg_layers : L;
     if (s->cfg.no_eff) {
-        LAUNCH(K_EMBED, dc_launch_embed_front_full(st, fs, s->d_model, x_src, s->d_h, s->d_kv_sa[0], M, T, B, s->KT));
+        LAUNCH(K_EMBED, dc_launch_embed_front_full(st, fs, ss, dmod, x_src, s->d_h, s->d_kv_sa[0], M, T, B, s->KT));
         for (int l = 0; l < nl_run; ++l) {
             DcUpdate u = upd;              // (stage stamps of layer 3, tools/stage_stamps_full.py + a -DDC_FULL_STAMPS build: DcUpdate::stamps carries the buffer)
             u.stamps = (want_stamps && l == 3) ? s->d_stamps : nullptr;
-            LAUNCH(K_LAYER, dc_launch_layer_full(st, fs, s->d_model, l, s->d_h, s->d_E, s->NT, s->d_kv_sa[l & 1], s->d_kv_sa[(l + 1) & 1],
+            LAUNCH(K_LAYER, dc_launch_layer_full(st, fs, ss, dmod, l, s->d_h, s->d_E, s->NT, s->d_kv_sa[l & 1], s->d_kv_sa[(l + 1) & 1],
                                                  s->d_kv_ca, s->d_length, x_src, x_dst, loop_mode ? 1 : 0, s->d_coef_cur,
                                                  s->d_snap_cur, s->d_snaps, M, T, B, s->KT,
                                                  (l == nl_run - 1) ? (s->dbg_stage ? s->dbg_stage : (nl_run < L ? 3 : 0)) : 0, u));
@@ -1014,6 +1047,18 @@ int steps_per_graph(int S) {
 }
 
 // h_coef: [S][DC_COEF] per-timestep scalars (dc_common.h); flags: DC_UPD_*; d_step_noise: [S][B][Tx][P] or nullptr
+#ifndef DC_BF16_TAIL_DEFAULT
+#define DC_BF16_TAIL_DEFAULT 4
+#endif
+}  // namespace
+extern "C" DC_EXPORT int32_t dc_precise_tail_default(int32_t precision);
+namespace {
+// split-operand evaluations (the precise tail, dc_sampler_set_precise_forward) exist for: fp16 / bf16 precision, linear attention, no test hooks
+bool can_split_steps(const dc_sampler* s) {
+    return (s->cfg.precision == DC_PREC_FP16 || s->cfg.precision == DC_PREC_BF16) && s->dbg_layers < 0 && s->dbg_first < 0 &&
+           s->dbg_stage == 0 && s->d_model_split;
+}
+
 int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const float* h_coef,
                 const int32_t* h_snap_iters, int n_snap, float* d_snaps_user, hipStream_t user, bool profile,
                 int flags = 0, const float* d_step_noise = nullptr) {
@@ -1087,7 +1132,7 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     const bool no_graph = getenv("DC_DISABLE_GRAPH") != nullptr;
     // precise tail: the loop's last `tail` model evaluations on split operands (dc_sampler_set_precise_tail; DC_PRECISE_TAIL=k overrides):
     // fp16 / bf16 precision, linear attention, no test hooks
-    int tail = s->tail_split >= 0 ? s->tail_split : (s->cfg.precision == DC_PREC_BF16 ? 8 : 1);
+    int tail = s->tail_split >= 0 ? s->tail_split : dc_precise_tail_default(s->cfg.precision);
     bool tail_asked = s->tail_split >= 0;
     if (const char* e = getenv("DC_PRECISE_TAIL")) tail = atoi(e), tail_asked = true;
     // An EPSILON model's final sample is sqrt(1 / abar) x_t - sqrt(1 / abar - 1) eps, not the last evaluations' prediction: what the plain
@@ -1096,9 +1141,7 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     if (!tail_asked && (flags & DC_UPD_EPS)) tail = S;
     // (clip strides that are not whole 32-frame groups - T = 900 x 128 unpadded - and short clips run the split evaluations in the
     // per-group record form with its combine launches: no measurable cost at one evaluation per loop, 70.6 vs 70.6 ms at bs = 128 x 900)
-    if ((s->cfg.precision != DC_PREC_FP16 && s->cfg.precision != DC_PREC_BF16) || s->cfg.no_eff || s->dbg_layers >= 0 || s->dbg_first >= 0 || s->dbg_stage != 0 ||
-        !s->d_model_split)
-        tail = 0;
+    if (!can_split_steps(s)) tail = 0;
     // (a tail of the whole loop splits every replay's graph; any shorter one lives in the last replay and is clipped to its steps)
     const bool tail_all = tail >= S;
     tail = std::max(0, std::min(tail, std::min(S, steps_per_graph(S))));
@@ -1117,7 +1160,9 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
       for (int part = 0; part < ((tail && replays > 1) ? 2 : 1); ++part) {
         const int tail_here = (part == 1 || replays == 1) ? tail : (tail_all ? K : 0);
         const int launches = (tail && replays > 1) ? (part == 0 ? replays - 1 : 1) : replays;
-        const unsigned long long fk = form_key(s) | ((unsigned long long)tail_here << 40);
+        // (g1 bit: the plain evaluations of a loop WITH a tail read G' scale tiles, those of a loop without one G' - 1 tiles - two
+        // different captures of the same part-0 graph when S > 64)
+        const unsigned long long fk = form_key(s) | ((unsigned long long)tail_here << 40) | ((tail > 0 ? 1ull : 0ull) << 39);
         auto current = [&]() {
             return s->graph && s->graph_B == s->B && s->graph_T == s->T && s->graph_Tx == s->Tx && s->graph_K == K && s->graph_form == fk;
         };
@@ -1455,8 +1500,31 @@ int dc_sampler_set_conditioning(dc_sampler* s, const float* d_xf_proj, const flo
 
 int dc_sampler_set_precise_tail(dc_sampler* s, int32_t steps) {
     if (!s) return fail(DC_ERR_INVALID, "null sampler");
-    if (steps < 0) return fail(DC_ERR_INVALID, "precise tail: steps >= 0");
+    if (steps < -1) return fail(DC_ERR_INVALID, "precise tail: steps >= 0, or -1 for the precision's default");
     s->tail_split = steps;
+    return DC_OK;
+}
+
+int32_t dc_precise_tail_default(int32_t precision) {
+    return precision == DC_PREC_FP16 ? 1 : precision == DC_PREC_BF16 ? DC_BF16_TAIL_DEFAULT : 0;
+}
+
+int dc_sampler_set_clip_aligned(dc_sampler* s, int32_t mode) {
+    if (!s) return fail(DC_ERR_INVALID, "null sampler");
+    if (mode < -1 || mode > 1) return fail(DC_ERR_INVALID, "clip-aligned units: 1 (always), 0 (flat units), -1 (the library's rule)");
+    s->clip_aligned = mode;
+    return DC_OK;
+}
+
+int dc_sampler_set_precise_forward(dc_sampler* s, int32_t on) {
+    if (!s) return fail(DC_ERR_INVALID, "null sampler");
+    s->precise_forward = on != 0;
+    return DC_OK;
+}
+
+int dc_sampler_set_combine_exchange(dc_sampler* s, int32_t on) {
+    if (!s) return fail(DC_ERR_INVALID, "null sampler");
+    s->l16_own = on == 0;
     return DC_OK;
 }
 
@@ -1595,7 +1663,7 @@ int dc_sampler_denoise(dc_sampler* s, const float* d_x, const int32_t* h_timeste
     if ((rc = sync_in(s, user))) return rc;
     HIP_TRY(hipMemcpyAsync(s->d_t_clip, h_timesteps, (size_t)s->B * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if ((rc = enqueue_step(s, st, false, d_x, d_out))) return rc;
+    if ((rc = enqueue_step(s, st, false, d_x, d_out, -1, s->precise_forward && can_split_steps(s)))) return rc;
     return sync_out(s, user);
 }
 
@@ -1653,7 +1721,10 @@ int dc_sampler_status(dc_sampler* s, int32_t* h_status, int32_t clear) {
     HIP_TRY(hipSetDevice(s->cfg.device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     HIP_TRY(hipMemcpy(h_status, s->d_status, 4, hipMemcpyDeviceToHost));
-    if ((*h_status & DC_STATUS_NONFINITE) && s->d_E && s->G > 0) {
+    // a timed-out combine exchange means the launch's workgroups were not co-resident (a shared GPU, or a second sampler's launches
+    // on another stream): this sampler's later loops run the form without the exchange (a re-run of the failed loop is then valid)
+    if (*h_status & DC_STATUS_SYNC_TIMEOUT) s->l16_own = true;
+    if ((*h_status & DC_STATUS_NONFINITE) && !(*h_status & DC_STATUS_SYNC_TIMEOUT) && s->d_E && s->G > 0) {
         // diagnosis (failure path only): was it the fp16 storage of the FiLM tiles?  The range check is not in the production GEMM's
         // epilogue (it measured at 4 % of that kernel); the tiles are scanned here instead - the last step's as they stand, then,
         // while nothing was found, the tiles of every other timestep of the last loop (the GEMM re-run per timestep: the modulation

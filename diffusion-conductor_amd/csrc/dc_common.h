@@ -83,6 +83,7 @@ struct DcModel {
     // row 16 fb + pi(l & 15), k = 32 ks32 + 8 (l >> 4) + j with pi = (0..3, 8..11, 4..7, 12..15); constants [tile][fb][l >> 4][4]
     const bf16x8* film_w16;
     const float* film_b16;
+    const bf16x8* film_w16_tail;                // bf16 precision: the same image in fp16, the FiLM GEMM operand of the precise tail's evaluations (dc_ddim.h)
     const float *film_b_g1, *film_b16_g1;     // the same constants with the scale tiles holding G' instead of G' - 1 (plain-operand consumers)
     const float* lin_wt;     // `linear` weight transposed [64][512]
     const bf16x8* lin_pack;  // `linear` weight [512][64] as natural-k fragments [ot 16][ks 4], bf16 hi + lo (k_cond_pp64)

@@ -1285,10 +1285,92 @@ DEV float film_affine(uint32_t g2, float n, uint32_t h2) {
         return add_mix_h<HI>(h2, fma_mix_h<HI>(g2, n, n));
 }
 
+// ---- packed-fp16 form of the stylization's elementwise chain (fp16 precision, plain-operand evaluations of a loop with a precise
+// tail: G1).  The chain's result is rounded to fp16 for the MFMA anyway; computing it in fp16 from the affine on saves one vector
+// instruction per element (DC_STYL_PK16 = 1: n-hat through v_fma_mix{lo,hi}_f16 - fp32 arithmetic on the fp32 statistics, ONE rounding -,
+// then v_pk_fma_f16 / v_pk_add_f16 / v_pk_mul_f16 with v_exp_f16 / v_rcp_f16 per half: 4.5 instead of 5.5 per element, -192 of
+// 4 537 per wave and layer) or 1.5 (DC_STYL_PK16 = 2: n-hat as v_pk_fma_f16 on fp16 copies of rstd / shift as well: 4.0).  hipcc
+// extracts the high half of a pair through SDWA and re-packs with v_pack_b32_f16; the SDWA forms below write the high half in place
+// (tools/probe_pk16.hip checks them on the box).
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+// The high half is written in place by a second SDWA instruction (dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE).  It must not issue right
+// behind the instruction that wrote the low half of the same register: a transcendental's result is not forwarded to a dependent
+// instruction in the next slots (gfx940+ "trans use" hazard; the compiler's hazard recognizer does not look inside asm statements) -
+// back to back, a quarter of the values came out wrong on the box (tools/probe_pk16.hip).  The callers therefore run the eight low
+// halves of a tile first and the eight high halves after them, with a scheduling barrier between the two groups.
+DEV uint32_t exp2neg_lo16(uint32_t u) {                       // {2^-u.lo, 0}
+    uint32_t e;
+    asm("v_exp_f16_sdwa %0, -%1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(e) : "v"(u));
+    return e;
+}
+DEV void exp2neg_hi16(uint32_t& e, uint32_t u) {             // e.hi = 2^-u.hi, e.lo kept
+    asm("v_exp_f16_sdwa %0, -%1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(e) : "v"(u));
+}
+DEV uint32_t rcp_lo16(uint32_t d) {
+    uint32_t r;
+    asm("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(d));
+    return r;
+}
+DEV void rcp_hi16(uint32_t& r, uint32_t d) {
+    asm("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(r) : "v"(d));
+}
+DEV uint32_t nhat_mix16(uint32_t y2, float rstd, float shift) {      // {fp16(y.lo * rstd + shift), fp16(y.hi * rstd + shift)}, fp32 inside
+    uint32_t n;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(n) : "v"(y2), "v"(rstd), "v"(shift));
+    return n;
+}
+// u / (1 + 2^-u) on the eight packed pairs of a tile (in place)
+DEV void silu_l2_tile16(uint32_t (&u)[8]) {
+    uint32_t e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = exp2neg_lo16(u[k]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) exp2neg_hi16(e[k], u[k]);
+    __builtin_amdgcn_sched_barrier(0);
+    const h16x2 one = {(_Float16)1.f, (_Float16)1.f};
+    uint32_t r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        e[k] = __builtin_bit_cast(uint32_t, (h16x2)(__builtin_bit_cast(h16x2, e[k]) + one));
+        r[k] = rcp_lo16(e[k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rcp_hi16(r[k], e[k]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u[k] = __builtin_bit_cast(uint32_t, (h16x2)(__builtin_bit_cast(h16x2, u[k]) * __builtin_bit_cast(h16x2, r[k])));
+}
+
 // one k-tile of the FiLM-modulated, SiLU'ed operand: z = SiLU(nhat*G' + H'), gp = G' - 1 (split operands) or G'; everything in the log2(e)
 // scaling of silu_l2_pair: rstd / shift arrive multiplied by log2(e), hp = log2(e) H', z = log2(e) SiLU(.)
 template <class T16, bool SPLIT, class YTile, bool G1 = false>
 DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shift, const f16x16& gp, const f16x16& hp) {
+#if defined(DC_STYL_PK16) && DC_STYL_PK16
+    if constexpr (std::is_same<YTile, f16x16>::value && std::is_same<T16, _Float16>::value && !SPLIT && G1) {
+        const u32x8 yw = __builtin_bit_cast(u32x8, y), gw = __builtin_bit_cast(u32x8, gp), hw = __builtin_bit_cast(u32x8, hp);
+        uint32_t zw[8];
+#if DC_STYL_PK16 == 2
+        const h16x2 rs = {(_Float16)rstd, (_Float16)rstd}, sh = {(_Float16)shift, (_Float16)shift};
+#endif
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#if DC_STYL_PK16 == 2
+            const h16x2 n = __builtin_elementwise_fma(__builtin_bit_cast(h16x2, yw[k]), rs, sh);
+#else
+            const h16x2 n = __builtin_bit_cast(h16x2, nhat_mix16(yw[k], rstd, shift));
+#endif
+            zw[k] = __builtin_bit_cast(uint32_t, (h16x2)__builtin_elementwise_fma(__builtin_bit_cast(h16x2, gw[k]), n, __builtin_bit_cast(h16x2, hw[k])));
+        }
+        silu_l2_tile16(zw);
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+        zf.hi[0] = __builtin_bit_cast(v8<T16>, (u32x4_){zw[0], zw[1], zw[2], zw[3]});
+        zf.hi[1] = __builtin_bit_cast(v8<T16>, (u32x4_){zw[4], zw[5], zw[6], zw[7]});
+        return;
+    }
+#endif
     f32x16 z;
     if constexpr (std::is_same<YTile, f16x16>::value) {      // packed y (non-split formats): three mixed-precision FMAs per element
         const u32x8 yw = __builtin_bit_cast(u32x8, y), gw = __builtin_bit_cast(u32x8, gp), hw = __builtin_bit_cast(u32x8, hp);

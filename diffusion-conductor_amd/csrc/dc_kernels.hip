@@ -1864,11 +1864,13 @@ DEV void store_h_lanes(const f32x16 (&h)[4], float* __restrict__ hbuf, int g, in
 }
 
 // K (FT form) and V (TF form) of n = LN(h) -> the 16 fragments of this group's key tile
-template <class T16>
-DEV void front_full(const XFrag<T16, false> (&nf)[4], const v8<T16>* __restrict__ wk, const v8<T16>* __restrict__ wv,
+// SPLIT: the projections on split operands (hi + lo images, three MFMAs per product); the key tile's fragments stay plain 16-bit.
+template <class T16, bool SPLIT = false>
+DEV void front_full(const XFrag<T16, SPLIT> (&nf)[4], const v8<T16>* __restrict__ wk, const v8<T16>* __restrict__ wv,
                     v8<T16>* __restrict__ tile, int lane, int c, int hh) {
-    const float* bk = reinterpret_cast<const float*>(wk + 32 * 64);     // plain bias[128] behind the 32 fragments
-    const float* bv = reinterpret_cast<const float*>(wv + 32 * 64);
+    constexpr int HL = SPLIT ? 2 : 1;
+    const float* bk = reinterpret_cast<const float*>(wk + 32 * 64 * HL);     // plain bias[128] behind the 32 (split: 64) fragments
+    const float* bv = reinterpret_cast<const float*>(wv + 32 * 64 * HL);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         f32x16 K;
@@ -1878,13 +1880,13 @@ DEV void front_full(const XFrag<T16, false> (&nf)[4], const v8<T16>* __restrict_
 #pragma unroll
             for (int i = 0; i < 4; ++i) K[4 * q + i] = v[i];
         }
-        mma_ot<4, 4, T16, false>(K, wk, t, nf, lane);
+        mma_ot<4, 4, T16, SPLIT>(K, wk, t, nf, lane);
         XFrag<T16, false> kf;
         make_frag<T16, false>(K, kf);
         tile[(2 * t) * 64 + lane] = kf.hi[0];
         tile[(2 * t + 1) * 64 + lane] = kf.hi[1];
         f32x16 V = splat(bv[32 * t + c]);
-        mmb_oc<4, 4, T16, false>(V, wv, t, nf, lane);
+        mmb_oc<4, 4, T16, SPLIT>(V, wv, t, nf, lane);
         XFrag<T16, false> vf;
         make_frag<T16, false>(V, vf);
         tile[(8 + 2 * t) * 64 + lane] = vf.hi[0];
@@ -1899,8 +1901,8 @@ DEV void front_full(const XFrag<T16, false> (&nf)[4], const v8<T16>* __restrict_
 #ifndef DC_FULL_PRIO
 #define DC_FULL_PRIO 1
 #endif
-template <class T16>
-DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const f32x16 (&h)[4],
+template <class T16, bool SPLIT = false /* the query projection on split operands; scores, weights and values stay plain 16-bit */>
+DEV void full_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const f32x16 (&h)[4],
                      const v8<T16>* __restrict__ wq, const v8<T16>* __restrict__ kv, int nkt, int tok0, int key_lo,
                      int key_hi, bool q_pad, bool any_pad, char* lds, bool active, int wave, int lane, int hh,
                      unsigned long long* stamps = nullptr /* diagnostic builds: two slots of this wave */) {
@@ -1908,12 +1910,12 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
     XFrag<T16, false> qf[4];
     {
         f32x16 q[4];
-        XFrag<T16, false> nf[4];
-        ln_frags<T16, false>(nf, h);
-        const float* bq = reinterpret_cast<const float*>(wq + 32 * 64);
+        XFrag<T16, SPLIT> nf[4];
+        ln_frags<T16, SPLIT>(nf, h);
+        const float* bq = reinterpret_cast<const float*>(wq + 32 * 64 * (SPLIT ? 2 : 1));
 #pragma unroll
         for (int t = 0; t < 4; ++t) q[t] = ld_ft(bq, t, hh);
-        gemm_wa<4, 4, T16, false>(q, wq, nf, lane);
+        gemm_wa<4, 4, T16, SPLIT>(q, wq, nf, lane);
 #pragma unroll
         for (int t = 0; t < 4; ++t) make_frag<T16, false>(q[t], qf[t]);
     }
@@ -2114,12 +2116,12 @@ DEV void full_attend(ytile<false> (&y)[4], float& y_rstd, float& y_shift, const 
             for (int r = 0; r < 8; ++r) Y[t][8 * sh + r] *= inv;
         }
         st.add(Y[t]);
-        put_y<false>(y[t], Y[t]);
+        put_y<SPLIT>(y[t], Y[t]);
     }
     st.finish(y_rstd, y_shift);
 }
 
-template <class T16>
+template <class T16, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void k_embed_front_full(const DcModel* __restrict__ dm, const float* __restrict__ x,
                                                              float* __restrict__ hbuf, v8<T16>* __restrict__ kv_next,
                                                              int M, int T, int KT, int WPC) {
@@ -2157,10 +2159,10 @@ __global__ __launch_bounds__(512, 2) void k_embed_front_full(const DcModel* __re
         }
     store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok);
     const DcLayer& L = dm->layer[0];
-    XFrag<T16, false> nf[4];
-    ln_frags<T16, false>(nf, h);
-    front_full<T16>(nf, reinterpret_cast<const W*>(L.img_sa_k), reinterpret_cast<const W*>(L.img_sa_v),
-                    kv_next + ((size_t)cx.b * KT + (cx.g - cx.g_lo)) * 16 * 64, lane, cx.c, cx.hh);
+    XFrag<T16, SPLIT> nf[4];
+    ln_frags<T16, SPLIT>(nf, h);
+    front_full<T16, SPLIT>(nf, reinterpret_cast<const W*>(L.img_sa_k), reinterpret_cast<const W*>(L.img_sa_v),
+                           kv_next + ((size_t)cx.b * KT + (cx.g - cx.g_lo)) * 16 * 64, lane, cx.c, cx.hh);
 }
 
 #ifdef DC_FULL_STAMPS          // diagnostic build: s_memrealtime of workgroup 3's waves at the block boundaries of k_layer_full
@@ -2174,7 +2176,11 @@ __global__ __launch_bounds__(512, 2) void k_embed_front_full(const DcModel* __re
 #define FSTAMP(i) do {} while (0)
 #define FSTAMP_PTR(i) nullptr
 #endif
-template <class T16>
+// SPLIT (the precise tail's evaluations, EPSILON loops; dc_ddim.h): every 128-wide GEMM - query / key / value projections, the three
+// stylization out-projections, the FFN - on split operands through the model record's split stage images; the attention itself
+// (scores, weights, values: activations, whose rounding averages out over the keys) stays plain 16-bit.  Same register bound: what does
+// not fit goes to scratch - this instantiation runs a few evaluations per loop, or the loops of an EPSILON model.
+template <class T16, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf,
                                                        const f16x16* __restrict__ E, int NT, const v8<T16>* __restrict__ kv_cur,
                                                        v8<T16>* __restrict__ kv_next, const v8<T16>* __restrict__ kv_ca,
@@ -2194,28 +2200,29 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
     const bool q_pad = cx.n >= len;
     const int key_lo = cx.b * T, key_hi = min((cx.b + 1) * T, M);
     const f16x8* Eg = reinterpret_cast<const f16x8*>(E) + ((size_t)cx.g * NT + (size_t)l * 24) * 128;
-    auto consts = [](const bf16x8* img) { return reinterpret_cast<const float*>(reinterpret_cast<const W*>(img) + 32 * 64); };
+    constexpr int HL = SPLIT ? 2 : 1;
+    auto consts = [](const bf16x8* img) { return reinterpret_cast<const float*>(reinterpret_cast<const W*>(img) + 32 * 64 * HL); };
     f32x16 h[4];
-    ytile<false> y[4];
+    ytile<SPLIT> y[4];
     float y_rstd, y_shift;
     // ---- self-attention
     FSTAMP(0);
     load_h(h, hbuf, cx.g, lane);
-    full_attend<T16>(y, y_rstd, y_shift, h, reinterpret_cast<const W*>(L.img_sa_q), kv_cur + (size_t)cx.b * KT * 16 * 64, cx.nkt,
+    full_attend<T16, SPLIT>(y, y_rstd, y_shift, h, reinterpret_cast<const W*>(L.img_sa_q), kv_cur + (size_t)cx.b * KT * 16 * 64, cx.nkt,
                      cx.g_lo * 32, key_lo, key_hi, q_pad, any_pad, lds, cx.active, wave, lane, cx.hh, FSTAMP_PTR(8));
     FSTAMP(1);
     load_h(h, hbuf, cx.g, lane);           // not kept live across the key loop
-    styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg, consts(L.img_sa_o), reinterpret_cast<const W*>(L.img_sa_o), lane,
+    styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg, consts(L.img_sa_o), reinterpret_cast<const W*>(L.img_sa_o), lane,
                                 cx.hh);
     if (stop_after == 1) { store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok); return; }
     // ---- cross-attention (no mask, transformer.py:244-264)
     FSTAMP(2);
     store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok);
-    full_attend<T16>(y, y_rstd, y_shift, h, reinterpret_cast<const W*>(L.img_ca_q), kv_ca + ((size_t)l * B + cx.b) * KT * 16 * 64,
+    full_attend<T16, SPLIT>(y, y_rstd, y_shift, h, reinterpret_cast<const W*>(L.img_ca_q), kv_ca + ((size_t)l * B + cx.b) * KT * 16 * 64,
                      cx.nkt, cx.g_lo * 32, key_lo, key_hi, false, false, lds, cx.active, wave, lane, cx.hh, FSTAMP_PTR(10));
     FSTAMP(3);
     load_h(h, hbuf, cx.g, lane);
-    styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg + 8 * 128, consts(L.img_ca_o), reinterpret_cast<const W*>(L.img_ca_o), lane,
+    styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 8 * 128, consts(L.img_ca_o), reinterpret_cast<const W*>(L.img_ca_o), lane,
                                 cx.hh);
     if (stop_after == 2) { store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok); return; }
     // ---- FFN
@@ -2223,17 +2230,17 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
     {
         const W* w1 = reinterpret_cast<const W*>(L.img_ffn_w1);
         const W* w2 = reinterpret_cast<const W*>(L.img_ffn_w2);
-        const float* cb = reinterpret_cast<const float*>(w2 + 16 * 64);          // b1 ftvec[2] | b2 ftvec[4]
+        const float* cb = reinterpret_cast<const float*>(w2 + 16 * 64 * HL);          // b1 ftvec[2] | b2 ftvec[4]
         f32x16 u[2];
         {
-            XFrag<T16, false> hf[4];
+            XFrag<T16, SPLIT> hf[4];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) make_frag<T16, false>(h[kt], hf[kt]);
+            for (int kt = 0; kt < 4; ++kt) make_frag<T16, SPLIT>(h[kt], hf[kt]);
 #pragma unroll
             for (int t = 0; t < 2; ++t) u[t] = ld_ft(cb, t, cx.hh);
-            gemm_wa<2, 4, T16, false>(u, w1, hf, lane);
+            gemm_wa<2, 4, T16, SPLIT>(u, w1, hf, lane);
         }
-        XFrag<T16, false> uf[2];
+        XFrag<T16, SPLIT> uf[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -2242,30 +2249,30 @@ __global__ __launch_bounds__(512, 2) void k_layer_full(const DcModel* __restrict
                 u[kt][2 * r] = gg.x;
                 u[kt][2 * r + 1] = gg.y;
             }
-            make_frag<T16, false>(u[kt], uf[kt]);
+            make_frag<T16, SPLIT>(u[kt], uf[kt]);
         }
         RowStats st;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f32x16 yf = ld_ft(cb + 64, t, cx.hh);
-            mma_ot<4, 2, T16, false>(yf, w2, t, uf, lane);
+            mma_ot<4, 2, T16, SPLIT>(yf, w2, t, uf, lane);
             st.add(yf);
-            put_y<false>(y[t], yf);
+            put_y<SPLIT>(y[t], yf);
         }
         st.finish(y_rstd, y_shift);
     }
     FSTAMP(5);
-    styl_accumulate<T16, false>(h, y, y_rstd, y_shift, Eg + 16 * 128, consts(L.img_ffn_o), reinterpret_cast<const W*>(L.img_ffn_o), lane,
+    styl_accumulate<T16, SPLIT>(h, y, y_rstd, y_shift, Eg + 16 * 128, consts(L.img_ffn_o), reinterpret_cast<const W*>(L.img_ffn_o), lane,
                                 cx.hh);
     FSTAMP(6);
     if (!cx.active) return;
     if (!last || stop_after == 3) {
         store_h_lanes(h, hbuf, cx.g, lane, cx.lane_ok);
         if (last) return;
-        XFrag<T16, false> nf[4];
-        ln_frags<T16, false>(nf, h);
+        XFrag<T16, SPLIT> nf[4];
+        ln_frags<T16, SPLIT>(nf, h);
         const DcLayer& Ln = dm->layer[l + 1];
-        front_full<T16>(nf, reinterpret_cast<const W*>(Ln.img_sa_k), reinterpret_cast<const W*>(Ln.img_sa_v),
+        front_full<T16, SPLIT>(nf, reinterpret_cast<const W*>(Ln.img_sa_k), reinterpret_cast<const W*>(Ln.img_sa_v),
                         kv_next + ((size_t)cx.b * KT + (cx.g - cx.g_lo)) * 16 * 64, lane, cx.c, cx.hh);
         FSTAMP(7);
         return;
@@ -2700,38 +2707,36 @@ hipError_t dc_launch_layer(hipStream_t st, int fmt, bool split, bool wgr, const 
 }
 
 // ---- no_eff variant ------------------------------------------------------------------
-template <class T16>
+template <class T16, bool SP>
 static hipError_t launch_full_t(hipStream_t st, int which, const DcModel* dm, int l, const float* x, float* hbuf, const void* E,
                                 int NT, const void* kv_cur, void* kv_next, const void* kv_ca, const int* length,
                                 const float* xin, float* xout, int out_mode, const float* coef_cur, const int* snap_cur,
                                 float* snaps, int M, int T, int B, int KT, int stop_after, const DcUpdate& upd) {
     const int WPC = (KT + 7) / 8;
     static unsigned long long optin_done = 0;   // key-tile double buffer (32 KiB) + per-wave query fragments (64 KiB) > 64 KiB of dynamic LDS
-    if (hipError_t e = lds_optin((const void*)k_layer_full<T16>, DC_FULL_LDS, optin_done)) return e;
+    if (hipError_t e = lds_optin((const void*)k_layer_full<T16, SP>, DC_FULL_LDS, optin_done)) return e;
     if (which == 0)
-        k_embed_front_full<T16><<<dim3(B * WPC), dim3(512), 0, st>>>(dm, x, hbuf, (v8<T16>*)kv_next, M, T, KT, WPC);
+        k_embed_front_full<T16, SP><<<dim3(B * WPC), dim3(512), 0, st>>>(dm, x, hbuf, (v8<T16>*)kv_next, M, T, KT, WPC);
     else
-        k_layer_full<T16><<<dim3(B * WPC), dim3(512), DC_FULL_LDS, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const v8<T16>*)kv_cur,
-                                                                   (v8<T16>*)kv_next, (const v8<T16>*)kv_ca, length, xin, xout,
-                                                                   out_mode, coef_cur, snap_cur, snaps, M, T, B, KT, WPC,
-                                                                   stop_after, upd);
+        k_layer_full<T16, SP><<<dim3(B * WPC), dim3(512), DC_FULL_LDS, st>>>(dm, l, hbuf, (const f16x16*)E, NT, (const v8<T16>*)kv_cur,
+                                                                       (v8<T16>*)kv_next, (const v8<T16>*)kv_ca, length, xin, xout,
+                                                                       out_mode, coef_cur, snap_cur, snaps, M, T, B, KT, WPC,
+                                                                       stop_after, upd);
     return hipGetLastError();
 }
-hipError_t dc_launch_embed_front_full(hipStream_t st, int fmt, const DcModel* dm, const float* x, float* hbuf, void* kv_next,
+hipError_t dc_launch_embed_front_full(hipStream_t st, int fmt, bool split, const DcModel* dm, const float* x, float* hbuf, void* kv_next,
                                       int M, int T, int B, int KT) {
-    return fmt == 1 ? launch_full_t<_Float16>(st, 0, dm, 0, x, hbuf, nullptr, 0, nullptr, kv_next, nullptr, nullptr, nullptr, nullptr,
-                                              0, nullptr, nullptr, nullptr, M, T, B, KT, 0, DcUpdate{})
-                    : launch_full_t<__bf16>(st, 0, dm, 0, x, hbuf, nullptr, 0, nullptr, kv_next, nullptr, nullptr, nullptr, nullptr, 0,
-                                            nullptr, nullptr, nullptr, M, T, B, KT, 0, DcUpdate{});
+    DISPATCH(fmt, split, (launch_full_t<T16, SP>(st, 0, dm, 0, x, hbuf, nullptr, 0, nullptr, kv_next, nullptr, nullptr, nullptr, nullptr,
+                                                 0, nullptr, nullptr, nullptr, M, T, B, KT, 0, DcUpdate{})));
+    return LAUNCH_CHECK();
 }
-hipError_t dc_launch_layer_full(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
+hipError_t dc_launch_layer_full(hipStream_t st, int fmt, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                 const void* kv_cur, void* kv_next, const void* kv_ca, const int* length, const float* xin,
                                 float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps, int M,
                                 int T, int B, int KT, int stop_after, const DcUpdate& upd) {
-    return fmt == 1 ? launch_full_t<_Float16>(st, 1, dm, l, nullptr, hbuf, E, NT, kv_cur, kv_next, kv_ca, length, xin, xout, out_mode,
-                                              coef_cur, snap_cur, snaps, M, T, B, KT, stop_after, upd)
-                    : launch_full_t<__bf16>(st, 1, dm, l, nullptr, hbuf, E, NT, kv_cur, kv_next, kv_ca, length, xin, xout, out_mode,
-                                            coef_cur, snap_cur, snaps, M, T, B, KT, stop_after, upd);
+    DISPATCH(fmt, split, (launch_full_t<T16, SP>(st, 1, dm, l, nullptr, hbuf, E, NT, kv_cur, kv_next, kv_ca, length, xin, xout, out_mode,
+                                                 coef_cur, snap_cur, snaps, M, T, B, KT, stop_after, upd)));
+    return LAUNCH_CHECK();
 }
 hipError_t dc_launch_ca_kv(hipStream_t st, int fmt, const DcModel* dm, const void* nh_hi, const void* nh_lo, void* kv_ca,
                            int M, int T, int G, int B, int KT, int L) {

@@ -80,12 +80,13 @@ hipError_t dc_launch_step_noise(hipStream_t st, float* z, size_t n, unsigned lon
 hipError_t dc_launch_scan_f16(hipStream_t st, const void* e, size_t bytes, int* status);
 // rec_stride: floats between the two alternating unit-record buffers (0 = single buffer, non-wgr)
 
-// ---- no_eff variant (full T x T attention); non-split formats only.  KT = key tiles per clip array.
+// ---- no_eff variant (full T x T attention).  KT = key tiles per clip array.  split: the 128-wide GEMMs on split operands (`dm` is then
+// the model record with the split stage images); the attention's own operands stay plain 16-bit.
 hipError_t dc_launch_ca_kv(hipStream_t st, int fmt, const DcModel* dm, const void* nh_hi, const void* nh_lo, void* kv_ca,
                            int M, int T, int G, int B, int KT, int L);
-hipError_t dc_launch_embed_front_full(hipStream_t st, int fmt, const DcModel* dm, const float* x, float* hbuf, void* kv_next,
+hipError_t dc_launch_embed_front_full(hipStream_t st, int fmt, bool split, const DcModel* dm, const float* x, float* hbuf, void* kv_next,
                                       int M, int T, int B, int KT);
-hipError_t dc_launch_layer_full(hipStream_t st, int fmt, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
+hipError_t dc_launch_layer_full(hipStream_t st, int fmt, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                 const void* kv_cur, void* kv_next, const void* kv_ca, const int* length, const float* xin,
                                 float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps, int M,
                                 int T, int B, int KT, int stop_after, const DcUpdate& upd);

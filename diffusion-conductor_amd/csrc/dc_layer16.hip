@@ -520,6 +520,12 @@ DEV void gather16_finish(Gran16 r, const unsigned long long* __restrict__ gran, 
         const bool ok = (unsigned)(r.g[0] >> 32) == tag && (unsigned)(r.g[1] >> 32) == tag && (unsigned)(r.g[2] >> 32) == tag &&
                         (unsigned)(r.g[3] >> 32) == tag;
         if (ok || ++spins > L16_POLL_LIMIT) break;
+        // another workgroup of this loop has already given up: the loop's results are void whatever arrives now, so the launches
+        // that follow must not each wait out the limit again (one timeout per loop, not one per layer launch)
+        if ((spins & 63u) == 0u && status && (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & DC_STATUS_SYNC_TIMEOUT)) {
+            spins = L16_POLL_LIMIT + 1;
+            break;
+        }
         __builtin_amdgcn_s_sleep(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) r.g[i] = __hip_atomic_load(G + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

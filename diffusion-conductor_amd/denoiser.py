@@ -94,6 +94,10 @@ class MotionTransformer(nn.Module):
                 self._native.set_encoder_format(self.encoder_format)
             if self.precise_tail is not None:
                 self._native.set_precise_tail(self.precise_tail)
+            if self._combine_exchange is not None:
+                self._native.set_combine_exchange(self._combine_exchange)
+            if self._precise_forward:
+                self._native.set_precise_forward(True)
             self._native_dirty = True
         if self._native_dirty:
             self._native.load_state_dict(self.state_dict())
@@ -143,6 +147,35 @@ class MotionTransformer(nn.Module):
     # fp16 precision: the sampling loops' last `precise_tail` model evaluations on split fp16 operands (include/dc_ddim.h,
     # dc_sampler_set_precise_tail); set before the first forward.  DC_PRECISE_TAIL=k in the environment overrides it.
     precise_tail = None       # None: the library's default (1 for fp16, 8 for bf16)
+
+    # Small batches (at most one 64-token unit per CU): whether a clip's workgroups share the attention combine inside a layer launch
+    # (None / True: the library's default) or every workgroup combines alone (False: no in-launch wait - for a GPU shared with other
+    # work, several samplers on streams of one process, or loops whose status nobody reads; dc_ddim.h, dc_sampler_set_combine_exchange).
+    _combine_exchange = None
+
+    @property
+    def combine_exchange(self):
+        return self._combine_exchange
+
+    @combine_exchange.setter
+    def combine_exchange(self, on):
+        self._combine_exchange = None if on is None else bool(on)
+        if self._native is not None:
+            self._native.set_combine_exchange(True if on is None else bool(on))
+
+    # forward() on split operands (the precise tail's evaluation form; dc_ddim.h, dc_sampler_set_precise_forward): the sampler's
+    # step-through path switches it on for the loops whose update keeps the evaluations' error (EPSILON / PREVIOUS_X models, cond_fn).
+    _precise_forward = False
+
+    @property
+    def precise_forward(self):
+        return self._precise_forward
+
+    @precise_forward.setter
+    def precise_forward(self, on):
+        self._precise_forward = bool(on)
+        if self._native is not None:
+            self._native.set_precise_forward(bool(on))
 
     h2d_chunk = 8        # a pinned host batch of at least 2 x this many clips is copied in chunks beside the encoder
     h2d_schedule = (8, 8, 4)     # ... of B/8, B/8, B/4 clips and the rest: the first copy is the only one the encoder waits for

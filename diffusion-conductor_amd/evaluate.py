@@ -215,7 +215,7 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
     out_h = [None, None]
     slot_free = [None, None]             # event: the GPU has consumed the slot's pinned mel / noise buffers
     results = {}
-    own_before = None
+    exchange_before = getattr(enc, "combine_exchange", None)
     ev_first = ev_last = None            # completion events of the first and the last batch: the GPU's own steady-state period
     n_after_first = 0
     waits = {"loader": 0.0, "enqueue": 0.0, "scorer": 0.0}      # where the main thread spent its time (seconds): waiting for the next
@@ -225,8 +225,7 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
             enc.check_numerics = False   # (see above: checked on the scoring thread instead)
             # ... which cannot see the one failure that leaves finite poses: a timed-out combine exchange of the small-batch layer kernel
             # (dc_ddim.h, DC_STATUS_TIMEOUT; possible only on a GPU shared with other work).  Unchecked loops run the form without it.
-            own_before = os.environ.get("DC_L16_OWN_COMBINE")
-            os.environ["DC_L16_OWN_COMBINE"] = "1"
+            enc.combine_exchange = False
         for k in range(nb):
             tw = time.perf_counter()
             bid, mel, gts = pf.take()
@@ -276,10 +275,7 @@ def evaluate_dataset(trainer, root, dim_pose=26, batch_size=32, limit=None, seed
         scorer.close()
         if checked:
             enc.check_numerics = checked
-            if own_before is None:
-                os.environ.pop("DC_L16_OWN_COMBINE", None)
-            else:
-                os.environ["DC_L16_OWN_COMBINE"] = own_before
+            enc.combine_exchange = exchange_before
     dt = time.perf_counter() - t0
     per_clip, total_loss = {}, 0.0
     for k in range(nb):

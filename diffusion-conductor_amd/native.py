@@ -20,7 +20,7 @@ DC_PREC = {"bf16": 0, "mixed": 1, "bf16x3": 2, "fp16": 3}
 EXPORTS = [
     "dc_last_error", "dc_version", "dc_linear_beta_schedule", "dc_ddim_coefficients", "dc_pack_weight",
     "dc_sampler_create", "dc_sampler_destroy", "dc_sampler_set_param", "dc_sampler_finalize_params",
-    "dc_sampler_set_conditioning", "dc_sampler_encode_music", "dc_sampler_set_encoder_format", "dc_sampler_set_precise_tail", "dc_sampler_denoise", "dc_sampler_ddim_loop", "dc_sampler_profile_loop",
+    "dc_sampler_set_conditioning", "dc_sampler_encode_music", "dc_sampler_set_encoder_format", "dc_sampler_set_precise_tail", "dc_precise_tail_default", "dc_sampler_set_precise_forward", "dc_sampler_set_combine_exchange", "dc_sampler_set_clip_aligned", "dc_sampler_denoise", "dc_sampler_ddim_loop", "dc_sampler_profile_loop",
     "dc_kernel_name", "dc_kernel_count", "dc_sampler_workspace_bytes", "dc_sampler_clip_stride", "dc_sampler_debug_denoise",
     "dc_sampler_debug_read", "dc_sampler_debug_layer", "dc_savgol_coefficients", "dc_savgol_filter",
     "dc_ddim_coefficients_ex", "dc_sampler_ddim_loop_ex", "dc_sampler_status", "dc_sampler_set_smoothing",
@@ -116,6 +116,11 @@ def lib():
                                           C.c_void_p]
     L.dc_sampler_set_encoder_format.argtypes = [C.c_void_p, C.c_int32]
     L.dc_sampler_set_precise_tail.argtypes = [C.c_void_p, C.c_int32]
+    L.dc_sampler_set_combine_exchange.argtypes = [C.c_void_p, C.c_int32]
+    L.dc_sampler_set_clip_aligned.argtypes = [C.c_void_p, C.c_int32]
+    L.dc_precise_tail_default.argtypes = [C.c_int32]
+    L.dc_precise_tail_default.restype = C.c_int32
+    L.dc_sampler_set_precise_forward.argtypes = [C.c_void_p, C.c_int32]
     L.dc_sampler_denoise.argtypes = [C.c_void_p, C.c_void_p, ip, C.c_void_p, C.c_void_p]
     L.dc_savgol_coefficients.argtypes = [C.c_int32, C.c_int32, fp]
     L.dc_savgol_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
@@ -220,14 +225,21 @@ def describe_status(st: int, precision: str) -> str:
     return "; ".join(msg) or "ok"
 
 
+def precise_tail_default(precision: str) -> int:
+    """The number of split-operand evaluations at the end of a sampling loop a precision runs unless told otherwise (dc_ddim.h)."""
+    return int(lib().dc_precise_tail_default(DC_PREC[precision])) if precision in DC_PREC else 0
+
+
 def algorithmic_work(n_tokens: int) -> dict:
-    """Algorithmic work per launch of the loop's two big kernels at `n_tokens` = B*T, the
-    numerators of bench.py's roofline objects.  k_layer (one decoder layer for all tokens) moves per token the
-    residual stream 512 B in + 512 B out, its 24 FiLM tiles x 64 B and the workgroup records 72 B out + 36 B in:
-    HBM is its nearer roof.  k_film_gemm is the [6144 x 512] x [512 x tokens] FiLM GEMM: MFMA roof."""
+    """Algorithmic work per launch of the loop's two big kernels at `n_tokens` = B*T, the numerators of
+    bench.py's roofline objects.  Both are priced against the MFMA roof, the path's primary bound:
+    k_film_gemm is the [6144 x 512] x [512 x tokens] FiLM GEMM; k_layer (one decoder layer for all tokens) carries an eighth of
+    the step's remaining algorithmic FLOPs.  `design_bytes`: what THIS decomposition moves through HBM per k_layer launch - per token
+    the fp32 residual stream 512 B in + 512 B out, its 24 FiLM tiles x 64 B (written by the GEMM one launch earlier) and the
+    workgroup records 72 B out + 36 B in - a property of the design, not SURVEY section 8d's compulsory bytes (2.3 MB per clip-step)."""
     # k_layer's FLOPs: the step's algorithmic 2 * 4 250 112 per token (SURVEY.md section 8d) minus the FiLM GEMM's, over 8 layers
-    return {"k_layer": {"bound": "hbm", "bytes": (512 + 512 + 24 * 64 + 72 + 36) * n_tokens,
-                        "flops": (2 * 4250112 - 2 * 512 * 6144) // 8 * n_tokens},
+    return {"k_layer": {"bound": "mfma", "flops": (2 * 4250112 - 2 * 512 * 6144) // 8 * n_tokens,
+                        "design_bytes": (512 + 512 + 24 * 64 + 72 + 36) * n_tokens},
             "k_film_gemm": {"bound": "mfma", "flops": 2 * 512 * 6144 * n_tokens}}
 
 
@@ -313,8 +325,22 @@ class NativeSampler:
 
     def set_precise_tail(self, steps):
         """The loop's last `steps` model evaluations on split operands (fp16: golden DDIM-50 5.0e-4 -> 2.3e-4 / 1.6e-4 with 1 / 2 steps at
-        +0.45 % of the loop each, default 1; bf16: 3.1e-3 -> 5.4e-4 with 8, its default).  DC_PRECISE_TAIL=k in the environment overrides it."""
+        +0.45 % of the loop each, default 1; bf16: see DESIGN.md section 5; -1: the precision's default).  DC_PRECISE_TAIL=k in the environment overrides it."""
         _check(lib().dc_sampler_set_precise_tail(self._h, int(steps)))
+
+    def set_clip_aligned(self, mode):
+        """Units of the wide launch form: True clip-aligned (batch-invariant results), False flat (throughput), None the library's rule -
+        aligned whenever that costs no extra round of workgroups (dc_ddim.h, dc_sampler_set_clip_aligned)."""
+        _check(lib().dc_sampler_set_clip_aligned(self._h, -1 if mode is None else (1 if mode else 0)))
+
+    def set_precise_forward(self, on):
+        """denoise() on split operands (the precise tail's evaluation form; dc_ddim.h, dc_sampler_set_precise_forward)."""
+        _check(lib().dc_sampler_set_precise_forward(self._h, 1 if on else 0))
+
+    def set_combine_exchange(self, on):
+        """Small batches: whether a clip's workgroups exchange their combine slices inside a layer launch (default) or every workgroup
+        combines alone (no in-launch wait; dc_ddim.h, dc_sampler_set_combine_exchange).  dc_sampler_status latches `off` after a timeout."""
+        _check(lib().dc_sampler_set_combine_exchange(self._h, 1 if on else 0))
 
     def set_encoder_format(self, fmt):
         """MusicEncoder activation format: "split" (two bf16 planes, 6e-6 at the encoder's output) or "f16" (one fp16 plane, 3.7e-4, half

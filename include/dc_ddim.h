@@ -157,6 +157,8 @@ DC_EXPORT int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t
  * in the final evaluations (DDIM's last step returns the model's own prediction of x0).  Golden DDIM-50, rel-L2 of x0:
  *   fp16:  5.0e-4 with steps = 0,  2.3e-4 with 1,  1.6e-4 with 2,  1.2e-4 with 4   (+0.45 % of the loop per step at bs = 32)
  *   bf16:  3.1e-3 with steps = 0,  9.5e-4 with 2,  6.8e-4 with 4,  5.4e-4 with 8   - the bf16-operand mode that meets the 1e-3 bound
+ *          (round 5's figures, the tail's FiLM GEMM on bf16 operands; since round 6 the tail's evaluations take the FiLM GEMM's operands
+ *          in fp16 - they are "mixed"-precision evaluations - see DESIGN.md section 5 for the measured figures and the default)
  * Default (steps never set): 1 for fp16, 8 for bf16.  (Clip strides of whole 32-frame groups run the split evaluations in the
  * workgroup-record form on clip-aligned units, others - T = 900 x 128 unpadded, short clips - in the per-group record form: 5.2e-4 ->
  * 2.6e-4 there at no measurable cost.)  Loops of an EPSILON model (DC_UPDATE_EPSILON) run EVERY evaluation on split operands unless a
@@ -165,7 +167,15 @@ DC_EXPORT int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t
  * overrides it.  (In a loop that has a tail the plain
  * evaluations read FiLM scale tiles that hold G' itself - one mixed-precision FMA per element instead of two -, the split ones G' - 1;
  * loops without a tail keep G' - 1 everywhere.) */
-DC_EXPORT int dc_sampler_set_precise_tail(dc_sampler* s, int32_t steps);
+DC_EXPORT int dc_sampler_set_precise_tail(dc_sampler* s, int32_t steps);      /* steps = -1: back to the precision's default */
+DC_EXPORT int32_t dc_precise_tail_default(int32_t precision);                    /* DC_PREC_FP16: 1, DC_PREC_BF16: see above, others 0 */
+
+/* dc_sampler_denoise (MotionTransformer.forward, transformer.py:469-497) on split operands - the precise tail's evaluation form - when
+ * on != 0; default off (plain operands of the precision).  For callers that step a sampler THROUGH single evaluations and whose update
+ * keeps the evaluations' error (an EPSILON or PREVIOUS_X model, cond_fn: gaussian_diffusion.py:510-520, 581-603): the Python sampler
+ * switches it on for exactly those loops.  The bf16 precision's split evaluations also take their FiLM GEMM operands in fp16 (they are
+ * then the evaluations of the "mixed" precision).  Ignored where no split kernels exist (split precisions: already split; `no_eff`). */
+DC_EXPORT int dc_sampler_set_precise_forward(dc_sampler* s, int32_t on);
 
 #define DC_ME_SPLIT 0
 #define DC_ME_FP16 1
@@ -239,12 +249,32 @@ DC_EXPORT int dc_step_noise_fill(float* d_out, int64_t n, uint64_t seed, int32_t
  *   DC_STATUS_TIMEOUT      small batches only (B * ceil(T / 64) <= CUs): a workgroup gave up waiting for the slices of its clip's attention
  *                          combine, which the clip's workgroups exchange inside a layer launch - they are co-resident by construction unless
  *                          the GPU is shared with other work; the wait is bounded (~0.1 s) and the loop's results are then invalid.
- *                          DC_L16_OWN_COMBINE=1 in the environment selects the form without the exchange.
+ *                          One timeout per loop at most: once the bit is set, the loop's remaining launches stop waiting.  Reading
+ *                          the bit through dc_sampler_status LATCHES the form without the exchange on this sampler
+ *                          (dc_sampler_set_combine_exchange(s, 0)), so re-running the loop gives a valid result; callers that share a
+ *                          GPU, or run several small-batch samplers on streams of one process, should select that form up front.
+ *                          DC_L16_OWN_COMBINE=1 in the environment selects it for every sampler of the process.
  * clear != 0 resets the word. */
 #define DC_STATUS_NONFINITE 1
 #define DC_STATUS_F16_SATURATED 2
 #define DC_STATUS_TIMEOUT 4
 DC_EXPORT int dc_sampler_status(dc_sampler* s, int32_t* h_status, int32_t clear);
+
+/* Batch invariance (the reference's key softmax is per clip, transformer.py:111): on clip-aligned units - no workgroup's tokens span two
+ * clips - a clip's result is bit-identical whatever the batch around it, and equal to sampling it alone in the same launch form.  Small
+ * batches and the split-operand evaluations always run them.  The wide form (the chip full: bs = 32 x 1800) runs them by default
+ * whenever they cost no extra round of workgroups over the chip (mode -1, the library's rule; +1.6 ... +2.1 % per loop at bs = 32 x 1800,
+ * 256 instead of 228 workgroups); otherwise flat 256-token units, where a unit that contains a clip edge exponentiates both clips' keys
+ * against one maximum and a clip depends on its neighbours at the rounding level (up to 4e-4, inside the parity bound).
+ * mode 1: clip-aligned units always; 0: flat units (the throughput form); -1: the rule.  Needs a clip stride of whole 32-frame groups
+ * (dc_sampler_clip_stride) and T >= 256; ignored otherwise. */
+DC_EXPORT int dc_sampler_set_clip_aligned(dc_sampler* s, int32_t mode);
+
+/* Small batches (B * ceil(T / 64) <= CUs): on != 0 (default) lets a clip's workgroups share the combine of the attention unit records
+ * inside a layer launch (-8 % per layer launch at one clip per call; needs the launch's workgroups co-resident, see DC_STATUS_TIMEOUT);
+ * on == 0 makes every workgroup combine alone - no in-launch wait, safe beside other work on the GPU.  No reference counterpart
+ * (the reference's attention is one einsum, transformer.py:113-116). */
+DC_EXPORT int dc_sampler_set_combine_exchange(dc_sampler* s, int32_t on);
 
 /* Timing hook for bench.py: device time (ms, HIP events on the library's own stream)
  * of the last dc_sampler_ddim_loop and the summed duration + launch count of its

@@ -150,7 +150,7 @@ def test_precise_tail_halves_the_fp16_error(models):
         assert rel_l2(_ddim(models["fp16"], 50, noise, xfp, xfo, [1800]), g["x0"]) == errs[2]
         from diffusion_conductor_amd import native
         with pytest.raises(native.DcError, match="precise tail"):
-            native._check(native.lib().dc_sampler_set_precise_tail(nat._h, -1))
+            native._check(native.lib().dc_sampler_set_precise_tail(nat._h, -2))          # (-1: back to the default)
     finally:
         nat.set_precise_tail(1)
     # a clip stride that is not a whole number of 32-frame groups (here forced: DC_NO_PAD) has no clip-aligned units: the split evaluation
@@ -450,7 +450,7 @@ def test_clip_layouts_agree_and_small_batches_are_batch_invariant(models):
     os.environ["DC_DISABLE_GRAPH"] = "1"          # eager launches: the switches are read when a launch is enqueued
     try:
         for name, env in (("aligned", {}), ("flat", {"DC_NO_ALIGN": "1"}), ("unpadded", {"DC_NO_PAD": "1"}),
-                          ("aligned-wide", {"DC_NO_NARROW": "1", "DC_ALIGN": "1"}), ("flat-wide", {"DC_NO_NARROW": "1"}),
+                          ("aligned-wide", {"DC_NO_NARROW": "1", "DC_ALIGN": "1"}), ("flat-wide", {"DC_NO_NARROW": "1", "DC_FLAT_UNITS": "1"}),
                           ("per-group records", {"DC_NO_WGREC": "1"})):
             os.environ.update(env)
             try:
@@ -522,12 +522,14 @@ def test_progressive_matches_fast_path(models):
 def test_bs32_full_size_properties(models):
     """BASELINE config 2 size (bs=32, T=1800, DDIM-50), checked through size-independent properties:
     (a) re-running is bit-identical (race check: all reductions are ordered);
-    (b) sharding: clips are independent; the partial softmax / K^T V records are summed per 256-token workgroup (128-token
-        units when the batch is small enough for narrow workgroups - compared at the noise level),
-        so a shard that starts on a workgroup edge (clips 0..15) equals the joint batch bit for bit, and one that
-        does not (clips 16..31: 16*1800 tokens = 112.5 workgroups) exponentiates the keys against different
-        workgroup maxima before the fp16 operand rounding - it agrees at the precision mode's noise level;
-    (c) clip 0 of the batch matches the golden single-clip result within the parity bound."""
+    (b) batch invariance (the reference's key softmax is per clip, transformer.py:111): the headline shape runs clip-aligned 256-token
+        units (dc_ddim.h, dc_sampler_set_clip_aligned: 256 workgroups instead of 228, one round over the chip either way), so a clip's
+        result does not depend on the batch around it: both 16-clip shards, a clip sampled ALONE and the batch in reverse order are
+        bit-identical to the joint batch (all in the same 8-wave launch form; the narrow small-batch form sums the unit records in
+        another tree and agrees at the precision mode's noise level);
+    (c) the flat-unit form (DC_FLAT_UNITS=1, the throughput option: a unit with a clip edge exponentiates both clips' keys against one
+        maximum) agrees with it at the noise level;
+    (d) clip 0 of the batch matches the golden single-clip result within the parity bound."""
     B, T = 32, 1800
     xfp, xfo = xf_pair(B, T)
     noise = torch.from_numpy(batch_noise(B, T))
@@ -535,18 +537,22 @@ def test_bs32_full_size_properties(models):
     a = _ddim(m, 50, noise, xfp, xfo, [T] * B)
     b = _ddim(m, 50, noise, xfp, xfo, [T] * B)
     assert torch.isfinite(a).all() and torch.equal(a, b)
-    # 16-clip shards fit one 128-token unit per CU and would run with narrow workgroups: the bit-for-bit statement is about
-    # equal unit sizes, so the shards are run in the 8-wave form here; the narrow form is compared at the noise level
+    # 16-clip shards and single clips fit one 128-token unit per CU and would run narrow workgroups: the bit-for-bit statement is about
+    # the same launch form, so they are run in the 8-wave form here; the narrow form is compared at the noise level
     os.environ["DC_NO_NARROW"] = "1"
     try:
         lo = _ddim(m, 50, noise[:16], xfp[:16].contiguous(), xfo[:16].contiguous(), [T] * 16)
         hi = _ddim(m, 50, noise[16:], xfp[16:].contiguous(), xfo[16:].contiguous(), [T] * 16)
+        solo = _ddim(m, 50, noise[21:22], xfp[21:22].contiguous(), xfo[21:22].contiguous(), [T])
     finally:
         del os.environ["DC_NO_NARROW"]
-    assert torch.equal(lo, a[:16])
-    e_hi = rel_l2(hi, a[16:])
-    print(f"shard 16..31 vs joint batch: rel-L2 {e_hi:.2e}")
-    assert e_hi <= TOL_PARITY
+    assert torch.equal(lo, a[:16]) and torch.equal(hi, a[16:]) and torch.equal(solo, a[21:22])
+    rev = _ddim(m, 50, noise.flip(0).contiguous(), xfp.flip(0).contiguous(), xfo.flip(0).contiguous(), [T] * B)      # other neighbours, other positions
+    assert torch.equal(rev.flip(0), a)
+    flat = _with_env({"DC_FLAT_UNITS": "1"}, lambda: _ddim(m, 50, noise, xfp, xfo, [T] * B))
+    e_flat = max(rel_l2(flat[c:c + 1], a[c:c + 1]) for c in range(B))
+    print(f"flat 256-token units vs clip-aligned units, worst clip: rel-L2 {e_flat:.2e}")
+    assert 0 < e_flat <= TOL_PARITY
     lo_n = _ddim(m, 50, noise[:8], xfp[:8].contiguous(), xfo[:8].contiguous(), [T] * 8)       # narrow workgroups (B = 8)
     e_n = rel_l2(lo_n, a[:8])
     print(f"shard 0..7 with narrow workgroups vs joint batch: rel-L2 {e_n:.2e}")
@@ -557,10 +563,8 @@ def test_bs32_full_size_properties(models):
 
 
 def test_bs32_interior_clips_vs_oracle(models):
-    """The headline configuration (bs=32 x 1800, DDIM-50) runs FLAT 256-token units: a unit that contains a clip edge exponentiates
-    both clips' keys against one shared maximum before the f16 rounding, so a clip's result depends on its neighbours (DESIGN
-    section 5).  Clip 0 starts on a unit edge and is the least affected clip of the batch; clips 13, 17 and 31 have both ends
-    (31: its head) inside units shared with a neighbour.  Each is compared with the CPU oracle's DDIM-50 of that clip ALONE
+    """The headline configuration (bs=32 x 1800, DDIM-50; clip-aligned 256-token units since round 6, flat units before): clips 13, 17
+    and 31 from inside the batch, each compared with the CPU oracle's DDIM-50 of that clip ALONE
     (gaussian_diffusion.py:871-915, transformer.py:96-196), in the default f16 mode and in the bf16-MFMA mode ("mixed", which
     always runs clip-aligned units)."""
     B, T = 32, 1800
@@ -605,8 +609,7 @@ def test_clip_stride_avoids_an_extra_round_of_layer_workgroups(models):
 
 
 def test_bs32_every_clip_vs_oracle(models):
-    """All 32 clips of the headline batch (bs=32 x 1800, DDIM-50, flat 256-token units: 28 of the 32 clips share a unit with a
-    neighbour at one end or both) against the CPU oracle's DDIM-50 of the same batch (the oracle has no cross-clip operation), per
+    """All 32 clips of the headline batch (bs=32 x 1800, DDIM-50, clip-aligned 256-token units) against the CPU oracle's DDIM-50 of the same batch (the oracle has no cross-clip operation), per
     clip, in the default f16 mode and the bf16-MFMA mode."""
     B, T = 32, 1800
     xfp, xfo = xf_pair(B, T)

@@ -117,10 +117,12 @@ def test_sampler_branches_graph_path_g9(tag, prec):
 
 @pytest.mark.parametrize("S", [50, 100])
 def test_epsilon_model_runs_every_evaluation_on_split_operands(S):
-    """ModelMeanType.EPSILON at eta = 0: the final sample is sqrt(1/abar) x_t - sqrt(1/abar - 1) eps, so the plain fp16 evaluations' error
-    stays in x_t whatever the precise tail (1.4 - 1.8e-3, found by tools/fuzz_sampler.py).  By default such a loop runs every evaluation on
-    split operands (S = 100: two graph replays, both split); an explicit tail is honoured."""
+    """ModelMeanType.EPSILON at eta = 0: the final sample is sqrt(1/abar) x_t - sqrt(1/abar - 1) eps, so the plain 16-bit evaluations' error
+    stays in x_t whatever the precise tail (fp16 1.4 - 1.8e-3, found by tools/fuzz_sampler.py).  By default such a loop runs every evaluation
+    on split operands (S = 100: two graph replays, both split) - in the bf16 precision with the FiLM GEMM's operands in fp16, i.e. as
+    "mixed"-precision evaluations; an explicit tail is honoured.  No warning: the results are inside the bound."""
     import os
+    import warnings
     from helpers import O
     sd, B, T, _, length, xfp, xfo, noise, _ = _g9_setup()
     gd = _diffusion(S, "EPSILON")
@@ -135,22 +137,80 @@ def test_epsilon_model_runs_every_evaluation_on_split_operands(S):
                                       model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.LongTensor(length)})
             torch.cuda.synchronize()
             return rel_l2(out, ref)
-        import warnings
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
             errs[prec] = run()
-        # (the bf16 precision stays outside the bound on this branch: it says so; fp16 does not warn)
-        assert any("EPSILON model at eta = 0" in str(x.message) for x in w) == (prec == "bf16")
+        assert not w, [str(x.message) for x in w]
         os.environ["DC_PRECISE_TAIL"] = "1"
         try:
             errs[prec + ", tail 1"] = run()
         finally:
             del os.environ["DC_PRECISE_TAIL"]
     print(f"EPSILON, eta = 0, S = {S}: " + "  ".join(f"{k} {v:.3e}" for k, v in errs.items()))
-    # (bf16: every evaluation split as well, but its FiLM GEMM keeps plain bf16 operands - the mode's floor, DESIGN.md section 5 - and an
-    # EPSILON loop accumulates it: 1 - 2e-3 instead of 1e-2; the bf16 precision is a START_X mode)
     assert errs["fp16"] <= 0.5 * TOL and errs["fp16, tail 1"] > 2 * errs["fp16"]
-    assert errs["bf16"] <= 3 * TOL and errs["bf16, tail 1"] > 3 * errs["bf16"]
+    assert errs["bf16"] <= 0.5 * TOL and errs["bf16, tail 1"] > 3 * errs["bf16"]
+
+
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_epsilon_model_full_attention_eta0_vs_oracle(prec):
+    """The same branch through the full-attention (`no_eff`) kernels: k_layer_full's split-operand instantiation (query / key / value
+    projections, stylization out-projections and FFN on split operands; scores, weights and values plain 16-bit) runs every evaluation
+    of an EPSILON loop - round 5 returned 1.4e-3 (fp16) / 1 - 2e-3 (bf16) here with a warning."""
+    from helpers import O
+    from diffusion_conductor_amd import MotionTransformer
+    sd, B, T, S, length, xfp, xfo, noise, _ = _g9_setup()
+    gd = _diffusion(S, "EPSILON")
+    with torch.no_grad():
+        ref = O.ddim_sample_loop(O.to_torch_params(sd, torch.float32), noise.cpu(), xfp.cpu(), xfo.cpu(), length, S, clip_denoised=True,
+                                 eps_model=True, no_eff=True)
+    m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cuda", no_clip=True, no_eff=True, precision=prec)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda").eval()
+    kw = dict(noise=noise, clip_denoised=True, progress=False, model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.LongTensor(length)})
+    if prec == "bf16":
+        # the attention's own bf16 operands leave 1.9e-3 even so: refused (captured loop and generator alike), not returned with a warning
+        with pytest.raises(NotImplementedError, match="precision='fp16'"):
+            gd.ddim_sample_loop(m, (B, T, 26), **kw)
+        with pytest.raises(NotImplementedError, match="outside the 1e-3 bound"):
+            next(gd.ddim_sample_loop_progressive(m, (B, T, 26), **kw))
+        gd.ddim_sample_loop(m, (B, T, 26), eta=0.5, **kw)          # (eta > 0: fresh noise damps what the evaluations left - G9's branch)
+        return
+    out = gd.ddim_sample_loop(m, (B, T, 26), **kw)
+    torch.cuda.synchronize()
+    err = rel_l2(out, ref)
+    import os
+    os.environ["DC_PRECISE_TAIL"] = "0"          # the plain-operand loop, for the record
+    try:
+        plain = rel_l2(gd.ddim_sample_loop(m, (B, T, 26), noise=noise, clip_denoised=True, progress=False,
+                                           model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.LongTensor(length)}), ref)
+    finally:
+        del os.environ["DC_PRECISE_TAIL"]
+    print(f"EPSILON, eta = 0, no_eff, {prec}: every evaluation split {err:.3e}   plain operands {plain:.3e}")
+    assert torch.isfinite(out).all() and err <= TOL and plain > err
+
+
+@pytest.mark.parametrize("prec,no_eff", [("fp16", False), ("bf16", False), ("fp16", True)])
+def test_epsilon_model_stepped_through_single_evaluations(prec, no_eff):
+    """ddim_sample_loop_progressive of an EPSILON model at eta = 0: the generator evaluates the native denoiser on split operands
+    (dc_sampler_set_precise_forward) for exactly such loops - on plain fp16 operands it ended at 1.5e-3."""
+    from helpers import O
+    from diffusion_conductor_amd import MotionTransformer
+    sd, B, T, S, length, xfp, xfo, noise, _ = _g9_setup()
+    gd = _diffusion(S, "EPSILON")
+    with torch.no_grad():
+        ref = O.ddim_sample_loop(O.to_torch_params(sd, torch.float32), noise.cpu(), xfp.cpu(), xfo.cpu(), length, S, clip_denoised=True,
+                                 eps_model=True, no_eff=no_eff)
+    m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cuda", no_clip=True, no_eff=no_eff, precision=prec)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to("cuda").eval()
+    last = None
+    for last in gd.ddim_sample_loop_progressive(m, (B, T, 26), noise=noise, clip_denoised=True, progress=False,
+                                                model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.LongTensor(length)}):
+        pass
+    torch.cuda.synchronize()
+    err = rel_l2(last["sample"], ref)
+    print(f"EPSILON, eta = 0, stepped through forward(), {prec}{', no_eff' if no_eff else ''}: {err:.3e}")
+    assert m.precise_forward is False and err <= TOL
 
 
 @pytest.mark.parametrize("tag", ["clip", "eta", "eps"])

@@ -120,8 +120,9 @@ def test_config4_ddim1000_bs32_full_size(models):
     err = rel_l2(a[:1], golden("g6_variants.npz")["ddim1000_x0"])
     print(f"config 4 clip 0 rel-L2 {err:.3e}")
     assert err <= 1e-3
-    # ... and two clips from inside the batch (both ends in units shared with a neighbour) against the oracle's DDIM-1000 of those clips
-    idx = [17, 31]
+    # ... and a clip from inside the batch (both ends in units shared with a neighbour) against the oracle's DDIM-1000 of that clip
+    # (one clip: the oracle's 1000 CPU steps per clip are the suite's longest single cost)
+    idx = [17]
     with torch.no_grad():
         ref = O.ddim_sample_loop(oracle_params(), noise[idx], xfp[idx], xfo[idx], [T] * len(idx), 1000)
     errs = [rel_l2(a[i:i + 1], ref[k:k + 1]) for k, i in enumerate(idx)]

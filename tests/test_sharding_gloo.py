@@ -121,3 +121,55 @@ def test_unsized_empty_shard_raises_on_every_rank(tmp_path):
     mp.spawn(_worker_unsized, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert "fewer clips than ranks" in (tmp_path / f"rank{r}.txt").read_text()
+
+
+def _worker_evidence(rank, world, port, out_dir, fault):
+    """bench.py's multi_gpu_evidence (the N > 1 branch of the bench line) on two gloo ranks with stub samplers: the identity
+    de-duplication, the per-rank time gather, gather_block_equals_local and sharded_equals_single_gpu."""
+    import json
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from diffusion_conductor_amd.sharding import gather_poses
+    B, T, P = 3, 5, 26
+
+    def shard(r):                     # any deterministic per-rank "sampling result"
+        return (torch.arange(B * T * P, dtype=torch.float32).reshape(B, T, P) + 1000.0 * r).sin()
+
+    local = shard(rank)
+    gathered = gather_poses(local, world * B)
+    if fault == "block" and rank == 1:
+        gathered = gathered.clone()
+        gathered[rank * B, 0, 0] += 1.0          # this rank's block of the gather differs from what it sampled
+    ident = "same device" if fault == "ident" else f"device {rank}"
+    res = None
+    try:
+        res = bench.multi_gpu_evidence(dist, torch.device("cpu"), ident, rank, world, B, 0.010 * (rank + 1), gathered,
+                                       lambda: shard(rank), shard)
+    except AssertionError as e:
+        res = {"assertion": str(e)}
+    with open(os.path.join(out_dir, f"ev{rank}.json"), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_multi_gpu_evidence_on_two_gloo_ranks(tmp_path):
+    import json
+    for fault in ("none", "block", "ident"):
+        d = tmp_path / fault
+        d.mkdir()
+        mp.spawn(_worker_evidence, args=(2, _free_port(), str(d), fault), nprocs=2, join=True)
+        ev = [json.load(open(d / f"ev{r}.json")) for r in range(2)]
+        if fault == "ident":             # two ranks on one device: refused on every rank (before any collective a rank could hang in)
+            assert all("ranks share a device" in e["assertion"] for e in ev)
+            continue
+        for r, e in enumerate(ev):
+            assert e["rccl_ranks"] == 2 and e["backend"] == "gloo" and e["devices"] == ["device 0", "device 1"]
+            assert e["ms_per_step_by_rank"] == {"min": 10.0, "max": 20.0}
+            assert e["gather_block_equals_local"] is (fault == "none")           # the MIN over ranks: one bad block fails every rank's line
+            assert e["all_gather_bytes_per_rank"] == 3 * 5 * 26 * 4
+            assert e["sharded_equals_single_gpu"] is (True if r == 0 else None)  # rank 0 re-samples the last rank's shard (its block is intact on rank 0)

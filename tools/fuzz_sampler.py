@@ -34,34 +34,45 @@ for case in range(N):
     idxs = sorted(set(int(v) for v in rng.integers(0, S, size=int(rng.integers(0, 4)))))
     length = [int(rng.integers(1, T + 1)) if rng.random() < 0.5 else T for _ in range(B)]
     prec = str(rng.choice(["fp16", "fp16", "mixed", "bf16"]))
+    no_eff = bool(prec in ("fp16", "bf16") and rng.random() < 0.25)          # (full attention is built for the two plain precisions)
     first = int(rng.integers(0, 100))
-    if prec not in models:
-        models[prec] = make_model(prec)
+    if (prec, no_eff) not in models:
+        models[(prec, no_eff)] = make_model(prec, no_eff=no_eff)
     xfp, xfo = xf_pair(B, T, first=first)
     noise = torch.from_numpy(batch_noise(B, T, first=first))
     z = torch.from_numpy(batch_step_noise(S, B, T, first=first)) if eta else None
     with torch.no_grad():
         ref = O.ddim_sample_loop(oracle_params(), noise, xfp, xfo, length, S, eta=eta, idxs=tuple(idxs), clip_denoised=clip,
-                                 eps_model=eps_model, step_noise=z)
+                                 eps_model=eps_model, step_noise=z, no_eff=no_eff)
     gd = GaussianDiffusion(betas=get_named_beta_schedule("linear", S), model_mean_type=ModelMeanType.EPSILON if eps_model else ModelMeanType.START_X,
                            model_var_type=ModelVarType.FIXED_SMALL, loss_type=LossType.MSE)
     kw = {"step_noise": z.cuda()} if eta else {}
-    out = gd.ddim_sample_loop(models[prec], (B, T, 26), noise=noise.cuda(), clip_denoised=clip, progress=False, eta=eta, idxs=idxs,
-                              model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor(length)}, **kw)
+    refused = eps_model and eta == 0.0 and no_eff and prec == "bf16"        # the one combination outside the bound: refused, not returned (sampler.py)
+    try:
+        out = gd.ddim_sample_loop(models[(prec, no_eff)], (B, T, 26), noise=noise.cuda(), clip_denoised=clip, progress=False, eta=eta, idxs=idxs,
+                                  model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor(length)}, **kw)
+    except NotImplementedError as e:
+        bad += not refused
+        print(f"case {case:3d} B={B} T={T:3d} S={S:3d} eta={eta:.1f} clip={int(clip)} eps={int(eps_model)} {prec}+no_eff: refused ({str(e)[:60]}...){'' if refused else '   <-- FAIL'}", flush=True)
+        continue
+    if refused:
+        bad += 1
+        print(f"case {case:3d}: a combination outside the bound was not refused   <-- FAIL", flush=True)
+        continue
     torch.cuda.synchronize()
     if not idxs:
         out, ref = {S: out}, {S: ref}
     ok = set(out) == set(ref)
-    # (bf16 + EPSILON + eta = 0: outside the bound even with every evaluation split - the mode's plain-bf16 FiLM GEMM)
     # (an epsilon model divides by sqrt(1 / abar - 1) -> the snapshots of early iterations are compared as they are; the bound is the
     # parity bound of the final sample, snapshots may sit a little above it in the 16-bit modes: 2e-3; bf16's snapshots in front of its
     # precise tail are plain bf16: 2e-2)
     e_fin = rel_l2(out[S], ref[S]) if ok else float("inf")
     e_snap = max([rel_l2(out[k], ref[k]) for k in ref if k != S] + [0.0]) if ok else float("inf")
-    ok = ok and all(bool(torch.isfinite(v).all()) for v in out.values()) and e_fin <= (3e-3 if prec == "bf16" and eps_model and eta == 0.0 else 1e-3) and e_snap <= (2e-2 if prec == "bf16" and not eps_model else 2e-3)
+    ok = ok and all(bool(torch.isfinite(v).all()) for v in out.values()) and e_fin <= 1e-3 and e_snap <= (2e-2 if prec == "bf16" and not eps_model else 2e-3)
     bad += not ok
-    worst[prec] = max(worst.get(prec, 0.0), e_fin)
-    print(f"case {case:3d} B={B} T={T:3d} S={S:3d} eta={eta:.1f} clip={int(clip)} eps={int(eps_model)} idxs={idxs} {prec:5s}: final {e_fin:.3e} "
+    tagp = prec + ("+no_eff" if no_eff else "")
+    worst[tagp] = max(worst.get(tagp, 0.0), e_fin)
+    print(f"case {case:3d} B={B} T={T:3d} S={S:3d} eta={eta:.1f} clip={int(clip)} eps={int(eps_model)} idxs={idxs} {tagp:11s}: final {e_fin:.3e} "
           f"snapshots {e_snap:.3e}{'' if ok else '   <-- FAIL'}", flush=True)
 print(f"{N} cases, {bad} failures, {time.perf_counter() - t0:.0f} s; worst final sample per precision: " + ", ".join(f"{k} {v:.3e}" for k, v in sorted(worst.items())))
 sys.exit(1 if bad else 0)

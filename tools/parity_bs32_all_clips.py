@@ -11,10 +11,16 @@ B, T, S = 32, 1800, 50
 xfp, xfo = xf_pair(B, T); noise = torch.from_numpy(batch_noise(B, T))
 torch.set_num_threads(min(16, os.cpu_count() or 8))
 p = oracle_params()
-with torch.no_grad():
-    refs = [O.ddim_sample_loop(p, noise[c:c + 1], xfp[c:c + 1], xfo[c:c + 1], [T], S) for c in range(B)]
+cache = os.environ.get("DC_REFS_CACHE")        # (several libraries compared in one session: the 32 oracle loops run once)
+if cache and os.path.exists(cache):
+    refs = list(torch.load(cache))
+else:
+    with torch.no_grad():
+        refs = [O.ddim_sample_loop(p, noise[c:c + 1], xfp[c:c + 1], xfo[c:c + 1], [T], S) for c in range(B)]
+    if cache:
+        torch.save(refs, cache)
 gd = make_diffusion(S)
-for mode in ("fp16", "mixed"):
+for mode in os.environ.get("DC_PARITY_MODES", "fp16,mixed").split(","):
     m = make_model(mode)
     nat = m.set_conditioning(xfp.cuda(), xfo.cuda(), [T] * B)
     out, _ = nat.ddim_loop(noise.cuda(), gd.native_coefficients())
