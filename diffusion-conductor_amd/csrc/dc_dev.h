@@ -1293,11 +1293,12 @@ DEV float film_affine(uint32_t g2, float n, uint32_t h2) {
 // extracts the high half of a pair through SDWA and re-packs with v_pack_b32_f16; the SDWA forms below write the high half in place
 // (tools/probe_pk16.hip checks them on the box).
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-// The high half is written in place by a second SDWA instruction (dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE).  It must not issue right
-// behind the instruction that wrote the low half of the same register: a transcendental's result is not forwarded to a dependent
-// instruction in the next slots (gfx940+ "trans use" hazard; the compiler's hazard recognizer does not look inside asm statements) -
-// back to back, a quarter of the values came out wrong on the box (tools/probe_pk16.hip).  The callers therefore run the eight low
-// halves of a tile first and the eight high halves after them, with a scheduling barrier between the two groups.
+// The high half is written in place by a second SDWA instruction (dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE).  Two gfx940+ hazards apply
+// that the compiler's hazard recognizer cannot see inside asm statements: a transcendental's result, and any result written through a
+// destination select (SDWA dst_sel, the high-half write of v_fma_mixhi_f16), is not forwarded to an instruction in the next slot - back
+// to back, a quarter of the values came out wrong on the box (tools/probe_pk16.hip).  So a tile's eight low halves run first, the eight
+// high halves after them, and a phase that ends in such writes closes with s_nop 1 before the compiler's own instructions consume them
+// (whatever order the scheduler then picks); scheduling barriers keep the phases apart.
 DEV uint32_t exp2neg_lo16(uint32_t u) {                       // {2^-u.lo, 0}
     uint32_t e;
     asm("v_exp_f16_sdwa %0, -%1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(e) : "v"(u));
@@ -1314,11 +1315,17 @@ DEV uint32_t rcp_lo16(uint32_t d) {
 DEV void rcp_hi16(uint32_t& r, uint32_t d) {
     asm("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(r) : "v"(d));
 }
-DEV uint32_t nhat_mix16(uint32_t y2, float rstd, float shift) {      // {fp16(y.lo * rstd + shift), fp16(y.hi * rstd + shift)}, fp32 inside
+DEV uint32_t nhat_lo16(uint32_t y2, float rstd, float shift) {       // {fp16(y.lo * rstd + shift), -}: fp32 arithmetic, one rounding
     uint32_t n;
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(n) : "v"(y2), "v"(rstd), "v"(shift));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(n) : "v"(y2), "v"(rstd), "v"(shift));
     return n;
+}
+DEV void nhat_hi16(uint32_t& n, uint32_t y2, float rstd, float shift) {
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(n) : "v"(y2), "v"(rstd), "v"(shift));
+}
+DEV void phase_end16() {
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
 }
 // u / (1 + 2^-u) on the eight packed pairs of a tile (in place)
 DEV void silu_l2_tile16(uint32_t (&u)[8]) {
@@ -1328,18 +1335,18 @@ DEV void silu_l2_tile16(uint32_t (&u)[8]) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) exp2neg_hi16(e[k], u[k]);
-    __builtin_amdgcn_sched_barrier(0);
+    phase_end16();
     const h16x2 one = {(_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = __builtin_bit_cast(uint32_t, (h16x2)(__builtin_bit_cast(h16x2, e[k]) + one));
+    __builtin_amdgcn_sched_barrier(0);
     uint32_t r[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        e[k] = __builtin_bit_cast(uint32_t, (h16x2)(__builtin_bit_cast(h16x2, e[k]) + one));
-        r[k] = rcp_lo16(e[k]);
-    }
+    for (int k = 0; k < 8; ++k) r[k] = rcp_lo16(e[k]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) rcp_hi16(r[k], e[k]);
-    __builtin_amdgcn_sched_barrier(0);
+    phase_end16();
 #pragma unroll
     for (int k = 0; k < 8; ++k) u[k] = __builtin_bit_cast(uint32_t, (h16x2)(__builtin_bit_cast(h16x2, u[k]) * __builtin_bit_cast(h16x2, r[k])));
 }
@@ -1351,19 +1358,31 @@ DEV void styl_tile(XFrag<T16, SPLIT>& zf, const YTile& y, float rstd, float shif
 #if defined(DC_STYL_PK16) && DC_STYL_PK16
     if constexpr (std::is_same<YTile, f16x16>::value && std::is_same<T16, _Float16>::value && !SPLIT && G1) {
         const u32x8 yw = __builtin_bit_cast(u32x8, y), gw = __builtin_bit_cast(u32x8, gp), hw = __builtin_bit_cast(u32x8, hp);
+        // (every vector element goes through a scalar copy first: __builtin_bit_cast of an ext-vector ELEMENT expression reads the vector's
+        // first element whatever the index - hipcc 7.2 - which cost round 6 two GPU sessions)
         uint32_t zw[8];
 #if DC_STYL_PK16 == 2
         const h16x2 rs = {(_Float16)rstd, (_Float16)rstd}, sh = {(_Float16)shift, (_Float16)shift};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t yk = yw[k];
+            zw[k] = __builtin_bit_cast(uint32_t, (h16x2)__builtin_elementwise_fma(__builtin_bit_cast(h16x2, yk), rs, sh));
+        }
+#else
+#pragma unroll
+        for (int k = 0; k < 8; ++k) zw[k] = nhat_lo16(yw[k], rstd, shift);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) nhat_hi16(zw[k], yw[k], rstd, shift);
+        phase_end16();
 #endif
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-#if DC_STYL_PK16 == 2
-            const h16x2 n = __builtin_elementwise_fma(__builtin_bit_cast(h16x2, yw[k]), rs, sh);
-#else
-            const h16x2 n = __builtin_bit_cast(h16x2, nhat_mix16(yw[k], rstd, shift));
-#endif
-            zw[k] = __builtin_bit_cast(uint32_t, (h16x2)__builtin_elementwise_fma(__builtin_bit_cast(h16x2, gw[k]), n, __builtin_bit_cast(h16x2, hw[k])));
+            const uint32_t gk = gw[k], hk = hw[k], nk = zw[k];
+            zw[k] = __builtin_bit_cast(uint32_t, (h16x2)__builtin_elementwise_fma(__builtin_bit_cast(h16x2, gk), __builtin_bit_cast(h16x2, nk),
+                                                                                  __builtin_bit_cast(h16x2, hk)));
         }
+        __builtin_amdgcn_sched_barrier(0);
         silu_l2_tile16(zw);
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
         zf.hi[0] = __builtin_bit_cast(v8<T16>, (u32x4_){zw[0], zw[1], zw[2], zw[3]});

@@ -166,7 +166,11 @@ def test_precise_tail_halves_the_fp16_error(models):
     eb = {k: rel_l2(_with_env({"DC_PRECISE_TAIL": str(k)}, lambda: _ddim(models["bf16"], 50, noise, xfp, xfo, [1800])), g["x0"]) for k in (0, 2, 8)}
     print("bf16, precise tail 0 / 2 / 8: " + " ".join(f"{eb[k]:.3e}" for k in (0, 2, 8)))
     assert eb[0] > TOL_PARITY and eb[8] <= 0.7 * TOL_PARITY and eb[8] < eb[2] < eb[0]
-    assert rel_l2(_ddim(models["bf16"], 50, noise, xfp, xfo, [1800]), g["x0"]) == eb[8]          # its default
+    from diffusion_conductor_amd import native as _nat
+    kd = _nat.precise_tail_default("bf16")
+    ed = rel_l2(_ddim(models["bf16"], 50, noise, xfp, xfo, [1800]), g["x0"])          # its default
+    print(f"bf16 default tail {kd}: {ed:.3e}")
+    assert kd == 4 and eb[8] < ed < eb[2] and ed <= 0.6 * TOL_PARITY
 
 
 @pytest.mark.parametrize("S", [1, 25])
@@ -385,10 +389,21 @@ def test_layer16_combine_exchange_timeout_is_bounded_and_reported(models):
     finally:
         del os.environ["DC_L16_TEST_DROP_SLICE"]
     print(f"forward with a dropped slice: {dt:.2f} s, status {st}")
-    assert st & native.STATUS_TIMEOUT and dt < 60
+    # one timeout per forward, not one per layer launch: once a workgroup has given up, the launches that follow stop waiting
+    # (8 launches x 0.1 s before round 6)
+    assert st & native.STATUS_TIMEOUT and dt < 1.0
+    # reading the timeout has latched the form without the exchange on this sampler (co-residency cannot be assumed on this GPU): the
+    # next call is healthy, and equal to what DC_L16_OWN_COMBINE=1 computes (another summation tree than the exchange: noise level)
     again = nat.denoise(x, np.array([7], np.int32))
     torch.cuda.synchronize()
-    assert nat.status() == 0 and torch.equal(again, good)
+    assert nat.status() == 0
+    own = _with_env({"DC_L16_OWN_COMBINE": "1"}, lambda: nat.denoise(x, np.array([7], np.int32)))
+    torch.cuda.synchronize()
+    assert torch.equal(again, own) and rel_l2(again, good) <= 1e-3
+    nat.set_combine_exchange(True)                     # (module-scoped model: back to the default for the tests that follow)
+    back = nat.denoise(x, np.array([7], np.int32))
+    torch.cuda.synchronize()
+    assert torch.equal(back, good)
 
 
 @pytest.mark.parametrize("B,T,length", [(1, 1800, [1800]), (3, 1800, [1800, 77, 1500]), (4, 1800, [1800, 1, 911, 1799]), (12, 1800, None), (6, 512, None)])

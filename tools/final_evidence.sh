@@ -7,7 +7,9 @@ cd "$(dirname "$0")/.."
 R="$(pwd)"
 O=gpurun_out
 mkdir -p $O
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/${TAG}_pytest_gpu.txt
+# the driver's own forms, from the repo root, no file arguments (round 5's suite was never run this way and was refused by the pool's gate)
+( time timeout 2400 python -m pytest tests/ -x -q -m gpu --durations=15 ) > $O/${TAG}_pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/${TAG}_pytest_gpu.txt
+( time python -c "import __graft_entry__ as g; g.smoke()" ) >> $O/${TAG}_pytest_gpu.txt 2>&1; echo "smoke rc=$?" >> $O/${TAG}_pytest_gpu.txt
 timeout 1500 bash tools/collect_profiles.sh $TAG > $O/${TAG}_collect.log 2>&1
 ( export TMPDIR=/tmp; cd /tmp
   BENCH="/usr/bin/python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
@@ -23,4 +25,4 @@ timeout 900 python bench.py --precision mixed --no-cpu-baseline --no-extras 2>/d
 timeout 900 python tools/batch_curve.py 2>/dev/null > $O/${TAG}_batch_curve.md
 timeout 600 python tools/time_evaluate.py --clips 294 2>/dev/null > $O/${TAG}_time_evaluate_294.json
 timeout 600 python tools/time_evaluate.py --clips 96 --ddim 1000 --repeat 1 2>/dev/null > $O/${TAG}_time_evaluate_ddim1000.json
-cat $O/${TAG}_pytest_gpu.txt; for f in default ddim1000 t900 noeff mixed; do echo -n "$f: "; grep -o "ms_per_step\": [0-9.]*" $O/${TAG}_bench_$f.json; done
+tail -40 $O/${TAG}_pytest_gpu.txt; for f in default ddim1000 t900 noeff mixed; do echo -n "$f: "; grep -o "ms_per_step\": [0-9.]*" $O/${TAG}_bench_$f.json; done

@@ -34,7 +34,7 @@ for case in range(N):
     idxs = sorted(set(int(v) for v in rng.integers(0, S, size=int(rng.integers(0, 4)))))
     length = [int(rng.integers(1, T + 1)) if rng.random() < 0.5 else T for _ in range(B)]
     prec = str(rng.choice(["fp16", "fp16", "mixed", "bf16"]))
-    no_eff = bool(prec in ("fp16", "bf16") and rng.random() < 0.25)          # (full attention is built for the two plain precisions)
+    no_eff = bool(prec in ("fp16", "bf16") and T >= 32 and rng.random() < 0.25)          # (full attention is built for the two plain precisions, from T = 32)
     first = int(rng.integers(0, 100))
     if (prec, no_eff) not in models:
         models[(prec, no_eff)] = make_model(prec, no_eff=no_eff)

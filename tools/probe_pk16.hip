@@ -45,6 +45,10 @@ DEV uint32_t exp2neg_lo16(uint32_t u) { uint32_t e; asm("v_exp_f16_sdwa %0, -%1 
 DEV void exp2neg_hi16(uint32_t& e, uint32_t u) { asm("v_exp_f16_sdwa %0, -%1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(e) : "v"(u)); }
 DEV uint32_t rcp_lo16(uint32_t d) { uint32_t r; asm("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(r) : "v"(d)); return r; }
 DEV void rcp_hi16(uint32_t& r, uint32_t d) { asm("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(r) : "v"(d)); }
+DEV void phase_end16() {
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
+}
 DEV void silu_l2_tile16(uint32_t (&u)[8]) {
     uint32_t e[8];
 #pragma unroll
@@ -52,20 +56,20 @@ DEV void silu_l2_tile16(uint32_t (&u)[8]) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) exp2neg_hi16(e[k], u[k]);
-    __builtin_amdgcn_sched_barrier(0);
+    phase_end16();
     const h16x2 one = {(_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = __builtin_bit_cast(uint32_t, (h16x2)(__builtin_bit_cast(h16x2, e[k]) + one));
+    __builtin_amdgcn_sched_barrier(0);
     uint32_t r[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        e[k] = __builtin_bit_cast(uint32_t, (h16x2)(__builtin_bit_cast(h16x2, e[k]) + one));
-        r[k] = rcp_lo16(e[k]);
-    }
+    for (int k = 0; k < 8; ++k) r[k] = rcp_lo16(e[k]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) rcp_hi16(r[k], e[k]);
-    __builtin_amdgcn_sched_barrier(0);
+    phase_end16();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) u[k] = __builtin_bit_cast(uint32_t, (h16x2)(__builtin_bit_cast(h16x2, u[k]) * __builtin_bit_cast(h16x2, r[k])));
+    for (int k = 7; k >= 0; --k) u[k] = __builtin_bit_cast(uint32_t, (h16x2)(__builtin_bit_cast(h16x2, u[k]) * __builtin_bit_cast(h16x2, r[k])));   // (last-written first)
 }
 template <int MODE>
 __global__ void k(const unsigned* u_in, unsigned* z, int n) {       // every thread: 8 consecutive pairs
