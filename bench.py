@@ -463,20 +463,21 @@ def main():
                                      "operands": f"every GEMM on plain bf16 MFMA operands; the last {tail2} of the loop's {S} model evaluations in the "
                                                  "'mixed' form: 128-wide GEMMs on split bf16 (hi*hi + lo*hi + hi*lo), FiLM GEMM on f16 operands.  "
                                                  "plain_bf16_rel_l2: the same mode without that tail"}
-                # the mode's own kernel-level evidence: one eager pass with per-launch events over the loop as it runs (tail included) and
-                # one with the tail off - k_layer's plain launches from the second, the split ones from the difference
+                # the mode's own kernel-level evidence: eager passes with per-launch events over the loop as it runs (tail included), with the
+                # tail off (the plain launches) and with every evaluation split (the split launches, the tail's f16 FiLM GEMM)
                 prof_t, _ = n2.profile_loop(noise, coef)
                 n2.set_precise_tail(0)
                 prof_p, _ = n2.profile_loop(noise, coef)
+                n2.set_precise_tail(S)                      # every evaluation split: the split instantiation's launch time directly
+                prof_s, _ = n2.profile_loop(noise, coef)
                 n2.set_precise_tail(-1)
-                lp_ms, lp_n = prof_p["k_layer"]
-                lt_ms, lt_n = prof_t["k_layer"]
                 n_split = tail2 * model.num_layers
-                split_us = (lt_ms - lp_ms * (lt_n - n_split) / max(lp_n, 1)) / max(n_split, 1) * 1e3
+                split_us = prof_s["k_layer"][0] / max(prof_s["k_layer"][1], 1) * 1e3
                 tot_t, tot_p = sum(v[0] for v in prof_t.values()), sum(v[0] for v in prof_p.values())
                 line["bf16_mode"]["roofline"] = {
                     "k_film_gemm": roof("k_film_gemm", prof_p, {}), "k_layer_plain": roof("k_layer", prof_p, {}),
                     "k_layer_split_launch_us": round(split_us, 1), "k_layer_split_launches": n_split,
+                    "k_film_gemm_tail_f16_launch_us": round(prof_s["k_film_gemm"][0] / max(prof_s["k_film_gemm"][1], 1) * 1e3, 1),
                     "tail_share_of_loop": round(1.0 - tot_p / tot_t * (S - tail2) / S, 4) if tot_t > 0 else None,
                     "eager_kernel_ms": {"with_tail": {k: round(v[0], 3) for k, v in prof_t.items() if v[1]},
                                         "tail_off": {k: round(v[0], 3) for k, v in prof_p.items() if v[1]}},

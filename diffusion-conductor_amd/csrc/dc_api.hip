@@ -1048,7 +1048,7 @@ int steps_per_graph(int S) {
 
 // h_coef: [S][DC_COEF] per-timestep scalars (dc_common.h); flags: DC_UPD_*; d_step_noise: [S][B][Tx][P] or nullptr
 #ifndef DC_BF16_TAIL_DEFAULT
-#define DC_BF16_TAIL_DEFAULT 4
+#define DC_BF16_TAIL_DEFAULT 6
 #endif
 }  // namespace
 extern "C" DC_EXPORT int32_t dc_precise_tail_default(int32_t precision);
@@ -1133,9 +1133,6 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     // precise tail: the loop's last `tail` model evaluations on split operands (dc_sampler_set_precise_tail; DC_PRECISE_TAIL=k overrides):
     // fp16 / bf16 precision, linear attention, no test hooks
     int tail = s->tail_split >= 0 ? s->tail_split : dc_precise_tail_default(s->cfg.precision);
-    // (full attention in the bf16 precision keeps bf16 scores, weights and values in its split evaluations too: a tail of 4 left
-    // 1.06e-3 on one case of tools/fuzz_sampler.py - clip_denoised, eta = 0.5, DDIM-39 - where the linear-attention mode has 6e-4; 8 there)
-    if (s->tail_split < 0 && s->cfg.no_eff && s->cfg.precision == DC_PREC_BF16) tail = 2 * DC_BF16_TAIL_DEFAULT;
     bool tail_asked = s->tail_split >= 0;
     if (const char* e = getenv("DC_PRECISE_TAIL")) tail = atoi(e), tail_asked = true;
     // An EPSILON model's final sample is sqrt(1 / abar) x_t - sqrt(1 / abar - 1) eps, not the last evaluations' prediction: what the plain
@@ -1313,8 +1310,10 @@ int dc_sampler_create(const dc_config* cfg, dc_sampler** out) {
                     "(transformer.py:385,404,482)", cfg->latent_dim, cfg->num_heads, cfg->ff_size);
     if (cfg->input_feats < 1 || cfg->input_feats > DC_PMAX) return fail(DC_ERR_UNSUPPORTED, "input_feats must be in [1,32]");
     if (cfg->num_layers < 1 || cfg->num_layers > DC_MAX_LAYERS) return fail(DC_ERR_UNSUPPORTED, "num_layers must be in [1,%d]", DC_MAX_LAYERS);
-    if (cfg->no_eff && cfg->precision != DC_PREC_FP16 && cfg->precision != DC_PREC_BF16)
-        return fail(DC_ERR_UNSUPPORTED, "no_eff (full T x T attention) is built for the fp16 and bf16 precision modes only");
+    // (bf16 attention operands - scores, weights and values on 8 mantissa bits - leave 1.0 - 1.8e-3 on x0 whatever the precise tail
+    // (tools/fuzz_shapes.py, profiles/r06_fuzz_bf16_tail.txt): outside the parity bound, so the combination is not offered)
+    if (cfg->no_eff && cfg->precision != DC_PREC_FP16)
+        return fail(DC_ERR_UNSUPPORTED, "no_eff (full T x T attention) is built for the fp16 precision only (bf16 attention operands leave 1 - 2e-3 on x0: outside the 1e-3 parity bound)");
     if (cfg->precision < DC_PREC_BF16 || cfg->precision > DC_PREC_FP16) return fail(DC_ERR_INVALID, "unknown precision %d", cfg->precision);
     if (cfg->max_timesteps < 1) return fail(DC_ERR_INVALID, "max_timesteps must be >= 1");
     int ndev = 0;

@@ -2724,27 +2724,32 @@ static hipError_t launch_full_t(hipStream_t st, int which, const DcModel* dm, in
                                                                        stop_after, upd);
     return hipGetLastError();
 }
+// (fp16 only: with bf16 scores, weights and values x0 sits 1 - 2e-3 from the reference - dc_sampler_create refuses the combination)
 hipError_t dc_launch_embed_front_full(hipStream_t st, int fmt, bool split, const DcModel* dm, const float* x, float* hbuf, void* kv_next,
                                       int M, int T, int B, int KT) {
-    DISPATCH(fmt, split, (launch_full_t<T16, SP>(st, 0, dm, 0, x, hbuf, nullptr, 0, nullptr, kv_next, nullptr, nullptr, nullptr, nullptr,
-                                                 0, nullptr, nullptr, nullptr, M, T, B, KT, 0, DcUpdate{})));
-    return LAUNCH_CHECK();
+    if (fmt != 1) return hipErrorInvalidValue;
+    if (split)
+        return launch_full_t<_Float16, true>(st, 0, dm, 0, x, hbuf, nullptr, 0, nullptr, kv_next, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                                             nullptr, M, T, B, KT, 0, DcUpdate{});
+    return launch_full_t<_Float16, false>(st, 0, dm, 0, x, hbuf, nullptr, 0, nullptr, kv_next, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                                          nullptr, M, T, B, KT, 0, DcUpdate{});
 }
 hipError_t dc_launch_layer_full(hipStream_t st, int fmt, bool split, const DcModel* dm, int l, float* hbuf, const void* E, int NT,
                                 const void* kv_cur, void* kv_next, const void* kv_ca, const int* length, const float* xin,
                                 float* xout, int out_mode, const float* coef_cur, const int* snap_cur, float* snaps, int M,
                                 int T, int B, int KT, int stop_after, const DcUpdate& upd) {
-    DISPATCH(fmt, split, (launch_full_t<T16, SP>(st, 1, dm, l, nullptr, hbuf, E, NT, kv_cur, kv_next, kv_ca, length, xin, xout, out_mode,
-                                                 coef_cur, snap_cur, snaps, M, T, B, KT, stop_after, upd)));
-    return LAUNCH_CHECK();
+    if (fmt != 1) return hipErrorInvalidValue;
+    if (split)
+        return launch_full_t<_Float16, true>(st, 1, dm, l, nullptr, hbuf, E, NT, kv_cur, kv_next, kv_ca, length, xin, xout, out_mode, coef_cur, snap_cur,
+                                             snaps, M, T, B, KT, stop_after, upd);
+    return launch_full_t<_Float16, false>(st, 1, dm, l, nullptr, hbuf, E, NT, kv_cur, kv_next, kv_ca, length, xin, xout, out_mode, coef_cur, snap_cur,
+                                          snaps, M, T, B, KT, stop_after, upd);
 }
 hipError_t dc_launch_ca_kv(hipStream_t st, int fmt, const DcModel* dm, const void* nh_hi, const void* nh_lo, void* kv_ca,
                            int M, int T, int G, int B, int KT, int L) {
     const dim3 grid((G + 3) / 4, L);
-    if (fmt == 1)
-        k_cond_ca_kv<_Float16><<<grid, dim3(256), 0, st>>>(dm, (const bf16x8*)nh_hi, (const bf16x8*)nh_lo, (f16x8*)kv_ca, M, T, G, B, KT);
-    else
-        k_cond_ca_kv<__bf16><<<grid, dim3(256), 0, st>>>(dm, (const bf16x8*)nh_hi, (const bf16x8*)nh_lo, (bf16x8*)kv_ca, M, T, G, B, KT);
+    if (fmt != 1) return hipErrorInvalidValue;
+    k_cond_ca_kv<_Float16><<<grid, dim3(256), 0, st>>>(dm, (const bf16x8*)nh_hi, (const bf16x8*)nh_lo, (f16x8*)kv_ca, M, T, G, B, KT);
     return hipGetLastError();
 }
 

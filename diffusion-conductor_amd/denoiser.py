@@ -58,6 +58,9 @@ class MotionTransformer(nn.Module):
         # (bf16-range operands) and re-runs that loop; the switch is sticky for this module (numerics_fallback).
         if precision not in ("fp16", "mixed", "bf16x3", "bf16", "auto"):
             raise ValueError(f"unknown precision {precision!r}")
+        if no_eff and precision not in ("fp16", "auto"):
+            raise ValueError(f"no_eff=True (full T x T attention, transformer.py:198-287) is built for precision='fp16' only, not {precision!r}: "
+                             "bf16 attention operands leave 1 - 2e-3 on x0 (outside the 1e-3 parity bound), the split precisions have no full-attention kernels")
         self.precision = precision
         self.active_precision = "fp16" if precision == "auto" else precision
         self.check_numerics = True          # one dc_sampler_status per sampling loop (a stream synchronisation)
@@ -112,8 +115,8 @@ class MotionTransformer(nn.Module):
         storage range is outside every mode."""
         from . import native
         # (exactly NONFINITE: with the saturation bit the values are outside every mode, and no other bit is a precision problem)
-        if self.precision != "auto" or self.active_precision != "fp16" or status != native.STATUS_NONFINITE:
-            return False
+        if self.precision != "auto" or self.active_precision != "fp16" or status != native.STATUS_NONFINITE or self.cfg.no_eff:
+            return False          # (full attention exists in fp16 only: nothing to fall back to)
         if self._native is not None:
             self._native.close()
         self._native = None
@@ -146,7 +149,7 @@ class MotionTransformer(nn.Module):
     encoder_format = None
     # fp16 precision: the sampling loops' last `precise_tail` model evaluations on split fp16 operands (include/dc_ddim.h,
     # dc_sampler_set_precise_tail); set before the first forward.  DC_PRECISE_TAIL=k in the environment overrides it.
-    precise_tail = None       # None: the library's default (1 for fp16, 8 for bf16)
+    precise_tail = None       # None: the library's default (1 for fp16, 6 for bf16)
 
     # Small batches (at most one 64-token unit per CU): whether a clip's workgroups share the attention combine inside a layer launch
     # (None / True: the library's default) or every workgroup combines alone (False: no in-launch wait - for a GPU shared with other

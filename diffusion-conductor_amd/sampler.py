@@ -251,16 +251,6 @@ class GaussianDiffusion:
             self._native_coef[key] = native.ddim_coefficients(self.alphas_cumprod, key)
         return self._native_coef[key]
 
-    def _refuse_outside_the_bound(self, model, eta):
-        """The one (precision x attention x sampler branch) combination whose result would be outside the 1e-3 parity bound is refused,
-        not returned: full attention (`no_eff`) in the bf16 precision with an update that keeps the evaluations' error at eta = 0 (EPSILON /
-        PREVIOUS_X) - the attention's own bf16 operands (scores, weights, values: 8 mantissa bits) leave 1.9e-3 even with every 128-wide
-        GEMM on split operands (round 6, tests/test_gpu_robust.py); the same model in precision="fp16" is inside the bound."""
-        if (isinstance(model, MotionTransformer) and self.model_mean_type != ModelMeanType.START_X and eta == 0.0
-                and getattr(model, "active_precision", None) == "bf16" and bool(getattr(getattr(model, "cfg", None), "no_eff", False))):
-            raise NotImplementedError(f"{self.model_mean_type.name} model, eta = 0, full attention (no_eff) in precision 'bf16': the result would be "
-                                      "1.9e-3 from the fp32 reference (outside the 1e-3 bound); build the MotionTransformer with precision='fp16'")
-
     def _native_loop(self, model, img, mk, clip_denoised, eta, snap, step_noise, smooth=None, step_noise_seed=None):
         """The captured loop on `model`'s sampler; returns (out, snaps).  Numeric health is checked once per call
         (`model.check_numerics`): a non-finite x0 under precision="auto" falls back to the bf16-range mode in a fresh sampler."""
@@ -282,9 +272,8 @@ class GaussianDiffusion:
                 zseed = int(th.randint(0, 2 ** 62, (1,)).item())
         plain = flags == 0 and eta == 0.0
         # (An EPSILON model's final sample carries what the evaluations left in x_t: the library runs EVERY evaluation of such a loop on
-        # split operands - in the fp16 and bf16 precisions, linear and full attention alike (dc_ddim.h, dc_sampler_set_precise_tail; the bf16
+        # split operands - in the fp16 and bf16 precisions, linear and (fp16) full attention alike (dc_ddim.h, dc_sampler_set_precise_tail; the bf16
         # precision's split evaluations take the FiLM GEMM's operands in fp16).)
-        self._refuse_outside_the_bound(model, eta)
         coef = self.native_coefficients(None if plain else eta)
         retried = False
         while True:
@@ -366,7 +355,6 @@ class GaussianDiffusion:
             indices = tqdm(indices)
         # The update of an EPSILON / PREVIOUS_X model, and a conditioned score, keep what the evaluations' 16-bit operands left in x_t
         # (fp16, EPSILON, eta = 0: 1.5e-3 on plain operands): these loops evaluate the native denoiser on split operands
-        self._refuse_outside_the_bound(model, eta)
         precise = isinstance(model, MotionTransformer) and (self.model_mean_type != ModelMeanType.START_X or cond_fn is not None)
         before = model.precise_forward if precise else None
         if precise:

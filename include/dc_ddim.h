@@ -48,7 +48,7 @@ typedef enum dc_status {
  * two tiny pose projections (joint_embed 26->128, out 128->26) run split, and the one-time
  * cross-attention pre-pass runs split-bf16.  Measured rel-L2 on x0, DDIM-50: see DESIGN.md. */
 typedef enum dc_precision {
-    DC_PREC_BF16 = 0,   /* every GEMM plain bf16 (does NOT meet the 1e-3 parity bound)              */
+    DC_PREC_BF16 = 0,   /* every GEMM plain bf16; meets the 1e-3 bound through its precise tail (below) */
     DC_PREC_MIXED = 1,  /* 128-wide GEMMs (Q/K/V, attention, out-proj, FFN) split-bf16; FiLM GEMM f16 */
     DC_PREC_BF16X3 = 2, /* split-bf16 everywhere (validation mode)                                   */
     DC_PREC_FP16 = 3    /* default: every GEMM plain f16, one MFMA per product                       */
@@ -64,7 +64,7 @@ typedef struct dc_config {
     int32_t ff_size;       /* 64                                       */
     int32_t num_layers;    /* 8                                        */
     int32_t num_heads;     /* 8                                        */
-    int32_t no_eff;        /* 0 = linear attention (default), 1 = full T x T attention */
+    int32_t no_eff;        /* 0 = linear attention (default), 1 = full T x T attention (DC_PREC_FP16 only: bf16 attention operands are outside the parity bound) */
     int32_t precision;     /* dc_precision                             */
     int32_t max_timesteps; /* size of the timestep-embedding table (>= diffusion_steps), e.g. 1000 */
     int32_t device;        /* HIP device ordinal                       */
@@ -157,13 +157,15 @@ DC_EXPORT int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t
  * in the final evaluations (DDIM's last step returns the model's own prediction of x0).  Golden DDIM-50, rel-L2 of x0:
  *   fp16:  5.0e-4 with steps = 0,  2.3e-4 with 1,  1.6e-4 with 2,  1.2e-4 with 4   (+0.45 % of the loop per step at bs = 32)
  *   bf16:  3.1e-3 with steps = 0,  9.5e-4 with 2,  6.8e-4 with 4,  5.4e-4 with 8   - the bf16-operand mode that meets the 1e-3 bound
- *          (round 5's figures, the tail's FiLM GEMM on bf16 operands; since round 6 the tail's evaluations take the FiLM GEMM's operands
- *          in fp16 - they are "mixed"-precision evaluations - see DESIGN.md section 5 for the measured figures and the default)
- * Default (steps never set): 1 for fp16, 8 for bf16.  (Clip strides of whole 32-frame groups run the split evaluations in the
+ *          (round 5's figures, the tail's FiLM GEMM on bf16 operands).  Since round 6 the bf16 precision's split evaluations take the FiLM
+ *          GEMM's operands in fp16 - they are "mixed"-precision evaluations: 1.42e-3 with 1, 8.5e-4 with 2, 5.6e-4 with 4, 3.5e-4 with 8;
+ *          default 6 (4 left 1.1e-3 on one short ragged batch of tools/fuzz_shapes.py, 6: 8.6e-4, 8: 7.3e-4)
+ * Default (steps never set): 1 for fp16, 6 for bf16 (dc_precise_tail_default).  (Clip strides of whole 32-frame groups run the split evaluations in the
  * workgroup-record form on clip-aligned units, others - T = 900 x 128 unpadded, short clips - in the per-group record form: 5.2e-4 ->
  * 2.6e-4 there at no measurable cost.)  Loops of an EPSILON model (DC_UPDATE_EPSILON) run EVERY evaluation on split operands unless a
  * number was set here: their final sample carries what the plain evaluations left in x_t (fp16, eta = 0: 1.4 - 1.8e-3 with any shorter
- * tail, 2.1e-4 all split).  Ignored for the split precisions and for `no_eff`.  DC_PRECISE_TAIL=k in the environment
+ * tail, 1.5e-4 all split).  Applies to linear and full attention alike (`no_eff`, fp16: its split instantiation keeps scores, weights and
+ * values plain 16-bit); ignored for the split precisions.  DC_PRECISE_TAIL=k in the environment
  * overrides it.  (In a loop that has a tail the plain
  * evaluations read FiLM scale tiles that hold G' itself - one mixed-precision FMA per element instead of two -, the split ones G' - 1;
  * loops without a tail keep G' - 1 everywhere.) */
@@ -174,7 +176,7 @@ DC_EXPORT int32_t dc_precise_tail_default(int32_t precision);                   
  * on != 0; default off (plain operands of the precision).  For callers that step a sampler THROUGH single evaluations and whose update
  * keeps the evaluations' error (an EPSILON or PREVIOUS_X model, cond_fn: gaussian_diffusion.py:510-520, 581-603): the Python sampler
  * switches it on for exactly those loops.  The bf16 precision's split evaluations also take their FiLM GEMM operands in fp16 (they are
- * then the evaluations of the "mixed" precision).  Ignored where no split kernels exist (split precisions: already split; `no_eff`). */
+ * then the evaluations of the "mixed" precision).  Ignored for the split precisions (already split). */
 DC_EXPORT int dc_sampler_set_precise_forward(dc_sampler* s, int32_t on);
 
 #define DC_ME_SPLIT 0

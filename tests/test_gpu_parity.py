@@ -112,7 +112,7 @@ def test_ddim25_odd_shapes_wide_units_vs_oracle(models, B, T):
         assert torch.isfinite(a).all() and max(errs) <= TOL_PARITY, errs
 
 
-@pytest.mark.parametrize("prec,tol", [("fp16", TOL_PARITY), ("mixed", TOL_PARITY), ("bf16x3", TOL_X3), ("bf16", TOL_PARITY)])      # (bf16: with its precise tail of 8)
+@pytest.mark.parametrize("prec,tol", [("fp16", TOL_PARITY), ("mixed", TOL_PARITY), ("bf16x3", TOL_X3), ("bf16", TOL_PARITY)])      # (bf16: with its precise tail of 6)
 def test_ddim50_config1_golden(models, prec, tol):
     """G5 = BASELINE config 1: single 60 s clip, DDIM-50, with the idxs=[0,24] intermediates."""
     g = golden("g5_ddim50_b1.npz")
@@ -162,24 +162,28 @@ def test_precise_tail_halves_the_fp16_error(models):
                     g6["t900_x0"]) for k in ("0", "1")}
     print(f"T = 900 unpadded: precise tail 0 / 1: {e9['0']:.3e} {e9['1']:.3e}")
     assert e9["0"] <= TOL_PARITY and e9["1"] <= 0.7 * e9["0"]
-    # the bf16 precision: plain bf16 operands cannot meet the bound (8 mantissa bits), the last 8 of 50 evaluations on split bf16 can
-    eb = {k: rel_l2(_with_env({"DC_PRECISE_TAIL": str(k)}, lambda: _ddim(models["bf16"], 50, noise, xfp, xfo, [1800])), g["x0"]) for k in (0, 2, 8)}
-    print("bf16, precise tail 0 / 2 / 8: " + " ".join(f"{eb[k]:.3e}" for k in (0, 2, 8)))
-    assert eb[0] > TOL_PARITY and eb[8] <= 0.7 * TOL_PARITY and eb[8] < eb[2] < eb[0]
+    # the bf16 precision: plain bf16 operands cannot meet the bound (8 mantissa bits); its last evaluations in the "mixed" form (128-wide
+    # GEMMs on split bf16, FiLM GEMM on f16 operands) can - 6 of 50 by default (4 left 1.1e-3 on one short ragged batch of
+    # tools/fuzz_shapes.py, 6: 8.6e-4, 8: 7.3e-4 - profiles/r06_fuzz_bf16_tail.txt); round 5's form (bf16 FiLM operands in the tail too)
+    # needed 8 for what 4 give now
+    eb = {k: rel_l2(_with_env({"DC_PRECISE_TAIL": str(k)}, lambda: _ddim(models["bf16"], 50, noise, xfp, xfo, [1800])), g["x0"]) for k in (0, 2, 4, 8)}
+    print("bf16, precise tail 0 / 2 / 4 / 8: " + " ".join(f"{eb[k]:.3e}" for k in (0, 2, 4, 8)))
+    assert eb[0] > TOL_PARITY and eb[8] <= 0.5 * TOL_PARITY and eb[8] < eb[4] < eb[2] < eb[0]
+    r5 = rel_l2(_with_env({"DC_PRECISE_TAIL": "8", "DC_TAIL_FILM_BF16": "1"}, lambda: _ddim(models["bf16"], 50, noise, xfp, xfo, [1800])), g["x0"])
     from diffusion_conductor_amd import native as _nat
     kd = _nat.precise_tail_default("bf16")
     ed = rel_l2(_ddim(models["bf16"], 50, noise, xfp, xfo, [1800]), g["x0"])          # its default
-    print(f"bf16 default tail {kd}: {ed:.3e}")
-    assert kd == 4 and eb[8] < ed < eb[2] and ed <= 0.6 * TOL_PARITY
+    print(f"bf16 default tail {kd}: {ed:.3e}; round 5's form (tail 8, bf16 FiLM operands in the tail): {r5:.3e}")
+    assert kd == 6 and eb[8] < ed < eb[4] and ed <= 0.5 * TOL_PARITY and ed < r5
 
 
 @pytest.mark.parametrize("S", [1, 25])
 def test_precise_tail_in_short_loops(models, S):
     """A loop of fewer steps than the tail asks for runs every evaluation on split operands (the tail is clipped to the loop: S = 1 - the only
-    length below bf16's default of 8 that the reference's linear schedule admits, betas <= 1 -; S = 25: seventeen plain evaluations in front
-    of eight split ones), on a short ragged batch (T = 96: the per-group record form) and on clip-aligned units (T = 320), against the
-    oracle.  One all-split evaluation: fp16 6 - 7e-5; bf16 3.6 - 4.0e-4, the floor of that mode's tail (its FiLM GEMM keeps plain bf16
-    operands in the tail's evaluations too)."""
+    length below bf16's default of 6 that the reference's linear schedule admits, betas <= 1 -; S = 25: nineteen plain evaluations in front
+    of six split ones), on a short ragged batch (T = 96: the per-group record form) and on clip-aligned units (T = 320), against the
+    oracle.  One all-split evaluation: fp16 6 - 7e-5, bf16 the same since round 6 (its split evaluations take the FiLM GEMM's operands in f16;
+    round 5: 3.6 - 4.0e-4)."""
     for B, T, length in ((2, 96, [96, 61]), (2, 320, [320, 1])):
         xfp, xfo = xf_pair(B, T, first=40)
         noise = torch.from_numpy(batch_noise(B, T, first=40))
@@ -194,7 +198,7 @@ def test_precise_tail_in_short_loops(models, S):
             assert torch.isfinite(a).all() and err <= TOL_PARITY and asked <= TOL_PARITY
             assert err < plain
             if S == 1:
-                assert err == asked and err <= (1e-4 if mode == "fp16" else 5e-4)        # every evaluation split
+                assert err == asked and err <= 1.5e-4        # every evaluation split
 
 
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (40, 7), (5, 31), (2, 33)])
@@ -790,7 +794,7 @@ def test_error_behaviour(models):
         s.denoise(x, [0])
     s.close()
     with pytest.raises(native.DcError, match="no_eff"):
-        native.NativeSampler(DenoiserConfig(no_eff=True), "bf16x3")     # full attention: fp16 / bf16 modes only
+        native.NativeSampler(DenoiserConfig(no_eff=True), "bf16x3")     # full attention: fp16 only
     with pytest.raises(RuntimeError, match="no CPU path"):
         make_model("fp16", device="cpu")(torch.zeros(1, 64, 26), torch.zeros(1, dtype=torch.long),
                                           length=[64], xf_proj=torch.zeros(1, 64, 64), xf_out=torch.zeros(1, 64, 64))
@@ -999,23 +1003,17 @@ def test_no_eff_bs32_full_size_properties(model_no_eff):
     assert max(errs) <= TOL_PARITY
 
 
-def test_no_eff_bf16_mode_vs_oracle():
-    """The bf16 build of the full-attention kernels (same code, v_mfma_*_bf16 and the bf16 reference-point slot): loosely
-    bounded like every plain-bf16 result (8 mantissa bits), ragged lengths and a clip edge inside a key tile."""
-    m = make_model("bf16", no_eff=True)
-    B, T = 3, 200
-    p = oracle_params()
-    xfp, xfo = xf_pair(B, T, first=50)
-    x = torch.from_numpy(batch_noise(B, T, first=50))
-    t = torch.tensor([3, 30, 49])
-    length = [200, 117, 200]
-    with torch.no_grad():
-        ref = O.denoiser_forward(p, x, t, length, xfp, xfo, no_eff=True)
-    out = m(x.cuda(), t, length=torch.tensor(length), xf_proj=xfp.cuda(), xf_out=xfo.cuda())
-    torch.cuda.synchronize()
-    err = rel_l2(out, ref)
-    print(f"no_eff bf16 mode rel-L2 {err:.3e}")
-    assert torch.isfinite(out).all() and err <= TOL_BF16
+def test_no_eff_is_offered_in_fp16_only():
+    """Full attention with bf16 scores, weights and values sits 1.0 - 1.8e-3 from the reference on x0 whatever the precise tail
+    (profiles/r06_fuzz_bf16_tail.txt): outside the 1e-3 parity bound, so the combination is refused at construction - by the Python
+    class and by dc_sampler_create - instead of returning such results (round 5 built it, loosely bounded)."""
+    from diffusion_conductor_amd import MotionTransformer, native
+    from diffusion_conductor_amd.param_spec import DenoiserConfig
+    for prec in ("bf16", "mixed", "bf16x3"):
+        with pytest.raises(ValueError, match="precision='fp16' only"):
+            MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cuda", no_eff=True, precision=prec)
+        with pytest.raises(native.DcError, match="fp16 precision only"):
+            native.NativeSampler(DenoiserConfig(no_eff=True), prec)
 
 
 # ---- SURVEY section 8f: post-processing and the batched evaluation driver ------------------------------------------

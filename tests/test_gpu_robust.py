@@ -151,11 +151,12 @@ def test_epsilon_model_runs_every_evaluation_on_split_operands(S):
     assert errs["bf16"] <= 0.5 * TOL and errs["bf16, tail 1"] > 3 * errs["bf16"]
 
 
-@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp16"])
 def test_epsilon_model_full_attention_eta0_vs_oracle(prec):
     """The same branch through the full-attention (`no_eff`) kernels: k_layer_full's split-operand instantiation (query / key / value
     projections, stylization out-projections and FFN on split operands; scores, weights and values plain 16-bit) runs every evaluation
-    of an EPSILON loop - round 5 returned 1.4e-3 (fp16) / 1 - 2e-3 (bf16) here with a warning."""
+    of an EPSILON loop - round 5 returned 1.4e-3 here with a warning.  (Full attention is offered in fp16 only: bf16 attention operands
+    leave 1.9e-3 on this branch even with every GEMM split, 1.0 - 1.8e-3 on START_X loops - test_no_eff_is_offered_in_fp16_only.)"""
     from helpers import O
     from diffusion_conductor_amd import MotionTransformer
     sd, B, T, S, length, xfp, xfo, noise, _ = _g9_setup()
@@ -167,14 +168,6 @@ def test_epsilon_model_full_attention_eta0_vs_oracle(prec):
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     m = m.to("cuda").eval()
     kw = dict(noise=noise, clip_denoised=True, progress=False, model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.LongTensor(length)})
-    if prec == "bf16":
-        # the attention's own bf16 operands leave 1.9e-3 even so: refused (captured loop and generator alike), not returned with a warning
-        with pytest.raises(NotImplementedError, match="precision='fp16'"):
-            gd.ddim_sample_loop(m, (B, T, 26), **kw)
-        with pytest.raises(NotImplementedError, match="outside the 1e-3 bound"):
-            next(gd.ddim_sample_loop_progressive(m, (B, T, 26), **kw))
-        gd.ddim_sample_loop(m, (B, T, 26), eta=0.5, **kw)          # (eta > 0: fresh noise damps what the evaluations left - G9's branch)
-        return
     out = gd.ddim_sample_loop(m, (B, T, 26), **kw)
     torch.cuda.synchronize()
     err = rel_l2(out, ref)

@@ -34,7 +34,7 @@ for case in range(N):
     idxs = sorted(set(int(v) for v in rng.integers(0, S, size=int(rng.integers(0, 4)))))
     length = [int(rng.integers(1, T + 1)) if rng.random() < 0.5 else T for _ in range(B)]
     prec = str(rng.choice(["fp16", "fp16", "mixed", "bf16"]))
-    no_eff = bool(prec in ("fp16", "bf16") and T >= 32 and rng.random() < 0.25)          # (full attention is built for the two plain precisions, from T = 32)
+    no_eff = bool(prec == "fp16" and T >= 32 and rng.random() < 0.35)          # (full attention is offered in fp16, from T = 32)
     first = int(rng.integers(0, 100))
     if (prec, no_eff) not in models:
         models[(prec, no_eff)] = make_model(prec, no_eff=no_eff)
@@ -47,18 +47,8 @@ for case in range(N):
     gd = GaussianDiffusion(betas=get_named_beta_schedule("linear", S), model_mean_type=ModelMeanType.EPSILON if eps_model else ModelMeanType.START_X,
                            model_var_type=ModelVarType.FIXED_SMALL, loss_type=LossType.MSE)
     kw = {"step_noise": z.cuda()} if eta else {}
-    refused = eps_model and eta == 0.0 and no_eff and prec == "bf16"        # the one combination outside the bound: refused, not returned (sampler.py)
-    try:
-        out = gd.ddim_sample_loop(models[(prec, no_eff)], (B, T, 26), noise=noise.cuda(), clip_denoised=clip, progress=False, eta=eta, idxs=idxs,
-                                  model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor(length)}, **kw)
-    except NotImplementedError as e:
-        bad += not refused
-        print(f"case {case:3d} B={B} T={T:3d} S={S:3d} eta={eta:.1f} clip={int(clip)} eps={int(eps_model)} {prec}+no_eff: refused ({str(e)[:60]}...){'' if refused else '   <-- FAIL'}", flush=True)
-        continue
-    if refused:
-        bad += 1
-        print(f"case {case:3d}: a combination outside the bound was not refused   <-- FAIL", flush=True)
-        continue
+    out = gd.ddim_sample_loop(models[(prec, no_eff)], (B, T, 26), noise=noise.cuda(), clip_denoised=clip, progress=False, eta=eta, idxs=idxs,
+                              model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor(length)}, **kw)
     torch.cuda.synchronize()
     if not idxs:
         out, ref = {S: out}, {S: ref}

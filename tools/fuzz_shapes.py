@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: randomized (B, T, length, precision, steps) cases of the whole DDIM loop against the oracle - shapes off every grid the
 fixed tests name (T from 1 frame up, batches on both sides of every dispatch switch, ragged lengths down to 1).  Test infrastructure:
-the oracle is the checker here, never the thing measured.  usage: python tools/fuzz_shapes.py [cases] [seed]"""
+the oracle is the checker here, never the thing measured.  usage: python tools/fuzz_shapes.py [cases] [seed] [precision: every case in it]"""
 import os
 import sys
 import time
@@ -36,6 +36,9 @@ for case in range(N):
         T = min(T, 700)
     length = [int(rng.integers(1, T + 1)) if rng.random() < 0.6 else T for _ in range(B)]
     prec = str(rng.choice(["fp16"] if no_eff else ["fp16", "fp16", "bf16", "mixed", "bf16x3"]))
+    if len(sys.argv) > 3:
+        prec = sys.argv[3]
+        no_eff = no_eff and prec == "fp16"
     S = int(rng.choice([21, 25, 50] if B * T <= 2500 else [21, 25]))
     first = int(rng.integers(0, 200))
     mk = (prec, no_eff)
