@@ -1386,6 +1386,16 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     __syncthreads(); sprio<3>();
     __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifdef DC_DIAG_HALF_SHIFT
+    // diagnostic build (timing only, results invalid: the upper half reads weight images that are being overwritten): waves 4-7 run
+    // stages 1-6 ONE STAGE behind waves 0-3 (an extra barrier in front for them, one behind stage 6 for the others), so that the two
+    // waves of a SIMD are never in the same stage - the bound on what a staggered form (MI355X_MICROARCH.md, two waves per SIMD, item 9)
+    // could gain over the lockstep of the shipped form
+    if constexpr (WGR && !SPLIT && !NARROW && !DBG) {
+        if (wave >= NW / 2) { for (int i_ = 0; i_ < DC_DIAG_HALF_SHIFT; ++i_) __builtin_amdgcn_s_barrier(); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     DC_STAMP(1);
 
     // ---- stage 1: SA query + attention apply [buf0]; prefetch SA out-proj -> buf1
@@ -1541,6 +1551,12 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
     if constexpr (DBG) if ((dbg & 0xff) == 3) { if (active) store_h(h, hbuf, g, lane); return; }   // test hook: stop after the FFN
     DC_STAMP(10);
     stage_sync();
+#ifdef DC_DIAG_HALF_SHIFT
+    if constexpr (WGR && !SPLIT && !NARROW && !DBG) {
+        if (wave < NW / 2) { for (int i_ = 0; i_ < DC_DIAG_HALF_SHIFT; ++i_) __builtin_amdgcn_s_barrier(); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     DC_STAMP(11);
 
     if (!last) {
@@ -1901,6 +1917,9 @@ DEV void front_full(const XFrag<T16, SPLIT> (&nf)[4], const v8<T16>* __restrict_
 #ifndef DC_FULL_PRIO
 #define DC_FULL_PRIO 1
 #endif
+#ifndef DC_FULL_PF
+#define DC_FULL_PF 2       // key loop: 0 = fragment reads at their MFMAs (round 5), 1 = two heads ahead, 2 = + the common tile software-pipelined inside the wave (-3 % per loop, bit-identical; profiles/r06_ab_full_pf.txt)
+#endif
 template <class T16, bool SPLIT = false /* the query projection on split operands; scores, weights and values stay plain 16-bit */>
 DEV void full_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const f32x16 (&h)[4],
                      const v8<T16>* __restrict__ wq, const v8<T16>* __restrict__ kv, int nkt, int tok0, int key_lo,
@@ -1972,6 +1991,11 @@ DEV void full_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const 
         if (fold) S0 = mfma(kone, __builtin_bit_cast(v8<T16>, u32x4{negm[hd], 0u, 0u, 0u}), S0);
         return S0;
     };
+    auto scores_fr = [&](const v8<T16>& kf, const v8<T16>& qf, int hd) {      // the same from fragments already in registers
+        f32x16 S0 = mfma(kf, qf, splat(0.f));
+        if (fold) S0 = mfma(kone, __builtin_bit_cast(v8<T16>, u32x4{negm[hd], 0u, 0u, 0u}), S0);
+        return S0;
+    };
 #ifdef DC_DIAG_FULL_NKT               // diagnostic builds (results invalid): the key loop cut short, to split a layer's time
     nkt = min(nkt, DC_DIAG_FULL_NKT);
 #endif
@@ -1995,7 +2019,15 @@ DEV void full_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const 
             // head loop instead of three wave-uniform branches per head.
             auto tile_body = [&](auto common_tag) {
                 constexpr bool COMMON = decltype(common_tag)::value;
+#if DC_FULL_PF
+                // fragment reads two heads ahead of their MFMAs (key / query fragments of head hd + 2 and this head's two value
+                // fragments are requested in front of this head's exponentials): the LDS round trip that sat in front of every pair of
+                // MFMAs (ds_read, s_waitcnt, MFMA) now runs under the 16 exponentials - 16 more live registers inside the loop
+                v8<T16> kfr[2] = {fr[lane], fr[64 + lane]}, qfr[2] = {qs[lane], qs[64 + lane]};
+                f32x16 Snext = scores_fr(kfr[0], qfr[0], 0);
+#else
                 f32x16 Snext = scores(fr, 0);
+#endif
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     // progress priority across the tile's eight heads (dc_dev.h, sprio): the waves of a workgroup meet at a barrier per
@@ -2011,10 +2043,21 @@ DEV void full_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const 
                     for (int sh = 0; sh < 2; ++sh) {
                         const int hd = 2 * t + sh;
                         f32x16 S = Snext;
+#if DC_FULL_PF
+                        if (hd < 7) Snext = scores_fr(kfr[(hd + 1) & 1], qfr[(hd + 1) & 1], hd + 1);
+                        if (hd < 6) {
+                            kfr[hd & 1] = fr[(hd + 2) * 64 + lane];
+                            qfr[hd & 1] = qs[(hd + 2) * 64 + lane];
+                        }
+                        const v8<T16> vf0 = *reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t) * 1024);
+                        const v8<T16> vf1 = *reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t + 1) * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+#else
                         if (hd < 7) {
                             Snext = scores(fr, hd + 1);
                             __builtin_amdgcn_sched_barrier(0);
                         }
+#endif
                         if constexpr (!COMMON) {
                             if (edge) {
                                 int kb = k0 + 4 * hh;
@@ -2092,16 +2135,119 @@ DEV void full_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const 
                             weights(mn - base, true);
                         }
                         ls[hd] += tsum;
+#if DC_FULL_PF
+                        Y[t] = mfma(vf0, pf.hi[0], Y[t]);
+                        Y[t] = mfma(vf1, pf.hi[1], Y[t]);
+#else
                         Y[t] = mfma(*reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t) * 1024), pf.hi[0], Y[t]);
                         Y[t] = mfma(*reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t + 1) * 1024), pf.hi[1], Y[t]);
+#endif
                         __builtin_amdgcn_sched_barrier(0);      // one head at a time: bounds the fragment-read lookahead
                     }
                 }
             };
+#if DC_FULL_PF == 2
+            // The common tile, software-pipelined inside the wave: a head's four MFMAs (the next head's score and reference-point
+            // MFMAs, the PREVIOUS head's two P V MFMAs) sit between the quarters of its 16 exponentials instead of in front of them -
+            // four exponentials are the 32 cycles the matrix pipe needs per MFMA, so the wave no longer waits out a burst of four MFMAs
+            // (in-order issue: ~100 cycles per head) before its vector work.  Same products in the same order per accumulator as
+            // tile_body: bit-identical results.
+            auto tile_body_pipe = [&]() {
+                v8<T16> kfr[2] = {fr[lane], fr[64 + lane]}, qfr[2] = {qs[lane], qs[64 + lane]};
+                f32x16 Snext = scores_fr(kfr[0], qfr[0], 0);
+                XFrag<T16, false> pfp;
+                v8<T16> vfp0, vfp1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#if DC_FULL_PRIO
+                    if (t == 0) __builtin_amdgcn_s_setprio(3);
+                    if (t == 1) __builtin_amdgcn_s_setprio(2);
+                    if (t == 2) __builtin_amdgcn_s_setprio(1);
+                    if (t == 3) __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+                    for (int sh = 0; sh < 2; ++sh) {
+                        const int hd = 2 * t + sh;
+                        const int tp = (hd - 1) >> 1;                 // the previous head's feature tile
+                        const f32x16 S = Snext;
+                        f32x16 Pw;
+                        if (hd < 7) Snext = mfma(kfr[(hd + 1) & 1], qfr[(hd + 1) & 1], splat(0.f));
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Pw[r] = exp2f_fast(S[r]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (hd < 7) Snext = mfma(kone, __builtin_bit_cast(v8<T16>, u32x4{negm[hd + 1], 0u, 0u, 0u}), Snext);
+                        if (hd < 6) {
+                            kfr[hd & 1] = fr[(hd + 2) * 64 + lane];
+                            qfr[hd & 1] = qs[(hd + 2) * 64 + lane];
+                        }
+                        const v8<T16> vf0 = *reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t) * 1024);
+                        const v8<T16> vf1 = *reinterpret_cast<const v8<T16>*>(vb[sh] + (8 + 2 * t + 1) * 1024);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 4; r < 8; ++r) Pw[r] = exp2f_fast(S[r]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (hd > 0) Y[tp] = mfma(vfp0, pfp.hi[0], Y[tp]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 8; r < 12; ++r) Pw[r] = exp2f_fast(S[r]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (hd > 0) Y[tp] = mfma(vfp1, pfp.hi[1], Y[tp]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 12; r < 16; ++r) Pw[r] = exp2f_fast(S[r]);
+                        XFrag<T16, false> pf;
+                        float tsum;
+                        auto finish = [&](const f32x16& P_) {
+                            make_frag<T16, false>(P_, pf);
+                            if constexpr (DC_FULL_SUM_ADDS == 2 && std::is_same<T16, _Float16>::value)
+                                tsum = sum16_pk(pf.hi[0], pf.hi[1]);
+                            else {
+                                tsum = 0.f;
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) tsum += P_[r];
+                            }
+                        };
+                        finish(Pw);
+                        if (__builtin_amdgcn_ballot_w64(!(tsum <= 64.f)) != 0) {      // the reference point moves (tile_body's rare path)
+                            const float base = mx[hd];
+                            float mt = S[0];
+#pragma unroll
+                            for (int r = 1; r < 16; ++r) mt = fmaxf(mt, S[r]);
+                            mt = xhalf_max(mt) + base;
+                            const T16 m16 = (T16)fmaxf(mx[hd], mt);
+                            const float mn = (float)m16;
+                            negm[hd] = lane < 32 ? (unsigned)__builtin_bit_cast(unsigned short, (T16)(-mn)) : 0u;
+                            const float alpha = exp2f_fast(mx[hd] - mn);
+                            mx[hd] = mn;
+                            ls[hd] *= alpha;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) Y[t][8 * sh + r] *= alpha;
+                            const float off = mn - base;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) Pw[r] = exp2f_fast(S[r] - off);
+                            finish(Pw);
+                        }
+                        ls[hd] += tsum;
+                        pfp = pf;
+                        vfp0 = vf0;
+                        vfp1 = vf1;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                Y[3] = mfma(vfp0, pfp.hi[0], Y[3]);
+                Y[3] = mfma(vfp1, pfp.hi[1], Y[3]);
+            };
+            if (kt > 0 && !edge && fold)
+                tile_body_pipe();
+            else
+                tile_body(std::false_type{});
+#else
             if (kt > 0 && !edge && fold)
                 tile_body(std::true_type{});
             else
                 tile_body(std::false_type{});
+#endif
         }
         __syncthreads();             // the buffer just read is the next-but-one tile's target
     }
