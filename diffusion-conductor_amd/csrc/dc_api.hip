@@ -1050,6 +1050,9 @@ int steps_per_graph(int S) {
 #ifndef DC_BF16_TAIL_DEFAULT
 #define DC_BF16_TAIL_DEFAULT 6
 #endif
+#ifndef DC_BF16_SHORT_CLIP
+#define DC_BF16_SHORT_CLIP 100     // bf16 precision: loops over clips of fewer frames run every evaluation split (loop_common)
+#endif
 }  // namespace
 extern "C" DC_EXPORT int32_t dc_precise_tail_default(int32_t precision);
 namespace {
@@ -1139,6 +1142,11 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     // 16-bit evaluations left in x_t stays (eta = 0: fp16 1.4 - 1.8e-3 whatever the tail, tools/fuzz_sampler.py).  Parity first: unless a
     // tail was asked for, such a loop runs EVERY evaluation on split operands (2.1e-4, at the split precisions' speed).
     if (!tail_asked && (flags & DC_UPD_EPS)) tail = S;
+    // Clips of fewer than 100 frames in the bf16 precision: a clip's error is a norm over a few hundred numbers (26 per frame), and the worst of
+    // a batch of dozens of such clips reached 1.27e-3 with the default tail (39 clips of 36 frames, lengths down to 1: tools/fuzz_shapes.py,
+    // profiles/r06_fuzz_final.txt; 8.6e-4 at 39 frames, <= 7.2e-4 from 100 frames up).  Such loops are bound by launch latency, not by the
+    // kernels: they run every evaluation in the split form (the `mixed` precision's evaluations, 9e-5) unless a tail was asked for.
+    if (!tail_asked && s->cfg.precision == DC_PREC_BF16 && s->Tx < DC_BF16_SHORT_CLIP) tail = S;
     // (clip strides that are not whole 32-frame groups - T = 900 x 128 unpadded - and short clips run the split evaluations in the
     // per-group record form with its combine launches: no measurable cost at one evaluation per loop, 70.6 vs 70.6 ms at bs = 128 x 900)
     if (!can_split_steps(s)) tail = 0;

@@ -497,6 +497,45 @@ def test_mixed_mode_clip_aligned_units_edge_shapes(B, T):
     assert torch.equal(again[S], res[S]) and torch.equal(again[3], res[3])
 
 
+def test_bf16_precision_short_ragged_clips_every_clip_inside_the_bound():
+    """Found by tools/fuzz_shapes.py (seed 601, case 117: 39 clips of 36 frames, lengths down to 1, DDIM-50): the worst clip read 1.27e-3 in
+    the bf16 precision with its default tail of 6 - a clip's error is then a norm over a few hundred numbers and the worst of dozens of clips
+    left the bound (8.6e-4 at 39 frames, <= 7.2e-4 from 100 frames up).  Loops of that precision over clips of fewer than 100 frames run
+    every evaluation in the split form (loop_common in dc_api.hip): every clip of three such batches at the split level, and a 100-frame
+    batch keeps the tail (the two settings give different results there)."""
+    sd = synthetic_state_dict(DenoiserConfig(), seed=0)
+    p = O.to_torch_params(sd)
+    m = _model(sd, "bf16")
+    gd = make_diffusion(50)
+    rng = np.random.default_rng(117)
+    worst = 0.0
+    for B, T, first in [(39, 36, 11), (32, 39, 64), (29, 67, 150)]:
+        xfp, xfo = _features(sd, B, T, first)
+        x = torch.from_numpy(batch_noise(B, T, first=first))
+        length = [int(rng.integers(1, T + 1)) if rng.random() < 0.6 else T for _ in range(B)]
+        length[0] = 1
+        with torch.no_grad():
+            ref = O.ddim_sample_loop(p, x, xfp, xfo, length, 50)
+        out = gd.ddim_sample_loop(m, (B, T, 26), noise=x.cuda(), clip_denoised=False, progress=False,
+                                  model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor(length)})
+        torch.cuda.synchronize()
+        errs = [rel_l2(out[c:c + 1], ref[c:c + 1]) for c in range(B)]
+        print(f"bf16 B={B} T={T}: worst clip {max(errs):.2e}, whole batch {rel_l2(out, ref):.2e}")
+        assert torch.isfinite(out).all()
+        worst = max(worst, max(errs))
+    assert worst <= 3e-4, worst          # the split form's level (9e-5 on the fuzz runs), far inside 1e-3
+    B, T = 4, 100                        # from 100 frames on the precision keeps its plain evaluations + tail
+    xfp, xfo = _features(sd, B, T, 5)
+    x = torch.from_numpy(batch_noise(B, T, first=5))
+    kw = {"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor([T] * B)}
+    a = gd.ddim_sample_loop(m, (B, T, 26), noise=x.cuda(), clip_denoised=False, progress=False, model_kwargs=kw)
+    m._native.set_precise_tail(50)
+    b = gd.ddim_sample_loop(m, (B, T, 26), noise=x.cuda(), clip_denoised=False, progress=False, model_kwargs=kw)
+    m._native.set_precise_tail(-1)
+    torch.cuda.synchronize()
+    assert not torch.equal(a, b)
+
+
 def test_fp16_plane_encoder_overflow_is_resampled_on_split_planes():
     """The fp16-plane MusicEncoder holds activations up to 65504.  A checkpoint whose encoder runs at 3e5 times the usual scale
     inside (conv1.0 scaled up, conv4 scaled down by the same factor: ReLU and the max-pools are positively homogeneous, so its output
