@@ -979,6 +979,13 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
 #endif
     const float* film_b = g1_tiles ? s->h_model.film_b_g1 : s->h_model.film_b;
     const float* film_b16 = g1_tiles ? s->h_model.film_b16_g1 : s->h_model.film_b16;
+    // DC_DIAG_SKIP_FILM=1 (diagnostic, eager passes only, results invalid): the FiLM GEMM is launched once and never again - the layers then
+    // read stale tiles and run without the GEMM's 300 us of power-limited matrix work between them (what the chip's clock management
+    // does to the layer launches that follow a GEMM: tools/diag_clock_coupling.py)
+    static bool diag_film_done = false;
+    const bool diag_skip_film = getenv("DC_DIAG_SKIP_FILM") && !fuse_embed && !fuse_extra && diag_film_done;
+    diag_film_done = true;
+    if (!diag_skip_film)
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
                                        film_rounds, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
                                        want_stamps_film ? s->d_stamps + 252 : nullptr,
