@@ -2006,7 +2006,9 @@ DEV void full_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const 
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+#ifndef DC_DIAG_FULL_NOSYNC           // diagnostic build (timing only, results invalid): the key loop without its two barriers per key tile
         __syncthreads();
+#endif
         if (active) {
             const char* frc = lds + (kt & 1) * 16384;
             const v8<T16>* fr = reinterpret_cast<const v8<T16>*>(frc);
@@ -2249,7 +2251,9 @@ DEV void full_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const 
                 tile_body(std::false_type{});
 #endif
         }
+#ifndef DC_DIAG_FULL_NOSYNC
         __syncthreads();             // the buffer just read is the next-but-one tile's target
+#endif
     }
     if (stamps && lane == 0) stamps[1] = __builtin_amdgcn_s_memrealtime();       // key loop done
     RowStats st;
