@@ -238,6 +238,7 @@ struct dc_sampler {
     Prof prof;
     int dbg_layers = -1, dbg_stage = 0;   // test hooks (dc_sampler_debug_denoise)
     int dbg_first = -1;                   // test hook (dc_sampler_debug_layer): start at this layer from the residual stream in d_h
+    bool embedded_by_prev = false;        // enqueue_step: the step just enqueued also did the next step's front work (DC_UPD_EMBED_NEXT)
 };
 
 namespace {
@@ -860,7 +861,8 @@ struct Timed {   // RAII-less helper: wraps a launch with events when profiling
 // that one process can A/B them: a change re-captures) and the update options of the loop.
 unsigned long long form_key(const dc_sampler* s) {
     static const char* sw[] = {"DC_NO_WGREC", "DC_NO_NARROW", "DC_NO_ALIGN", "DC_ALIGN", "DC_NO_FUSE_EMBED", "DC_FILM_STATIC",
-                               "DC_BEGIN_STEP", "DC_NO_PAD", "DC_NO_LAYER16", "DC_L16_OWN_COMBINE", "DC_L16_TEST_DROP_SLICE", "DC_TAIL_FILM_BF16", "DC_FLAT_UNITS"};
+                               "DC_BEGIN_STEP", "DC_NO_PAD", "DC_NO_LAYER16", "DC_L16_OWN_COMBINE", "DC_L16_TEST_DROP_SLICE", "DC_TAIL_FILM_BF16", "DC_FLAT_UNITS",
+                               "DC_NO_EMBED_NEXT"};
     unsigned long long k = 0;
     for (size_t i = 0; i < sizeof sw / sizeof *sw; ++i) k |= (getenv(sw[i]) ? 1ull : 0ull) << i;
     k |= (unsigned long long)(s->upd_flags & 0xff) << 16;     // (the noise tensor's address is not baked in: the kernels read it from d_zslot)
@@ -876,8 +878,11 @@ unsigned long long form_key(const dc_sampler* s) {
 // (k_begin_step, 5 us + a launch gap) is dropped.
 int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_src, float* x_dst, int graph_step = -1,
                  bool split_step = false /* this evaluation's 128-wide GEMMs on split operands (the fp16 images' hi + lo halves) */,
-                 bool g1_loop = false /* a loop with a precise tail: its plain-operand evaluations read G' scale tiles */) {
+                 bool g1_loop = false /* a loop with a precise tail: its plain-operand evaluations read G' scale tiles */,
+                 bool next_plain = false /* loops: another step follows in this enqueue sequence (same graph) and it is a plain-operand evaluation */) {
     const int B = s->B, T = s->T, M = s->M, G = s->G, L = s->cfg.num_layers;
+    const bool embedded = s->embedded_by_prev;      // the previous step's last layer has embedded x and run layer 0's front half for this step
+    s->embedded_by_prev = false;
     const bool ss = s->split_small || split_step, sf = s->split_film;
     const DcModel* dmod = (split_step && !s->split_small) ? s->d_model_split : s->d_model;      // (the precise tail's split stage images)
     // (bf16 precision, split evaluations: the f16 FiLM image - the step is then exactly a "mixed" evaluation)
@@ -958,7 +963,15 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     // per-kernel profile pass keep the two launches): one kernel boundary less per step, -1.3 % per loop at bs=32
     // (flat units in the non-split formats; the "mixed" mode - f16 GEMM, split-bf16 embedding - on its clip-aligned units)
     const bool mixed_form = ss && !sf && ff == 1 && fs == 0;
-    const bool fuse_embed = wgr && !narrow && (ss ? (aligned && mixed_form) : ff == fs) && fuse_silu && s->dbg_layers < 0 &&
+    // The last layer of a plain wide step does the NEXT step's front work (embedding of x_{t-1} + layer 0's self-attention front half:
+    // k_layer, DC_UPD_EMBED_NEXT) when that step is a plain wide step of the same enqueue sequence; its FiLM launch is then the bare GEMM
+    // and it has no front launch.  DC_NO_EMBED_NEXT=1 keeps the front work in every step's own FiLM launch.
+    const bool embed_next_on = !getenv("DC_NO_EMBED_NEXT");            // (read per call: a test toggles it)
+    const bool wide_plain = wgr && !narrow && !ss && fuse_silu && ff == fs && s->dbg_layers < 0 && s->dbg_stage == 0 && s->dbg_first < 0 &&
+                            !want_stamps && !s->cfg.no_eff;
+    const bool embed_next = embed_next_on && loop_mode && next_plain && wide_plain;
+    if (embedded && !(loop_mode && wide_plain)) return fail(DC_ERR_INVALID, "internal: a step whose front work was done by its predecessor changed its launch form");
+    const bool fuse_embed = !embedded && wgr && !narrow && (ss ? (aligned && mixed_form) : ff == fs) && fuse_silu && s->dbg_layers < 0 &&
                             s->dbg_stage == 0 && nwg <= s->num_cu && !want_stamps && !s->prof.on && !getenv("DC_NO_FUSE_EMBED");
     // small batches (narrow clip-aligned units): the embedding's workgroups ride BEHIND the GEMM's in the FiLM launch
     // (film_extra_workgroups, dc_kernels.hip): one launch (15 us at one clip) and one kernel boundary less per step.  DC_NO_FUSE_EMBED=1 keeps the two launches.
@@ -967,7 +980,8 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     DcEmbedArgs ea{};
     if (fuse_embed) ea = DcEmbedArgs{dmod, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, aligned ? upc : 0, ss ? 1 : 0, 0};
     if (fuse_extra) ea = DcEmbedArgs{s->d_model, x_src, s->d_h, s->d_recs, s->d_length, M, Tx, nwg, upc, 0, 1};
-    const DcUpdate upd{s->d_zslot, s->d_status, (loop_mode ? s->upd_flags : 0) | (getenv("DC_L16_TEST_DROP_SLICE") ? DC_UPD_TEST_DROP_SLICE : 0),
+    const DcUpdate upd{s->d_zslot, s->d_status, (loop_mode ? s->upd_flags : 0) | (getenv("DC_L16_TEST_DROP_SLICE") ? DC_UPD_TEST_DROP_SLICE : 0) |
+                                                (embed_next ? DC_UPD_EMBED_NEXT : 0),
                        folded ? graph_step : -1, nullptr};
     const int film_rounds = s->NT / 16;
     // scale tiles: G' for the plain-operand consumers of this step, G' - 1 for the split-operand ones (dc_dev.h, film_affine)
@@ -1007,8 +1021,8 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
         }
         return DC_OK;
     }
-    if (fuse_embed || fuse_extra) {
-        // (embedded by the FiLM launch)
+    if (fuse_embed || fuse_extra || embedded) {
+        // (embedded by the FiLM launch, or by the previous step's last layer)
     } else if (s->dbg_first >= 0)
         LAUNCH(K_EMBED, dc_launch_front_from_h(st, fs, ss, dmod, s->d_h, s->d_recs, s->d_length, M, T, G, B, s->dbg_first));
     else
@@ -1032,6 +1046,7 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
                                         s->d_snaps, M, T, G, B, dbg, ((l == 3 || l == 4) && want_stamps) ? s->d_stamps : nullptr, rec_stride,
                                         iter_base, narrow, Tx, upc, upd, g1_tiles));
     }
+    s->embedded_by_prev = embed_next;
     return DC_OK;
 }
 
@@ -1160,10 +1175,12 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
     // (a tail of the whole loop splits every replay's graph; any shorter one lives in the last replay and is clipped to its steps)
     const bool tail_all = tail >= S;
     tail = std::max(0, std::min(tail, std::min(S, steps_per_graph(S))));
+    s->embedded_by_prev = false;
     if (profile || no_graph) {
         s->prof.on = profile;
         for (int i = 0; i < S; ++i)
-            if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, -1, tail_all || i >= S - tail, tail > 0))) {
+            if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, -1, tail_all || i >= S - tail, tail > 0,
+                                   i + 1 < S && !(tail_all || i + 1 >= S - tail)))) {
                 s->prof.on = false;
                 return rc;
             }
@@ -1203,8 +1220,9 @@ int loop_common(dc_sampler* s, const float* d_noise, float* d_out, int S, const 
         if (!current()) {
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            s->embedded_by_prev = false;      // (a graph's first step does its own front work, its last step nobody else's)
             for (int i = 0; i < K; ++i)
-                if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, i, i >= K - tail_here, tail > 0))) {
+                if ((rc = enqueue_step(s, st, true, s->d_x, s->d_x, i, i >= K - tail_here, tail > 0, i + 1 < K && !(i + 1 >= K - tail_here)))) {
                     hipStreamEndCapture(st, &g);
                     if (g) hipGraphDestroy(g);
                     return rc;

@@ -104,6 +104,7 @@ struct DcModel {
 #define DC_UPD_NOISY 4       // (internal) eta > 0: sigma z is added; the draws are read from *zslot
 #define DC_UPD_ZSTEP 8       // (internal) *zslot holds ONE iteration's draws [B][Tx][P], refilled by k_step_noise at the head of every step
 #define DC_UPD_TEST_DROP_SLICE 16   // (test hook, DC_L16_TEST_DROP_SLICE=1) workgroup 0 of k_layer16 publishes nothing: its neighbours' bounded wait must end in DC_STATUS_SYNC_TIMEOUT
+#define DC_UPD_EMBED_NEXT 32  // (internal) the last layer of this step also embeds x_{t-1} and runs layer 0's self-attention front half for the NEXT step (k_layer, wide non-split production form)
 #define DC_STATUS_NONFINITE 1    // a predicted x0 was inf / nan
 #define DC_STATUS_F16_SAT 2      // a FiLM modulation value exceeded the fp16 range when stored
 #define DC_STATUS_SYNC_TIMEOUT 4 // a workgroup of the small-batch layer kernel gave up waiting for its clip's combine slices (GPU shared?)

@@ -1559,9 +1559,153 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
 #endif
     DC_STAMP(11);
 
-    if (!last) {
+    // The last layer of a step can also do the NEXT step's front work (dc_api.hip, DC_UPD_EMBED_NEXT; production form of the wide non-split
+    // kernel, captured and eager loops): x_{t-1} is in this wave's registers when the DDIM update has been applied, so the embedding
+    // (joint_embed + sequence_embedding, the same split-operand GEMM in the same order as embed_front_body: h bit-identical) and layer 0's
+    // self-attention front half (stage 7 below, with layer 0's images) follow at once - the next step's FiLM launch is then the bare GEMM.
+    // What that saves is the front kernel's cold start (x, the embedding image and the sequence rows through a cold cache: 8 of its 22 us)
+    // and the difference between its record pass and this kernel's.
+    bool embed_next = false;
+    if constexpr (WGR && !SPLIT && !NARROW && !DBG) embed_next = last && out_mode == 1 && (upd.flags & DC_UPD_EMBED_NEXT) != 0;
+    if (last) {
+    if (embed_next) {      // layer 0's key image -> buf1 (the FFN out-projection image, consumed); the embedding image -> the idle FiLM rings
+        stage_frags<NW>(dm->layer[0].img_sa_k, buf1, NFW + 1, wave, lane);
+        stage_frags<NW>(dm->img_je, lds + OFF_ER, 17, wave, lane);
+    }
+    // ---- output projection [buf0, split] + DDIM update
+    f32x16 x0[1];
+    const int P = dm->input_feats;
+    // embed_next: x_t of this lane's token is requested in front of the projection, so that its latency runs under the MFMAs and the barrier
+    // behind them; the sequence_embedding rows behind the barrier (64 registers: in front of the projection they spill)
+    const int e_xb = min(cx.tok, M - 1) / T, e_xn = cx.tok - e_xb * T;
+    const bool e_live = cx.tok < M && e_xn < Tx;                      // (frames Tx .. T-1 of a clip stride are padding)
+    f32x4 sev[16];
+    float xtv[16];
+    {
+        XFrag<T16, true> hf[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) make_frag<T16, true>(h[kt], hf[kt]);
+        if (embed_next) {
+            const size_t xrow = (size_t)e_xb * Tx + e_xn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = tile_row(r, cx.hh);
+                xtv[r] = (active && e_live && f < P) ? xin[xrow * P + f] : 0.f;
+            }
+        }
+        x0[0] = ld_ft(reinterpret_cast<const float*>(buf0 + 16 * 1024), 0, cx.hh);
+        gemm_wa<1, 4, T16, true>(x0, w0, hf, lane);
+    }
+    if (embed_next) {
+        if constexpr (WGR && !SPLIT && !NARROW && !DBG) {
+            // the two images have landed (nothing else of this wave is in flight: stage 6's closer drained it) and nobody reads the
+            // output image in buf0 any more: layer 0's value image goes there, ahead of everything the update and the embedding issue
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads(); sprio<3>();
+            __builtin_amdgcn_sched_barrier(0);
+            stage_frags<NW>(dm->layer[0].img_sa_v, buf0, NFW + 1, wave, lane);
+            const int xb = e_xb, xn = e_xn;
+            const bool live = e_live;
+            {
+                const float* se = dm->seq_emb + (size_t)(e_live ? e_xn : 0) * DC_D;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sev[4 * t + q] = *reinterpret_cast<const f32x4*>(se + 32 * t + 8 * q + 4 * cx.hh);
+            }
+            f32x16 xv = splat(0.f);
+            if (active && live) {
+                const size_t xrow = (size_t)xb * Tx + xn;
+                const int ib = iter_base ? *iter_base : 0;
+                const float* cc = coef_cur + DC_COEF * ib;
+                const int snap = snap_cur[ib];
+                const bool noisy = (upd.flags & DC_UPD_NOISY) != 0;
+                const float* zrow = nullptr;
+                if (noisy) zrow = *upd.zslot + ((upd.flags & DC_UPD_ZSTEP) ? (size_t)0 : (size_t)(iter_base ? upd.step + ib : snap_cur[1]) * B * Tx * P);
+                bool bad = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = tile_row(r, cx.hh);
+                    if (f < P) {
+                        const size_t o = xrow * P + f;
+                        const float xnew = ddim_update(x0[0][r], xtv[r], cc, upd.flags, noisy, noisy ? zrow[o] : 0.f, bad);
+                        xout[o] = xnew;
+                        if (snap >= 0) snaps[(size_t)snap * B * Tx * P + o] = xnew;
+                        xv[r] = xnew;
+                    }
+                }
+                if (bad && upd.status) atomicOr(upd.status, DC_STATUS_NONFINITE);
+            }
+            if (active) {      // (idle waves keep the h they have: their rows are outside every valid range below)
+                XFrag<T16, true> xf[1];
+                make_frag<T16, true>(xv, xf[0]);
+                const W* img = reinterpret_cast<const W*>(lds + OFF_ER);      // (pst, which overlays it, is first written behind stage 7's barrier)
+                const float* je_b = reinterpret_cast<const float*>(img + 16 * 64);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) h[t] = ld_ft(je_b, t, cx.hh);
+                gemm_wa<4, 1, T16, true>(h, img, xf, lane);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) h[t][4 * q + i] += sev[4 * t + q][i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+    if (!active || cx.tok >= M) return;
+    const int xb = cx.tok / T, xn = cx.tok - xb * T;
+    if (xn >= Tx) return;                                           // padding frame
+    const size_t xrow = (size_t)xb * Tx + xn;                       // row of xin / xout / snaps
+    if (out_mode == 0) {
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = tile_row(r, cx.hh);
+            if (f < P) {
+                xout[xrow * P + f] = x0[0][r];
+                bad = bad || !(fabsf(x0[0][r]) <= 3.0e38f);
+            }
+        }
+        if (bad && upd.status) atomicOr(upd.status, DC_STATUS_NONFINITE);
+    } else {
+        // graph-captured loop: coef_cur / snap_cur point at this step's slot of the per-iteration tables and *iter_base is
+        // the iteration at which the graph replay began; otherwise they are the scalars k_begin_step prepared
+        const int ib = iter_base ? *iter_base : 0;
+        coef_cur += DC_COEF * ib;
+        const int snap = snap_cur[ib];
+        const bool noisy = (upd.flags & DC_UPD_NOISY) != 0;
+        const float* zrow = nullptr;
+        if (noisy) zrow = *upd.zslot + ((upd.flags & DC_UPD_ZSTEP) ? (size_t)0 : (size_t)(iter_base ? upd.step + ib : snap_cur[1]) * B * Tx * P);
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = tile_row(r, cx.hh);
+            if (f < P) {
+                const size_t o = xrow * P + f;
+                const float xnew = ddim_update(x0[0][r], xin[o], coef_cur, upd.flags, noisy, noisy ? zrow[o] : 0.f, bad);
+                xout[o] = xnew;
+                if (snap >= 0) snaps[(size_t)snap * B * Tx * P + o] = xnew;
+            }
+        }
+        if (bad && upd.status) atomicOr(upd.status, DC_STATUS_NONFINITE);
+    }
+    return;
+    }      // (!embed_next)
+    }          // (last)
+    {
+        // (embed_next: the front half of the NEXT STEP's layer 0 - key image in buf1, value image into buf0)
+        const DcLayer& Ln = dm->layer[last ? 0 : l + 1];
+        char* const bufK = last ? buf1 : buf0;
+        char* const bufV = last ? buf0 : buf1;
+        const W* const wK = reinterpret_cast<const W*>(bufK);
+        const W* const wV = reinterpret_cast<const W*>(bufV);
+        const float* const cK = reinterpret_cast<const float*>(bufK + NFW * 1024);
+        const float* const cV = reinterpret_cast<const float*>(bufV + NFW * 1024);
         // ---- stage 7: next layer's SA front half: K [buf0] and V [buf1], partial records
-        stage_frags<NW>(dm->layer[l + 1].img_sa_v, buf1, NFW + 1, wave, lane);
+        if (!last) stage_frags<NW>(Ln.img_sa_v, bufV, NFW + 1, wave, lane);      // (embed_next: requested behind the output projection)
         // h goes out right behind the value-image DMA: vmcnt counts in issue order, so waiting until only the 16
         // youngest operations (the 16 dwordx4 stores of h) are outstanding means "the image has landed" while the
         // stores keep draining behind the K/V projections.
@@ -1595,10 +1739,10 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             // split formats (no FiLM rings; clip-aligned units, so no wave spans two clips and xp stays unused): the staged blocks go
             // to buf0 once its key image is consumed (behind the barrier below), the rescale factors to the upper half of AF
             float* mx = reinterpret_cast<float*>(lds + OFF_AF);
-            f32x8* pst = reinterpret_cast<f32x8*>(SPLIT ? buf0 : lds + OFF_ER);
+            f32x8* pst = reinterpret_cast<f32x8*>(SPLIT ? bufK : lds + OFF_ER);
             f32x8* xp = reinterpret_cast<f32x8*>(lds + OFF_AF + 8192);
             float* ss = reinterpret_cast<float*>(lds + OFF_SS);
-            float* scw = reinterpret_cast<float*>(SPLIT ? lds + OFF_AF + 8192 : buf0) + wave * 2 * 4 * 32;   // this wave's rescale factors
+            float* scw = reinterpret_cast<float*>(SPLIT ? lds + OFF_AF + 8192 : bufK) + wave * 2 * 4 * 32;   // this wave's rescale factors
                                                    // [2 slots][4 oc][32 cols]; (buf0's key image is consumed before the barrier below)
             const RowRange vr0 = valid_rows_clip(cx, ub0, B, M, T, length, active);
             const RowRange vr1 = valid_rows_clip(cx, ub0 + 1, B, M, T, length, active);
@@ -1633,8 +1777,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 ssum = xhalf_sum(sacc);
                 make_frag<T16, SPLIT>(Ee, ef);
             };
-            f32x16 Kp[4] = {splat(c0[cx.c]), splat(c0[32 + cx.c]), splat(c0[64 + cx.c]), splat(c0[96 + cx.c])};
-            mmb_oc_quad<4, 4, T16, SPLIT>(Kp[0], Kp[1], Kp[2], Kp[3], w0, nf, lane);
+            f32x16 Kp[4] = {splat(cK[cx.c]), splat(cK[32 + cx.c]), splat(cK[64 + cx.c]), splat(cK[96 + cx.c])};
+            mmb_oc_quad<4, 4, T16, SPLIT>(Kp[0], Kp[1], Kp[2], Kp[3], wK, nf, lane);
             sprio<2, 2>();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1707,8 +1851,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
                 }
                 return keep;
             };
-            f32x16 Vp[4] = {splat(c1[cx.c]), splat(c1[32 + cx.c]), splat(c1[64 + cx.c]), splat(c1[96 + cx.c])};
-            mmb_oc_quad<4, 4, T16, SPLIT>(Vp[0], Vp[1], Vp[2], Vp[3], w1, nf, lane);
+            f32x16 Vp[4] = {splat(cV[cx.c]), splat(cV[32 + cx.c]), splat(cV[64 + cx.c]), splat(cV[96 + cx.c])};
+            mmb_oc_quad<4, 4, T16, SPLIT>(Vp[0], Vp[1], Vp[2], Vp[3], wV, nf, lane);
             sprio<2, 2>();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1732,8 +1876,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             f32x16 K[4];                  // keys from buf0 while the value image lands in buf1
 #pragma unroll
             for (int oc = 0; oc < 4; ++oc) {
-                K[oc] = splat(c0[32 * oc + cx.c]);
-                mmb_oc<4, 4, T16, SPLIT>(K[oc], w0, oc, nf, lane);
+                K[oc] = splat(cK[32 * oc + cx.c]);
+                mmb_oc<4, 4, T16, SPLIT>(K[oc], wK, oc, nf, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (st_h)
@@ -1748,8 +1892,8 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
             const RowRange valid1 = valid_rows(cx, cx.straddle ? 1 : 0, M, T, length);
 #pragma unroll
             for (int oc = 0; oc < 4; ++oc) {
-                f32x16 V = splat(c1[32 * oc + cx.c]);
-                mmb_oc<4, 4, T16, SPLIT>(V, w1, oc, nf, lane);
+                f32x16 V = splat(cV[32 * oc + cx.c]);
+                mmb_oc<4, 4, T16, SPLIT>(V, wV, oc, nf, lane);
                 if (active) {
                     emit_partial<T16, SPLIT>(K[oc], V, oc, valid0, rec, cx);
                     if (cx.straddle) emit_partial<T16, SPLIT>(K[oc], V, oc, valid1, rec + DC_REC_FLOATS, cx);
@@ -1762,54 +1906,6 @@ void k_layer(const DcModel* __restrict__ dm, int l, float* __restrict__ hbuf, co
         DC_WGSTAMP(1);
         return;
     }
-    // ---- output projection [buf0, split] + DDIM update
-    f32x16 x0[1];
-    {
-        XFrag<T16, true> hf[4];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) make_frag<T16, true>(h[kt], hf[kt]);
-        x0[0] = ld_ft(reinterpret_cast<const float*>(buf0 + 16 * 1024), 0, cx.hh);
-        gemm_wa<1, 4, T16, true>(x0, w0, hf, lane);
-    }
-    if (!active || cx.tok >= M) return;
-    const int P = dm->input_feats;
-    const int xb = cx.tok / T, xn = cx.tok - xb * T;
-    if (xn >= Tx) return;                                           // padding frame
-    const size_t xrow = (size_t)xb * Tx + xn;                       // row of xin / xout / snaps
-    if (out_mode == 0) {
-        bool bad = false;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = tile_row(r, cx.hh);
-            if (f < P) {
-                xout[xrow * P + f] = x0[0][r];
-                bad = bad || !(fabsf(x0[0][r]) <= 3.0e38f);
-            }
-        }
-        if (bad && upd.status) atomicOr(upd.status, DC_STATUS_NONFINITE);
-    } else {
-        // graph-captured loop: coef_cur / snap_cur point at this step's slot of the per-iteration tables and *iter_base is
-        // the iteration at which the graph replay began; otherwise they are the scalars k_begin_step prepared
-        const int ib = iter_base ? *iter_base : 0;
-        coef_cur += DC_COEF * ib;
-        const int snap = snap_cur[ib];
-        const bool noisy = (upd.flags & DC_UPD_NOISY) != 0;
-        const float* zrow = nullptr;
-        if (noisy) zrow = *upd.zslot + ((upd.flags & DC_UPD_ZSTEP) ? (size_t)0 : (size_t)(iter_base ? upd.step + ib : snap_cur[1]) * B * Tx * P);
-        bool bad = false;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = tile_row(r, cx.hh);
-            if (f < P) {
-                const size_t o = xrow * P + f;
-                const float xnew = ddim_update(x0[0][r], xin[o], coef_cur, upd.flags, noisy, noisy ? zrow[o] : 0.f, bad);
-                xout[o] = xnew;
-                if (snap >= 0) snaps[(size_t)snap * B * Tx * P + o] = xnew;
-            }
-        }
-        if (bad && upd.status) atomicOr(upd.status, DC_STATUS_NONFINITE);
-    }
-    return;
   }
 }
 

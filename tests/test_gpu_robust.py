@@ -497,6 +497,59 @@ def test_mixed_mode_clip_aligned_units_edge_shapes(B, T):
     assert torch.equal(again[S], res[S]) and torch.equal(again[3], res[3])
 
 
+@pytest.mark.parametrize("prec", ["fp16", "bf16"])
+def test_last_layer_does_the_next_steps_front_work(prec, monkeypatch):
+    """Round 6: in the wide plain form the last layer of a step embeds x_{t-1} and runs layer 0's self-attention front half for the next
+    step (k_layer, DC_UPD_EMBED_NEXT; dc_api.hip, enqueue_step) - the next FiLM launch is the bare GEMM.  DC_NO_EMBED_NEXT=1 keeps the
+    front work in every step's own launch (round 5's form).  Both against the oracle and against each other, on the branches the fused
+    tail re-implements: ragged lengths down to one frame, a padded and an unpadded clip stride, eta > 0 with seeded step noise,
+    clip_denoised, an EPSILON-free START_X model with snapshots of intermediate iterations (captured graph and eager launches)."""
+    monkeypatch.setenv("DC_NO_NARROW", "1")            # the wide 8-wave form at a batch the oracle finishes in seconds
+    sd = synthetic_state_dict(DenoiserConfig(), seed=0)
+    p = O.to_torch_params(sd)
+    m = _model(sd, prec)
+    S = 25
+    gd = make_diffusion(S)
+    for B, T, eta, clip in [(3, 300, 0.0, False), (2, 777, 0.5, True), (5, 256, 0.0, False)]:
+        xfp, xfo = _features(sd, B, T, 21)
+        x = torch.from_numpy(batch_noise(B, T, first=21))
+        length = [T, 1, max(1, T - 37), T // 2, 2][:B]
+        z = torch.from_numpy(batch_step_noise(S, B, T, first=21)) if eta > 0 else None
+        with torch.no_grad():
+            ref = O.ddim_sample_loop(p, x, xfp, xfo, length, S, idxs=(5, S - 2), eta=eta, clip_denoised=clip, step_noise=z)
+        kw = dict(noise=x.cuda(), clip_denoised=clip, progress=False, idxs=[5, S - 2], eta=eta,
+                  model_kwargs={"xf_proj": xfp.cuda(), "xf_out": xfo.cuda(), "length": torch.LongTensor(length)})
+        if z is not None:
+            kw["step_noise"] = z.cuda()
+        outs = {}
+        for form in ("fused", "own"):
+            for graph in (True, False):
+                if form == "own":
+                    monkeypatch.setenv("DC_NO_EMBED_NEXT", "1")
+                else:
+                    monkeypatch.delenv("DC_NO_EMBED_NEXT", raising=False)
+                if graph:
+                    monkeypatch.delenv("DC_DISABLE_GRAPH", raising=False)
+                else:
+                    monkeypatch.setenv("DC_DISABLE_GRAPH", "1")
+                res = gd.ddim_sample_loop(m, (B, T, 26), **kw)
+                torch.cuda.synchronize()
+                outs[(form, graph)] = res
+                for k in (5, S - 2, S):
+                    assert torch.isfinite(res[k]).all()
+                    e = max(rel_l2(res[k][c:c + 1], ref[k][c:c + 1]) for c in range(B))
+                    assert e <= TOL, (prec, B, T, form, graph, k, e)
+        for k in (5, S - 2, S):
+            assert torch.equal(outs[("fused", True)][k], outs[("fused", False)][k])        # captured == eager, either form
+            assert torch.equal(outs[("own", True)][k], outs[("own", False)][k])
+            d = rel_l2(outs[("fused", True)][k], outs[("own", True)][k])
+            print(f"{prec} B={B} T={T} eta={eta}: iteration {k}: fused vs own front work {d:.2e}")
+            assert d <= 5e-4, d
+        assert not torch.equal(outs[("fused", True)][S], outs[("own", True)][S])            # (the switch does switch)
+    monkeypatch.delenv("DC_NO_EMBED_NEXT", raising=False)
+    monkeypatch.delenv("DC_DISABLE_GRAPH", raising=False)
+
+
 def test_bf16_precision_short_ragged_clips_every_clip_inside_the_bound():
     """Found by tools/fuzz_shapes.py (seed 601, case 117: 39 clips of 36 frames, lengths down to 1, DDIM-50): the worst clip read 1.27e-3 in
     the bf16 precision with its default tail of 6 - a clip's error is then a norm over a few hundred numbers and the worst of dozens of clips
