@@ -408,6 +408,10 @@ def main():
                 # wrote one launch earlier + unit records) over the launch time - design bytes, not section 8d's compulsory bytes
                 r["hbm_design_bytes"] = int(w["design_bytes"])
                 r["hbm_design_frac"] = round(w["design_bytes"] / per / PEAK_HBM_BYTES, 4)
+            if name == "k_layer":
+                r["note"] = ("the eighth layer launch of a step also does the NEXT step's front work (embedding of x_{t-1} + layer 0's self-attention "
+                             "front half: there is no front kernel beside the first step's); flops per launch = the step's non-FiLM algorithmic "
+                             "FLOPs / 8, front half included - as in the rounds in which a separate launch did that part")
             if name == "k_film_gemm":
                 r["graph_kernel"] = "k_film_embed: the captured loop runs this GEMM and k_embed_front as ONE launch; this eager pass times them apart"
             return r
