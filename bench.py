@@ -420,10 +420,11 @@ def main():
         if not args.no_eff and big:
             line["roofline"] = roof(big[0])
             line["roofline"]["time_share_by_kernel"] = {k: round(v[0] / tot, 3) for k, v in prof.items() if v[1]}
-            if "k_layer" in tj and "k_film_embed" in tj:
-                # memory-side bytes of ONE step from the committed PMC passes (fused front kernel + the layer launches) and the rate
-                # the timed loop sustains with them; SURVEY section 8d's compulsory bytes per step beside it (x_t in/out, pp, A_ca)
-                sb = tj["k_film_embed"]["traffic_bytes"] + model.num_layers * tj["k_layer"]["traffic_bytes"]
+            if "k_layer" in tj and ("k_film_gemm" in tj or "k_film_embed" in tj):
+                # memory-side bytes of ONE step from the committed PMC passes (the FiLM launch + the layer launches, whose eighth carries the
+                # next step's front work since round 6) and the rate the timed loop sustains with them; SURVEY section 8d's compulsory bytes
+                # per step beside it (x_t in/out, pp, A_ca)
+                sb = tj.get("k_film_gemm", tj.get("k_film_embed"))["traffic_bytes"] + model.num_layers * tj["k_layer"]["traffic_bytes"]
                 line["roofline"]["step_bytes_pmc"] = int(sb)
                 line["roofline"]["loop_avg_TBps"] = round(sb * S / (dt / args.steps) / 1e12, 3)
                 line["roofline"]["step_bytes_compulsory"] = int(B * (2 * T * 26 * 4 + T * 512 * 4 + 8 * 16 * 1024))
