@@ -164,7 +164,8 @@ DC_EXPORT int dc_sampler_encode_music(dc_sampler* s, const float* d_mel, int32_t
  * workgroup-record form on clip-aligned units, others - T = 900 x 128 unpadded, short clips - in the per-group record form: 5.2e-4 ->
  * 2.6e-4 there at no measurable cost.)  Loops of an EPSILON model (DC_UPDATE_EPSILON) run EVERY evaluation on split operands unless a
  * number was set here: their final sample carries what the plain evaluations left in x_t (fp16, eta = 0: 1.4 - 1.8e-3 with any shorter
- * tail, 1.5e-4 all split), and so do loops of the bf16 precision over clips of fewer than 100 frames (a clip's error is then a norm over
+ * tail, 1.5e-4 all split; with full attention such a loop is REFUSED at eta = 0 - DC_ERR_UNSUPPORTED: 2.3e-4 ... 1.26e-3 over randomized loops even
+ * with every GEMM split, the attention's scores, weights and values being plain fp16 - and runs at eta > 0, <= 2e-4), and so do loops of the bf16 precision over clips of fewer than 100 frames (a clip's error is then a norm over
  * few numbers and the worst clip of a batch of dozens reached 1.27e-3 with the default tail: 39 clips of 36 frames, tools/fuzz_shapes.py;
  * such loops are launch-bound, the split form costs them little).  Applies to linear and full attention alike (`no_eff`, fp16: its split instantiation keeps scores, weights and
  * values plain 16-bit); ignored for the split precisions.  DC_PRECISE_TAIL=k in the environment

@@ -151,38 +151,45 @@ def test_epsilon_model_runs_every_evaluation_on_split_operands(S):
     assert errs["bf16"] <= 0.5 * TOL and errs["bf16, tail 1"] > 3 * errs["bf16"]
 
 
-@pytest.mark.parametrize("prec", ["fp16"])
-def test_epsilon_model_full_attention_eta0_vs_oracle(prec):
-    """The same branch through the full-attention (`no_eff`) kernels: k_layer_full's split-operand instantiation (query / key / value
-    projections, stylization out-projections and FFN on split operands; scores, weights and values plain 16-bit) runs every evaluation
-    of an EPSILON loop - round 5 returned 1.4e-3 here with a warning.  (Full attention is offered in fp16 only: bf16 attention operands
-    leave 1.9e-3 on this branch even with every GEMM split, 1.0 - 1.8e-3 on START_X loops - test_no_eff_is_offered_in_fp16_only.)"""
+def test_epsilon_model_full_attention_eta0_is_refused_eta_above_zero_is_inside_the_bound(monkeypatch):
+    """EPSILON model x full attention (`no_eff`): k_layer_full's split-operand instantiation (query / key / value projections, stylization
+    out-projections and FFN on split operands; scores, weights and values plain fp16) runs every evaluation of such a loop.  At eta = 0 that
+    is NOT robustly inside the bound - 2.3e-4 ... 1.26e-3 over 14 randomized loops of tools/fuzz_sampler.py (this fixed case: 4.4e-4; round 5
+    returned 1.4e-3 here with a warning) - so the combination is refused by the sampler and by the library's loop; with eta > 0 the fresh
+    noise damps what the evaluations leave in x_t (<= 2e-4 on the same tool) and the loop runs.  DC_ALLOW_EPSILON_NO_EFF_ETA0=1 lets the
+    refused loop run for the record."""
     from helpers import O
-    from diffusion_conductor_amd import MotionTransformer
-    sd, B, T, S, length, xfp, xfo, noise, _ = _g9_setup()
+    from diffusion_conductor_amd import MotionTransformer, native
+    sd, B, T, S, length, xfp, xfo, noise, z = _g9_setup()
     gd = _diffusion(S, "EPSILON")
-    with torch.no_grad():
-        ref = O.ddim_sample_loop(O.to_torch_params(sd, torch.float32), noise.cpu(), xfp.cpu(), xfo.cpu(), length, S, clip_denoised=True,
-                                 eps_model=True, no_eff=True)
-    m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cuda", no_clip=True, no_eff=True, precision=prec)
+    m = MotionTransformer(input_feats=26, num_frames=1800, num_layers=8, latent_dim=128, device="cuda", no_clip=True, no_eff=True, precision="fp16")
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     m = m.to("cuda").eval()
     kw = dict(noise=noise, clip_denoised=True, progress=False, model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.LongTensor(length)})
-    out = gd.ddim_sample_loop(m, (B, T, 26), **kw)
+    with pytest.raises(ValueError, match="no_eff"):
+        gd.ddim_sample_loop(m, (B, T, 26), **kw)
+    with pytest.raises(ValueError, match="no_eff"):
+        next(gd.ddim_sample_loop_progressive(m, (B, T, 26), **kw))
+    nat = m.set_conditioning(xfp, xfo, length)                       # ... and the library's own loop, under the Python layer
+    with pytest.raises(native.DcError):
+        nat.ddim_loop(noise, gd.native_coefficients(0.0), [], native.UPDATE_CLIP_DENOISED | native.UPDATE_EPSILON, None, None)
+    out = gd.ddim_sample_loop(m, (B, T, 26), eta=0.3, step_noise=z, **kw)
     torch.cuda.synchronize()
-    err = rel_l2(out, ref)
-    import os
-    os.environ["DC_PRECISE_TAIL"] = "0"          # the plain-operand loop, for the record
-    try:
-        plain = rel_l2(gd.ddim_sample_loop(m, (B, T, 26), noise=noise, clip_denoised=True, progress=False,
-                                           model_kwargs={"xf_proj": xfp, "xf_out": xfo, "length": torch.LongTensor(length)}), ref)
-    finally:
-        del os.environ["DC_PRECISE_TAIL"]
-    print(f"EPSILON, eta = 0, no_eff, {prec}: every evaluation split {err:.3e}   plain operands {plain:.3e}")
-    assert torch.isfinite(out).all() and err <= TOL and plain > err
+    with torch.no_grad():
+        ref = O.ddim_sample_loop(O.to_torch_params(sd, torch.float32), noise.cpu(), xfp.cpu(), xfo.cpu(), length, S, clip_denoised=True,
+                                 eps_model=True, no_eff=True, eta=0.3, step_noise=z.cpu())
+    e_eta = rel_l2(out, ref)
+    monkeypatch.setenv("DC_ALLOW_EPSILON_NO_EFF_ETA0", "1")
+    out0 = gd.ddim_sample_loop(m, (B, T, 26), **kw)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref0 = O.ddim_sample_loop(O.to_torch_params(sd, torch.float32), noise.cpu(), xfp.cpu(), xfo.cpu(), length, S, clip_denoised=True,
+                                  eps_model=True, no_eff=True)
+    print(f"EPSILON, no_eff, fp16: eta = 0.3: {e_eta:.3e}   eta = 0 (refused by default; forced here): {rel_l2(out0, ref0):.3e}")
+    assert torch.isfinite(out).all() and e_eta <= TOL
 
 
-@pytest.mark.parametrize("prec,no_eff", [("fp16", False), ("bf16", False), ("fp16", True)])
+@pytest.mark.parametrize("prec,no_eff", [("fp16", False), ("bf16", False)])
 def test_epsilon_model_stepped_through_single_evaluations(prec, no_eff):
     """ddim_sample_loop_progressive of an EPSILON model at eta = 0: the generator evaluates the native denoiser on split operands
     (dc_sampler_set_precise_forward) for exactly such loops - on plain fp16 operands it ended at 1.5e-3."""
