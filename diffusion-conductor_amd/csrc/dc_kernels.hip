@@ -2255,6 +2255,8 @@ DEV void full_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const 
                 f32x16 Snext = scores_fr(kfr[0], qfr[0], 0);
                 XFrag<T16, false> pfp;
                 v8<T16> vfp0, vfp1;
+                u32x4 fz = {0u, 0u, 0u, 0u};      // the reference-point operand: one live register group, only its first word changes per head
+                asm volatile("" : "+v"(fz));       // (opaque: or its zeros are re-materialised in front of every head's MFMA)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
 #if DC_FULL_PRIO
@@ -2274,7 +2276,10 @@ DEV void full_attend(ytile<SPLIT> (&y)[4], float& y_rstd, float& y_shift, const 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) Pw[r] = exp2f_fast(S[r]);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (hd < 7) Snext = mfma(kone, __builtin_bit_cast(v8<T16>, u32x4{negm[hd + 1], 0u, 0u, 0u}), Snext);
+                        if (hd < 7) {
+                            fz[0] = negm[hd + 1];
+                            Snext = mfma(kone, __builtin_bit_cast(v8<T16>, fz), Snext);
+                        }
                         if (hd < 6) {
                             kfr[hd & 1] = fr[(hd + 2) * 64 + lane];
                             qfr[hd & 1] = qs[(hd + 2) * 64 + lane];
