@@ -239,6 +239,7 @@ struct dc_sampler {
     int dbg_layers = -1, dbg_stage = 0;   // test hooks (dc_sampler_debug_denoise)
     int dbg_first = -1;                   // test hook (dc_sampler_debug_layer): start at this layer from the residual stream in d_h
     bool embedded_by_prev = false;        // enqueue_step: the step just enqueued also did the next step's front work (DC_UPD_EMBED_NEXT)
+    bool diag_film_done = false;          // DC_DIAG_SKIP_FILM (diagnostic): the FiLM GEMM has been launched once on this sampler
 };
 
 namespace {
@@ -996,9 +997,8 @@ int enqueue_step(dc_sampler* s, hipStream_t st, bool loop_mode, const float* x_s
     // DC_DIAG_SKIP_FILM=1 (diagnostic, eager passes only, results invalid): the FiLM GEMM is launched once and never again - the layers then
     // read stale tiles and run without the GEMM's 300 us of power-limited matrix work between them (what the chip's clock management
     // does to the layer launches that follow a GEMM: tools/diag_clock_coupling.py)
-    static bool diag_film_done = false;
-    const bool diag_skip_film = getenv("DC_DIAG_SKIP_FILM") && !fuse_embed && !fuse_extra && diag_film_done;
-    diag_film_done = true;
+    const bool diag_skip_film = getenv("DC_DIAG_SKIP_FILM") && !fuse_embed && !fuse_extra && s->diag_film_done;
+    s->diag_film_done = true;
     if (!diag_skip_film)
     LAUNCH(K_FILM, dc_launch_film_gemm(st, ff, sf, s->h_model.film_w, film_b, s->d_s_hi, s->d_s_lo, s->d_E, G, s->NT, 0,
                                        film_rounds, fuse_silu ? s->d_pp : nullptr, s->h_model.temb, t_src, T, B,
